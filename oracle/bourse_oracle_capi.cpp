@@ -1,0 +1,473 @@
+// bourse_oracle_capi.cpp — C ABI over the CPU ORACLE, for ctypes (tests/, smoke(),
+// bench.py cpu_baseline only — see bourse_oracle.hpp).  Test infrastructure.
+#include <atomic>
+#include <cstring>
+#include <memory>
+#include <thread>
+
+#include "bourse_oracle.hpp"
+
+using namespace orc;
+
+namespace {
+
+struct OrcEnv {  // mirrors the PyO3 pyclass: Env + its own RNG (ref rust/src/step_sim.rs:55-75)
+  Env env;
+  Rng rng;
+  OrcEnv(uint64_t seed, Nanos start, Price tick, Nanos step, bool trading, int levels)
+      : env(start, tick, step, trading, levels), rng(Rng::seed_from_u64(seed)) {}
+};
+
+struct OrcAgents {  // an AgentSet: groups updated in declaration order (ref crates/macros/src/lib.rs:57-73)
+  std::vector<RandomAgents> groups;
+};
+
+struct OrcOrderRec {  // PyOrder layout, ref rust/src/types.rs:17-31
+  uint8_t side_is_bid;
+  uint8_t status;
+  uint8_t pad[6];
+  uint64_t arr_time, end_time;
+  uint32_t vol, start_vol, price, trader_id;
+  uint64_t order_id;
+};
+static_assert(sizeof(OrcOrderRec) == 48, "layout");
+
+struct OrcTradeRec {  // PyTrade layout, ref rust/src/types.rs:4-15
+  uint64_t t;
+  uint32_t side_is_bid;
+  uint32_t price;
+  uint32_t vol;
+  uint32_t pad;
+  uint64_t active_id, passive_id;
+};
+static_assert(sizeof(OrcTradeRec) == 40, "layout");
+
+std::optional<uint32_t> opt(int has, uint32_t v) { return has ? std::optional<uint32_t>(v) : std::nullopt; }
+
+// numpy `level_2_data` layout, ref rust/src/step_sim_numpy.rs:351-368 (with L levels):
+// [trade_vol, bid_price, ask_price, ask_vol, bid_vol, {bid_vol_i, bid_n_i, ask_vol_i, ask_n_i}...]
+void pack_l2(const Level2Data& d, Vol trade_vol, int levels, uint32_t* out) {
+  out[0] = trade_vol;
+  out[1] = d.bid_price;
+  out[2] = d.ask_price;
+  out[3] = d.ask_vol;
+  out[4] = d.bid_vol;
+  for (int i = 0; i < levels; ++i) {
+    out[5 + 4 * i + 0] = d.bid_price_levels[i].first;
+    out[5 + 4 * i + 1] = d.bid_price_levels[i].second;
+    out[5 + 4 * i + 2] = d.ask_price_levels[i].first;
+    out[5 + 4 * i + 3] = d.ask_price_levels[i].second;
+  }
+}
+
+void fill_order(const Order& o, OrcOrderRec* r) {
+  std::memset(r, 0, sizeof(*r));
+  r->side_is_bid = side_to_bool(o.side);
+  r->status = static_cast<uint8_t>(o.status);
+  r->arr_time = o.arr_time;
+  r->end_time = o.end_time;
+  r->vol = o.vol;
+  r->start_vol = o.start_vol;
+  r->price = o.price;
+  r->trader_id = o.trader_id;
+  r->order_id = o.order_id;
+}
+
+void fill_trade(const Trade& t, OrcTradeRec* r) {
+  std::memset(r, 0, sizeof(*r));
+  r->t = t.t;
+  r->side_is_bid = side_to_bool(t.side);
+  r->price = t.price;
+  r->vol = t.vol;
+  r->active_id = t.active_order_id;
+  r->passive_id = t.passive_order_id;
+}
+
+// One independent simulated market: Env + agents + RNG, as sim_runner owns them
+// (ref crates/step_sim/src/runner.rs:46-69).
+struct ManyBook {
+  Env env;
+  OrcAgents agents;
+  Rng rng;
+  ManyBook(Nanos start, Price tick, Nanos step, bool trading, int levels, uint64_t seed)
+      : env(start, tick, step, trading, levels), rng(Rng::seed_from_u64(seed)) {}
+};
+
+struct OrcMany {
+  int levels;
+  std::vector<std::unique_ptr<ManyBook>> books;
+};
+
+}  // namespace
+
+extern "C" {
+
+// ------------------------------------------------------------------ RNG ----
+void orc_rng_seed(uint64_t seed, uint64_t* st) {
+  Rng r = Rng::seed_from_u64(seed);
+  st[0] = r.s0;
+  st[1] = r.s1;
+}
+uint64_t orc_rng_next_u64(uint64_t* st) {
+  Rng r{st[0], st[1]};
+  uint64_t v = r.next_u64();
+  st[0] = r.s0;
+  st[1] = r.s1;
+  return v;
+}
+uint32_t orc_rng_next_u32(uint64_t* st) {
+  Rng r{st[0], st[1]};
+  uint32_t v = r.next_u32();
+  st[0] = r.s0;
+  st[1] = r.s1;
+  return v;
+}
+float orc_rng_f32(uint64_t* st) {
+  Rng r{st[0], st[1]};
+  float v = r.gen_f32();
+  st[0] = r.s0;
+  st[1] = r.s1;
+  return v;
+}
+uint32_t orc_rng_range(uint64_t* st, uint32_t lo, uint32_t hi) {
+  Rng r{st[0], st[1]};
+  uint32_t v = r.gen_range_u32(lo, hi);
+  st[0] = r.s0;
+  st[1] = r.s1;
+  return v;
+}
+void orc_rng_shuffle_u32(uint64_t* st, uint32_t* v, uint64_t n) {
+  Rng r{st[0], st[1]};
+  for (uint64_t i = n; i-- > 1;) {
+    uint32_t j = r.gen_index(static_cast<uint32_t>(i + 1));
+    std::swap(v[i], v[j]);
+  }
+  st[0] = r.s0;
+  st[1] = r.s1;
+}
+
+// ------------------------------------------------- OrderBookSide (unit KATs) --
+// kind: 0 = raw OrderBookSide, 1 = AskSide, 2 = BidSide (ref side.rs:36-43,148-152)
+struct OrcSide { int kind; OrderBookSide s; };
+void* orc_side_new(int kind) { return new OrcSide{kind, {}}; }
+void orc_side_free(void* p) { delete static_cast<OrcSide*>(p); }
+static OrderKey side_key(OrcSide* x, uint64_t t, uint32_t price) {
+  if (x->kind == 2) return get_bid_key(t, price);
+  if (x->kind == 1) return get_ask_key(t, price);
+  return OrderKey{Side::Ask, price, t};
+}
+void orc_side_insert(void* p, uint64_t t, uint32_t price, uint64_t idx, uint32_t vol) {
+  auto* x = static_cast<OrcSide*>(p);
+  x->s.insert_order(side_key(x, t, price), idx, vol);
+}
+void orc_side_remove_order(void* p, uint64_t t, uint32_t price, uint32_t vol) {
+  auto* x = static_cast<OrcSide*>(p);
+  x->s.remove_order(side_key(x, t, price), vol);
+}
+void orc_side_remove_vol(void* p, uint32_t price, uint32_t vol) {
+  auto* x = static_cast<OrcSide*>(p);
+  x->s.remove_vol(side_key(x, 0, price).price_key, vol);
+}
+uint32_t orc_side_vol(void* p) { return static_cast<OrcSide*>(p)->s.vol; }
+uint32_t orc_side_best_price(void* p) {
+  auto* x = static_cast<OrcSide*>(p);
+  return x->kind == 2 ? PRICE_MAX - x->s.best_price() : x->s.best_price();
+}
+void orc_side_best_vol_and_orders(void* p, uint32_t* out2) {
+  auto v = static_cast<OrcSide*>(p)->s.best_vol_and_orders();
+  out2[0] = v.first;
+  out2[1] = v.second;
+}
+// returns 1 and writes *out if the side is non-empty
+int orc_side_best_order_idx(void* p, uint64_t* out) {
+  auto v = static_cast<OrcSide*>(p)->s.best_order_idx();
+  if (!v) return 0;
+  *out = *v;
+  return 1;
+}
+void orc_side_vol_and_orders_at_price(void* p, uint32_t price, uint32_t* out2) {
+  auto* x = static_cast<OrcSide*>(p);
+  auto v = x->s.vol_and_orders_at_price(side_key(x, 0, price).price_key);
+  out2[0] = v.first;
+  out2[1] = v.second;
+}
+
+// ------------------------------------------------ immediate-mode OrderBook --
+void* orc_book_new(uint64_t start, uint32_t tick, int trading, int levels) {
+  return new OrderBook(start, tick, trading != 0, levels);
+}
+void orc_book_free(void* b) { delete static_cast<OrderBook*>(b); }
+void orc_book_set_time(void* b, uint64_t t) { static_cast<OrderBook*>(b)->t = t; }
+uint64_t orc_book_get_time(void* b) { return static_cast<OrderBook*>(b)->t; }
+void orc_book_set_trading(void* b, int on) { static_cast<OrderBook*>(b)->trading = on != 0; }
+int orc_book_create_order(void* b, int bid, uint32_t vol, uint32_t trader, int has_price, uint32_t price,
+                          uint64_t* out_id) {
+  return static_cast<OrderBook*>(b)->create_order(side_from_bool(bid != 0), vol, trader, opt(has_price, price),
+                                                  out_id);
+}
+int orc_book_place_order(void* b, uint64_t id) {
+  auto* ob = static_cast<OrderBook*>(b);
+  if (id >= ob->orders.size()) return ORC_UNKNOWN_ORDER_ID;
+  ob->place_order(id);
+  return ORC_OK;
+}
+// create_and_place_order, ref orderbook.rs:411-421
+int orc_book_create_and_place(void* b, int bid, uint32_t vol, uint32_t trader, int has_price, uint32_t price,
+                              uint64_t* out_id) {
+  auto* ob = static_cast<OrderBook*>(b);
+  uint64_t id = 0;
+  int rc = ob->create_order(side_from_bool(bid != 0), vol, trader, opt(has_price, price), &id);
+  if (rc != ORC_OK) return rc;
+  ob->place_order(id);
+  if (out_id) *out_id = id;
+  return ORC_OK;
+}
+int orc_book_cancel(void* b, uint64_t id) { return static_cast<OrderBook*>(b)->cancel_order(id); }
+int orc_book_modify(void* b, uint64_t id, int has_price, uint32_t price, int has_vol, uint32_t vol) {
+  return static_cast<OrderBook*>(b)->modify_order(id, opt(has_price, price), opt(has_vol, vol));
+}
+void orc_book_bid_ask(void* b, uint32_t* out2) {
+  auto [bid, ask] = static_cast<OrderBook*>(b)->bid_ask();
+  out2[0] = bid;
+  out2[1] = ask;
+}
+uint32_t orc_book_bid_vol(void* b) { return static_cast<OrderBook*>(b)->bid_vol(); }
+uint32_t orc_book_ask_vol(void* b) { return static_cast<OrderBook*>(b)->ask_vol(); }
+uint32_t orc_book_trade_vol(void* b) { return static_cast<OrderBook*>(b)->trade_vol; }
+void orc_book_best_bid_vol_and_orders(void* b, uint32_t* out2) {  // orderbook.rs:249-251
+  auto v = static_cast<OrderBook*>(b)->bid_side.s.best_vol_and_orders();
+  out2[0] = v.first;
+  out2[1] = v.second;
+}
+void orc_book_best_ask_vol_and_orders(void* b, uint32_t* out2) {  // orderbook.rs:221-223
+  auto v = static_cast<OrderBook*>(b)->ask_side.s.best_vol_and_orders();
+  out2[0] = v.first;
+  out2[1] = v.second;
+}
+double orc_book_mid_price(void* b) { return static_cast<OrderBook*>(b)->mid_price(); }
+// out = [bid_price, ask_price, bid_vol, ask_vol, bid_levels (vol,n)*L, ask_levels (vol,n)*L]
+void orc_book_level2(void* b, uint32_t* out) {
+  auto* ob = static_cast<OrderBook*>(b);
+  Level2Data d = ob->level_2_data();
+  out[0] = d.bid_price;
+  out[1] = d.ask_price;
+  out[2] = d.bid_vol;
+  out[3] = d.ask_vol;
+  for (int i = 0; i < ob->levels; ++i) {
+    out[4 + 2 * i] = d.bid_price_levels[i].first;
+    out[4 + 2 * i + 1] = d.bid_price_levels[i].second;
+    out[4 + 2 * ob->levels + 2 * i] = d.ask_price_levels[i].first;
+    out[4 + 2 * ob->levels + 2 * i + 1] = d.ask_price_levels[i].second;
+  }
+}
+uint64_t orc_book_n_orders(void* b) { return static_cast<OrderBook*>(b)->orders.size(); }
+uint64_t orc_book_n_trades(void* b) { return static_cast<OrderBook*>(b)->trades.size(); }
+int orc_book_order_status(void* b, uint64_t id, uint8_t* out) {
+  auto* ob = static_cast<OrderBook*>(b);
+  if (id >= ob->orders.size()) return ORC_UNKNOWN_ORDER_ID;
+  *out = static_cast<uint8_t>(ob->orders[id].order.status);
+  return ORC_OK;
+}
+void orc_book_get_orders(void* b, void* out, uint64_t first, uint64_t n) {
+  auto* ob = static_cast<OrderBook*>(b);
+  auto* r = static_cast<OrcOrderRec*>(out);
+  for (uint64_t i = 0; i < n; ++i) fill_order(ob->orders[first + i].order, r + i);
+}
+void orc_book_get_trades(void* b, void* out, uint64_t first, uint64_t n) {
+  auto* ob = static_cast<OrderBook*>(b);
+  auto* r = static_cast<OrcTradeRec*>(out);
+  for (uint64_t i = 0; i < n; ++i) fill_trade(ob->trades[first + i], r + i);
+}
+
+// ---------------------------------------------------------------- Env ------
+void* orc_env_new(uint64_t seed, uint64_t start, uint32_t tick, uint64_t step, int trading, int levels) {
+  return new OrcEnv(seed, start, tick, step, trading != 0, levels);
+}
+void orc_env_free(void* e) { delete static_cast<OrcEnv*>(e); }
+void* orc_env_book(void* e) { return &static_cast<OrcEnv*>(e)->env.order_book; }
+void orc_env_rng_state(void* e, uint64_t* st) {
+  auto* x = static_cast<OrcEnv*>(e);
+  st[0] = x->rng.s0;
+  st[1] = x->rng.s1;
+}
+int orc_env_place_order(void* e, int bid, uint32_t vol, uint32_t trader, int has_price, uint32_t price,
+                        uint64_t* out_id) {
+  return static_cast<OrcEnv*>(e)->env.place_order(side_from_bool(bid != 0), vol, trader, opt(has_price, price),
+                                                  out_id);
+}
+void orc_env_cancel_order(void* e, uint64_t id) { static_cast<OrcEnv*>(e)->env.cancel_order(id); }
+void orc_env_modify_order(void* e, uint64_t id, int has_price, uint32_t price, int has_vol, uint32_t vol) {
+  static_cast<OrcEnv*>(e)->env.modify_order(id, opt(has_price, price), opt(has_vol, vol));
+}
+uint64_t orc_env_n_transactions(void* e) { return static_cast<OrcEnv*>(e)->env.transactions.size(); }
+// kinds of queued events (0 New, 1 Cancellation, 2 Modify) — for the agent structure tests
+void orc_env_transaction_kinds(void* e, uint8_t* out) {
+  auto& tx = static_cast<OrcEnv*>(e)->env.transactions;
+  for (size_t i = 0; i < tx.size(); ++i) out[i] = tx[i].kind;
+}
+int orc_env_step(void* e) {  // StepEnv.step, ref rust/src/step_sim.rs:200-203
+  auto* x = static_cast<OrcEnv*>(e);
+  return x->env.step(x->rng);
+}
+// numpy level_2_data layout: snapshot + LIVE trade_vol (ref step_sim_numpy.rs:351-368)
+void orc_env_level2(void* e, uint32_t* out) {
+  auto* x = static_cast<OrcEnv*>(e);
+  pack_l2(x->env.level_2_data, x->env.order_book.trade_vol, x->env.order_book.levels, out);
+}
+uint64_t orc_env_n_steps(void* e) { return static_cast<OrcEnv*>(e)->env.trade_vols.size(); }
+// history in the same layout: out[step][5+4L], trade_vol = recorded per-step value
+void orc_env_history(void* e, uint32_t* out) {
+  auto* x = static_cast<OrcEnv*>(e);
+  const auto& r = x->env.level_2_data_records;
+  const int L = r.n;
+  const size_t T = x->env.trade_vols.size();
+  const size_t W = 5 + 4 * static_cast<size_t>(L);
+  for (size_t s = 0; s < T; ++s) {
+    uint32_t* o = out + s * W;
+    o[0] = x->env.trade_vols[s];
+    o[1] = r.bid_prices[s];
+    o[2] = r.ask_prices[s];
+    o[3] = r.ask_vols[s];
+    o[4] = r.bid_vols[s];
+    for (int i = 0; i < L; ++i) {
+      o[5 + 4 * i + 0] = r.bid_vols_at_levels[i][s];
+      o[5 + 4 * i + 1] = r.bid_orders_at_levels[i][s];
+      o[5 + 4 * i + 2] = r.ask_vols_at_levels[i][s];
+      o[5 + 4 * i + 3] = r.ask_orders_at_levels[i][s];
+    }
+  }
+}
+
+// ------------------------------------------------------------- agents ------
+void* orc_agents_new() { return new OrcAgents(); }
+void orc_agents_free(void* a) { delete static_cast<OrcAgents*>(a); }
+void orc_agents_add_random(void* a, uint64_t n, uint32_t tick_lo, uint32_t tick_hi, uint32_t vol_lo,
+                           uint32_t vol_hi, uint32_t tick_size, float rate) {
+  static_cast<OrcAgents*>(a)->groups.emplace_back(n, tick_lo, tick_hi, vol_lo, vol_hi, tick_size, rate);
+}
+// held ids of group g: out[i] = id or u64::MAX for None
+void orc_agents_held_ids(void* a, int g, uint64_t* out) {
+  auto& grp = static_cast<OrcAgents*>(a)->groups[g];
+  for (size_t i = 0; i < grp.orders.size(); ++i) out[i] = grp.orders[i].value_or(ORDER_ID_MAX);
+}
+// agents.update(env, rng) with the env's own RNG — one call of the AgentSet
+void orc_agents_update(void* a, void* e) {
+  auto* x = static_cast<OrcEnv*>(e);
+  for (auto& g : static_cast<OrcAgents*>(a)->groups) g.update(x->env, x->rng);
+}
+// sim_runner body (ref runner.rs:53-68) continuing from an explicit RNG state;
+// st = seed_from_u64(seed) for a fresh run.  The env's own RNG is not touched.
+int orc_sim_run(void* e, void* a, uint64_t* st, uint64_t n_steps) {
+  auto* x = static_cast<OrcEnv*>(e);
+  auto* ag = static_cast<OrcAgents*>(a);
+  Rng rng{st[0], st[1]};
+  int rc = ORC_OK;
+  for (uint64_t s = 0; s < n_steps; ++s) {
+    for (auto& g : ag->groups) g.update(x->env, rng);
+    int r = x->env.step(rng);
+    if (r != ORC_OK) rc = r;
+  }
+  st[0] = rng.s0;
+  st[1] = rng.s1;
+  return rc;
+}
+
+// ---------------------------------------------- many independent books -----
+// B independent (Env, agents, rng) triples, book b seeded seed_base + b.
+// groups: n_groups rows of {n, tick_lo, tick_hi, vol_lo, vol_hi, tick_size, rate_bits(f32)}
+void* orc_many_new(uint32_t n_books, uint64_t seed_base, uint64_t start, uint32_t tick, uint64_t step,
+                   int trading, int levels, int n_groups, const uint32_t* groups) {
+  auto* m = new OrcMany();
+  m->levels = levels;
+  m->books.reserve(n_books);
+  for (uint32_t b = 0; b < n_books; ++b) {
+    auto bk = std::make_unique<ManyBook>(start, tick, step, trading != 0, levels, seed_base + b);
+    for (int g = 0; g < n_groups; ++g) {
+      const uint32_t* r = groups + 7 * g;
+      float rate;
+      std::memcpy(&rate, &r[6], 4);
+      bk->agents.groups.emplace_back(r[0], r[1], r[2], r[3], r[4], r[5], rate);
+    }
+    m->books.push_back(std::move(bk));
+  }
+  return m;
+}
+void orc_many_free(void* m) { delete static_cast<OrcMany*>(m); }
+
+// Run n_steps of sim_runner's loop for every book, books statically partitioned
+// over n_threads host threads.
+int orc_many_run(void* mp, uint64_t n_steps, int n_threads) {
+  auto* m = static_cast<OrcMany*>(mp);
+  const size_t B = m->books.size();
+  if (n_threads < 1) n_threads = 1;
+  std::atomic<int> rc{ORC_OK};
+  auto work = [&](size_t lo, size_t hi) {
+    for (size_t b = lo; b < hi; ++b) {
+      ManyBook& k = *m->books[b];
+      for (uint64_t s = 0; s < n_steps; ++s) {
+        for (auto& g : k.agents.groups) g.update(k.env, k.rng);
+        int r = k.env.step(k.rng);
+        if (r != ORC_OK) rc = r;
+      }
+    }
+  };
+  if (n_threads == 1) {
+    work(0, B);
+  } else {
+    std::vector<std::thread> th;
+    for (int t = 0; t < n_threads; ++t) {
+      size_t lo = B * t / n_threads, hi = B * (t + 1) / n_threads;
+      th.emplace_back(work, lo, hi);
+    }
+    for (auto& t : th) t.join();
+  }
+  return rc;
+}
+uint64_t orc_many_n_steps(void* mp) {
+  auto* m = static_cast<OrcMany*>(mp);
+  return m->books.empty() ? 0 : m->books[0]->env.trade_vols.size();
+}
+void* orc_many_book(void* mp, uint32_t b) { return &static_cast<OrcMany*>(mp)->books[b]->env.order_book; }
+void orc_many_rng_state(void* mp, uint32_t b, uint64_t* st) {
+  auto& k = *static_cast<OrcMany*>(mp)->books[b];
+  st[0] = k.rng.s0;
+  st[1] = k.rng.s1;
+}
+// out[step - first_step][book][5+4L] for steps [first_step, first_step + n)
+void orc_many_history(void* mp, uint64_t first_step, uint64_t n, uint32_t* out) {
+  auto* m = static_cast<OrcMany*>(mp);
+  const int L = m->levels;
+  const size_t W = 5 + 4 * static_cast<size_t>(L);
+  const size_t B = m->books.size();
+  for (size_t b = 0; b < B; ++b) {
+    const Env& env = m->books[b]->env;
+    const auto& r = env.level_2_data_records;
+    for (uint64_t s = 0; s < n; ++s) {
+      const size_t ss = first_step + s;
+      uint32_t* o = out + (s * B + b) * W;
+      o[0] = env.trade_vols[ss];
+      o[1] = r.bid_prices[ss];
+      o[2] = r.ask_prices[ss];
+      o[3] = r.ask_vols[ss];
+      o[4] = r.bid_vols[ss];
+      for (int i = 0; i < L; ++i) {
+        o[5 + 4 * i + 0] = r.bid_vols_at_levels[i][ss];
+        o[5 + 4 * i + 1] = r.bid_orders_at_levels[i][ss];
+        o[5 + 4 * i + 2] = r.ask_vols_at_levels[i][ss];
+        o[5 + 4 * i + 3] = r.ask_orders_at_levels[i][ss];
+      }
+    }
+  }
+}
+void orc_many_trade_counts(void* mp, uint64_t* out) {
+  auto* m = static_cast<OrcMany*>(mp);
+  for (size_t b = 0; b < m->books.size(); ++b) out[b] = m->books[b]->env.order_book.trades.size();
+}
+void orc_many_order_counts(void* mp, uint64_t* out) {
+  auto* m = static_cast<OrcMany*>(mp);
+  for (size_t b = 0; b < m->books.size(); ++b) out[b] = m->books[b]->env.order_book.orders.size();
+}
+
+int orc_version() { return 1; }
+
+}  // extern "C"

@@ -1,0 +1,744 @@
+"""ctypes front-end of the CPU ORACLE (test infrastructure, NOT product code).
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline``
+leg may import this module.  Nothing under ``bourse_amd/`` does.
+
+The classes mirror the reference's PyO3 classes so the oracle can stand in for
+``bourse.core`` when the reference's own Python callers/tests are exercised in
+the build container (see ``oracle/run_reference_pytests.py``):
+
+* ``StepEnv``        -- ref rust/src/step_sim.rs:55-607
+* ``StepEnvNumpy``   -- ref rust/src/step_sim_numpy.rs:66-516
+* ``OrderBook``      -- ref rust/src/order_book.rs:30-398
+* ``RandomAgents`` / ``sim_runner`` -- ref crates/step_sim/src/agents/random_agent.rs,
+  crates/step_sim/src/runner.rs:46-69
+"""
+from __future__ import annotations
+
+import ctypes as C
+import json
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libbourse_oracle.so")
+
+U64_MAX = 2**64 - 1
+MAX_PRICE = 2**32 - 1
+
+ORDER_DTYPE = np.dtype(
+    {
+        "names": ["side", "status", "arr_time", "end_time", "vol", "start_vol", "price", "trader_id", "order_id"],
+        "formats": ["u1", "u1", "<u8", "<u8", "<u4", "<u4", "<u4", "<u4", "<u8"],
+        "offsets": [0, 1, 8, 16, 24, 28, 32, 36, 40],
+        "itemsize": 48,
+    }
+)
+TRADE_DTYPE = np.dtype(
+    {
+        "names": ["t", "side", "price", "vol", "active_id", "passive_id"],
+        "formats": ["<u8", "<u4", "<u4", "<u4", "<u8", "<u8"],
+        "offsets": [0, 8, 12, 16, 24, 32],
+        "itemsize": 40,
+    }
+)
+
+
+def build(force: bool = False) -> str:
+    """Compile the oracle with g++ (seconds).  Returns the library path."""
+    srcs = [os.path.join(_HERE, f) for f in ("bourse_oracle.cpp", "bourse_oracle_capi.cpp", "bourse_oracle.hpp")]
+    stale = force or not os.path.exists(_LIB_PATH) or any(
+        os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in srcs
+    )
+    if stale:
+        subprocess.run(["make", "-C", _HERE, "libbourse_oracle.so"], check=True, capture_output=True)
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    build()
+    L = C.CDLL(_LIB_PATH)
+    u64, u32, i32, vp, f32 = C.c_uint64, C.c_uint32, C.c_int, C.c_void_p, C.c_float
+    p64, p32, p8 = C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(C.c_uint8)
+
+    def sig(name, res, *args):
+        fn = getattr(L, name)
+        fn.restype = res
+        fn.argtypes = list(args)
+
+    sig("orc_rng_seed", None, u64, p64)
+    sig("orc_rng_next_u64", u64, p64)
+    sig("orc_rng_next_u32", u32, p64)
+    sig("orc_rng_f32", f32, p64)
+    sig("orc_rng_range", u32, p64, u32, u32)
+    sig("orc_rng_shuffle_u32", None, p64, p32, u64)
+
+    sig("orc_side_new", vp, i32)
+    sig("orc_side_free", None, vp)
+    sig("orc_side_insert", None, vp, u64, u32, u64, u32)
+    sig("orc_side_remove_order", None, vp, u64, u32, u32)
+    sig("orc_side_remove_vol", None, vp, u32, u32)
+    sig("orc_side_vol", u32, vp)
+    sig("orc_side_best_price", u32, vp)
+    sig("orc_side_best_vol_and_orders", None, vp, p32)
+    sig("orc_side_best_order_idx", i32, vp, p64)
+    sig("orc_side_vol_and_orders_at_price", None, vp, u32, p32)
+
+    sig("orc_book_new", vp, u64, u32, i32, i32)
+    sig("orc_book_free", None, vp)
+    sig("orc_book_set_time", None, vp, u64)
+    sig("orc_book_get_time", u64, vp)
+    sig("orc_book_set_trading", None, vp, i32)
+    sig("orc_book_create_order", i32, vp, i32, u32, u32, i32, u32, p64)
+    sig("orc_book_place_order", i32, vp, u64)
+    sig("orc_book_create_and_place", i32, vp, i32, u32, u32, i32, u32, p64)
+    sig("orc_book_cancel", i32, vp, u64)
+    sig("orc_book_modify", i32, vp, u64, i32, u32, i32, u32)
+    sig("orc_book_bid_ask", None, vp, p32)
+    sig("orc_book_bid_vol", u32, vp)
+    sig("orc_book_ask_vol", u32, vp)
+    sig("orc_book_trade_vol", u32, vp)
+    sig("orc_book_best_bid_vol_and_orders", None, vp, p32)
+    sig("orc_book_best_ask_vol_and_orders", None, vp, p32)
+    sig("orc_book_mid_price", C.c_double, vp)
+    sig("orc_book_level2", None, vp, p32)
+    sig("orc_book_n_orders", u64, vp)
+    sig("orc_book_n_trades", u64, vp)
+    sig("orc_book_order_status", i32, vp, u64, p8)
+    sig("orc_book_get_orders", None, vp, vp, u64, u64)
+    sig("orc_book_get_trades", None, vp, vp, u64, u64)
+
+    sig("orc_env_new", vp, u64, u64, u32, u64, i32, i32)
+    sig("orc_env_free", None, vp)
+    sig("orc_env_book", vp, vp)
+    sig("orc_env_rng_state", None, vp, p64)
+    sig("orc_env_place_order", i32, vp, i32, u32, u32, i32, u32, p64)
+    sig("orc_env_cancel_order", None, vp, u64)
+    sig("orc_env_modify_order", None, vp, u64, i32, u32, i32, u32)
+    sig("orc_env_n_transactions", u64, vp)
+    sig("orc_env_transaction_kinds", None, vp, p8)
+    sig("orc_env_step", i32, vp)
+    sig("orc_env_level2", None, vp, p32)
+    sig("orc_env_n_steps", u64, vp)
+    sig("orc_env_history", None, vp, p32)
+
+    sig("orc_agents_new", vp)
+    sig("orc_agents_free", None, vp)
+    sig("orc_agents_add_random", None, vp, u64, u32, u32, u32, u32, u32, f32)
+    sig("orc_agents_held_ids", None, vp, i32, p64)
+    sig("orc_agents_update", None, vp, vp)
+    sig("orc_sim_run", i32, vp, vp, p64, u64)
+
+    sig("orc_many_new", vp, u32, u64, u64, u32, u64, i32, i32, i32, p32)
+    sig("orc_many_free", None, vp)
+    sig("orc_many_run", i32, vp, u64, i32)
+    sig("orc_many_n_steps", u64, vp)
+    sig("orc_many_book", vp, vp, u32)
+    sig("orc_many_rng_state", None, vp, u32, p64)
+    sig("orc_many_history", None, vp, u64, u64, p32)
+    sig("orc_many_trade_counts", None, vp, p64)
+    sig("orc_many_order_counts", None, vp, p64)
+    sig("orc_version", i32)
+    _lib = L
+    return L
+
+
+def _p32(a):
+    return a.ctypes.data_as(C.POINTER(C.c_uint32))
+
+
+def _p64(a):
+    return a.ctypes.data_as(C.POINTER(C.c_uint64))
+
+
+def _price_error(price, tick):
+    # ref orderbook.rs:135-139 Display text; surfaced as ValueError (step_sim.rs:239-242)
+    return ValueError(f"Price {price} was not a multiple of tick-size {tick}")
+
+
+# ---------------------------------------------------------------------------- RNG
+class Rng:
+    """xoroshiro128** stream as the reference seeds it (seed_from_u64)."""
+
+    def __init__(self, seed=None, state=None):
+        self.st = np.zeros(2, dtype=np.uint64)
+        if state is not None:
+            self.st[:] = state
+        else:
+            lib().orc_rng_seed(int(seed), _p64(self.st))
+
+    def next_u64(self):
+        return int(lib().orc_rng_next_u64(_p64(self.st)))
+
+    def next_u32(self):
+        return int(lib().orc_rng_next_u32(_p64(self.st)))
+
+    def gen_f32(self):
+        return np.float32(lib().orc_rng_f32(_p64(self.st)))
+
+    def gen_range(self, lo, hi):
+        return int(lib().orc_rng_range(_p64(self.st), lo, hi))
+
+    def shuffle(self, arr):
+        a = np.ascontiguousarray(arr, dtype=np.uint32)
+        lib().orc_rng_shuffle_u32(_p64(self.st), _p32(a), len(a))
+        return a
+
+
+# ------------------------------------------------------------------------ side
+class BookSide:
+    """One side of the book (ref crates/order_book/src/side.rs); kind in {"raw","ask","bid"}."""
+
+    def __init__(self, kind="raw"):
+        self._s = lib().orc_side_new({"raw": 0, "ask": 1, "bid": 2}[kind])
+
+    def __del__(self):
+        if getattr(self, "_s", None):
+            lib().orc_side_free(self._s)
+            self._s = None
+
+    def insert_order(self, t, price, idx, vol):
+        lib().orc_side_insert(self._s, int(t), int(price), int(idx), int(vol))
+
+    def remove_order(self, t, price, vol):
+        lib().orc_side_remove_order(self._s, int(t), int(price), int(vol))
+
+    def remove_vol(self, price, vol):
+        lib().orc_side_remove_vol(self._s, int(price), int(vol))
+
+    def vol(self):
+        return int(lib().orc_side_vol(self._s))
+
+    def best_price(self):
+        return int(lib().orc_side_best_price(self._s))
+
+    def best_vol_and_orders(self):
+        o = np.zeros(2, dtype=np.uint32)
+        lib().orc_side_best_vol_and_orders(self._s, _p32(o))
+        return int(o[0]), int(o[1])
+
+    def best_vol(self):
+        return self.best_vol_and_orders()[0]
+
+    def best_order_idx(self):
+        out = C.c_uint64(0)
+        return int(out.value) if lib().orc_side_best_order_idx(self._s, C.byref(out)) else None
+
+    def vol_and_orders_at_price(self, price):
+        o = np.zeros(2, dtype=np.uint32)
+        lib().orc_side_vol_and_orders_at_price(self._s, int(price), _p32(o))
+        return int(o[0]), int(o[1])
+
+
+# ------------------------------------------------------------------- book views
+class _BookView:
+    """Queries on an oracle OrderBook pointer (owned elsewhere)."""
+
+    def __init__(self, ptr, levels, tick):
+        self._b = ptr
+        self._levels = levels
+        self._tick = tick
+
+    def bid_ask(self):
+        o = np.zeros(2, dtype=np.uint32)
+        lib().orc_book_bid_ask(self._b, _p32(o))
+        return int(o[0]), int(o[1])
+
+    def bid_vol(self):
+        return int(lib().orc_book_bid_vol(self._b))
+
+    def ask_vol(self):
+        return int(lib().orc_book_ask_vol(self._b))
+
+    def best_bid_vol_and_orders(self):
+        o = np.zeros(2, dtype=np.uint32)
+        lib().orc_book_best_bid_vol_and_orders(self._b, _p32(o))
+        return int(o[0]), int(o[1])
+
+    def best_ask_vol_and_orders(self):
+        o = np.zeros(2, dtype=np.uint32)
+        lib().orc_book_best_ask_vol_and_orders(self._b, _p32(o))
+        return int(o[0]), int(o[1])
+
+    def best_bid_vol(self):
+        return self.best_bid_vol_and_orders()[0]
+
+    def best_ask_vol(self):
+        return self.best_ask_vol_and_orders()[0]
+
+    def mid_price(self):
+        return float(lib().orc_book_mid_price(self._b))
+
+    def trade_vol(self):
+        return int(lib().orc_book_trade_vol(self._b))
+
+    def get_time(self):
+        return int(lib().orc_book_get_time(self._b))
+
+    def level2(self):
+        """(bid_price, ask_price, bid_vol, ask_vol, bid_levels[L,2], ask_levels[L,2])"""
+        L = self._levels
+        o = np.zeros(4 + 4 * L, dtype=np.uint32)
+        lib().orc_book_level2(self._b, _p32(o))
+        return int(o[0]), int(o[1]), int(o[2]), int(o[3]), o[4 : 4 + 2 * L].reshape(L, 2), o[4 + 2 * L :].reshape(L, 2)
+
+    def order_status(self, order_id):
+        out = C.c_uint8(0)
+        rc = lib().orc_book_order_status(self._b, int(order_id), C.byref(out))
+        if rc != 0:
+            raise IndexError(f"No order with id {order_id} exists")
+        return int(out.value)
+
+    def n_orders(self):
+        return int(lib().orc_book_n_orders(self._b))
+
+    def n_trades(self):
+        return int(lib().orc_book_n_trades(self._b))
+
+    def orders_array(self):
+        n = self.n_orders()
+        a = np.zeros(n, dtype=ORDER_DTYPE)
+        if n:
+            lib().orc_book_get_orders(self._b, a.ctypes.data_as(C.c_void_p), 0, n)
+        return a
+
+    def trades_array(self):
+        n = self.n_trades()
+        a = np.zeros(n, dtype=TRADE_DTYPE)
+        if n:
+            lib().orc_book_get_trades(self._b, a.ctypes.data_as(C.c_void_p), 0, n)
+        return a
+
+    def get_orders(self):
+        # PyOrder tuples, ref rust/src/types.rs:17-31
+        return [
+            (bool(r["side"]), int(r["status"]), int(r["arr_time"]), int(r["end_time"]), int(r["vol"]),
+             int(r["start_vol"]), int(r["price"]), int(r["trader_id"]), int(r["order_id"]))
+            for r in self.orders_array()
+        ]
+
+    def get_trades(self):
+        # PyTrade tuples, ref rust/src/types.rs:4-15
+        return [
+            (int(r["t"]), bool(r["side"]), int(r["price"]), int(r["vol"]), int(r["active_id"]), int(r["passive_id"]))
+            for r in self.trades_array()
+        ]
+
+
+class OrderBook(_BookView):
+    """Immediate-mode book; mirrors ``bourse.core.OrderBook`` (ref rust/src/order_book.rs)."""
+
+    def __init__(self, start_time, tick_size, trading=True, levels=10):
+        ptr = lib().orc_book_new(int(start_time), int(tick_size), int(bool(trading)), int(levels))
+        super().__init__(ptr, levels, tick_size)
+        self._trading = bool(trading)
+        self._own = True
+
+    def __del__(self):
+        if getattr(self, "_own", False) and self._b:
+            lib().orc_book_free(self._b)
+            self._b = None
+
+    def set_time(self, t):
+        lib().orc_book_set_time(self._b, int(t))
+
+    def enable_trading(self):
+        self._trading = True
+        lib().orc_book_set_trading(self._b, 1)
+
+    def disable_trading(self):
+        self._trading = False
+        lib().orc_book_set_trading(self._b, 0)
+
+    def create_order(self, bid, vol, trader_id, price=None):
+        out = C.c_uint64(0)
+        rc = lib().orc_book_create_order(self._b, int(bool(bid)), int(vol), int(trader_id), int(price is not None),
+                                         int(price or 0), C.byref(out))
+        if rc == 1:
+            raise _price_error(price, self._tick)
+        return int(out.value)
+
+    def place_order_id(self, order_id):
+        rc = lib().orc_book_place_order(self._b, int(order_id))
+        if rc != 0:
+            raise IndexError(order_id)
+
+    def place_order(self, bid, vol, trader_id, price=None):
+        out = C.c_uint64(0)
+        rc = lib().orc_book_create_and_place(self._b, int(bool(bid)), int(vol), int(trader_id),
+                                             int(price is not None), int(price or 0), C.byref(out))
+        if rc == 1:
+            raise _price_error(price, self._tick)
+        return int(out.value)
+
+    def cancel_order(self, order_id):
+        rc = lib().orc_book_cancel(self._b, int(order_id))
+        if rc != 0:
+            raise RuntimeError(f"No order with id {order_id} exists")  # reference: panic!
+
+    def modify_order(self, order_id, new_price=None, new_vol=None):
+        rc = lib().orc_book_modify(self._b, int(order_id), int(new_price is not None), int(new_price or 0),
+                                   int(new_vol is not None), int(new_vol or 0))
+        if rc != 0:
+            raise IndexError(order_id)
+
+    # JSON snapshot: OUT OF SCOPE for the HIP path; the oracle keeps
+    # a minimal own-format round trip so the reference's Python test-suite can run.
+    def save_json_snapshot(self, path, pretty=False):
+        state = {
+            "t": self.get_time(), "tick_size": self._tick, "trading": self._trading, "levels": self._levels,
+            "trade_vol": self.trade_vol(), "orders": self.get_orders(), "trades": self.get_trades(),
+        }
+        with open(path, "w") as f:
+            json.dump(state, f, indent=2 if pretty else None)
+
+
+def order_book_from_json(path):
+    with open(path) as f:
+        s = json.load(f)
+    ob = _LoadedBook(s)
+    return ob
+
+
+class _LoadedBook:
+    """Snapshot view: aggregates rebuilt from Active orders (ref orderbook.rs:891-918)."""
+
+    def __init__(self, s):
+        self._s = s
+        self._orders = [tuple(o) for o in s["orders"]]
+        self._trades = [tuple(t) for t in s["trades"]]
+
+    def _side(self, bid):
+        return [o for o in self._orders if o[1] == 1 and o[0] == bid]
+
+    def bid_ask(self):
+        b, a = self._side(True), self._side(False)
+        return (max(o[6] for o in b) if b else 0, min(o[6] for o in a) if a else MAX_PRICE)
+
+    def best_bid_vol_and_orders(self):
+        b = self._side(True)
+        if not b:
+            return (0, 0)
+        p = max(o[6] for o in b)
+        return (sum(o[4] for o in b if o[6] == p), sum(1 for o in b if o[6] == p))
+
+    def best_ask_vol_and_orders(self):
+        a = self._side(False)
+        if not a:
+            return (0, 0)
+        p = min(o[6] for o in a)
+        return (sum(o[4] for o in a if o[6] == p), sum(1 for o in a if o[6] == p))
+
+    def get_orders(self):
+        return list(self._orders)
+
+    def get_trades(self):
+        return list(self._trades)
+
+
+# ------------------------------------------------------------------------- Env
+class _EnvBase:
+    LEVELS = 10
+
+    def __init__(self, seed, start_time, tick_size, step_size, trading=True, levels=None):
+        self._levels = int(levels if levels is not None else self.LEVELS)
+        self._tick = int(tick_size)
+        self._e = lib().orc_env_new(int(seed), int(start_time), int(tick_size), int(step_size), int(bool(trading)),
+                                    self._levels)
+        self._book = _BookView(lib().orc_env_book(self._e), self._levels, self._tick)
+
+    def __del__(self):
+        if getattr(self, "_e", None):
+            lib().orc_env_free(self._e)
+            self._e = None
+
+    @property
+    def book(self):
+        return self._book
+
+    def rng_state(self):
+        st = np.zeros(2, dtype=np.uint64)
+        lib().orc_env_rng_state(self._e, _p64(st))
+        return st
+
+    def enable_trading(self):
+        lib().orc_book_set_trading(self._book._b, 1)
+
+    def disable_trading(self):
+        lib().orc_book_set_trading(self._book._b, 0)
+
+    def step(self):
+        rc = lib().orc_env_step(self._e)
+        if rc == 2:
+            raise RuntimeError("No order with that id exists")  # reference: panic! (orderbook.rs:642)
+
+    def _place(self, bid, vol, trader_id, price):
+        out = C.c_uint64(0)
+        rc = lib().orc_env_place_order(self._e, int(bool(bid)), int(vol), int(trader_id), int(price is not None),
+                                       int(price if price is not None else 0), C.byref(out))
+        if rc == 1:
+            raise _price_error(price, self._tick)
+        return int(out.value)
+
+    def n_transactions(self):
+        return int(lib().orc_env_n_transactions(self._e))
+
+    def transaction_kinds(self):
+        n = self.n_transactions()
+        out = np.zeros(n, dtype=np.uint8)
+        if n:
+            lib().orc_env_transaction_kinds(self._e, out.ctypes.data_as(C.POINTER(C.c_uint8)))
+        return out
+
+    def _l2(self):
+        o = np.zeros(5 + 4 * self._levels, dtype=np.uint32)
+        lib().orc_env_level2(self._e, _p32(o))
+        return o
+
+    def history(self):
+        """u32[T, 5+4L] in the numpy level_2_data layout (trade_vol = per-step record)."""
+        T = int(lib().orc_env_n_steps(self._e))
+        o = np.zeros((T, 5 + 4 * self._levels), dtype=np.uint32)
+        if T:
+            lib().orc_env_history(self._e, _p32(o))
+        return o
+
+    def get_orders(self):
+        return self._book.get_orders()
+
+    def get_trades(self):
+        return self._book.get_trades()
+
+    def get_market_data(self):
+        # ref rust/src/step_sim.rs:562-607 / step_sim_numpy.rs:471-516
+        h = self.history()
+        d = {
+            "bid_price": h[:, 1].copy(), "ask_price": h[:, 2].copy(),
+            "bid_vol": h[:, 4].copy(), "ask_vol": h[:, 3].copy(), "trade_vol": h[:, 0].copy(),
+        }
+        for i in range(self._levels):
+            d[f"bid_vol_{i}"] = h[:, 5 + 4 * i].copy()
+            d[f"n_bid_{i}"] = h[:, 6 + 4 * i].copy()
+            d[f"ask_vol_{i}"] = h[:, 7 + 4 * i].copy()
+            d[f"n_ask_{i}"] = h[:, 8 + 4 * i].copy()
+        return d
+
+
+class StepEnv(_EnvBase):
+    """Mirrors ``bourse.core.StepEnv`` (ref rust/src/step_sim.rs:55-607)."""
+
+    @property
+    def time(self):
+        return self._book.get_time()
+
+    @property
+    def ask_vol(self):
+        return int(self._l2()[3])
+
+    @property
+    def bid_vol(self):
+        return int(self._l2()[4])
+
+    @property
+    def best_ask_vol(self):
+        return int(self._l2()[7])
+
+    @property
+    def best_ask_vol_and_orders(self):
+        l2 = self._l2()
+        return int(l2[7]), int(l2[8])
+
+    @property
+    def best_bid_vol(self):
+        return int(self._l2()[5])
+
+    @property
+    def best_bid_vol_and_orders(self):
+        l2 = self._l2()
+        return int(l2[5]), int(l2[6])
+
+    @property
+    def trade_vol(self):
+        return self._book.trade_vol()
+
+    @property
+    def bid_ask(self):
+        l2 = self._l2()
+        return int(l2[1]), int(l2[2])
+
+    def order_status(self, order_id):
+        return self._book.order_status(order_id)
+
+    def place_order(self, bid, vol, trader_id, price=None):
+        return self._place(bid, vol, trader_id, price)
+
+    def cancel_order(self, order_id):
+        lib().orc_env_cancel_order(self._e, int(order_id))
+
+    def modify_order(self, order_id, new_price=None, new_vol=None):
+        lib().orc_env_modify_order(self._e, int(order_id), int(new_price is not None), int(new_price or 0),
+                                   int(new_vol is not None), int(new_vol or 0))
+
+    def get_prices(self):
+        h = self.history()
+        return h[:, 1].copy(), h[:, 2].copy()
+
+    def get_volumes(self):
+        h = self.history()
+        return h[:, 4].copy(), h[:, 3].copy()
+
+    def get_touch_volumes(self):
+        h = self.history()
+        return h[:, 5].copy(), h[:, 7].copy()
+
+    def get_touch_order_counts(self):
+        h = self.history()
+        return h[:, 6].copy(), h[:, 8].copy()
+
+    def get_trade_volumes(self):
+        return self.history()[:, 0].copy()
+
+    def level_1_data_array(self):
+        # 8 values, no trade_vol (ref step_sim.rs:383-392)
+        l2 = self._l2()
+        return l2[1:9].copy()
+
+    def level_2_data_array(self):
+        return self._l2()
+
+
+class StepEnvNumpy(_EnvBase):
+    """Mirrors ``bourse.core.StepEnvNumpy`` (ref rust/src/step_sim_numpy.rs:66-516)."""
+
+    def submit_limit_orders(self, orders):
+        sides, vols, traders, prices = orders
+        ids = []
+        for i in range(len(sides)):  # short-circuits at the first error, earlier ones stay queued
+            ids.append(self._place(bool(sides[i]), int(vols[i]), int(traders[i]), int(prices[i])))
+        return np.array(ids, dtype=np.uint64)
+
+    def submit_cancellations(self, order_ids):
+        for i in np.asarray(order_ids):
+            lib().orc_env_cancel_order(self._e, int(i))
+
+    def submit_instructions(self, instructions):
+        action, sides, vols, traders, prices, order_ids = instructions
+        ids = []
+        for i in range(len(action)):
+            a = int(action[i])
+            if a == 1:
+                ids.append(self._place(bool(sides[i]), int(vols[i]), int(traders[i]), int(prices[i])))
+            elif a == 2:
+                lib().orc_env_cancel_order(self._e, int(order_ids[i]))
+                ids.append(U64_MAX)
+            else:
+                ids.append(U64_MAX)
+        return np.array(ids, dtype=np.uint64)
+
+    def level_1_data(self):
+        return self._l2()[:9].copy()
+
+    def level_2_data(self):
+        return self._l2()
+
+
+# ---------------------------------------------------------------------- agents
+class RandomAgentSet:
+    """An AgentSet of RandomAgents groups, updated in declaration order."""
+
+    def __init__(self, groups):
+        """groups: iterable of (n, (tick_lo, tick_hi), (vol_lo, vol_hi), tick_size, activity_rate)"""
+        self._a = lib().orc_agents_new()
+        self.groups = list(groups)
+        for n, tr, vr, ts, rate in self.groups:
+            lib().orc_agents_add_random(self._a, int(n), int(tr[0]), int(tr[1]), int(vr[0]), int(vr[1]), int(ts),
+                                        C.c_float(float(np.float32(rate))))
+
+    def __del__(self):
+        if getattr(self, "_a", None):
+            lib().orc_agents_free(self._a)
+            self._a = None
+
+    def held_ids(self, g):
+        out = np.zeros(self.groups[g][0], dtype=np.uint64)
+        lib().orc_agents_held_ids(self._a, g, _p64(out))
+        return out
+
+    def update(self, env):
+        """agents.update(env, rng) with the env's own RNG."""
+        lib().orc_agents_update(self._a, env._e)
+
+
+def sim_runner(env, agents, seed, n_steps, rng_state=None):
+    """ref crates/step_sim/src/runner.rs:46-69.  Returns the RNG state after the run."""
+    st = np.zeros(2, dtype=np.uint64)
+    if rng_state is None:
+        lib().orc_rng_seed(int(seed), _p64(st))
+    else:
+        st[:] = rng_state
+    rc = lib().orc_sim_run(env._e, agents._a, _p64(st), int(n_steps))
+    if rc != 0:
+        raise RuntimeError(f"oracle sim_run status {rc}")
+    return st
+
+
+class ManyBooks:
+    """B independent (Env, RandomAgents groups, RNG) simulations; book b seeded seed + b."""
+
+    def __init__(self, n_books, seed, start_time, tick_size, step_size, trading, levels, groups):
+        g = np.zeros((len(groups), 7), dtype=np.uint32)
+        for i, (n, tr, vr, ts, rate) in enumerate(groups):
+            g[i, :6] = (n, tr[0], tr[1], vr[0], vr[1], ts)
+            g[i, 6] = np.float32(rate).view(np.uint32)
+        self.n_books, self.levels, self.tick = int(n_books), int(levels), int(tick_size)
+        self._m = lib().orc_many_new(self.n_books, int(seed), int(start_time), int(tick_size), int(step_size),
+                                     int(bool(trading)), self.levels, len(groups), _p32(g))
+
+    def __del__(self):
+        if getattr(self, "_m", None):
+            lib().orc_many_free(self._m)
+            self._m = None
+
+    def run(self, n_steps, n_threads=1):
+        rc = lib().orc_many_run(self._m, int(n_steps), int(n_threads))
+        if rc != 0:
+            raise RuntimeError(f"oracle many_run status {rc}")
+
+    def n_steps(self):
+        return int(lib().orc_many_n_steps(self._m))
+
+    def history(self, first_step=0, n=None):
+        """u32[n, B, 5+4L]"""
+        if n is None:
+            n = self.n_steps() - first_step
+        o = np.zeros((n, self.n_books, 5 + 4 * self.levels), dtype=np.uint32)
+        if n:
+            lib().orc_many_history(self._m, int(first_step), int(n), _p32(o))
+        return o
+
+    def book(self, b):
+        return _BookView(lib().orc_many_book(self._m, int(b)), self.levels, self.tick)
+
+    def rng_states(self):
+        out = np.zeros((self.n_books, 2), dtype=np.uint64)
+        for b in range(self.n_books):
+            lib().orc_many_rng_state(self._m, b, _p64(out[b]))
+        return out
+
+    def trade_counts(self):
+        out = np.zeros(self.n_books, dtype=np.uint64)
+        lib().orc_many_trade_counts(self._m, _p64(out))
+        return out
+
+    def order_counts(self):
+        out = np.zeros(self.n_books, dtype=np.uint64)
+        lib().orc_many_order_counts(self._m, _p64(out))
+        return out
