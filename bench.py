@@ -1,0 +1,198 @@
+#!/usr/bin/env python3
+"""Headline benchmark: book-steps/sec of the many-book LOB step simulator on MI355X.
+
+Workload (BASELINE.json configs[2], SURVEY §8d "C3"): 65 536 independent books per GPU x 128
+on-device RandomAgents (64 x rate 0.8 vol [10,20) + 64 x rate 0.2 vol [50,70), ticks [32,64)),
+32 levels/side, tick 2, step_size 100 000, seed 101 + global book index.  One "step" = one
+agents.update + Env::step for EVERY book (ref crates/step_sim/src/runner.rs:58-59).
+
+  python bench.py --gpus N --steps K --warmup W
+
+N > 1 is launched by torch.distributed.run (one rank per GPU, RCCL): books are independent, so
+each rank steps its own shard with NO data-path collective; the only exchange is a 64-byte
+market-stats all-gather per launch (weak scaling: 65 536 books per GPU).
+
+Prints ONE JSON line (rank 0) incl. `roofline` (HIP-event kernel time vs. HBM peak) and, at
+N = 1, `cpu_baseline` (the CPU oracle = literal restatement of the reference algorithm, timed on
+this machine's host cores on a bounded sample of the same workload).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
+
+WORKLOADS = {
+    # name: (books_per_gpu, levels, groups)                                   SURVEY §8d
+    "C2": (4096, 16, [(32, (40, 56), (10, 20), 2, 0.8), (32, (40, 56), (50, 70), 2, 0.2)]),
+    "C3": (65536, 32, [(64, (32, 64), (10, 20), 2, 0.8), (64, (32, 64), (50, 70), 2, 0.2)]),
+    "C5": (8192, 64, [(256, (100, 164), (10, 20), 2, 0.8), (256, (100, 164), (50, 70), 2, 0.2)]),
+}
+TICK, STEP_SIZE, SEED = 2, 100_000, 101
+
+
+def cpu_baseline(groups, levels, budget_s=15.0):
+    """Time the CPU oracle (kind "port": C++ restatement of the reference algorithm, ordered maps per
+    side, one Env per book) on all host cores, on a bounded sample of the same workload."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pyoracle
+
+    cores = os.cpu_count() or 1
+    warm, steps = 20, 40
+    # size the sample from a quick single-thread probe so the leg takes ~budget_s
+    probe = pyoracle.ManyBooks(64, SEED, 0, TICK, STEP_SIZE, True, levels, groups)
+    t = time.perf_counter()
+    probe.run(warm + 10, 1)
+    rate1 = 64 * (warm + 10) / (time.perf_counter() - t)
+    books = int(max(cores * 8, min(8192, rate1 * cores * 0.5 * budget_s / (warm + steps))))
+    many = pyoracle.ManyBooks(books, SEED, 0, TICK, STEP_SIZE, True, levels, groups)
+    many.run(warm, cores)
+    t = time.perf_counter()
+    many.run(steps, cores)
+    dt = time.perf_counter() - t
+    return {
+        "value": books * steps / dt, "unit": "book-steps/s", "cores": cores, "kind": "port",
+        "sample": f"{books} books x {steps} steps after {warm} warm-up steps, same agents/levels/seeds, "
+                  f"{cores} host threads (books statically partitioned), oracle/libbourse_oracle.so -O3",
+        "single_thread_probe": rate1,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--workload", default="C3", choices=sorted(WORKLOADS))
+    ap.add_argument("--books", type=int, default=0, help="books per GPU (default: the workload's)")
+    ap.add_argument("--steps-per-launch", type=int, default=50)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-history", action="store_true", help="keep only the latest L2 record (diagnostic)")
+    args = ap.parse_args()
+
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no GPU visible (bourse_amd has no CPU path)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    import bourse_amd
+    from bourse_amd import parallel
+
+    books_default, levels, groups = WORKLOADS[args.workload]
+    B = args.books or books_default
+    n_agents = sum(g[0] for g in groups)
+    spl = max(1, min(args.steps_per_launch, args.steps))
+    hist_cap = 0 if args.no_history else spl
+    trade_cap = 64 * spl  # ~35 trades/book-step measured for C3; overflow is flagged and checked below
+    stream = torch.cuda.current_stream().cuda_stream
+    env = bourse_amd.ManyBookEnv(B, SEED, 0, TICK, STEP_SIZE, True, levels=levels, max_live_orders=n_agents,
+                                 trade_capacity=trade_cap, history_capacity=hist_cap,
+                                 book_offset=rank * B, device=local_rank, stream=stream)
+    env.set_random_agents(groups)
+    gather = parallel.StatsGather(env, dist) if world > 1 else None
+
+    def run_steps(n):
+        done = 0
+        while done < n:
+            c = min(spl, n - done)
+            env.clear_history()   # the consumer has drained the previous launch's records
+            env.clear_trades()
+            env.run(c, sync=False)
+            if gather is not None:
+                gather.all_gather()   # 64 B per GPU over RCCL; never on the stepping critical path
+            done += c
+
+    run_steps(args.warmup)
+    torch.cuda.synchronize()
+    tc0 = int(env.trade_counts().sum())
+    env.profile(True)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run_steps(args.steps)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    env.profile(False)
+    kern_ms, n_launch = env.profile_read()
+    if dist is not None:
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    flags = env.flags()
+    if flags.any():
+        raise SystemExit(f"device flags set during the timed region: {np.unique(flags)} (trade/history capacity?)")
+    n_trades = int(env.trade_counts().sum()) - tc0
+    st = env.stats()
+
+    value = world * B * args.steps / dt
+    # algorithmic bytes per launch for the dominant kernel (k_run_random), DESIGN.md "Roofline accounting":
+    #   per book: state in + out, per step: one L2 record + 32 B per trade
+    S = env.state_bytes_per_book()
+    W4 = env.width * 4
+    tr_per_bs = n_trades / (B * args.steps)
+    bytes_per_bookstep = 2.0 * S / spl + (W4 if hist_cap else W4) + 32.0 * tr_per_bs
+    launches = max(n_launch, 1)
+    avg_ms = kern_ms / launches
+    achieved = (bytes_per_bookstep * B * spl) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(pmc):
+        try:
+            traffic = json.load(open(pmc)).get(args.workload, {}).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    out = {
+        "metric": "book-steps/sec", "value": value, "unit": "book-steps/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": dt * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+        "config": {
+            "workload": f"{args.workload}: {B} books/GPU x {n_agents} on-device RandomAgents "
+                        f"({len(groups)} groups), {levels} levels/side, tick {TICK}, step_size {STEP_SIZE}, "
+                        f"seed {SEED}+book",
+            "books_per_gpu": B, "agents_per_book": n_agents, "levels": levels, "steps_per_launch": spl,
+            "parallelism": f"independent book shards x{world}, 64 B stats all-gather per launch" if world > 1
+            else "single GPU",
+            "trades_per_book_step": tr_per_bs, "events_per_book_step": st["sum_events"] / (B * (args.steps + args.warmup)),
+        },
+        "roofline": {
+            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "kernel": "k_run_random",
+            "avg_launch_ms": avg_ms, "launches": n_launch, "bytes_per_book_step": bytes_per_bookstep,
+        },
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(groups, levels)
+    env.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,12 @@
+"""bourse_amd: many-book limit-order-book step simulator for AMD MI355X (gfx950).
+
+Drop-in for the ``bourse_de::Env::step`` hot path of zombie-einstein/bourse: thousands of
+independent books stepped in lockstep by hand-written HIP kernels (one wavefront per book)
+behind a C ABI (include/bourse_amd.h).  See DESIGN.md / INTEGRATION.md.
+"""
+from . import _lib, core, step_sim
+from ._lib import BourseError, CapacityError, NoDeviceError
+from .env import MAX_PRICE, ManyBookEnv, RandomAgents, sim_runner
+
+__all__ = ["core", "step_sim", "ManyBookEnv", "RandomAgents", "sim_runner", "MAX_PRICE", "BourseError",
+           "CapacityError", "NoDeviceError"]

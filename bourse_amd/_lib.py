@@ -1,0 +1,168 @@
+"""ctypes binding of the C ABI declared in include/bourse_amd.h.
+
+The HIP extension is the only execution path: if libbourse_amd.so is missing this raises,
+and if no GPU is usable every env-creating call raises ``NoDeviceError``.  There is no CPU
+fallback (the CPU oracle under oracle/ is test infrastructure and is never imported here).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _build
+
+BK_OK, BK_PRICE, BK_UNKNOWN_ORDER, BK_CAPACITY, BK_STEP_SIZE, BK_INVALID, BK_HIP, BK_NO_DEVICE = range(8)
+
+FLAG_POOL_OVERFLOW, FLAG_TRADE_OVERFLOW, FLAG_STEP_SIZE, FLAG_ORDER_LOG_FULL = 1, 2, 4, 8
+FLAG_UNKNOWN_ORDER, FLAG_HIST_OVERFLOW = 16, 32
+
+
+class BourseError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"bourse_amd status {code}: {msg}")
+        self.code = code
+
+
+class NoDeviceError(BourseError):
+    pass
+
+
+class CapacityError(BourseError):
+    pass
+
+
+class Config(C.Structure):
+    _fields_ = [
+        ("n_books", C.c_uint32), ("levels", C.c_uint32), ("start_time", C.c_uint64),
+        ("tick_size", C.c_uint32), ("trading", C.c_uint32), ("step_size", C.c_uint64),
+        ("seed", C.c_uint64), ("book_offset", C.c_uint64), ("max_live_orders", C.c_uint32),
+        ("max_orders", C.c_uint32), ("trade_capacity", C.c_uint32), ("history_capacity", C.c_uint32),
+        ("device", C.c_int32), ("reserved", C.c_uint32),
+    ]
+
+
+class RandomAgentsCfg(C.Structure):
+    _fields_ = [
+        ("n_agents", C.c_uint32), ("tick_lo", C.c_uint32), ("tick_hi", C.c_uint32),
+        ("vol_lo", C.c_uint32), ("vol_hi", C.c_uint32), ("tick_size", C.c_uint32),
+        ("activity_rate", C.c_float),
+    ]
+
+
+class Stats(C.Structure):
+    _fields_ = [
+        ("n_books", C.c_uint64), ("sum_trade_vol", C.c_uint64), ("sum_trades", C.c_uint64),
+        ("sum_events", C.c_uint64), ("sum_bid_vol", C.c_uint64), ("sum_ask_vol", C.c_uint64),
+        ("min_bid", C.c_uint32), ("max_bid", C.c_uint32), ("min_ask", C.c_uint32), ("max_ask", C.c_uint32),
+    ]
+
+
+TRADE_DTYPE = np.dtype(
+    {"names": ["t", "side", "price", "vol", "active_id", "passive_id"],
+     "formats": ["<u8", "<u4", "<u4", "<u4", "<u8", "<u8"], "offsets": [0, 8, 12, 16, 24, 32], "itemsize": 40})
+ORDER_DTYPE = np.dtype(
+    {"names": ["side", "status", "arr_time", "end_time", "vol", "start_vol", "price", "trader_id", "order_id"],
+     "formats": ["u1", "u1", "<u8", "<u8", "<u4", "<u4", "<u4", "<u4", "<u8"],
+     "offsets": [0, 1, 8, 16, 24, 28, 32, 36, 40], "itemsize": 48})
+
+# every symbol include/bourse_amd.h declares: name -> (restype, argtypes)
+_u64, _u32, _i32, _vp, _sz = C.c_uint64, C.c_uint32, C.c_int, C.c_void_p, C.c_size_t
+_p64, _p32, _p8 = C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(C.c_uint8)
+SIGNATURES = {
+    "bk_last_error": (C.c_char_p, []),
+    "bk_device_count": (_i32, [C.POINTER(C.c_int)]),
+    "bk_env_create": (_i32, [C.POINTER(Config), C.POINTER(_vp)]),
+    "bk_env_destroy": (None, [_vp]),
+    "bk_env_set_stream": (_i32, [_vp, _vp]),
+    "bk_env_sync": (_i32, [_vp]),
+    "bk_place_order": (_i32, [_vp, _u32, _i32, _u32, _u32, _i32, _u32, _p64]),
+    "bk_cancel_order": (_i32, [_vp, _u32, _u64]),
+    "bk_modify_order": (_i32, [_vp, _u32, _u64, _i32, _u32, _i32, _u32]),
+    "bk_submit_instructions": (_i32, [_vp, _u32, _sz, _p32, _p8, _p32, _p32, _p32, _p64, _p64, C.POINTER(_sz)]),
+    "bk_enable_trading": (_i32, [_vp, _i32]),
+    "bk_step": (_i32, [_vp]),
+    "bk_order_status": (_i32, [_vp, _u32, _u64, _p8]),
+    "bk_order_count": (_i32, [_vp, _u32, _p64]),
+    "bk_get_orders": (_i32, [_vp, _u32, _u64, _u64, _vp]),
+    "bk_set_random_agents": (_i32, [_vp, _u32, C.POINTER(RandomAgentsCfg)]),
+    "bk_run": (_i32, [_vp, _u64]),
+    "bk_l2_width": (_u32, [_vp]),
+    "bk_level2": (_i32, [_vp, _u32, _u32, _p32]),
+    "bk_history_len": (_i32, [_vp, _p64, _p64]),
+    "bk_history": (_i32, [_vp, _u64, _u64, _u32, _u32, _p32]),
+    "bk_clear_history": (_i32, [_vp]),
+    "bk_trade_count": (_i32, [_vp, _u32, _p64, _p64]),
+    "bk_trade_counts": (_i32, [_vp, _p64]),
+    "bk_get_trades": (_i32, [_vp, _u32, _u64, _u64, _vp]),
+    "bk_clear_trades": (_i32, [_vp]),
+    "bk_time": (_i32, [_vp, _u32, _p64]),
+    "bk_trade_vol": (_i32, [_vp, _u32, _p32]),
+    "bk_steps_done": (_i32, [_vp, _p64]),
+    "bk_book_flags": (_i32, [_vp, _p32]),
+    "bk_rng_state": (_i32, [_vp, _u32, _p64]),
+    "bk_live_orders": (_i32, [_vp, _u32, _u32, _vp, _p32]),
+    "bk_stats_compute": (_i32, [_vp, C.POINTER(Stats)]),
+    "bk_stats_device_ptr": (_i32, [_vp, C.POINTER(_vp)]),
+    "bk_profile_enable": (_i32, [_vp, _i32]),
+    "bk_profile_read": (_i32, [_vp, C.POINTER(C.c_double), _p64, _i32]),
+    "bk_state_bytes_per_book": (_u64, [_vp]),
+}
+
+_lib = None
+
+
+def lib_path() -> str:
+    return _build.LIB
+
+
+def load() -> C.CDLL:
+    """Load libbourse_amd.so (building it first if hipcc is here and the sources are newer)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = _build.LIB
+    if _build.is_stale():
+        try:
+            _build.build()
+        except Exception as e:  # no toolchain on this machine
+            if not os.path.exists(path):
+                raise ImportError(
+                    f"bourse_amd: HIP extension {path} is missing and could not be built ({e}). "
+                    "There is no CPU fallback."
+                ) from e
+    L = C.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(L, name)  # AttributeError = header/library mismatch: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    L.bk_selftest_reduce.restype = _i32
+    L.bk_selftest_reduce.argtypes = [_p32, _u32, _p32]
+    _lib = L
+    return L
+
+
+def check(rc: int):
+    if rc == BK_OK:
+        return
+    msg = load().bk_last_error().decode()
+    if rc == BK_PRICE:
+        raise ValueError(msg)  # reference: PyValueError(e.to_string()), rust/src/step_sim.rs:239-242
+    if rc == BK_NO_DEVICE:
+        raise NoDeviceError(rc, msg)
+    if rc == BK_CAPACITY:
+        raise CapacityError(rc, msg)
+    if rc == BK_UNKNOWN_ORDER:
+        raise IndexError(msg)
+    raise BourseError(rc, msg)
+
+
+def p32(a):
+    return a.ctypes.data_as(_p32)
+
+
+def p64(a):
+    return a.ctypes.data_as(_p64)
+
+
+def p8(a):
+    return a.ctypes.data_as(_p8)

@@ -1,0 +1,850 @@
+// book_device.hpp — gfx950 device code of the many-book LOB step simulator.
+//
+// Execution model: ONE WAVEFRONT (64 lanes) OWNS ONE BOOK.  The whole book lives in the
+// wave's registers for the duration of a launch:
+//   * live-order pool: 64*R slots, slot (r, lane) = {price, vol, id, seq} in VGPRs,
+//     liveness / side / pending as three 64-bit wave-uniform masks per r (SGPRs);
+//   * RNG state, clock, counters: wave-uniform scalars (SGPRs, SALU arithmetic);
+//   * the step's event list and the step's trade records: one entry per lane (VGPRs).
+// Strictly sequential semantics (RNG stream, shuffled event order) run as scalar control
+// flow; wave parallelism is used INSIDE an event: DPP min/max reductions over the pool to
+// find the touch, ballot + s_ff1 to pick the oldest order at the touch, and lane-parallel
+// LDS binning for the level-2 ladder.  No MFMA: this is branchy integer work.
+//
+// Semantics restated from the reference (paths relative to the reference repo):
+//   Env::step                     crates/step_sim/src/env.rs:116-135
+//   OrderBook::place/cancel/modify crates/order_book/src/orderbook.rs:429-792,843-870
+//   OrderBook::level_2_data       orderbook.rs:229-264,314-324
+//   RandomAgents::update          crates/step_sim/src/agents/random_agent.rs:85-119
+//   RNG (rand 0.8.5 / rand_xoshiro 0.6.0): SURVEY App. B
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace bkd {
+
+constexpr int HDR_DW = 64;  // per-book header: 64 dwords, lane i holds dword i
+enum Hdr : int {
+  H_T_LO = 0, H_T_HI, H_S0_LO, H_S0_HI, H_S1_LO, H_S1_HI,
+  H_NEXT_ID, H_SEQ, H_TRADES_LO, H_TRADES_HI, H_FLAGS, H_TRADING,
+  H_STEPS_LO, H_STEPS_HI, H_EVENTS_LO, H_EVENTS_HI, H_TRADE_VOL,
+  H_TRADE_BASE_LO, H_TRADE_BASE_HI, H_LAST_NTRADES, H_LAST_NEVENTS,
+};
+constexpr int POOL_FIELDS = 5;  // price, vol, id, seq, meta(bit0 live, bit1 bid)
+constexpr int MAX_GROUPS = 8;
+
+constexpr uint32_t FLAG_POOL_OVERFLOW = 1u, FLAG_TRADE_OVERFLOW = 2u, FLAG_STEP_SIZE = 4u,
+                   FLAG_ORDER_LOG_FULL = 8u, FLAG_UNKNOWN_ORDER = 16u, FLAG_HIST_OVERFLOW = 32u;
+
+struct Group {  // RandomAgents::new, host-preprocessed
+  uint32_t n;          // agents in the group
+  uint32_t thr;        // activity: (u32 >> 8) < thr  <=>  f32 draw < activity_rate (exact, see host)
+  uint32_t tick_lo, tick_rng, tick_zone;
+  uint32_t vol_lo, vol_rng, vol_zone;
+  uint32_t tick_size;  // the agents' tick size
+  uint32_t pad[3];
+};
+
+struct DevTrade {  // 32 B device trade record
+  uint32_t t_lo, t_hi, price, vol, active, passive, side_is_bid, pad;
+};
+
+struct DevOrderLog {  // 32 B mutable part of an order (host keeps the immutable part)
+  uint32_t status, vol, price, pad;
+  uint32_t arr_lo, arr_hi, end_lo, end_hi;
+};
+
+struct DevArgs {
+  uint32_t n_books, levels, tick_size, n_groups;
+  uint32_t step_lo, step_hi;    // step_size
+  uint32_t state_stride;        // dwords per book
+  uint32_t l2_width;            // 5 + 4*levels
+  uint32_t trade_cap, hist_cap;
+  uint32_t hist_base_lo, hist_base_hi;  // step index stored in history slot 0
+  uint32_t n_agents_total, log_cap;
+  uint32_t* state;
+  uint32_t* l2_last;
+  uint32_t* hist;
+  DevTrade* trades;
+  DevOrderLog* order_log;
+  // host-driven event batch (k_step_events only); CSR per book
+  const uint32_t* ev_off;    // [n_books + 1]
+  const uint32_t* ev_word;   // kind | bid<<8 | has_price<<9 | has_vol<<10
+  const uint32_t* ev_id;
+  const uint32_t* ev_price;
+  const uint32_t* ev_vol;
+  Group groups[MAX_GROUPS];
+};
+
+// ----------------------------------------------------------------------------------
+// wave primitives
+// ----------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t rfl(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ uint32_t rdl(uint32_t v, uint32_t lane) { return __builtin_amdgcn_readlane(v, lane); }
+// v_writelane_b32: clang 22 has no builtin for it; bind the LLVM intrinsic by its mangled name
+// (the compiler then legalises the operands, e.g. lane select through M0 on gfx9).
+extern "C" __device__ uint32_t bk_llvm_writelane(uint32_t val, uint32_t lane, uint32_t old) __asm(
+    "llvm.amdgcn.writelane.i32");
+__device__ __forceinline__ uint32_t wrl(uint32_t val, uint32_t lane, uint32_t old) {
+  return bk_llvm_writelane(val, lane, old);
+}
+
+// dst[lane] = mask[lane] ? if_set : if_clear, mask wave-uniform in an SGPR pair (one VALU op)
+__device__ __forceinline__ uint32_t sel(uint64_t mask, uint32_t if_set, uint32_t if_clear) {
+  return __builtin_amdgcn_inverse_ballot_w64(mask) ? if_set : if_clear;  // v_cndmask_b32 with the SGPR mask
+}
+__device__ __forceinline__ bool lane_bit(uint64_t mask) { return __builtin_amdgcn_inverse_ballot_w64(mask); }
+
+// Full-wave (all 64 lanes active) reductions on the DPP network: butterfly inside each row
+// of 16, then row_bcast:15 / row_bcast:31 carry the row results into lane 63.
+#define BK_DPP_REDUCE(OP)                                                                      \
+  asm("s_nop 1\n\t" OP " %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"        \
+      "s_nop 1\n\t" OP " %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"        \
+      "s_nop 1\n\t" OP " %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"            \
+      "s_nop 1\n\t" OP " %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"                 \
+      "s_nop 1\n\t" OP " %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"               \
+      "s_nop 1\n\t" OP " %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"               \
+      "s_nop 1"                                                                                \
+      : "+v"(x))
+__device__ __forceinline__ uint32_t wave_umin(uint32_t x) {
+  BK_DPP_REDUCE("v_min_u32_dpp");
+  return rdl(x, 63);
+}
+__device__ __forceinline__ uint32_t wave_umax(uint32_t x) {
+  BK_DPP_REDUCE("v_max_u32_dpp");
+  return rdl(x, 63);
+}
+__device__ __forceinline__ uint32_t wave_add(uint32_t x) {  // wrapping u32 sum
+  BK_DPP_REDUCE("v_add_u32_dpp");
+  return rdl(x, 63);
+}
+
+__device__ __forceinline__ uint64_t mk64(uint32_t lo, uint32_t hi) { return ((uint64_t)hi << 32) | lo; }
+
+// ----------------------------------------------------------------------------------
+// RNG: xoroshiro128** in wave-uniform scalars (the compiler keeps this on the SALU)
+// ----------------------------------------------------------------------------------
+struct Rng {
+  uint64_t s0, s1;
+  __device__ __forceinline__ uint32_t next_u32() {  // low 32 bits of next_u64
+    uint64_t r = s0 * 5ull;
+    r = (r << 7) | (r >> 57);
+    r *= 9ull;
+    uint64_t t1 = s1 ^ s0;
+    s0 = ((s0 << 24) | (s0 >> 40)) ^ t1 ^ (t1 << 16);
+    s1 = (t1 << 37) | (t1 >> 27);
+    return (uint32_t)r;
+  }
+  // UniformInt<u32>::sample_single with precomputed zone (App. B.3): returns value in [0, range)
+  __device__ __forceinline__ uint32_t below(uint32_t range, uint32_t zone) {
+    for (;;) {
+      uint32_t v = next_u32();
+      uint64_t m = (uint64_t)v * range;
+      if ((uint32_t)m <= zone) return (uint32_t)(m >> 32);
+    }
+  }
+  __device__ __forceinline__ uint32_t below(uint32_t range) {
+    uint32_t zone = (range << __builtin_clz(range)) - 1u;
+    return below(range, zone);
+  }
+};
+
+// ----------------------------------------------------------------------------------
+// Book state in registers
+// ----------------------------------------------------------------------------------
+template <int R>
+struct Book {
+  // pool (VGPR): slot (r, lane)
+  uint32_t price[R], vol[R], id[R], seq[R];
+  // wave-uniform masks
+  uint64_t live[R], bid[R], pend[R];
+  // scalars
+  uint64_t t;
+  uint32_t next_id, seq_ctr, trade_vol, flags, trading;
+  uint64_t n_trades, n_events, trade_base;
+  // this step's trade records, one per lane (flushed when 64 are buffered)
+  uint32_t tr_k, tr_price, tr_vol, tr_act, tr_pas;
+  uint32_t tr_n;  // records buffered
+};
+
+template <int R>
+__device__ __forceinline__ uint32_t slot_read(const uint32_t (&v)[R], uint32_t n) {
+  uint32_t out = rdl(v[0], n & 63);
+#pragma unroll
+  for (int r = 1; r < R; ++r) {
+    uint32_t x = rdl(v[r], n & 63);
+    out = ((n >> 6) == (uint32_t)r) ? x : out;
+  }
+  return out;
+}
+template <int R>
+__device__ __forceinline__ void slot_write(uint32_t (&v)[R], uint32_t n, uint32_t val) {
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+    if ((n >> 6) == (uint32_t)r) v[r] = wrl(val, n & 63, v[r]);
+}
+template <int R>
+__device__ __forceinline__ bool mask_test(const uint64_t (&m)[R], uint32_t n) {
+  uint64_t w = m[0];
+#pragma unroll
+  for (int r = 1; r < R; ++r) w = ((n >> 6) == (uint32_t)r) ? m[r] : w;
+  return (w >> (n & 63)) & 1ull;
+}
+template <int R>
+__device__ __forceinline__ void mask_set(uint64_t (&m)[R], uint32_t n, bool on) {
+  const uint64_t bit = 1ull << (n & 63);
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+    if ((n >> 6) == (uint32_t)r) m[r] = on ? (m[r] | bit) : (m[r] & ~bit);
+}
+
+// ----------------------------------------------------------------------------------
+// trade records: buffered one per lane, written out as coalesced 32-byte records
+// ----------------------------------------------------------------------------------
+template <int R>
+__device__ __forceinline__ void flush_trades(Book<R>& B, const DevArgs& a, uint32_t book, uint64_t t0, int lane) {
+  if (B.tr_n == 0) return;
+  const uint64_t first = B.n_trades - B.tr_n;  // global index of lane 0's record
+  const uint64_t pos0 = first - B.trade_base;
+  if ((uint32_t)lane < B.tr_n) {
+    const uint64_t pos = pos0 + (uint32_t)lane;
+    if (pos < a.trade_cap) {
+      const uint64_t t = t0 + (B.tr_k & 0x7FFFFFFFu);
+      DevTrade rec;
+      rec.t_lo = (uint32_t)t;
+      rec.t_hi = (uint32_t)(t >> 32);
+      rec.price = B.tr_price;
+      rec.vol = B.tr_vol;
+      rec.active = B.tr_act;
+      rec.passive = B.tr_pas;
+      rec.side_is_bid = B.tr_k >> 31;
+      rec.pad = 0;
+      uint4* dst = reinterpret_cast<uint4*>(a.trades + (size_t)book * a.trade_cap + pos);
+      const uint4* src = reinterpret_cast<const uint4*>(&rec);
+      dst[0] = src[0];
+      dst[1] = src[1];
+    }
+  }
+  if (pos0 + B.tr_n > a.trade_cap) B.flags |= FLAG_TRADE_OVERFLOW;
+  B.tr_n = 0;
+}
+
+template <int R>
+__device__ __forceinline__ void emit_trade(Book<R>& B, const DevArgs& a, uint32_t book, uint64_t t0, int lane,
+                                           uint32_t k, bool passive_is_bid, uint32_t price, uint32_t vol,
+                                           uint32_t active, uint32_t passive) {
+  if (B.tr_n == 64) flush_trades(B, a, book, t0, lane);
+  const uint32_t l = B.tr_n;
+  B.tr_k = wrl(k | (passive_is_bid ? 0x80000000u : 0u), l, B.tr_k);
+  B.tr_price = wrl(price, l, B.tr_price);
+  B.tr_vol = wrl(vol, l, B.tr_vol);
+  B.tr_act = wrl(active, l, B.tr_act);
+  B.tr_pas = wrl(passive, l, B.tr_pas);
+  B.tr_n = l + 1;
+  B.n_trades += 1;
+}
+
+// ----------------------------------------------------------------------------------
+// order log (host-driven path only): single-lane scattered 32-byte updates
+// ----------------------------------------------------------------------------------
+struct LogCtx {
+  DevOrderLog* base;  // this book's log or nullptr
+  uint32_t cap;
+};
+__device__ __forceinline__ void log_write(const LogCtx& lg, uint32_t& flags, int lane, uint32_t id, uint32_t status,
+                                          uint32_t vol, uint32_t price, uint64_t arr, uint64_t end,
+                                          bool set_arr) {
+  if (!lg.base) return;
+  if (id >= lg.cap) {
+    flags |= FLAG_ORDER_LOG_FULL;
+    return;
+  }
+  if (lane == 0) {
+    DevOrderLog* e = lg.base + id;
+    e->status = status;
+    e->vol = vol;
+    e->price = price;
+    if (set_arr) {
+      e->arr_lo = (uint32_t)arr;
+      e->arr_hi = (uint32_t)(arr >> 32);
+    }
+    e->end_lo = (uint32_t)end;
+    e->end_hi = (uint32_t)(end >> 32);
+  }
+}
+// passive order touched by a fill: vol / status / end_time only
+__device__ __forceinline__ void log_fill(const LogCtx& lg, uint32_t& flags, int lane, uint32_t id, uint32_t vol,
+                                         uint64_t t) {
+  if (!lg.base) return;
+  if (id >= lg.cap) {
+    flags |= FLAG_ORDER_LOG_FULL;
+    return;
+  }
+  if (lane == 0) {
+    DevOrderLog* e = lg.base + id;
+    e->vol = vol;
+    if (vol == 0) {
+      e->status = 2;  // Filled
+      e->end_lo = (uint32_t)t;
+      e->end_hi = (uint32_t)(t >> 32);
+    }
+  }
+}
+
+// ----------------------------------------------------------------------------------
+// matching: match_bid / match_ask + match_orders (orderbook.rs:429-487, 843-870)
+// Returns true iff the aggressor ended Filled (its volume hit zero in a match).
+// ----------------------------------------------------------------------------------
+template <int R>
+__device__ __forceinline__ bool match(Book<R>& B, const DevArgs& a, uint32_t book, uint64_t t0, int lane, uint32_t k,
+                                      bool agg_bid, uint32_t p, uint32_t& v, uint32_t agg_id, const LogCtx& lg) {
+  bool filled = false;
+  while (v > 0) {
+    // candidates: live orders on the opposite side
+    uint64_t cand[R];
+    uint64_t any = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      cand[r] = B.live[r] & (agg_bid ? ~B.bid[r] : B.bid[r]);
+      any |= cand[r];
+    }
+    if (!any) break;  // best_order_idx() == None (orderbook.rs:449-451)
+    // touch of the opposite side: min ask / max bid
+    uint32_t m = agg_bid ? 0xFFFFFFFFu : 0u;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const uint32_t pr = sel(cand[r], B.price[r], agg_bid ? 0xFFFFFFFFu : 0u);
+      m = agg_bid ? min(m, pr) : max(m, pr);
+    }
+    const uint32_t best = agg_bid ? wave_umin(m) : wave_umax(m);
+    if (agg_bid ? (p < best) : (p > best)) break;  // inclusive crossing test (:430 / :463)
+    // oldest order at the touch: min seq among equal-price candidates
+    uint64_t eq[R];
+    uint32_t cnt = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      eq[r] = cand[r] & __ballot(B.price[r] == best);
+      cnt += __builtin_popcountll(eq[r]);
+    }
+    uint32_t pn = 0;  // passive slot index
+    if (cnt == 1) {
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+        if (eq[r]) pn = r * 64 + __builtin_ctzll(eq[r]);
+    } else {
+      uint32_t bs = 0xFFFFFFFFu;
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        uint64_t w = eq[r];
+        while (w) {
+          const uint32_t l = __builtin_ctzll(w);
+          w &= w - 1;
+          const uint32_t s = rdl(B.seq[r], l);
+          if (s < bs) {  // seq stamps are unique per book and < 0xFFFFFFFF
+            bs = s;
+            pn = r * 64 + l;
+          }
+        }
+      }
+    }
+    // match_orders
+    uint32_t pv = slot_read<R>(B.vol, pn);
+    const uint32_t pid = slot_read<R>(B.id, pn);
+    const uint32_t tv = v < pv ? v : pv;
+    v -= tv;
+    pv -= tv;
+    slot_write<R>(B.vol, pn, pv);
+    emit_trade(B, a, book, t0, lane, k, !agg_bid, best, tv, agg_id, pid);
+    B.trade_vol += tv;
+    if (pv == 0) mask_set<R>(B.live, pn, false);  // passive Filled -> remove_order
+    log_fill(lg, B.flags, lane, pid, pv, t0 + k);
+    if (v == 0) filled = true;
+  }
+  return filled;
+}
+
+// place_order for a limit/market order that already sits in slot n with pend set
+// (fused RandomAgents path: slot == agent).  orderbook.rs:583-611
+template <int R>
+__device__ __forceinline__ void process_new_in_slot(Book<R>& B, const DevArgs& a, uint32_t book, uint64_t t0, int lane,
+                                                    uint32_t k, uint32_t n) {
+  const LogCtx nolog{nullptr, 0};
+  mask_set<R>(B.pend, n, false);
+  const bool is_bid = mask_test<R>(B.bid, n);
+  const uint32_t p = slot_read<R>(B.price, n);
+  uint32_t v = slot_read<R>(B.vol, n);
+  const uint32_t id = slot_read<R>(B.id, n);
+  const bool market = is_bid ? (p == 0xFFFFFFFFu) : (p == 0u);
+  bool filled = false;
+  if (B.trading) filled = match<R>(B, a, book, t0, lane, k, is_bid, p, v, id, nolog);
+  if (!market && !filled) {  // rest the remainder with a fresh priority stamp
+    slot_write<R>(B.vol, n, v);
+    slot_write<R>(B.seq, n, B.seq_ctr);
+    B.seq_ctr += 1;
+    mask_set<R>(B.live, n, true);
+  }
+}
+
+// ----------------------------------------------------------------------------------
+// level-2 snapshot (orderbook.rs:229-264,314-324) -> [trade_vol, bid, ask, ask_vol, bid_vol, levels...]
+// ----------------------------------------------------------------------------------
+template <int R>
+__device__ __forceinline__ void snapshot(const Book<R>& B, const DevArgs& a, uint32_t book, int lane,
+                                         uint32_t* __restrict__ bins /* LDS, >= 4*levels */, uint64_t step_index,
+                                         uint32_t& flags, bool write_last) {
+  const uint32_t L = a.levels;
+  uint32_t mb = 0u, ma = 0xFFFFFFFFu, sb = 0u, sa = 0u;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const uint64_t lb = B.live[r] & B.bid[r], la = B.live[r] & ~B.bid[r];
+    mb = max(mb, sel(lb, B.price[r], 0u));
+    ma = min(ma, sel(la, B.price[r], 0xFFFFFFFFu));
+    sb += sel(lb, B.vol[r], 0u);
+    sa += sel(la, B.vol[r], 0u);
+  }
+  const uint32_t bid_best = wave_umax(mb);  // empty side -> 0        (side.rs:194-196)
+  const uint32_t ask_best = wave_umin(ma);  // empty side -> u32::MAX (side.rs:99-104)
+  const uint32_t bid_vol = wave_add(sb), ask_vol = wave_add(sa);
+
+  for (uint32_t j = lane; j < 4 * L; j += 64) bins[j] = 0;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  const uint32_t tick = a.tick_size;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const bool is_live = lane_bit(B.live[r]);
+    const bool is_bid = lane_bit(B.bid[r]);
+    if (is_live) {
+      // level i of a side holds the orders priced touch -/+ i*tick (wrapping arithmetic never matches)
+      const uint32_t d = is_bid ? (bid_best - B.price[r]) : (B.price[r] - ask_best);
+      const uint32_t q = d / tick;
+      if (q * tick == d && q < L) {
+        atomicAdd(&bins[4 * q + (is_bid ? 0 : 2)], B.vol[r]);
+        atomicAdd(&bins[4 * q + (is_bid ? 1 : 3)], 1u);
+      }
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+
+  const uint32_t W = a.l2_width;
+  uint32_t* last = a.l2_last + (size_t)book * W;
+  uint32_t* hist = nullptr;
+  if (a.hist_cap) {
+    const uint64_t slot = step_index - mk64(a.hist_base_lo, a.hist_base_hi);
+    if (slot < a.hist_cap)
+      hist = a.hist + ((size_t)slot * a.n_books + book) * W;
+    else
+      flags |= FLAG_HIST_OVERFLOW;
+  }
+  uint32_t h = 0;
+  h = lane == 0 ? B.trade_vol : h;
+  h = lane == 1 ? bid_best : h;
+  h = lane == 2 ? ask_best : h;
+  h = lane == 3 ? ask_vol : h;
+  h = lane == 4 ? bid_vol : h;
+  if (lane < 5) {
+    if (write_last) last[lane] = h;
+    if (hist) hist[lane] = h;
+  }
+  for (uint32_t j = lane; j < 4 * L; j += 64) {
+    const uint32_t x = bins[j];
+    if (write_last) last[5 + j] = x;
+    if (hist) hist[5 + j] = x;
+  }
+}
+
+// ----------------------------------------------------------------------------------
+// state load / store (coalesced: lane-contiguous dwords)
+// ----------------------------------------------------------------------------------
+template <int R>
+__device__ __forceinline__ void load_book(Book<R>& B, Rng& rng, const uint32_t* __restrict__ st, int lane) {
+  const uint32_t hdr = st[lane];
+  uint32_t meta[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const uint32_t* p = st + HDR_DW + r * POOL_FIELDS * 64;
+    B.price[r] = p[0 * 64 + lane];
+    B.vol[r] = p[1 * 64 + lane];
+    B.id[r] = p[2 * 64 + lane];
+    B.seq[r] = p[3 * 64 + lane];
+    meta[r] = p[4 * 64 + lane];
+  }
+  B.t = mk64(rdl(hdr, H_T_LO), rdl(hdr, H_T_HI));
+  rng.s0 = mk64(rdl(hdr, H_S0_LO), rdl(hdr, H_S0_HI));
+  rng.s1 = mk64(rdl(hdr, H_S1_LO), rdl(hdr, H_S1_HI));
+  B.next_id = rdl(hdr, H_NEXT_ID);
+  B.seq_ctr = rdl(hdr, H_SEQ);
+  B.n_trades = mk64(rdl(hdr, H_TRADES_LO), rdl(hdr, H_TRADES_HI));
+  B.flags = rdl(hdr, H_FLAGS);
+  B.trading = rdl(hdr, H_TRADING);
+  B.n_events = mk64(rdl(hdr, H_EVENTS_LO), rdl(hdr, H_EVENTS_HI));
+  B.trade_vol = rdl(hdr, H_TRADE_VOL);
+  B.trade_base = mk64(rdl(hdr, H_TRADE_BASE_LO), rdl(hdr, H_TRADE_BASE_HI));
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    B.live[r] = __ballot((meta[r] & 1u) != 0);
+    B.bid[r] = __ballot((meta[r] & 2u) != 0);
+    B.pend[r] = 0;
+  }
+  B.tr_k = B.tr_price = B.tr_vol = B.tr_act = B.tr_pas = 0;
+  B.tr_n = 0;
+}
+
+template <int R>
+__device__ __forceinline__ void store_book(const Book<R>& B, const Rng& rng, uint32_t* __restrict__ st, int lane,
+                                           uint64_t steps_done, uint32_t last_ntrades, uint32_t last_nevents) {
+  uint32_t hdr = st[lane];  // keep reserved words
+  auto put = [&](int idx, uint32_t v) { hdr = (lane == idx) ? v : hdr; };
+  put(H_T_LO, (uint32_t)B.t);
+  put(H_T_HI, (uint32_t)(B.t >> 32));
+  put(H_S0_LO, (uint32_t)rng.s0);
+  put(H_S0_HI, (uint32_t)(rng.s0 >> 32));
+  put(H_S1_LO, (uint32_t)rng.s1);
+  put(H_S1_HI, (uint32_t)(rng.s1 >> 32));
+  put(H_NEXT_ID, B.next_id);
+  put(H_SEQ, B.seq_ctr);
+  put(H_TRADES_LO, (uint32_t)B.n_trades);
+  put(H_TRADES_HI, (uint32_t)(B.n_trades >> 32));
+  put(H_FLAGS, B.flags);
+  put(H_STEPS_LO, (uint32_t)steps_done);
+  put(H_STEPS_HI, (uint32_t)(steps_done >> 32));
+  put(H_EVENTS_LO, (uint32_t)B.n_events);
+  put(H_EVENTS_HI, (uint32_t)(B.n_events >> 32));
+  put(H_TRADE_VOL, B.trade_vol);
+  put(H_LAST_NTRADES, last_ntrades);
+  put(H_LAST_NEVENTS, last_nevents);
+  st[lane] = hdr;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    uint32_t* p = st + HDR_DW + r * POOL_FIELDS * 64;
+    p[0 * 64 + lane] = B.price[r];
+    p[1 * 64 + lane] = B.vol[r];
+    p[2 * 64 + lane] = B.id[r];
+    p[3 * 64 + lane] = B.seq[r];
+    p[4 * 64 + lane] = (lane_bit(B.live[r]) ? 1u : 0u) | (lane_bit(B.bid[r]) ? 2u : 0u);
+  }
+}
+
+constexpr int LDS_DW_PER_WAVE = 4 * 64;  // level bins: 4 * levels dwords, levels <= 64
+
+// ==================================================================================
+// Kernel 1: fused on-device order flow.  n_steps x { RandomAgents::update for every
+// group (random_agent.rs:85-119); Env::step (env.rs:116-135) } per book, state kept in
+// registers across the steps of the launch (sim_runner, runner.rs:53-68).
+// ==================================================================================
+template <int R>
+__global__ __launch_bounds__(256) void k_run_random(DevArgs a, uint64_t first_step, uint32_t n_steps) {
+  __shared__ uint32_t lds[4][LDS_DW_PER_WAVE];
+  const int lane = threadIdx.x & 63;
+  const int wv = threadIdx.x >> 6;
+  const uint32_t book = rfl(blockIdx.x * 4 + wv);
+  if (book >= a.n_books) return;
+  uint32_t* st = a.state + (size_t)book * a.state_stride;
+  uint32_t* bins = lds[wv];
+
+  Book<R> B;
+  Rng rng;
+  load_book<R>(B, rng, st, lane);
+  const uint64_t step_size = mk64(a.step_lo, a.step_hi);
+  uint32_t last_ntr = 0, last_nev = 0;
+  uint32_t ev[R];  // this step's event list: entry k (lane k & 63 of ev[k >> 6]) = agent/slot index
+#pragma unroll
+  for (int r = 0; r < R; ++r) ev[r] = 0;
+
+  for (uint32_t s = 0; s < n_steps; ++s) {
+    // ---------------- agents.update(env, rng): groups in declaration order -------------
+    uint32_t n_ev = 0;
+    {
+      uint32_t g = 0;
+      Group G = a.groups[0];
+      uint32_t gend = G.n;
+      uint32_t n = 0;
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        for (uint32_t l = 0; l < 64; ++l, ++n) {
+          if (n >= a.n_agents_total) break;
+          while (n >= gend) {
+            ++g;
+            G = a.groups[g];
+            gend += G.n;
+          }
+          const uint32_t x = rng.next_u32();  // p = gen::<f32>()  (random_agent.rs:91)
+          if ((x >> 8) < G.thr) {             // p < activity_rate
+            slot_write<R>(ev, n_ev, n);
+            n_ev += 1;
+            const uint64_t bit = 1ull << l;
+            if (!(B.live[r] & bit)) {
+              // no Active order held: place a new one.  Draw order: side, tick, vol (:99-101)
+              const uint32_t side = rng.below(2u, 0xFFFFFFFFu);  // [Ask, Bid].choose: 0 = Ask, 1 = Bid
+              const uint32_t tick = G.tick_lo + rng.below(G.tick_rng, G.tick_zone);
+              const uint32_t vol = G.vol_lo + rng.below(G.vol_rng, G.vol_zone);
+              B.price[r] = wrl(tick * G.tick_size, l, B.price[r]);
+              B.vol[r] = wrl(vol, l, B.vol[r]);
+              B.id[r] = wrl(B.next_id, l, B.id[r]);  // create_order: id = orders.len() (orderbook.rs:363)
+              B.next_id += 1;
+              B.bid[r] = side ? (B.bid[r] | bit) : (B.bid[r] & ~bit);
+              B.pend[r] |= bit;
+            }
+            // else: holds an Active order -> queue its cancellation (:95-97); nothing to store,
+            // the event is told apart from a New by the slot's pend bit.
+          }
+        }
+      }
+    }
+    // ---------------- Env::step -----------------------------------------------------
+    const uint64_t t0 = B.t;
+    B.trade_vol = 0;  // reset_trade_vol (env.rs:118)
+    const uint64_t trades_before = B.n_trades;
+    if ((uint64_t)n_ev >= step_size) B.flags |= FLAG_STEP_SIZE;
+    // transactions.shuffle(rng) (env.rs:121; App. B.4)
+    for (uint32_t i = n_ev; i-- > 1;) {
+      const uint32_t j = rng.below(i + 1);
+      const uint32_t ai = slot_read<R>(ev, i), aj = slot_read<R>(ev, j);
+      slot_write<R>(ev, i, aj);
+      slot_write<R>(ev, j, ai);
+    }
+    // process events at t0 + k (env.rs:123-127)
+    for (uint32_t k = 0; k < n_ev; ++k) {
+      const uint32_t n = slot_read<R>(ev, k);
+      if (mask_test<R>(B.pend, n)) {
+        process_new_in_slot<R>(B, a, book, t0, lane, k, n);
+      } else {
+        mask_set<R>(B.live, n, false);  // cancel_order (orderbook.rs:622-644); no-op if filled meanwhile
+      }
+    }
+    B.n_events += n_ev;
+    B.t = t0 + step_size;  // env.rs:129
+    // env.rs:132-134.  Env::level_2_data (the "latest" record) only needs the launch's final snapshot;
+    // with no history buffer every step's record is written there.
+    snapshot<R>(B, a, book, lane, bins, first_step + s, B.flags, s + 1 == n_steps || a.hist_cap == 0);
+    flush_trades<R>(B, a, book, t0, lane);
+    last_ntr = (uint32_t)(B.n_trades - trades_before);
+    last_nev = n_ev;
+  }
+  store_book<R>(B, rng, st, lane, first_step + n_steps, last_ntr, last_nev);
+}
+
+// ==================================================================================
+// Kernel 2: host-driven order flow.  One Env::step per book over an uploaded event batch
+// (New / Cancellation / Modify), shuffled on the device with the book's RNG.
+// One wave per workgroup; the shuffle permutation lives in LDS.
+// ==================================================================================
+constexpr uint32_t EV_LDS_CAP = 8192;  // events per book per step (u16 permutation in LDS)
+
+template <int R>
+__device__ __forceinline__ int find_live_by_id(const Book<R>& B, uint32_t id) {
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const uint64_t m = B.live[r] & __ballot(B.id[r] == id);
+    if (m) return r * 64 + (int)__builtin_ctzll(m);
+  }
+  return -1;
+}
+template <int R>
+__device__ __forceinline__ int find_free_slot(const Book<R>& B) {
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const uint64_t m = ~B.live[r];
+    if (m) return r * 64 + (int)__builtin_ctzll(m);
+  }
+  return -1;
+}
+
+template <int R>
+__global__ __launch_bounds__(64) void k_step_events(DevArgs a, uint64_t step_index) {
+  __shared__ uint32_t bins[LDS_DW_PER_WAVE];
+  __shared__ uint16_t perm[EV_LDS_CAP];
+  const int lane = threadIdx.x;
+  const uint32_t book = blockIdx.x;
+  uint32_t* st = a.state + (size_t)book * a.state_stride;
+  Book<R> B;
+  Rng rng;
+  load_book<R>(B, rng, st, lane);
+  const uint64_t step_size = mk64(a.step_lo, a.step_hi);
+  const uint32_t e0 = a.ev_off[book];
+  const uint32_t n_ev = a.ev_off[book + 1] - e0;
+  LogCtx lg{a.order_log ? a.order_log + (size_t)book * a.log_cap : nullptr, a.log_cap};
+
+  const uint64_t t0 = B.t;
+  B.trade_vol = 0;
+  const uint64_t trades_before = B.n_trades;
+  if ((uint64_t)n_ev >= step_size && n_ev > 0) B.flags |= FLAG_STEP_SIZE;
+  for (uint32_t j = lane; j < n_ev; j += 64) perm[j] = (uint16_t)j;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  for (uint32_t i = n_ev; i-- > 1;) {  // shuffle (env.rs:121)
+    const uint32_t j = rng.below(i + 1);
+    const uint32_t pi = rfl(perm[i]), pj = rfl(perm[j]);
+    if (lane == 0) {
+      perm[i] = (uint16_t)pj;
+      perm[j] = (uint16_t)pi;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+  for (uint32_t k = 0; k < n_ev; ++k) {
+    const uint32_t e = e0 + rfl(perm[k]);
+    const uint32_t w = rfl(a.ev_word[e]);
+    const uint32_t id = rfl(a.ev_id[e]);
+    const uint32_t ep = rfl(a.ev_price[e]);
+    const uint32_t evv = rfl(a.ev_vol[e]);
+    const uint32_t kind = w & 0xFFu;
+    const uint64_t tk = t0 + k;
+    if (kind == 0) {
+      // ---- New: place_order (orderbook.rs:583-611); a fresh id is New by construction
+      const bool is_bid = (w >> 8) & 1u;
+      const uint32_t p = ep;
+      uint32_t v = evv;
+      const bool market = is_bid ? (p == 0xFFFFFFFFu) : (p == 0u);
+      bool filled = false;
+      uint32_t status = 1;  // Active
+      uint64_t end = ~0ull;
+      if (B.trading) {
+        filled = match<R>(B, a, book, t0, lane, k, is_bid, p, v, id, lg);
+        if (filled) {
+          status = 2;
+          end = tk;
+        } else if (market) {
+          status = 3;  // unfilled market remainder -> Cancelled (:521-524,:564-567)
+          end = tk;
+        }
+      } else if (market) {
+        status = 4;  // Rejected (:526-529)
+        end = tk;
+      }
+      if (!market && !filled) {
+        const int n = find_free_slot<R>(B);
+        if (n < 0) {
+          B.flags |= FLAG_POOL_OVERFLOW;
+        } else {
+          slot_write<R>(B.price, n, p);
+          slot_write<R>(B.vol, n, v);
+          slot_write<R>(B.id, n, id);
+          slot_write<R>(B.seq, n, B.seq_ctr);
+          B.seq_ctr += 1;
+          mask_set<R>(B.bid, n, is_bid);
+          mask_set<R>(B.live, n, true);
+        }
+      }
+      log_write(lg, B.flags, lane, id, status, v, p, tk, end, true);
+    } else if (kind == 1) {
+      // ---- Cancellation (orderbook.rs:622-644): only an Active order changes
+      const int n = find_live_by_id<R>(B, id);
+      if (n >= 0) {
+        const uint32_t v = slot_read<R>(B.vol, n);
+        const uint32_t p = slot_read<R>(B.price, n);
+        mask_set<R>(B.live, n, false);
+        log_write(lg, B.flags, lane, id, 3, v, p, 0, tk, false);
+      }
+    } else {
+      // ---- Modify (orderbook.rs:743-772, 656-723): only an Active order changes
+      const int n = find_live_by_id<R>(B, id);
+      const bool has_p = (w >> 9) & 1u, has_v = (w >> 10) & 1u;
+      if (n >= 0 && (has_p || has_v)) {
+        const uint32_t cur_v = slot_read<R>(B.vol, n);
+        const uint32_t cur_p = slot_read<R>(B.price, n);
+        if (!has_p && evv < cur_v) {
+          // reduce in place, priority kept (reduce_order_vol)
+          slot_write<R>(B.vol, n, evv);
+          log_write(lg, B.flags, lane, id, 1, evv, cur_p, 0, ~0ull, false);
+        } else {
+          // replace_order: remove, re-match at the new price, re-insert with a new time stamp
+          const bool is_bid = mask_test<R>(B.bid, n);
+          const uint32_t np = has_p ? ep : cur_p;
+          uint32_t nv = has_v ? evv : cur_v;
+          mask_set<R>(B.live, n, false);
+          bool filled = false;
+          if (B.trading) filled = match<R>(B, a, book, t0, lane, k, is_bid, np, nv, id, lg);
+          if (!filled) {
+            slot_write<R>(B.price, n, np);
+            slot_write<R>(B.vol, n, nv);
+            slot_write<R>(B.seq, n, B.seq_ctr);
+            B.seq_ctr += 1;
+            mask_set<R>(B.live, n, true);
+            log_write(lg, B.flags, lane, id, 1, nv, np, 0, ~0ull, false);
+          } else {
+            log_write(lg, B.flags, lane, id, 2, 0, np, 0, tk, false);
+          }
+        }
+      }
+    }
+  }
+  B.n_events += n_ev;
+  B.t = t0 + step_size;
+  snapshot<R>(B, a, book, lane, bins, step_index, B.flags, true);
+  flush_trades<R>(B, a, book, t0, lane);
+  store_book<R>(B, rng, st, lane, step_index + 1, (uint32_t)(B.n_trades - trades_before), n_ev);
+}
+
+// ==================================================================================
+// small service kernels
+// ==================================================================================
+// set trade_base = n_trades for every book (bk_clear_trades) / set trading flag
+__global__ void k_book_service(uint32_t* state, uint32_t stride, uint32_t n_books, int op, uint32_t value) {
+  const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= n_books) return;
+  uint32_t* h = state + (size_t)b * stride;
+  if (op == 0) {
+    h[H_TRADE_BASE_LO] = h[H_TRADES_LO];
+    h[H_TRADE_BASE_HI] = h[H_TRADES_HI];
+  } else if (op == 1) {
+    h[H_TRADING] = value;
+  }
+}
+
+struct DevStats {  // == bk_stats
+  unsigned long long n_books, sum_trade_vol, sum_trades, sum_events, sum_bid_vol, sum_ask_vol;
+  uint32_t min_bid, max_bid, min_ask, max_ask;
+};
+
+// per-shard market statistics: one 64-byte record (the unit all-gathered across GPUs)
+__global__ void k_stats(const uint32_t* state, uint32_t stride, const uint32_t* l2_last, uint32_t W, uint32_t n_books,
+                        DevStats* out) {
+  unsigned long long tv = 0, tr = 0, ev = 0, bv = 0, av = 0;
+  uint32_t mnb = 0xFFFFFFFFu, mxb = 0, mna = 0xFFFFFFFFu, mxa = 0;
+  for (uint32_t b = blockIdx.x * blockDim.x + threadIdx.x; b < n_books; b += gridDim.x * blockDim.x) {
+    const uint32_t* h = state + (size_t)b * stride;
+    const uint32_t* l = l2_last + (size_t)b * W;
+    tv += l[0];
+    tr += mk64(h[H_TRADES_LO], h[H_TRADES_HI]);
+    ev += mk64(h[H_EVENTS_LO], h[H_EVENTS_HI]);
+    bv += l[4];
+    av += l[3];
+    if (l[4] != 0 || l[5 + 1] != 0) {  // bid side non-empty (touch level holds >= 1 order)
+      mnb = min(mnb, l[1]);
+      mxb = max(mxb, l[1]);
+    }
+    if (l[3] != 0 || l[5 + 3] != 0) {
+      mna = min(mna, l[2]);
+      mxa = max(mxa, l[2]);
+    }
+  }
+  atomicAdd(&out->sum_trade_vol, tv);
+  atomicAdd(&out->sum_trades, tr);
+  atomicAdd(&out->sum_events, ev);
+  atomicAdd(&out->sum_bid_vol, bv);
+  atomicAdd(&out->sum_ask_vol, av);
+  atomicMin(&out->min_bid, mnb);
+  atomicMax(&out->max_bid, mxb);
+  atomicMin(&out->min_ask, mna);
+  atomicMax(&out->max_ask, mxa);
+  if (blockIdx.x == 0 && threadIdx.x == 0) out->n_books = n_books;
+}
+
+// self-test of the DPP reductions (used by tests on the GPU box)
+__global__ void k_selftest_reduce(const uint32_t* in, uint32_t* out) {
+  const int lane = threadIdx.x & 63;
+  const uint32_t x = in[blockIdx.x * 64 + lane];
+  const uint32_t mn = wave_umin(x), mx = wave_umax(x), sm = wave_add(x);
+  const uint32_t s = sel(0xF0F0F0F0F0F0F0F0ull, 1u, 2u);
+  if (lane == 0) {
+    out[blockIdx.x * 4 + 0] = mn;
+    out[blockIdx.x * 4 + 1] = mx;
+    out[blockIdx.x * 4 + 2] = sm;
+  }
+  const uint32_t ssum = wave_add(s);
+  if (lane == 0) out[blockIdx.x * 4 + 3] = ssum;
+}
+
+}  // namespace bkd

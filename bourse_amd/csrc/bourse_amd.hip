@@ -1,0 +1,807 @@
+// bourse_amd.hip — C ABI (include/bourse_amd.h) over the gfx950 kernels in book_device.hpp.
+//
+// Host side of the drop-in boundary: owns the device state of B independent books, keeps the
+// host-visible half of `bourse_de::Env` (order creation, id assignment, the per-step event
+// queue — crates/step_sim/src/env.rs:166-219) and launches the step kernels.  There is no CPU
+// execution path: without a usable GPU every entry point fails with BK_NO_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/bourse_amd.h"
+#include "book_device.hpp"
+
+using namespace bkd;
+
+static_assert(sizeof(DevStats) == sizeof(bk_stats), "bk_stats layout");
+static_assert(sizeof(DevTrade) == 32 && sizeof(DevOrderLog) == 32, "device record layout");
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+
+#define HIPCHK(expr)                                                                              \
+  do {                                                                                            \
+    hipError_t _e = (expr);                                                                       \
+    if (_e != hipSuccess)                                                                         \
+      return fail(BK_HIP_ERROR, std::string(#expr) + ": " + hipGetErrorString(_e));               \
+  } while (0)
+
+// rand_xoshiro 0.6.0 `seed_from_u64` for Xoroshiro128StarStar: two SplitMix64 outputs
+void seed_from_u64(uint64_t seed, uint64_t& s0, uint64_t& s1) {
+  uint64_t x = seed;
+  auto next = [&x]() {
+    x += 0x9e3779b97f4a7c15ull;
+    uint64_t z = x;
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+    return z ^ (z >> 31);
+  };
+  s0 = next();
+  s1 = next();
+}
+
+// `gen::<f32>() < rate` with gen = (u32 >> 8) * 2^-24 (App. B.5) as an integer threshold on (u32 >> 8):
+// k * 2^-24 < rate  <=>  k < rate * 2^24 (exact in double)  <=>  k < ceil(rate * 2^24).
+uint32_t activity_threshold(float rate) {
+  if (!(rate > 0.0f)) return 0;  // also NaN
+  const double x = static_cast<double>(rate) * 16777216.0;
+  if (x >= 16777216.0) return 16777216u;
+  return static_cast<uint32_t>(std::ceil(x));
+}
+
+uint32_t sample_zone(uint32_t range) { return (range << __builtin_clz(range)) - 1u; }  // App. B.3
+
+struct HostOrder {  // immutable half of an order, fixed at create_order (orderbook.rs:356-396)
+  uint8_t bid;
+  uint32_t start_vol, price, trader;
+  uint64_t create_time;
+};
+struct HostEvent {
+  uint32_t word, id, price, vol;
+};
+struct BookHost {
+  std::vector<HostOrder> orders;
+  std::vector<HostEvent> queue;
+  std::vector<DevOrderLog> log_cache;
+  uint64_t n_uploaded = 0;  // orders whose New event has reached the device
+  bool log_fresh = false;
+};
+
+template <class T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t n = 0;
+  ~DevBuf() {
+    if (p) (void)hipFree(p);
+  }
+  hipError_t alloc(size_t count) {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    n = count;
+    if (count == 0) return hipSuccess;
+    return hipMalloc(reinterpret_cast<void**>(&p), count * sizeof(T));
+  }
+};
+
+}  // namespace
+
+struct bk_env {
+  bk_config cfg{};
+  int R = 1;
+  uint32_t W = 0, stride = 0;
+  hipStream_t stream = nullptr;
+  DevBuf<uint32_t> state, l2_last, hist, ev_off, ev_word, ev_id, ev_price, ev_vol;
+  DevBuf<DevTrade> trades;
+  DevBuf<DevOrderLog> order_log;
+  DevBuf<DevStats> stats;
+  std::vector<BookHost> books;
+  std::vector<Group> groups;
+  uint32_t n_agents_total = 0;
+  uint64_t steps_done = 0, hist_base = 0;
+  uint32_t trading = 1;
+  size_t ev_capacity = 0;
+  // profiling
+  bool profile = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
+  double prof_ms = 0.0;
+  uint64_t prof_launches = 0;
+
+  DevArgs args() const {
+    DevArgs a{};
+    a.n_books = cfg.n_books;
+    a.levels = cfg.levels;
+    a.tick_size = cfg.tick_size;
+    a.n_groups = static_cast<uint32_t>(groups.size());
+    a.step_lo = static_cast<uint32_t>(cfg.step_size);
+    a.step_hi = static_cast<uint32_t>(cfg.step_size >> 32);
+    a.state_stride = stride;
+    a.l2_width = W;
+    a.trade_cap = cfg.trade_capacity;
+    a.hist_cap = cfg.history_capacity;
+    a.hist_base_lo = static_cast<uint32_t>(hist_base);
+    a.hist_base_hi = static_cast<uint32_t>(hist_base >> 32);
+    a.n_agents_total = n_agents_total;
+    a.log_cap = cfg.max_orders;
+    a.state = state.p;
+    a.l2_last = l2_last.p;
+    a.hist = hist.p;
+    a.trades = trades.p;
+    a.order_log = order_log.p;
+    a.ev_off = ev_off.p;
+    a.ev_word = ev_word.p;
+    a.ev_id = ev_id.p;
+    a.ev_price = ev_price.p;
+    a.ev_vol = ev_vol.p;
+    for (size_t g = 0; g < groups.size(); ++g) a.groups[g] = groups[g];
+    return a;
+  }
+};
+
+namespace {
+
+int use_device(bk_env* env) {
+  HIPCHK(hipSetDevice(env->cfg.device));
+  return BK_OK;
+}
+
+struct ProfScope {  // HIP events around a launch on the env's stream
+  bk_env* env;
+  hipEvent_t a = nullptr, b = nullptr;
+  explicit ProfScope(bk_env* e) : env(e) {
+    if (env->profile && hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess)
+      (void)hipEventRecord(a, env->stream);
+  }
+  ~ProfScope() {
+    if (a && b) {
+      (void)hipEventRecord(b, env->stream);
+      env->prof_events.emplace_back(a, b);
+    }
+  }
+};
+
+template <int R>
+int launch_run(bk_env* env, const DevArgs& a, uint64_t first_step, uint32_t n_steps) {
+  const uint32_t blocks = (env->cfg.n_books + 3) / 4;
+  ProfScope ps(env);
+  hipLaunchKernelGGL(k_run_random<R>, dim3(blocks), dim3(256), 0, env->stream, a, first_step, n_steps);
+  HIPCHK(hipGetLastError());
+  return BK_OK;
+}
+template <int R>
+int launch_events(bk_env* env, const DevArgs& a, uint64_t step_index) {
+  ProfScope ps(env);
+  hipLaunchKernelGGL(k_step_events<R>, dim3(env->cfg.n_books), dim3(64), 0, env->stream, a, step_index);
+  HIPCHK(hipGetLastError());
+  return BK_OK;
+}
+
+int check_book(bk_env* env, uint32_t book) {
+  if (!env) return fail(BK_INVALID_ARGUMENT, "null env");
+  if (book >= env->cfg.n_books) return fail(BK_INVALID_ARGUMENT, "book index out of range");
+  return BK_OK;
+}
+
+int refresh_log(bk_env* env, uint32_t book) {
+  BookHost& bh = env->books[book];
+  if (bh.log_fresh) return BK_OK;
+  const uint64_t n = std::min<uint64_t>(bh.n_uploaded, env->cfg.max_orders);
+  bh.log_cache.resize(n);
+  if (n) {
+    HIPCHK(hipStreamSynchronize(env->stream));
+    HIPCHK(hipMemcpy(bh.log_cache.data(), env->order_log.p + static_cast<size_t>(book) * env->cfg.max_orders,
+                     n * sizeof(DevOrderLog), hipMemcpyDeviceToHost));
+  }
+  bh.log_fresh = true;
+  return BK_OK;
+}
+
+void fill_order(const bk_env* env, const BookHost& bh, uint64_t id, bk_order* o) {
+  const HostOrder& h = bh.orders[id];
+  std::memset(o, 0, sizeof(*o));
+  o->side_is_bid = h.bid;
+  o->start_vol = h.start_vol;
+  o->trader_id = h.trader;
+  o->order_id = id;
+  if (id < bh.n_uploaded && id < bh.log_cache.size()) {
+    const DevOrderLog& d = bh.log_cache[id];
+    o->status = static_cast<uint8_t>(d.status);
+    o->vol = d.vol;
+    o->price = d.price;
+    o->arr_time = (static_cast<uint64_t>(d.arr_hi) << 32) | d.arr_lo;
+    o->end_time = (static_cast<uint64_t>(d.end_hi) << 32) | d.end_lo;
+  } else {  // created, New event still queued (or beyond the log capacity)
+    o->status = 0;
+    o->vol = h.start_vol;
+    o->price = h.price;
+    o->arr_time = h.create_time;
+    o->end_time = ~0ull;
+  }
+  (void)env;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* bk_last_error(void) { return g_err.c_str(); }
+
+int bk_device_count(int* out) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) n = 0;
+  if (out) *out = n;
+  return BK_OK;
+}
+
+int bk_env_create(const bk_config* cfg, bk_env** out) {
+  if (!cfg || !out) return fail(BK_INVALID_ARGUMENT, "null argument");
+  *out = nullptr;
+  if (cfg->n_books == 0) return fail(BK_INVALID_ARGUMENT, "n_books must be >= 1");
+  if (cfg->tick_size == 0) return fail(BK_INVALID_ARGUMENT, "tick_size must be > 0");  // orderbook.rs:159
+  if (cfg->levels == 0 || cfg->levels > 64) return fail(BK_INVALID_ARGUMENT, "levels must be in 1..64");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(BK_NO_DEVICE, "no HIP device available: bourse_amd has no CPU execution path");
+  if (cfg->device < 0 || cfg->device >= ndev) return fail(BK_INVALID_ARGUMENT, "device ordinal out of range");
+
+  std::unique_ptr<bk_env> env(new bk_env());
+  env->cfg = *cfg;
+  uint32_t pool = cfg->max_live_orders ? cfg->max_live_orders : 128;
+  int R = 1;
+  while (R * 64u < pool) R *= 2;
+  if (R > 8) return fail(BK_INVALID_ARGUMENT, "max_live_orders must be <= 512");
+  env->R = R;
+  env->cfg.max_live_orders = R * 64;
+  env->W = 5 + 4 * cfg->levels;
+  env->stride = HDR_DW + R * POOL_FIELDS * 64;
+  env->trading = cfg->trading ? 1 : 0;
+  HIPCHK(hipSetDevice(cfg->device));
+
+  const size_t B = cfg->n_books;
+  HIPCHK(env->state.alloc(B * env->stride));
+  HIPCHK(env->l2_last.alloc(B * env->W));
+  HIPCHK(env->hist.alloc(static_cast<size_t>(cfg->history_capacity) * B * env->W));
+  HIPCHK(env->trades.alloc(B * cfg->trade_capacity));
+  HIPCHK(env->order_log.alloc(B * cfg->max_orders));
+  HIPCHK(env->stats.alloc(1));
+  HIPCHK(env->ev_off.alloc(B + 1));
+  HIPCHK(hipMemset(env->ev_off.p, 0, (B + 1) * sizeof(uint32_t)));
+
+  // initial device state: empty books, per-book RNG streams, Env::new's empty-book snapshot
+  std::vector<uint32_t> st(B * env->stride, 0u), l2(B * env->W, 0u);
+  for (size_t b = 0; b < B; ++b) {
+    uint32_t* h = st.data() + b * env->stride;
+    uint64_t s0, s1;
+    seed_from_u64(cfg->seed + cfg->book_offset + b, s0, s1);
+    h[H_T_LO] = static_cast<uint32_t>(cfg->start_time);
+    h[H_T_HI] = static_cast<uint32_t>(cfg->start_time >> 32);
+    h[H_S0_LO] = static_cast<uint32_t>(s0);
+    h[H_S0_HI] = static_cast<uint32_t>(s0 >> 32);
+    h[H_S1_LO] = static_cast<uint32_t>(s1);
+    h[H_S1_HI] = static_cast<uint32_t>(s1 >> 32);
+    h[H_TRADING] = env->trading;
+    uint32_t* l = l2.data() + b * env->W;
+    l[1] = 0u;           // bid touch of an empty side (side.rs:194-196)
+    l[2] = 0xFFFFFFFFu;  // ask touch of an empty side (side.rs:99-104)
+  }
+  HIPCHK(hipMemcpy(env->state.p, st.data(), st.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(env->l2_last.p, l2.data(), l2.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+  env->books.resize(B);
+  *out = env.release();
+  return BK_OK;
+}
+
+void bk_env_destroy(bk_env* env) {
+  if (!env) return;
+  (void)hipSetDevice(env->cfg.device);
+  (void)hipStreamSynchronize(env->stream);
+  for (auto& pr : env->prof_events) {
+    (void)hipEventDestroy(pr.first);
+    (void)hipEventDestroy(pr.second);
+  }
+  delete env;
+}
+
+int bk_env_set_stream(bk_env* env, void* hip_stream) {
+  if (!env) return fail(BK_INVALID_ARGUMENT, "null env");
+  env->stream = static_cast<hipStream_t>(hip_stream);
+  return BK_OK;
+}
+
+int bk_env_sync(bk_env* env) {
+  if (!env) return fail(BK_INVALID_ARGUMENT, "null env");
+  if (int rc = use_device(env)) return rc;
+  HIPCHK(hipStreamSynchronize(env->stream));
+  return BK_OK;
+}
+
+// ------------------------------------------------------------------ host-driven order flow
+int bk_place_order(bk_env* env, uint32_t book, int bid, uint32_t vol, uint32_t trader_id, int has_price,
+                   uint32_t price, uint64_t* out_order_id) {
+  if (int rc = check_book(env, book)) return rc;
+  if (has_price && price % env->cfg.tick_size != 0)  // create_order's tick check, orderbook.rs:367-382
+    return fail(BK_PRICE_NOT_TICK_MULTIPLE, "Price " + std::to_string(price) + " was not a multiple of tick-size " +
+                                                std::to_string(env->cfg.tick_size));
+  BookHost& bh = env->books[book];
+  const uint64_t id = bh.orders.size();  // current_order_id, orderbook.rs:327-329
+  if (id >= 0xFFFFFFFFull) return fail(BK_CAPACITY, "order id space exhausted");
+  const uint32_t p = has_price ? price : (bid ? 0xFFFFFFFFu : 0u);  // market sentinels, types.rs:168,221
+  const uint64_t now = env->cfg.start_time + env->steps_done * env->cfg.step_size;
+  bh.orders.push_back(HostOrder{static_cast<uint8_t>(bid ? 1 : 0), vol, p, trader_id, now});
+  bh.queue.push_back(HostEvent{0u | (bid ? 1u << 8 : 0u), static_cast<uint32_t>(id), p, vol});
+  if (out_order_id) *out_order_id = id;
+  return BK_OK;
+}
+
+int bk_cancel_order(bk_env* env, uint32_t book, uint64_t order_id) {
+  if (int rc = check_book(env, book)) return rc;
+  // an id that was never created panics only when the event is PROCESSED (orderbook.rs:642): checked in bk_step
+  env->books[book].queue.push_back(
+      HostEvent{1u, static_cast<uint32_t>(std::min<uint64_t>(order_id, 0xFFFFFFFFull)), 0u, 0u});
+  return BK_OK;
+}
+
+int bk_modify_order(bk_env* env, uint32_t book, uint64_t order_id, int has_price, uint32_t new_price, int has_vol,
+                    uint32_t new_vol) {
+  if (int rc = check_book(env, book)) return rc;
+  const uint32_t w = 2u | (has_price ? 1u << 9 : 0u) | (has_vol ? 1u << 10 : 0u);
+  env->books[book].queue.push_back(
+      HostEvent{w, static_cast<uint32_t>(std::min<uint64_t>(order_id, 0xFFFFFFFFull)), new_price, new_vol});
+  return BK_OK;
+}
+
+int bk_submit_instructions(bk_env* env, uint32_t book, size_t n, const uint32_t* action, const uint8_t* side,
+                           const uint32_t* vol, const uint32_t* trader_id, const uint32_t* price,
+                           const uint64_t* order_id, uint64_t* out_ids, size_t* n_done) {
+  if (int rc = check_book(env, book)) return rc;
+  if (n_done) *n_done = 0;
+  for (size_t i = 0; i < n; ++i) {
+    uint64_t id = ~0ull;  // usize::MAX for non-new instructions (step_sim_numpy.rs:255-268)
+    if (action[i] == 1) {
+      int rc = bk_place_order(env, book, side[i] != 0, vol[i], trader_id[i], 1, price[i], &id);
+      if (rc != BK_OK) return rc;  // earlier elements stay created and queued (:167-177)
+    } else if (action[i] == 2) {
+      int rc = bk_cancel_order(env, book, order_id[i]);
+      if (rc != BK_OK) return rc;
+    }
+    if (out_ids) out_ids[i] = id;
+    if (n_done) *n_done = i + 1;
+  }
+  return BK_OK;
+}
+
+int bk_enable_trading(bk_env* env, int enabled) {
+  if (!env) return fail(BK_INVALID_ARGUMENT, "null env");
+  if (int rc = use_device(env)) return rc;
+  env->trading = enabled ? 1 : 0;
+  const uint32_t B = env->cfg.n_books;
+  hipLaunchKernelGGL(k_book_service, dim3((B + 255) / 256), dim3(256), 0, env->stream, env->state.p, env->stride, B, 1,
+                     env->trading);
+  HIPCHK(hipGetLastError());
+  return BK_OK;
+}
+
+int bk_step(bk_env* env) {
+  if (!env) return fail(BK_INVALID_ARGUMENT, "null env");
+  if (int rc = use_device(env)) return rc;
+  const size_t B = env->cfg.n_books;
+  if (env->cfg.history_capacity && env->steps_done - env->hist_base >= env->cfg.history_capacity)
+    return fail(BK_CAPACITY, "L2 history buffer full: call bk_clear_history() or raise history_capacity");
+  // validate + flatten the queues (CSR)
+  std::vector<uint32_t> off(B + 1, 0u);
+  size_t total = 0;
+  for (size_t b = 0; b < B; ++b) {
+    const BookHost& bh = env->books[b];
+    if (bh.queue.size() > EV_LDS_CAP)
+      return fail(BK_CAPACITY, "more than 8192 events queued for one book in one step");
+    for (const HostEvent& e : bh.queue)
+      if ((e.word & 0xFFu) != 0 && e.id >= bh.orders.size())
+        return fail(BK_UNKNOWN_ORDER_ID, "No order with id " + std::to_string(e.id) + " exists");
+    off[b] = static_cast<uint32_t>(total);
+    total += bh.queue.size();
+  }
+  off[B] = static_cast<uint32_t>(total);
+  std::vector<uint32_t> w(total), id(total), pr(total), vo(total);
+  size_t k = 0;
+  for (size_t b = 0; b < B; ++b)
+    for (const HostEvent& e : env->books[b].queue) {
+      w[k] = e.word;
+      id[k] = e.id;
+      pr[k] = e.price;
+      vo[k] = e.vol;
+      ++k;
+    }
+  HIPCHK(hipStreamSynchronize(env->stream));  // previous step may still read the event buffers
+  if (total > env->ev_capacity) {
+    const size_t cap = std::max<size_t>(total * 2, 1024);
+    HIPCHK(env->ev_word.alloc(cap));
+    HIPCHK(env->ev_id.alloc(cap));
+    HIPCHK(env->ev_price.alloc(cap));
+    HIPCHK(env->ev_vol.alloc(cap));
+    env->ev_capacity = cap;
+  }
+  HIPCHK(hipMemcpyAsync(env->ev_off.p, off.data(), (B + 1) * 4, hipMemcpyHostToDevice, env->stream));
+  if (total) {
+    HIPCHK(hipMemcpyAsync(env->ev_word.p, w.data(), total * 4, hipMemcpyHostToDevice, env->stream));
+    HIPCHK(hipMemcpyAsync(env->ev_id.p, id.data(), total * 4, hipMemcpyHostToDevice, env->stream));
+    HIPCHK(hipMemcpyAsync(env->ev_price.p, pr.data(), total * 4, hipMemcpyHostToDevice, env->stream));
+    HIPCHK(hipMemcpyAsync(env->ev_vol.p, vo.data(), total * 4, hipMemcpyHostToDevice, env->stream));
+  }
+  HIPCHK(hipStreamSynchronize(env->stream));  // pageable sources must stay alive until copied
+  const DevArgs a = env->args();
+  int rc = BK_OK;
+  switch (env->R) {
+    case 1: rc = launch_events<1>(env, a, env->steps_done); break;
+    case 2: rc = launch_events<2>(env, a, env->steps_done); break;
+    case 4: rc = launch_events<4>(env, a, env->steps_done); break;
+    default: rc = launch_events<8>(env, a, env->steps_done); break;
+  }
+  if (rc != BK_OK) return rc;
+  env->steps_done += 1;
+  for (size_t b = 0; b < B; ++b) {
+    BookHost& bh = env->books[b];
+    bh.queue.clear();
+    bh.n_uploaded = bh.orders.size();
+    bh.log_fresh = false;
+  }
+  HIPCHK(hipStreamSynchronize(env->stream));
+  return BK_OK;
+}
+
+int bk_order_status(bk_env* env, uint32_t book, uint64_t order_id, uint8_t* out_status) {
+  if (int rc = check_book(env, book)) return rc;
+  BookHost& bh = env->books[book];
+  if (order_id >= bh.orders.size())
+    return fail(BK_UNKNOWN_ORDER_ID, "No order with id " + std::to_string(order_id) + " exists");
+  if (env->cfg.max_orders == 0) return fail(BK_INVALID_ARGUMENT, "order log disabled (max_orders == 0)");
+  if (order_id >= env->cfg.max_orders) return fail(BK_CAPACITY, "order id beyond the order-log capacity");
+  if (int rc = use_device(env)) return rc;
+  if (int rc = refresh_log(env, book)) return rc;
+  bk_order o;
+  fill_order(env, bh, order_id, &o);
+  if (out_status) *out_status = o.status;
+  return BK_OK;
+}
+
+int bk_order_count(bk_env* env, uint32_t book, uint64_t* out) {
+  if (int rc = check_book(env, book)) return rc;
+  if (out) *out = env->books[book].orders.size();
+  return BK_OK;
+}
+
+int bk_get_orders(bk_env* env, uint32_t book, uint64_t first, uint64_t n, bk_order* out) {
+  if (int rc = check_book(env, book)) return rc;
+  BookHost& bh = env->books[book];
+  if (first + n > bh.orders.size()) return fail(BK_INVALID_ARGUMENT, "order range out of bounds");
+  if (bh.orders.size() > env->cfg.max_orders && env->cfg.max_orders > 0 && bh.n_uploaded > env->cfg.max_orders)
+    return fail(BK_CAPACITY, "order log capacity exceeded");
+  if (int rc = use_device(env)) return rc;
+  if (env->cfg.max_orders)
+    if (int rc = refresh_log(env, book)) return rc;
+  for (uint64_t i = 0; i < n; ++i) fill_order(env, bh, first + i, out + i);
+  return BK_OK;
+}
+
+// ------------------------------------------------------------------ on-device order flow
+int bk_set_random_agents(bk_env* env, uint32_t n_groups, const bk_random_agents* groups) {
+  if (!env || (!groups && n_groups)) return fail(BK_INVALID_ARGUMENT, "null argument");
+  if (n_groups > MAX_GROUPS) return fail(BK_INVALID_ARGUMENT, "at most 8 agent groups");
+  std::vector<Group> gs;
+  uint64_t total = 0;
+  for (uint32_t g = 0; g < n_groups; ++g) {
+    const bk_random_agents& r = groups[g];
+    if (r.tick_lo >= r.tick_hi || r.vol_lo >= r.vol_hi)
+      return fail(BK_INVALID_ARGUMENT, "empty tick/vol range");  // gen_range asserts low < high
+    // every sampled price tick * tick_size must pass create_order's tick check (else `.unwrap()` panics,
+    // random_agent.rs:103-110)
+    if (r.tick_size % env->cfg.tick_size != 0)
+      return fail(BK_PRICE_NOT_TICK_MULTIPLE, "agent tick_size must be a multiple of the env tick_size");
+    if (static_cast<uint64_t>(r.tick_hi - 1) * r.tick_size >= 0xFFFFFFFFull || r.tick_lo == 0)
+      return fail(BK_INVALID_ARGUMENT, "limit prices must lie in (0, u32::MAX)");
+    Group G{};
+    G.n = r.n_agents;
+    G.thr = activity_threshold(r.activity_rate);
+    G.tick_lo = r.tick_lo;
+    G.tick_rng = r.tick_hi - r.tick_lo;
+    G.tick_zone = sample_zone(G.tick_rng);
+    G.vol_lo = r.vol_lo;
+    G.vol_rng = r.vol_hi - r.vol_lo;
+    G.vol_zone = sample_zone(G.vol_rng);
+    G.tick_size = r.tick_size;
+    total += r.n_agents;
+    gs.push_back(G);
+  }
+  if (total > env->cfg.max_live_orders)
+    return fail(BK_CAPACITY, "sum of n_agents exceeds max_live_orders (one pool slot per agent)");
+  env->groups = gs;
+  env->n_agents_total = static_cast<uint32_t>(total);
+  return BK_OK;
+}
+
+int bk_run(bk_env* env, uint64_t n_steps) {
+  if (!env) return fail(BK_INVALID_ARGUMENT, "null env");
+  if (n_steps == 0) return BK_OK;
+  if (n_steps > 0xFFFFFFFFull) return fail(BK_INVALID_ARGUMENT, "n_steps too large for one launch");
+  if (int rc = use_device(env)) return rc;
+  for (const BookHost& bh : env->books)
+    if (!bh.queue.empty() || !bh.orders.empty())
+      return fail(BK_INVALID_ARGUMENT, "bk_run cannot be mixed with host-driven orders on the same env");
+  if (env->cfg.history_capacity && env->steps_done - env->hist_base + n_steps > env->cfg.history_capacity)
+    return fail(BK_CAPACITY, "L2 history buffer too small for this run: bk_clear_history() or raise history_capacity");
+  DevArgs a = env->args();
+  if (a.n_groups == 0) {  // no agents: plain steps
+    a.groups[0] = Group{};
+    a.n_agents_total = 0;
+  }
+  int rc = BK_OK;
+  const uint32_t ns = static_cast<uint32_t>(n_steps);
+  switch (env->R) {
+    case 1: rc = launch_run<1>(env, a, env->steps_done, ns); break;
+    case 2: rc = launch_run<2>(env, a, env->steps_done, ns); break;
+    case 4: rc = launch_run<4>(env, a, env->steps_done, ns); break;
+    default: rc = launch_run<8>(env, a, env->steps_done, ns); break;
+  }
+  if (rc != BK_OK) return rc;
+  env->steps_done += n_steps;
+  return BK_OK;
+}
+
+// ------------------------------------------------------------------ readers
+uint32_t bk_l2_width(const bk_env* env) { return env ? env->W : 0; }
+
+int bk_level2(bk_env* env, uint32_t first_book, uint32_t n_books, uint32_t* out) {
+  if (!env || !out) return fail(BK_INVALID_ARGUMENT, "null argument");
+  if (static_cast<uint64_t>(first_book) + n_books > env->cfg.n_books)
+    return fail(BK_INVALID_ARGUMENT, "book range out of bounds");
+  if (int rc = use_device(env)) return rc;
+  HIPCHK(hipStreamSynchronize(env->stream));
+  HIPCHK(hipMemcpy(out, env->l2_last.p + static_cast<size_t>(first_book) * env->W,
+                   static_cast<size_t>(n_books) * env->W * 4, hipMemcpyDeviceToHost));
+  return BK_OK;
+}
+
+int bk_history_len(bk_env* env, uint64_t* first_step, uint64_t* n_steps) {
+  if (!env) return fail(BK_INVALID_ARGUMENT, "null env");
+  if (first_step) *first_step = env->hist_base;
+  if (n_steps) *n_steps = env->cfg.history_capacity ? env->steps_done - env->hist_base : 0;
+  return BK_OK;
+}
+
+int bk_history(bk_env* env, uint64_t first_step, uint64_t n_steps, uint32_t first_book, uint32_t n_books,
+               uint32_t* out) {
+  if (!env || !out) return fail(BK_INVALID_ARGUMENT, "null argument");
+  if (first_step < env->hist_base || first_step + n_steps > env->steps_done || !env->cfg.history_capacity)
+    return fail(BK_INVALID_ARGUMENT, "step range not retained");
+  if (static_cast<uint64_t>(first_book) + n_books > env->cfg.n_books)
+    return fail(BK_INVALID_ARGUMENT, "book range out of bounds");
+  if (int rc = use_device(env)) return rc;
+  HIPCHK(hipStreamSynchronize(env->stream));
+  const size_t W = env->W, B = env->cfg.n_books;
+  const uint32_t* src = env->hist.p + ((first_step - env->hist_base) * B + first_book) * W;
+  HIPCHK(hipMemcpy2D(out, static_cast<size_t>(n_books) * W * 4, src, B * W * 4, static_cast<size_t>(n_books) * W * 4,
+                     n_steps, hipMemcpyDeviceToHost));
+  return BK_OK;
+}
+
+int bk_clear_history(bk_env* env) {
+  if (!env) return fail(BK_INVALID_ARGUMENT, "null env");
+  env->hist_base = env->steps_done;
+  return BK_OK;
+}
+
+static int read_hdr(bk_env* env, uint32_t book, int first_dw, int n_dw, uint32_t* out) {
+  if (int rc = use_device(env)) return rc;
+  HIPCHK(hipStreamSynchronize(env->stream));
+  HIPCHK(hipMemcpy(out, env->state.p + static_cast<size_t>(book) * env->stride + first_dw, n_dw * 4,
+                   hipMemcpyDeviceToHost));
+  return BK_OK;
+}
+
+int bk_trade_count(bk_env* env, uint32_t book, uint64_t* total, uint64_t* first_retained) {
+  if (int rc = check_book(env, book)) return rc;
+  uint32_t h[HDR_DW];
+  if (int rc = read_hdr(env, book, 0, HDR_DW, h)) return rc;
+  if (total) *total = (static_cast<uint64_t>(h[H_TRADES_HI]) << 32) | h[H_TRADES_LO];
+  if (first_retained) *first_retained = (static_cast<uint64_t>(h[H_TRADE_BASE_HI]) << 32) | h[H_TRADE_BASE_LO];
+  return BK_OK;
+}
+
+int bk_trade_counts(bk_env* env, uint64_t* totals) {
+  if (!env || !totals) return fail(BK_INVALID_ARGUMENT, "null argument");
+  if (int rc = use_device(env)) return rc;
+  HIPCHK(hipStreamSynchronize(env->stream));
+  HIPCHK(hipMemcpy2D(totals, 8, env->state.p + H_TRADES_LO, static_cast<size_t>(env->stride) * 4, 8,
+                     env->cfg.n_books, hipMemcpyDeviceToHost));
+  return BK_OK;
+}
+
+int bk_get_trades(bk_env* env, uint32_t book, uint64_t first, uint64_t n, bk_trade* out) {
+  if (int rc = check_book(env, book)) return rc;
+  uint64_t total = 0, base = 0;
+  if (int rc = bk_trade_count(env, book, &total, &base)) return rc;
+  if (first < base || first + n > total) return fail(BK_INVALID_ARGUMENT, "trade range not retained");
+  if (first + n - base > env->cfg.trade_capacity)
+    return fail(BK_CAPACITY, "trade records beyond trade_capacity were dropped");
+  if (n == 0) return BK_OK;
+  std::vector<DevTrade> tmp(n);
+  HIPCHK(hipMemcpy(tmp.data(), env->trades.p + static_cast<size_t>(book) * env->cfg.trade_capacity + (first - base),
+                   n * sizeof(DevTrade), hipMemcpyDeviceToHost));
+  for (uint64_t i = 0; i < n; ++i) {
+    const DevTrade& d = tmp[i];
+    bk_trade& t = out[i];
+    t.t = (static_cast<uint64_t>(d.t_hi) << 32) | d.t_lo;
+    t.side_is_bid = d.side_is_bid;
+    t.price = d.price;
+    t.vol = d.vol;
+    t.reserved = 0;
+    t.active_order_id = d.active;
+    t.passive_order_id = d.passive;
+  }
+  return BK_OK;
+}
+
+int bk_clear_trades(bk_env* env) {
+  if (!env) return fail(BK_INVALID_ARGUMENT, "null env");
+  if (int rc = use_device(env)) return rc;
+  const uint32_t B = env->cfg.n_books;
+  hipLaunchKernelGGL(k_book_service, dim3((B + 255) / 256), dim3(256), 0, env->stream, env->state.p, env->stride, B, 0,
+                     0u);
+  HIPCHK(hipGetLastError());
+  return BK_OK;
+}
+
+int bk_time(bk_env* env, uint32_t book, uint64_t* out) {
+  if (int rc = check_book(env, book)) return rc;
+  uint32_t h[2];
+  if (int rc = read_hdr(env, book, H_T_LO, 2, h)) return rc;
+  if (out) *out = (static_cast<uint64_t>(h[1]) << 32) | h[0];
+  return BK_OK;
+}
+
+int bk_trade_vol(bk_env* env, uint32_t book, uint32_t* out) {
+  if (int rc = check_book(env, book)) return rc;
+  return read_hdr(env, book, H_TRADE_VOL, 1, out);
+}
+
+int bk_steps_done(bk_env* env, uint64_t* out) {
+  if (!env) return fail(BK_INVALID_ARGUMENT, "null env");
+  if (out) *out = env->steps_done;
+  return BK_OK;
+}
+
+int bk_book_flags(bk_env* env, uint32_t* out) {
+  if (!env || !out) return fail(BK_INVALID_ARGUMENT, "null argument");
+  if (int rc = use_device(env)) return rc;
+  HIPCHK(hipStreamSynchronize(env->stream));
+  HIPCHK(hipMemcpy2D(out, 4, env->state.p + H_FLAGS, static_cast<size_t>(env->stride) * 4, 4, env->cfg.n_books,
+                     hipMemcpyDeviceToHost));
+  return BK_OK;
+}
+
+int bk_rng_state(bk_env* env, uint32_t book, uint64_t out_state[2]) {
+  if (int rc = check_book(env, book)) return rc;
+  uint32_t h[4];
+  if (int rc = read_hdr(env, book, H_S0_LO, 4, h)) return rc;
+  out_state[0] = (static_cast<uint64_t>(h[1]) << 32) | h[0];
+  out_state[1] = (static_cast<uint64_t>(h[3]) << 32) | h[2];
+  return BK_OK;
+}
+
+int bk_live_orders(bk_env* env, uint32_t book, uint32_t cap, bk_order* out, uint32_t* n_out) {
+  if (int rc = check_book(env, book)) return rc;
+  std::vector<uint32_t> st(env->stride);
+  if (int rc = read_hdr(env, book, 0, static_cast<int>(env->stride), st.data())) return rc;
+  struct Live {
+    uint32_t price, vol, id, seq, bid;
+  };
+  std::vector<Live> v;
+  for (int r = 0; r < env->R; ++r) {
+    const uint32_t* p = st.data() + HDR_DW + r * POOL_FIELDS * 64;
+    for (int l = 0; l < 64; ++l)
+      if (p[4 * 64 + l] & 1u) v.push_back(Live{p[l], p[64 + l], p[128 + l], p[192 + l], (p[4 * 64 + l] >> 1) & 1u});
+  }
+  std::sort(v.begin(), v.end(), [](const Live& x, const Live& y) {
+    if (x.bid != y.bid) return x.bid > y.bid;  // bids first
+    if (x.price != y.price) return x.bid ? x.price > y.price : x.price < y.price;
+    return x.seq < y.seq;
+  });
+  if (n_out) *n_out = static_cast<uint32_t>(v.size());
+  for (size_t i = 0; i < v.size() && i < cap; ++i) {
+    std::memset(&out[i], 0, sizeof(bk_order));
+    out[i].side_is_bid = static_cast<uint8_t>(v[i].bid);
+    out[i].status = 1;
+    out[i].vol = v[i].vol;
+    out[i].price = v[i].price;
+    out[i].order_id = v[i].id;
+    out[i].end_time = ~0ull;
+  }
+  return BK_OK;
+}
+
+// ------------------------------------------------------------------ stats
+int bk_stats_compute(bk_env* env, bk_stats* out_host) {
+  if (!env) return fail(BK_INVALID_ARGUMENT, "null env");
+  if (int rc = use_device(env)) return rc;
+  DevStats init{};
+  init.min_bid = 0xFFFFFFFFu;
+  init.min_ask = 0xFFFFFFFFu;
+  HIPCHK(hipMemcpyAsync(env->stats.p, &init, sizeof(init), hipMemcpyHostToDevice, env->stream));
+  HIPCHK(hipStreamSynchronize(env->stream));
+  const uint32_t B = env->cfg.n_books;
+  const uint32_t blocks = std::min<uint32_t>((B + 255) / 256, 1024);
+  hipLaunchKernelGGL(k_stats, dim3(blocks), dim3(256), 0, env->stream, env->state.p, env->stride, env->l2_last.p,
+                     env->W, B, env->stats.p);
+  HIPCHK(hipGetLastError());
+  if (out_host) {
+    HIPCHK(hipStreamSynchronize(env->stream));
+    HIPCHK(hipMemcpy(out_host, env->stats.p, sizeof(bk_stats), hipMemcpyDeviceToHost));
+  }
+  return BK_OK;
+}
+
+int bk_stats_device_ptr(bk_env* env, void** out) {
+  if (!env || !out) return fail(BK_INVALID_ARGUMENT, "null argument");
+  *out = env->stats.p;
+  return BK_OK;
+}
+
+// ------------------------------------------------------------------ measurement
+int bk_profile_enable(bk_env* env, int on) {
+  if (!env) return fail(BK_INVALID_ARGUMENT, "null env");
+  env->profile = on != 0;
+  return BK_OK;
+}
+
+int bk_profile_read(bk_env* env, double* total_ms, uint64_t* n_launches, int reset) {
+  if (!env) return fail(BK_INVALID_ARGUMENT, "null env");
+  if (int rc = use_device(env)) return rc;
+  HIPCHK(hipStreamSynchronize(env->stream));
+  for (auto& pr : env->prof_events) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) {
+      env->prof_ms += ms;
+      env->prof_launches += 1;
+    }
+    (void)hipEventDestroy(pr.first);
+    (void)hipEventDestroy(pr.second);
+  }
+  env->prof_events.clear();
+  if (total_ms) *total_ms = env->prof_ms;
+  if (n_launches) *n_launches = env->prof_launches;
+  if (reset) {
+    env->prof_ms = 0.0;
+    env->prof_launches = 0;
+  }
+  return BK_OK;
+}
+
+uint64_t bk_state_bytes_per_book(const bk_env* env) { return env ? static_cast<uint64_t>(env->stride) * 4 : 0; }
+
+// DPP reduction self-test (tests only): in[n_waves*64] -> out[n_waves*4] = {min, max, sum, sel-sum}
+int bk_selftest_reduce(const uint32_t* in_host, uint32_t n_waves, uint32_t* out_host) {
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(BK_NO_DEVICE, "no HIP device available");
+  DevBuf<uint32_t> in, out;
+  HIPCHK(in.alloc(static_cast<size_t>(n_waves) * 64));
+  HIPCHK(out.alloc(static_cast<size_t>(n_waves) * 4));
+  HIPCHK(hipMemcpy(in.p, in_host, static_cast<size_t>(n_waves) * 64 * 4, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_selftest_reduce, dim3(n_waves), dim3(64), 0, nullptr, in.p, out.p);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpy(out_host, out.p, static_cast<size_t>(n_waves) * 4 * 4, hipMemcpyDeviceToHost));
+  return BK_OK;
+}
+
+}  // extern "C"

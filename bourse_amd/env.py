@@ -1,0 +1,263 @@
+"""``ManyBookEnv``: B independent ``bourse_de::Env`` instances stepped in lockstep on one MI355X.
+
+Host-side mirror of the reference's Rust surface for the hot path
+(``Env`` crates/step_sim/src/env.rs:58-295, ``RandomAgents`` agents/random_agent.rs:48-120,
+``sim_runner`` runner.rs:46-69), calling the HIP kernels through the C ABI
+(include/bourse_amd.h).  Book ``b`` owns the RNG stream
+``Xoroshiro128StarStar::seed_from_u64(seed + book_offset + b)``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Iterable, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _lib
+from ._lib import Config, RandomAgentsCfg, Stats, check
+
+MAX_PRICE = 2**32 - 1
+
+
+@dataclass(frozen=True)
+class RandomAgents:
+    """``RandomAgents::new(n_agents, tick_range, vol_range, tick_size, activity_rate)``
+    (ref agents/random_agent.rs:67-81).  One instance describes one group, replicated per book."""
+
+    n_agents: int
+    tick_range: Tuple[int, int]
+    vol_range: Tuple[int, int]
+    tick_size: int
+    activity_rate: float
+
+    def as_tuple(self):
+        return (self.n_agents, tuple(self.tick_range), tuple(self.vol_range), self.tick_size, self.activity_rate)
+
+
+class ManyBookEnv:
+    """B books on one GPU.  ``Env::new(start_time, tick_size, step_size, trading)`` per book."""
+
+    def __init__(self, n_books: int, seed: int, start_time: int, tick_size: int, step_size: int, trading: bool = True,
+                 levels: int = 10, max_live_orders: int = 128, max_orders: int = 0, trade_capacity: int = 4096,
+                 history_capacity: int = 0, book_offset: int = 0, device: int = 0, stream: Optional[int] = None):
+        self._L = _lib.load()
+        cfg = Config()
+        cfg.n_books, cfg.levels = int(n_books), int(levels)
+        cfg.start_time, cfg.tick_size, cfg.step_size = int(start_time), int(tick_size), int(step_size)
+        cfg.trading, cfg.seed, cfg.book_offset = int(bool(trading)), int(seed) & (2**64 - 1), int(book_offset)
+        cfg.max_live_orders, cfg.max_orders = int(max_live_orders), int(max_orders)
+        cfg.trade_capacity, cfg.history_capacity, cfg.device = int(trade_capacity), int(history_capacity), int(device)
+        self._h = C.c_void_p()
+        self.n_books, self.levels, self.tick_size = int(n_books), int(levels), int(tick_size)
+        self.step_size, self.start_time = int(step_size), int(start_time)
+        check(self._L.bk_env_create(C.byref(cfg), C.byref(self._h)))
+        self.width = int(self._L.bk_l2_width(self._h))
+        if stream is not None:
+            check(self._L.bk_env_set_stream(self._h, C.c_void_p(stream)))
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._L.bk_env_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------ host-driven flow (Env methods)
+    def place_order(self, book: int, bid: bool, vol: int, trader_id: int, price: Optional[int] = None) -> int:
+        """``Env::place_order`` (env.rs:166-176); raises ValueError on a non-tick-multiple price."""
+        out = C.c_uint64(0)
+        check(self._L.bk_place_order(self._h, book, int(bool(bid)), int(vol), int(trader_id), int(price is not None),
+                                     int(price if price is not None else 0), C.byref(out)))
+        return int(out.value)
+
+    def cancel_order(self, book: int, order_id: int):
+        check(self._L.bk_cancel_order(self._h, book, int(order_id)))
+
+    def modify_order(self, book: int, order_id: int, new_price: Optional[int] = None, new_vol: Optional[int] = None):
+        check(self._L.bk_modify_order(self._h, book, int(order_id), int(new_price is not None), int(new_price or 0),
+                                      int(new_vol is not None), int(new_vol or 0)))
+
+    def submit_instructions(self, book: int, instructions) -> np.ndarray:
+        """``StepEnvNumpy.submit_instructions`` (rust/src/step_sim_numpy.rs:233-275)."""
+        action, sides, vols, traders, prices, order_ids = instructions
+        action = np.ascontiguousarray(action, dtype=np.uint32)
+        sides = np.ascontiguousarray(np.asarray(sides).astype(np.uint8))
+        vols = np.ascontiguousarray(vols, dtype=np.uint32)
+        traders = np.ascontiguousarray(traders, dtype=np.uint32)
+        prices = np.ascontiguousarray(prices, dtype=np.uint32)
+        order_ids = np.ascontiguousarray(order_ids, dtype=np.uint64)
+        n = len(action)
+        out = np.full(n, 2**64 - 1, dtype=np.uint64)
+        done = C.c_size_t(0)
+        check(self._L.bk_submit_instructions(self._h, book, n, _lib.p32(action), _lib.p8(sides), _lib.p32(vols),
+                                             _lib.p32(traders), _lib.p32(prices), _lib.p64(order_ids),
+                                             _lib.p64(out), C.byref(done)))
+        return out
+
+    def enable_trading(self):
+        check(self._L.bk_enable_trading(self._h, 1))
+
+    def disable_trading(self):
+        check(self._L.bk_enable_trading(self._h, 0))
+
+    def step(self):
+        """``Env::step`` (env.rs:116-135) for every book over the queued events."""
+        check(self._L.bk_step(self._h))
+
+    def order_status(self, book: int, order_id: int) -> int:
+        out = C.c_uint8(0)
+        check(self._L.bk_order_status(self._h, book, int(order_id), C.byref(out)))
+        return int(out.value)
+
+    def order_count(self, book: int) -> int:
+        out = C.c_uint64(0)
+        check(self._L.bk_order_count(self._h, book, C.byref(out)))
+        return int(out.value)
+
+    def orders(self, book: int) -> np.ndarray:
+        n = self.order_count(book)
+        a = np.zeros(n, dtype=_lib.ORDER_DTYPE)
+        if n:
+            check(self._L.bk_get_orders(self._h, book, 0, n, a.ctypes.data_as(C.c_void_p)))
+        return a
+
+    # ------------------------------------------------------------ on-device flow
+    def set_random_agents(self, groups: Iterable[RandomAgents | tuple]):
+        gs = [g.as_tuple() if isinstance(g, RandomAgents) else g for g in groups]
+        arr = (RandomAgentsCfg * max(len(gs), 1))()
+        for i, (n, tr, vr, ts, rate) in enumerate(gs):
+            arr[i].n_agents, arr[i].tick_lo, arr[i].tick_hi = int(n), int(tr[0]), int(tr[1])
+            arr[i].vol_lo, arr[i].vol_hi, arr[i].tick_size = int(vr[0]), int(vr[1]), int(ts)
+            arr[i].activity_rate = float(np.float32(rate))
+        check(self._L.bk_set_random_agents(self._h, len(gs), arr))
+        self.groups = gs
+
+    def run(self, n_steps: int, sync: bool = True):
+        """``sim_runner``'s loop body ``n_steps`` times in ONE kernel launch (runner.rs:53-68)."""
+        check(self._L.bk_run(self._h, int(n_steps)))
+        if sync:
+            self.sync()
+
+    def sync(self):
+        check(self._L.bk_env_sync(self._h))
+
+    # ------------------------------------------------------------ readers
+    def level2(self, first_book: int = 0, n_books: Optional[int] = None) -> np.ndarray:
+        """u32[n_books, 5+4L]: end-of-step snapshot, numpy ``level_2_data`` layout."""
+        n = self.n_books - first_book if n_books is None else n_books
+        out = np.zeros((n, self.width), dtype=np.uint32)
+        check(self._L.bk_level2(self._h, first_book, n, _lib.p32(out)))
+        return out
+
+    def history_len(self) -> Tuple[int, int]:
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        check(self._L.bk_history_len(self._h, C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
+
+    def history(self, first_step: Optional[int] = None, n_steps: Optional[int] = None, first_book: int = 0,
+                n_books: Optional[int] = None) -> np.ndarray:
+        """u32[n_steps, n_books, 5+4L] (Level2DataRecords + trade_vols, data.rs:9-57)."""
+        f, n = self.history_len()
+        first_step = f if first_step is None else first_step
+        n_steps = (f + n - first_step) if n_steps is None else n_steps
+        nb = self.n_books - first_book if n_books is None else n_books
+        out = np.zeros((n_steps, nb, self.width), dtype=np.uint32)
+        if n_steps and nb:
+            check(self._L.bk_history(self._h, first_step, n_steps, first_book, nb, _lib.p32(out)))
+        return out
+
+    def clear_history(self):
+        check(self._L.bk_clear_history(self._h))
+
+    def trade_count(self, book: int) -> Tuple[int, int]:
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        check(self._L.bk_trade_count(self._h, book, C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
+
+    def trade_counts(self) -> np.ndarray:
+        out = np.zeros(self.n_books, dtype=np.uint64)
+        check(self._L.bk_trade_counts(self._h, _lib.p64(out)))
+        return out
+
+    def trades(self, book: int, first: Optional[int] = None, n: Optional[int] = None) -> np.ndarray:
+        total, base = self.trade_count(book)
+        first = base if first is None else first
+        n = total - first if n is None else n
+        a = np.zeros(n, dtype=_lib.TRADE_DTYPE)
+        if n:
+            check(self._L.bk_get_trades(self._h, book, first, n, a.ctypes.data_as(C.c_void_p)))
+        return a
+
+    def clear_trades(self):
+        check(self._L.bk_clear_trades(self._h))
+
+    def time(self, book: int = 0) -> int:
+        out = C.c_uint64(0)
+        check(self._L.bk_time(self._h, book, C.byref(out)))
+        return int(out.value)
+
+    def trade_vol(self, book: int = 0) -> int:
+        out = C.c_uint32(0)
+        check(self._L.bk_trade_vol(self._h, book, C.byref(out)))
+        return int(out.value)
+
+    def steps_done(self) -> int:
+        out = C.c_uint64(0)
+        check(self._L.bk_steps_done(self._h, C.byref(out)))
+        return int(out.value)
+
+    def flags(self) -> np.ndarray:
+        out = np.zeros(self.n_books, dtype=np.uint32)
+        check(self._L.bk_book_flags(self._h, _lib.p32(out)))
+        return out
+
+    def rng_state(self, book: int) -> Tuple[int, int]:
+        out = np.zeros(2, dtype=np.uint64)
+        check(self._L.bk_rng_state(self._h, book, _lib.p64(out)))
+        return int(out[0]), int(out[1])
+
+    def live_orders(self, book: int) -> np.ndarray:
+        cap = 1024
+        a = np.zeros(cap, dtype=_lib.ORDER_DTYPE)
+        n = C.c_uint32(0)
+        check(self._L.bk_live_orders(self._h, book, cap, a.ctypes.data_as(C.c_void_p), C.byref(n)))
+        return a[: n.value].copy()
+
+    def stats(self) -> dict:
+        s = Stats()
+        check(self._L.bk_stats_compute(self._h, C.byref(s)))
+        return {k: int(getattr(s, k)) for k, _ in Stats._fields_}
+
+    def stats_device_ptr(self) -> int:
+        out = C.c_void_p()
+        check(self._L.bk_stats_device_ptr(self._h, C.byref(out)))
+        return int(out.value)
+
+    def stats_compute_async(self):
+        check(self._L.bk_stats_compute(self._h, None))
+
+    # ------------------------------------------------------------ measurement
+    def profile(self, on: bool):
+        check(self._L.bk_profile_enable(self._h, int(on)))
+
+    def profile_read(self, reset: bool = True) -> Tuple[float, int]:
+        ms, n = C.c_double(0), C.c_uint64(0)
+        check(self._L.bk_profile_read(self._h, C.byref(ms), C.byref(n), int(reset)))
+        return float(ms.value), int(n.value)
+
+    def state_bytes_per_book(self) -> int:
+        return int(self._L.bk_state_bytes_per_book(self._h))
+
+
+def sim_runner(env: ManyBookEnv, agents: Sequence[RandomAgents | tuple], n_steps: int):
+    """``sim_runner(env, agents, seed, n_steps, _)`` (ref runner.rs:46-69) for every book of ``env``.
+
+    The seed is the env's (book b: seed + book_offset + b): in the reference the RNG is a local of
+    ``sim_runner``; here it is part of the device state so runs can be continued."""
+    env.set_random_agents(agents)
+    env.run(n_steps)

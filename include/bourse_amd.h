@@ -1,0 +1,189 @@
+/* bourse_amd.h — C ABI of the MI355X many-book limit-order-book step simulator.
+ *
+ * Drop-in boundary for the reference's `bourse_de::Env` hot path (plain pointers and
+ * sizes, no torch / C++ types).  One `bk_env` owns B >= 1 INDEPENDENT books on one GPU;
+ * book b behaves exactly like one reference `Env` driven by its own
+ * `Xoroshiro128StarStar::seed_from_u64(seed + book_offset + b)`.
+ *
+ * Each entry point cites the reference interface it replaces (paths relative to the
+ * reference repository).  INTEGRATION.md shows the Rust `extern "C"` / ctypes bindings.
+ *
+ * Status codes: every function returns one of these.
+ */
+#ifndef BOURSE_AMD_H
+#define BOURSE_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum bk_status {
+  BK_OK = 0,
+  BK_PRICE_NOT_TICK_MULTIPLE = 1, /* OrderError::PriceError, crates/order_book/src/orderbook.rs:127-142 */
+  BK_UNKNOWN_ORDER_ID = 2,        /* panic! at orderbook.rs:642 / index panic :338,:749 */
+  BK_CAPACITY = 3,                /* a fixed device capacity was exceeded (cannot occur in the reference) */
+  BK_STEP_SIZE_EXCEEDED = 4,      /* #events in a step >= step_size: (price,t) key collision hazard, SURVEY App. A.9 */
+  BK_INVALID_ARGUMENT = 5,
+  BK_HIP_ERROR = 6,               /* a HIP runtime call failed; bk_last_error() has the text */
+  BK_NO_DEVICE = 7                /* no usable GPU: the product path never falls back to a CPU */
+};
+
+/* per-book sticky flag bits reported by bk_book_flags() */
+#define BK_FLAG_POOL_OVERFLOW 1u   /* live-order pool full: an order that should rest was dropped */
+#define BK_FLAG_TRADE_OVERFLOW 2u  /* trade buffer full: records dropped (counts stay exact) */
+#define BK_FLAG_STEP_SIZE 4u       /* a step queued >= step_size events */
+#define BK_FLAG_ORDER_LOG_FULL 8u  /* order id beyond the order-log capacity */
+#define BK_FLAG_UNKNOWN_ORDER 16u  /* cancel/modify of an id that was never created */
+#define BK_FLAG_HIST_OVERFLOW 32u  /* L2 history buffer full: records dropped */
+
+typedef struct bk_env bk_env;
+
+/* Env::<LEVELS>::new(start_time, tick_size, step_size, trading) — crates/step_sim/src/env.rs:84-95,
+ * plus the sizes a fixed-capacity device implementation needs.  Zero-initialise, then set. */
+typedef struct bk_config {
+  uint32_t n_books;         /* B >= 1 independent books on this GPU */
+  uint32_t levels;          /* LEVELS: L2 depth per side (reference default 10; 16/32/64 in the benchmark configs) */
+  uint64_t start_time;
+  uint32_t tick_size;       /* > 0 (assert at orderbook.rs:159) */
+  uint32_t trading;         /* bool */
+  uint64_t step_size;
+  uint64_t seed;            /* book b is seeded seed + book_offset + b (identity for B = 1) */
+  uint64_t book_offset;     /* global index of this GPU's first book (multi-GPU sharding) */
+  uint32_t max_live_orders; /* live-order pool per book, rounded up to a multiple of 64 (<= 1024) */
+  uint32_t max_orders;      /* order-log capacity per book for the host-driven path (0 = no log) */
+  uint32_t trade_capacity;  /* trade records retained per book between bk_clear_trades() calls */
+  uint32_t history_capacity;/* L2 records (steps) retained between bk_clear_history() calls; 0 = keep only the latest */
+  int32_t device;           /* HIP device ordinal */
+  uint32_t reserved;
+} bk_config;
+
+/* RandomAgents::new(n_agents, tick_range, vol_range, tick_size, activity_rate)
+ * — crates/step_sim/src/agents/random_agent.rs:67-81 */
+typedef struct bk_random_agents {
+  uint32_t n_agents;
+  uint32_t tick_lo, tick_hi; /* tick_range (half-open) */
+  uint32_t vol_lo, vol_hi;   /* vol_range (half-open) */
+  uint32_t tick_size;        /* the AGENTS' tick size: price = tick * tick_size */
+  float activity_rate;
+} bk_random_agents;
+
+/* Trade — crates/order_book/src/types.rs:103-118; tuple order of PyTrade, rust/src/types.rs:4-15 */
+typedef struct bk_trade {
+  uint64_t t;
+  uint32_t side_is_bid; /* side of the PASSIVE order */
+  uint32_t price;
+  uint32_t vol;
+  uint32_t reserved;
+  uint64_t active_order_id;
+  uint64_t passive_order_id;
+} bk_trade;
+
+/* Order — crates/order_book/src/types.rs:79-99; tuple order of PyOrder, rust/src/types.rs:17-31 */
+typedef struct bk_order {
+  uint8_t side_is_bid;
+  uint8_t status; /* 0 New, 1 Active, 2 Filled, 3 Cancelled, 4 Rejected (types.rs:65-75) */
+  uint8_t reserved[6];
+  uint64_t arr_time;
+  uint64_t end_time;
+  uint32_t vol;
+  uint32_t start_vol;
+  uint32_t price;
+  uint32_t trader_id;
+  uint64_t order_id;
+} bk_order;
+
+/* whole-shard market statistics, modelled on Market's array-valued queries
+ * (crates/order_book/src/market.rs:137-216); the unit all-gathered across GPUs (64 bytes) */
+typedef struct bk_stats {
+  uint64_t n_books;
+  uint64_t sum_trade_vol;  /* sum over books of the last step's trade volume */
+  uint64_t sum_trades;     /* cumulative trade count over books */
+  uint64_t sum_events;     /* cumulative processed events over books */
+  uint64_t sum_bid_vol, sum_ask_vol;
+  uint32_t min_bid, max_bid, min_ask, max_ask; /* over books with a non-empty side; 0xFFFFFFFF/0 if none */
+} bk_stats;
+
+const char* bk_last_error(void);
+int bk_device_count(int* out);
+
+/* ------------------------------------------------------------------ lifetime */
+int bk_env_create(const bk_config* cfg, bk_env** out);   /* Env::new, env.rs:84-95 (x B) */
+void bk_env_destroy(bk_env* env);
+int bk_env_set_stream(bk_env* env, void* hip_stream);    /* run on the caller's hipStream_t (NULL = default) */
+int bk_env_sync(bk_env* env);                            /* wait for queued device work */
+
+/* ------------------------------------------- host-driven order flow (per book) */
+/* Env::place_order, env.rs:166-176: tick check + id assignment now, New event queued for the next step */
+int bk_place_order(bk_env* env, uint32_t book, int bid, uint32_t vol, uint32_t trader_id, int has_price,
+                   uint32_t price, uint64_t* out_order_id);
+/* Env::cancel_order, env.rs:189-191 */
+int bk_cancel_order(bk_env* env, uint32_t book, uint64_t order_id);
+/* Env::modify_order, env.rs:208-219 */
+int bk_modify_order(bk_env* env, uint32_t book, uint64_t order_id, int has_price, uint32_t new_price, int has_vol,
+                    uint32_t new_vol);
+/* StepEnvNumpy.submit_instructions, rust/src/step_sim_numpy.rs:233-275: action 0 none / 1 new limit / 2 cancel.
+ * out_ids[i] = new id or UINT64_MAX.  Stops at the first bad price (earlier elements stay queued) and
+ * returns BK_PRICE_NOT_TICK_MULTIPLE with *n_done = index of the offending element. */
+int bk_submit_instructions(bk_env* env, uint32_t book, size_t n, const uint32_t* action, const uint8_t* side,
+                           const uint32_t* vol, const uint32_t* trader_id, const uint32_t* price,
+                           const uint64_t* order_id, uint64_t* out_ids, size_t* n_done);
+int bk_enable_trading(bk_env* env, int enabled);         /* Env::{enable,disable}_trading, env.rs:138-145 */
+/* Env::step, env.rs:116-135, for every book: shuffle + process the queued events, snapshot L2 */
+int bk_step(bk_env* env);
+/* Env::order_status / Env::order, env.rs:283-290 (needs max_orders > 0) */
+int bk_order_status(bk_env* env, uint32_t book, uint64_t order_id, uint8_t* out_status);
+int bk_order_count(bk_env* env, uint32_t book, uint64_t* out);
+int bk_get_orders(bk_env* env, uint32_t book, uint64_t first, uint64_t n, bk_order* out); /* Env::get_orders */
+
+/* ---------------------------------------------------- on-device order flow */
+/* An AgentSet of RandomAgents groups, identical for every book, updated in declaration order
+ * (crates/macros/src/lib.rs:57-73).  Sum of n_agents <= max_live_orders. */
+int bk_set_random_agents(bk_env* env, uint32_t n_groups, const bk_random_agents* groups);
+/* sim_runner's loop body n_steps times for every book: agents.update(env, rng); env.step(rng)
+ * (crates/step_sim/src/runner.rs:53-68), sharing each book's RNG between agents and shuffle. */
+int bk_run(bk_env* env, uint64_t n_steps);
+
+/* ------------------------------------------------------------------ readers */
+/* Level-2 record width in u32: 5 + 4*levels, laid out as StepEnvNumpy.level_2_data
+ * (rust/src/step_sim_numpy.rs:351-368): [trade_vol, bid_price, ask_price, ask_vol, bid_vol,
+ * {bid_vol_i, bid_n_i, ask_vol_i, ask_n_i} for i < levels]. */
+uint32_t bk_l2_width(const bk_env* env);
+/* Env::level_2_data (end-of-step snapshot) for books [first, first+n): out[n][width] */
+int bk_level2(bk_env* env, uint32_t first_book, uint32_t n_books, uint32_t* out);
+/* Level2DataRecords + trade_vols (data.rs:9-57, env.rs:64,134): out[n_steps][n_books][width] for retained steps */
+int bk_history_len(bk_env* env, uint64_t* first_step, uint64_t* n_steps);
+int bk_history(bk_env* env, uint64_t first_step, uint64_t n_steps, uint32_t first_book, uint32_t n_books,
+               uint32_t* out);
+int bk_clear_history(bk_env* env);
+/* OrderBook::get_trades, orderbook.rs:800-802 */
+int bk_trade_count(bk_env* env, uint32_t book, uint64_t* total, uint64_t* first_retained);
+int bk_trade_counts(bk_env* env, uint64_t* totals /* [n_books] */);
+int bk_get_trades(bk_env* env, uint32_t book, uint64_t first, uint64_t n, bk_trade* out);
+int bk_clear_trades(bk_env* env);
+int bk_time(bk_env* env, uint32_t book, uint64_t* out);          /* OrderBook::get_time */
+int bk_trade_vol(bk_env* env, uint32_t book, uint32_t* out);     /* OrderBook::get_trade_vol (live) */
+int bk_steps_done(bk_env* env, uint64_t* out);
+int bk_book_flags(bk_env* env, uint32_t* out /* [n_books] */);   /* sticky BK_FLAG_* bits */
+int bk_rng_state(bk_env* env, uint32_t book, uint64_t out_state[2]);
+/* resting (Active) orders of one book in price-time priority per side: bids first, then asks */
+int bk_live_orders(bk_env* env, uint32_t book, uint32_t cap, bk_order* out, uint32_t* n_out);
+
+/* ------------------------------------------------------ stats / multi-GPU */
+/* reduce this shard's books into one 64-byte record on the device; host copy returned */
+int bk_stats_compute(bk_env* env, bk_stats* out_host);
+/* device address of the 64-byte record (for an RCCL all-gather issued by the caller) */
+int bk_stats_device_ptr(bk_env* env, void** out);
+
+/* ------------------------------------------------------------- measurement */
+/* accumulate HIP-event timings of the step kernels launched on the env's stream */
+int bk_profile_enable(bk_env* env, int on);
+int bk_profile_read(bk_env* env, double* total_ms, uint64_t* n_launches, int reset);
+uint64_t bk_state_bytes_per_book(const bk_env* env);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BOURSE_AMD_H */

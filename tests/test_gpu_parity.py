@@ -1,0 +1,328 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle, bit-exact.
+
+Everything here needs a real MI355X (``-m gpu``).  Inputs are seeded identically on both
+sides: book b's RNG is ``seed_from_u64(seed + b)``; outputs compared: level-2 history
+(every step, every book), trade records (order, times, prices, vols, fill ids), RNG state,
+order/trade counts and the resting orders in priority order.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+C2_GROUPS = [(32, (40, 56), (10, 20), 2, 0.8), (32, (40, 56), (50, 70), 2, 0.2)]
+C3_GROUPS = [(64, (32, 64), (10, 20), 2, 0.8), (64, (32, 64), (50, 70), 2, 0.2)]
+C5_GROUPS = [(256, (100, 164), (10, 20), 2, 0.8), (256, (100, 164), (50, 70), 2, 0.2)]  # §8d C5 stand-in
+
+
+@pytest.fixture(scope="module")
+def bk():
+    import bourse_amd
+
+    return bourse_amd
+
+
+def test_dpp_reductions(bk):
+    import ctypes as C
+
+    L = bk._lib.load()
+    rng = np.random.default_rng(5)
+    n = 64
+    x = rng.integers(0, 2**32, size=(n, 64), dtype=np.uint32)
+    x[0] = 7
+    x[1] = np.arange(64)
+    x[2] = np.arange(64)[::-1]
+    x[3, 17] = 0
+    x[4, 63] = 2**32 - 1
+    out = np.zeros((n, 4), dtype=np.uint32)
+    bk._lib.check(L.bk_selftest_reduce(bk._lib.p32(x), n, bk._lib.p32(out)))
+    assert np.array_equal(out[:, 0], x.min(axis=1))
+    assert np.array_equal(out[:, 1], x.max(axis=1))
+    assert np.array_equal(out[:, 2], x.sum(axis=1, dtype=np.uint64).astype(np.uint32))
+    assert np.all(out[:, 3] == 32 * 1 + 32 * 2)
+
+
+def _compare_random(bk, oracle, n_books, groups, levels, n_steps, seed=101, tick=2, step_size=100_000, chunks=None,
+                    max_live=None, trade_cap=None):
+    n_agents = sum(g[0] for g in groups)
+    env = bk.ManyBookEnv(n_books, seed, 0, tick, step_size, True, levels=levels,
+                         max_live_orders=max_live or n_agents, trade_capacity=trade_cap or 2 * n_agents * n_steps,
+                         history_capacity=n_steps)
+    env.set_random_agents(groups)
+    for c in (chunks or [n_steps]):
+        env.run(c)
+    ref = oracle.ManyBooks(n_books, seed, 0, tick, step_size, True, levels, groups)
+    ref.run(n_steps, n_threads=4)
+
+    assert not env.flags().any(), f"device flags {np.unique(env.flags())}"
+    hist = env.history()
+    want = ref.history()
+    assert hist.shape == want.shape
+    if not np.array_equal(hist, want):
+        bad = np.argwhere(hist != want)[0]
+        raise AssertionError(f"L2 history differs first at (step, book, word) = {bad}: {hist[tuple(bad)]} vs {want[tuple(bad)]}")
+    assert np.array_equal(env.level2(), want[-1])
+    assert np.array_equal(env.trade_counts(), ref.trade_counts())
+    want_rng = ref.rng_states()
+    for b in range(n_books):
+        assert env.rng_state(b) == (int(want_rng[b, 0]), int(want_rng[b, 1])), f"rng state book {b}"
+        assert env.time(b) == n_steps * step_size
+    for b in sorted(set([0, 1, n_books // 2, n_books - 1])):
+        got = env.trades(b, first=0)
+        exp = ref.book(b).trades_array()
+        assert len(got) == len(exp)
+        for f in ("t", "side", "price", "vol", "active_id", "passive_id"):
+            assert np.array_equal(got[f], exp[f]), f"trade field {f} book {b}"
+        # resting orders, in price-time priority per side
+        live = env.live_orders(b)
+        o = ref.book(b).orders_array()
+        act = o[o["status"] == 1]
+        assert len(live) == len(act)
+        assert set(zip(live["order_id"].tolist(), live["price"].tolist(), live["vol"].tolist(), live["side"].tolist())) == \
+            set(zip(act["order_id"].tolist(), act["price"].tolist(), act["vol"].tolist(), act["side"].tolist()))
+        # priority order: bids by price desc then arrival, asks by price asc then arrival
+        key = {int(r["order_id"]): int(r["arr_time"]) for r in act}
+        for side in (1, 0):
+            ids = [int(r["order_id"]) for r in live if r["side"] == side]
+            prices = [int(r["price"]) for r in live if r["side"] == side]
+            srt = sorted(zip(prices, ids), key=lambda pi: ((-pi[0]) if side else pi[0], key[pi[1]]))
+            assert [i for _, i in srt] == ids
+    env.close()
+    return hist
+
+
+def test_random_agents_c2_shape(bk, oracle):
+    _compare_random(bk, oracle, n_books=96, groups=C2_GROUPS, levels=16, n_steps=40)
+
+
+def test_random_agents_c3_shape(bk, oracle):
+    _compare_random(bk, oracle, n_books=64, groups=C3_GROUPS, levels=32, n_steps=40)
+
+
+def test_random_agents_c5_shape_deep_book(bk, oracle):
+    _compare_random(bk, oracle, n_books=8, groups=C5_GROUPS, levels=64, n_steps=12)
+
+
+def test_random_agents_reference_bench_workload(bk, oracle):
+    # the reference's own divan bench parameters scaled down (crates/step_sim/benches/benchmarks.rs:14-23):
+    # env tick 1, agents tick 2, two groups with different windows; 10 L2 levels
+    groups = [(100, (40, 60), (10, 20), 2, 0.8), (100, (10, 90), (50, 70), 2, 0.2)]
+    _compare_random(bk, oracle, n_books=5, groups=groups, levels=10, n_steps=60, tick=1, step_size=1_000_000)
+
+
+def test_random_agents_edge_shapes(bk, oracle):
+    # single agent, odd counts, rate 0 and rate 1 groups, books not a multiple of the 4 waves per block
+    _compare_random(bk, oracle, n_books=3, groups=[(1, (10, 20), (20, 30), 1, 1.0)], levels=10, n_steps=25, tick=1,
+                    step_size=1000)
+    _compare_random(bk, oracle, n_books=7, groups=[(5, (10, 14), (1, 3), 3, 0.0), (37, (10, 14), (1, 3), 3, 1.0),
+                                                   (23, (9, 13), (1, 2), 6, 0.5)], levels=4, n_steps=50, tick=3)
+
+
+def test_chunked_launches_equal_one_launch(bk, oracle):
+    a = _compare_random(bk, oracle, n_books=16, groups=C2_GROUPS, levels=16, n_steps=30, chunks=[1, 2, 3, 24])
+    b = _compare_random(bk, oracle, n_books=16, groups=C2_GROUPS, levels=16, n_steps=30)
+    assert np.array_equal(a, b)
+
+
+def test_book_offset_sharding_is_seed_transparent(bk):
+    # books [4, 12) of a 16-book run equal an 8-book env created with book_offset=4 (multi-GPU sharding rule)
+    full = bk.ManyBookEnv(16, 101, 0, 2, 100_000, levels=16, max_live_orders=64, trade_capacity=4096, history_capacity=20)
+    full.set_random_agents(C2_GROUPS)
+    full.run(20)
+    part = bk.ManyBookEnv(8, 101, 0, 2, 100_000, levels=16, max_live_orders=64, trade_capacity=4096, history_capacity=20,
+                          book_offset=4)
+    part.set_random_agents(C2_GROUPS)
+    part.run(20)
+    assert np.array_equal(full.history()[:, 4:12], part.history())
+    s_full, s_part = full.stats(), part.stats()
+    assert s_part["n_books"] == 8 and s_full["n_books"] == 16
+    assert s_part["sum_trades"] == int(part.trade_counts().sum())
+
+
+def test_trade_capacity_overflow_is_flagged_not_silent(bk):
+    env = bk.ManyBookEnv(4, 101, 0, 2, 100_000, levels=16, max_live_orders=64, trade_capacity=8, history_capacity=30)
+    env.set_random_agents(C2_GROUPS)
+    env.run(30)
+    assert (env.flags() & 2).all()
+    total, base = env.trade_count(0)
+    assert total > 8 and base == 0
+    with pytest.raises(bk.CapacityError):
+        env.trades(0, first=0)
+    assert len(env.trades(0, first=0, n=8)) == 8
+    with pytest.raises(bk.CapacityError):
+        env.run(1)  # history buffer full: reported before launching
+
+
+# ------------------------------------------------------------------- host-driven path (C ABI Env methods)
+def test_kat_env_three_steps_on_gpu(bk):  # SURVEY C.11, ref crates/step_sim/src/env.rs:312-368
+    env = bk.core.StepEnv(101, 0, 1, 1000)
+    env.place_order(True, 10, 101, 10)
+    env.place_order(False, 20, 101, 20)
+    env.step()
+    assert env.bid_ask == (10, 20) and [env.order_status(i) for i in range(2)] == [1, 1] and env.time == 1000
+    env.place_order(True, 10, 101, 11)
+    env.place_order(False, 20, 101, 21)
+    env.step()
+    assert env.bid_ask == (11, 20) and env.time == 2000
+    env.place_order(True, 30, 101, None)
+    env.step()
+    assert env.bid_ask == (11, 21) and env.ask_vol == 10 and env.time == 3000
+    assert env.order_status(1) == 2 and env.order_status(4) == 2 and len(env.get_trades()) == 2
+    bids, asks = env.get_prices()
+    assert bids.tolist() == [10, 11, 11] and asks.tolist() == [20, 20, 21]
+    bv, av = env.get_volumes()
+    assert bv.tolist() == [10, 20, 20] and av.tolist() == [20, 40, 10]
+    tb, ta = env.get_touch_volumes()
+    assert tb.tolist() == [10, 10, 10] and ta.tolist() == [20, 20, 10]
+    cb, ca = env.get_touch_order_counts()
+    assert cb.tolist() == [1, 1, 1] and ca.tolist() == [1, 1, 1]
+    assert env.get_trade_volumes().tolist() == [0, 0, 30]
+
+
+def test_kat_python_step_env_on_gpu(bk):  # SURVEY C.12, ref tests/test_step_sim/test_env.py:7-115
+    env = bk.core.StepEnv(101, 0, 1, 100_000)
+    env.place_order(True, 100, 101, price=50)
+    env.place_order(False, 100, 101, price=60)
+    env.step()
+    assert env.bid_ask == (50, 60) and (env.ask_vol, env.bid_vol, env.time) == (100, 100, 100_000)
+    env.place_order(True, 100, 101, price=55)
+    env.place_order(False, 100, 101, price=65)
+    env.step()
+    assert env.bid_ask == (55, 60) and (env.ask_vol, env.bid_vol, env.time) == (200, 200, 200_000)
+    env.place_order(True, 150, 101)
+    env.step()
+    assert env.bid_ask == (55, 65) and (env.ask_vol, env.bid_vol, env.time) == (50, 200, 300_000)
+    env.step()
+    d = env.get_market_data()
+    assert len(d) == 45
+    assert d["bid_price"].tolist() == [50, 55, 55, 55] and d["ask_price"].tolist() == [60, 60, 65, 65]
+    assert d["bid_vol"].tolist() == [100, 200, 200, 200] and d["ask_vol"].tolist() == [100, 200, 50, 50]
+    assert d["bid_vol_0"].tolist() == [100] * 4 and d["ask_vol_0"].tolist() == [100, 100, 50, 50]
+    assert d["n_bid_0"].tolist() == [1] * 4 and d["n_ask_0"].tolist() == [1] * 4
+    assert d["trade_vol"].tolist() == [0, 0, 150, 0]
+    bad = bk.core.StepEnv(101, 0, 2, 100_000)
+    with pytest.raises(ValueError, match="Price 21 was not a multiple of tick-size 2"):
+        bad.place_order(True, 100, 101, price=21)
+
+
+def test_kat_numpy_api_on_gpu(bk):  # SURVEY C.13, ref tests/test_step_sim/test_numpy_api.py:7-71
+    env = bk.core.StepEnvNumpy(101, 0, 1, 100_000)
+    sides = np.array([True, True, True, False, False, False])
+    vols = np.array([10, 11, 12, 10, 11, 12], dtype=np.uint32)
+    tr = np.array([1, 1, 1, 2, 2, 2], dtype=np.uint32)
+    prices = np.array([20, 20, 19, 22, 22, 23], dtype=np.uint32)
+    ids = env.submit_limit_orders((sides, vols, tr, prices))
+    env.step()
+    assert ids.tolist() == list(range(6))
+    assert env.level_1_data().tolist() == [0, 20, 22, 33, 33, 21, 2, 21, 2]
+    l2 = env.level_2_data()
+    assert l2.shape == (45,) and l2[:13].tolist() == [0, 20, 22, 33, 33, 21, 2, 21, 2, 12, 1, 12, 1] and not l2[13:].any()
+    env.submit_cancellations(np.array([0, 1, 3, 4], dtype=np.uint64))
+    env.step()
+    l1 = env.level_1_data()
+    assert (l1[1], l1[2]) == (19, 23) and (l1[5], l1[6]) == (12, 1) and (l1[7], l1[8]) == (12, 1)
+    bad = bk.core.StepEnvNumpy(101, 0, 2, 100_000)
+    with pytest.raises(ValueError):
+        bad.submit_limit_orders((sides[:2], vols[:2], tr[:2], np.array([20, 21], dtype=np.uint32)))
+
+
+def test_runner_with_deterministic_agents_on_gpu(bk):  # ref tests/test_step_sim/test_env.py:118-145, test_numpy_api.py:85-120
+    class A(bk.step_sim.agents.BaseAgent):
+        def __init__(self, side, start):
+            self.side, self.start, self.k = side, start, 0
+
+        def update(self, _rng, env):
+            env.place_order(self.side, 10, 101, price=self.start + self.k if self.side else self.start - self.k)
+            self.k += 1
+
+    data = bk.step_sim.run(bk.core.StepEnv(101, 0, 1, 100_000), [A(True, 10), A(False, 50)], 10, 101, show_progress=False)
+    assert data["bid_price"].tolist() == list(range(10, 20)) and data["ask_price"].tolist() == list(range(50, 40, -1))
+    assert data["bid_vol"].tolist() == [10 * k for k in range(1, 11)] and data["ask_vol"].tolist() == [10 * k for k in range(1, 11)]
+    assert data["bid_vol_0"].tolist() == [10] * 10 and data["trade_vol"].tolist() == [0] * 10
+
+    class N(bk.step_sim.agents.BaseNumpyAgent):
+        def __init__(self, side, start):
+            self.side, self.start, self.k = side, start, 0
+
+        def update(self, _rng, _l2):
+            p = self.start + self.k if self.side else self.start - self.k
+            self.k += 1
+            return (np.array([1], dtype=np.uint32), np.array([self.side]), np.array([10], dtype=np.uint32),
+                    np.array([101], dtype=np.uint32), np.array([p], dtype=np.uint32), np.array([0], dtype=np.uint64))
+
+    data = bk.step_sim.run(bk.core.StepEnvNumpy(101, 0, 1, 100_000), [N(True, 10), N(False, 50)], 10, 101,
+                           show_progress=False, use_numpy=True)
+    assert data["bid_price"].tolist() == list(range(10, 20)) and data["ask_price"].tolist() == list(range(50, 40, -1))
+
+
+def _random_host_stream(env_gpu, env_ref, seed, n_steps, n_traders=24, tick=2, with_modify=True):
+    """Drive both envs with the same pseudo-random mix of limit/market/cancel/modify instructions."""
+    rng = np.random.default_rng(seed)
+    ids = []
+    for _ in range(n_steps):
+        for _k in range(int(rng.integers(0, n_traders))):
+            u = rng.random()
+            if u < 0.55 or not ids:
+                side = bool(rng.integers(0, 2))
+                vol = int(rng.integers(0, 40))  # includes zero-volume orders (App. A quirk)
+                price = None if rng.random() < 0.1 else int(rng.integers(40, 60)) * tick
+                a = env_gpu.place_order(side, vol, 7, price)
+                b = env_ref.place_order(side, vol, 7, price)
+                assert a == b
+                ids.append(a)
+            elif u < 0.8:
+                i = int(rng.choice(ids))
+                env_gpu.cancel_order(i)
+                env_ref.cancel_order(i)
+            elif with_modify:
+                i = int(rng.choice(ids))
+                np_ = None if rng.random() < 0.4 else int(rng.integers(40, 60)) * tick
+                nv = None if rng.random() < 0.3 else int(rng.integers(0, 50))
+                env_gpu.modify_order(i, np_, nv)
+                env_ref.modify_order(i, np_, nv)
+        if rng.random() < 0.05:
+            env_gpu.disable_trading()
+            env_ref.disable_trading()
+        elif rng.random() < 0.3:
+            env_gpu.enable_trading()
+            env_ref.enable_trading()
+        env_gpu.step()
+        env_ref.step()
+        assert np.array_equal(env_gpu.level_2_data_array(), env_ref.level_2_data_array())
+    return ids
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_host_driven_random_stream_matches_oracle(bk, oracle, seed):
+    g = bk.core.StepEnv(seed, 0, 2, 100_000)
+    r = oracle.StepEnv(seed, 0, 2, 100_000)
+    _random_host_stream(g, r, seed, n_steps=60)
+    assert g.get_trades() == r.get_trades()
+    assert g.get_orders() == r.get_orders()
+    dg, dr = g.get_market_data(), r.get_market_data()
+    assert set(dg) == set(dr)
+    for k in dr:
+        assert np.array_equal(dg[k], dr[k]), k
+    assert g._env.rng_state(0) == tuple(int(x) for x in r.rng_state())
+
+
+def test_c1_random_trades_plumbing_on_gpu(bk, oracle):
+    # BASELINE config 1: examples/random_trades.py run(101, 200, 50) — Python RandomAgents over StepEnv
+    def agents(mod):
+        return [mod.RandomAgent(i, 0.5, (10, 100), (20, 50), 2) for i in range(50)]
+
+    g = bk.core.StepEnv(101, 0, 2, 100_000)
+    dg = bk.step_sim.run(g, agents(bk.step_sim.agents), 200, 101, show_progress=False)
+    # same agents over the oracle env (duck-typed: the agent only calls order_status/cancel/place)
+    r = oracle.StepEnv(101, 0, 2, 100_000)
+    rng = np.random.default_rng(101)
+    ags = agents(bk.step_sim.agents)
+    for _ in range(200):
+        for a in ags:
+            a.update(rng, r)
+        r.step()
+    dr = r.get_market_data()
+    for k in dr:
+        assert np.array_equal(dg[k], dr[k]), k
+    assert g.get_trades() == r.get_trades()
+    assert g.get_orders() == r.get_orders()
