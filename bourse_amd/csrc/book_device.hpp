@@ -576,7 +576,8 @@ __global__ __launch_bounds__(256) void k_run_random(DevArgs a, uint64_t first_st
             const uint64_t bit = 1ull << l;
             if (!(B.live[r] & bit)) {
               // no Active order held: place a new one.  Draw order: side, tick, vol (:99-101)
-              const uint32_t side = rng.below(2u, 0xFFFFFFFFu);  // [Ask, Bid].choose: 0 = Ask, 1 = Bid
+              // [Ask, Bid].choose -> gen_range(0..2): zone = (2 << 30) - 1, i.e. half the draws are rejected
+              const uint32_t side = rng.below(2u, 0x7FFFFFFFu);  // 0 = Ask, 1 = Bid
               const uint32_t tick = G.tick_lo + rng.below(G.tick_rng, G.tick_zone);
               const uint32_t vol = G.vol_lo + rng.below(G.vol_rng, G.vol_zone);
               B.price[r] = wrl(tick * G.tick_size, l, B.price[r]);
