@@ -20,6 +20,9 @@
 using namespace bkd;
 
 static_assert(sizeof(DevStats) == sizeof(bk_stats), "bk_stats layout");
+static_assert(sizeof(bk_config) == 72 && sizeof(bk_random_agents) == 28 && sizeof(bk_trade) == 40 &&
+                  sizeof(bk_order) == 48,
+              "C ABI struct layout (mirrored by bourse_amd/_lib.py)");
 static_assert(sizeof(DevTrade) == 32 && sizeof(DevOrderLog) == 32, "device record layout");
 
 namespace {

@@ -326,3 +326,100 @@ def test_c1_random_trades_plumbing_on_gpu(bk, oracle):
         assert np.array_equal(dg[k], dr[k]), k
     assert g.get_trades() == r.get_trades()
     assert g.get_orders() == r.get_orders()
+
+
+# ------------------------------------------------------------------- committed golden fixtures (no oracle needed)
+def _golden(name):
+    import os
+
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name))
+
+
+def test_golden_c1_instruction_stream_on_gpu(bk):
+    """Replay the instruction stream the REFERENCE's Python RandomAgents emitted (examples/random_trades.py,
+    run(101, 200, 50)) through the GPU StepEnv; outputs must equal the committed fixture."""
+    fx = _golden("c1_random_trades.npz")
+    env = bk.core.StepEnv(101, 0, 2, 100_000)
+    ins = fx["instructions"]
+    k = 0
+    for s in range(200):
+        while k < len(ins) and ins[k, 0] == s:
+            _, action, bid, vol, trader, price, oid = (int(x) for x in ins[k])
+            if action == 1:
+                assert env.place_order(bool(bid), vol, trader, price=price) == oid
+            else:
+                env.cancel_order(oid)
+            k += 1
+        env.step()
+    assert k == len(ins)
+    md = env.get_market_data()
+    for key, v in md.items():
+        assert np.array_equal(v, fx[f"md_{key}"]), key
+    assert np.array_equal(np.array(env.get_trades(), dtype=np.uint64), fx["trades"])
+    assert np.array_equal(np.array(env.get_orders(), dtype=np.uint64), fx["orders"])
+
+
+def test_golden_numpy_agents_on_gpu(bk):
+    fx = _golden("numpy_random_agents.npz")
+    env = bk.core.StepEnvNumpy(101, 0, 2, 100_000)
+    for s in range(40):
+        i = fx["instructions"][s]
+        ids = env.submit_instructions((i[0].astype(np.uint32), i[1].astype(bool), i[2].astype(np.uint32),
+                                       i[3].astype(np.uint32), i[4].astype(np.uint32), i[5]))
+        assert ids.tolist() == list(range(30 * s, 30 * s + 30))
+        env.step()
+    for key, v in env.get_market_data().items():
+        assert np.array_equal(v, fx[f"md_{key}"]), key
+    assert np.array_equal(np.array(env.get_trades(), dtype=np.uint64), fx["trades"])
+
+
+def test_golden_on_device_random_agents(bk):
+    fx = _golden("oracle_random_agents_c2x4.npz")
+    env = bk.ManyBookEnv(4, 101, 0, 2, 100_000, levels=16, max_live_orders=64, trade_capacity=4096, history_capacity=25)
+    env.set_random_agents(C2_GROUPS)
+    env.run(25)
+    assert np.array_equal(env.history(), fx["history"])
+    assert np.array_equal(env.trade_counts(), fx["trade_counts"])
+    assert [env.rng_state(b) for b in range(4)] == [tuple(int(x) for x in r) for r in fx["rng"]]
+    t = env.trades(0, first=0)
+    for f in t.dtype.names:
+        assert np.array_equal(t[f], fx["trades0"][f])
+
+
+# ------------------------------------------------------------------- full-size structural properties (headline shape)
+def test_full_size_invariants_c3(bk):
+    """65 536 books x 128 agents x 32 levels: properties that need no oracle at this size."""
+    B, T = 65536, 12
+    env = bk.ManyBookEnv(B, 101, 0, 2, 100_000, levels=32, max_live_orders=128, trade_capacity=128 * T, history_capacity=T)
+    env.set_random_agents(C3_GROUPS)
+    env.run(T)
+    assert not env.flags().any()
+    h = env.history()                                  # [T, B, 133]
+    lv = h[:, :, 5:].reshape(T, B, 32, 4)
+    # touch level is never empty on a non-empty side; level sums never exceed the side total
+    assert np.all((h[:, :, 4] == 0) == (lv[:, :, 0, 1] == 0))
+    assert np.all((h[:, :, 3] == 0) == (lv[:, :, 0, 3] == 0))
+    assert np.all(lv[:, :, :, 0].sum(axis=2) <= h[:, :, 4]) and np.all(lv[:, :, :, 2].sum(axis=2) <= h[:, :, 3])
+    # with a 32-tick price window and 32 levels/side the ladder is exact: level sums EQUAL the side totals
+    assert np.array_equal(lv[:, :, :, 0].sum(axis=2), h[:, :, 4]) and np.array_equal(lv[:, :, :, 2].sum(axis=2), h[:, :, 3])
+    # an uncrossed book after every step; prices inside the agents' window
+    both = (h[:, :, 4] > 0) & (h[:, :, 3] > 0)
+    assert np.all(h[:, :, 1][both] < h[:, :, 2][both])
+    assert np.all(h[:, :, 1][h[:, :, 4] > 0] >= 64) and np.all(h[:, :, 2][h[:, :, 3] > 0] < 128)
+    # per-step trade volume equals the sum of that step's trade records (checksum of checksums), sampled books
+    tc = env.trade_counts()
+    for b in (0, 1, 4097, 32768, 65535):
+        tr = env.trades(b, first=0)
+        assert len(tr) == tc[b]
+        step = (tr["t"] // 100_000).astype(np.int64)
+        vol_by_step = np.bincount(step, weights=tr["vol"].astype(np.float64), minlength=T)[:T]
+        assert np.array_equal(vol_by_step.astype(np.uint32), h[:, b, 0])
+        assert np.all(np.diff(tr["t"].astype(np.int64)) >= 0)          # records in processing order
+        assert np.all(tr["active_id"] != tr["passive_id"])
+    # books 0..63 equal a small run (independence of the batch size)
+    small = bk.ManyBookEnv(64, 101, 0, 2, 100_000, levels=32, max_live_orders=128, trade_capacity=128 * T, history_capacity=T)
+    small.set_random_agents(C3_GROUPS)
+    small.run(T)
+    assert np.array_equal(small.history(), h[:, :64])
+    st = env.stats()
+    assert st["n_books"] == B and st["sum_trades"] == int(tc.sum()) and st["sum_trade_vol"] == int(h[-1, :, 0].sum())
