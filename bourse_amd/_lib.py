@@ -105,6 +105,8 @@ SIGNATURES = {
     "bk_stats_device_ptr": (_i32, [_vp, C.POINTER(_vp)]),
     "bk_profile_enable": (_i32, [_vp, _i32]),
     "bk_profile_read": (_i32, [_vp, C.POINTER(C.c_double), _p64, _i32]),
+    "bk_profile_read_kind": (_i32, [_vp, _i32, C.POINTER(C.c_double), _p64]),
+    "bk_set_pipeline": (_i32, [_vp, _i32]),
     "bk_state_bytes_per_book": (_u64, [_vp]),
 }
 

@@ -29,6 +29,7 @@ enum Hdr : int {
   H_NEXT_ID, H_SEQ, H_TRADES_LO, H_TRADES_HI, H_FLAGS, H_TRADING,
   H_STEPS_LO, H_STEPS_HI, H_EVENTS_LO, H_EVENTS_HI, H_TRADE_VOL,
   H_TRADE_BASE_LO, H_TRADE_BASE_HI, H_LAST_NTRADES, H_LAST_NEVENTS,
+  H_LIVE0 = 32,  // live masks of the pool: dwords 32 + 2r (lo), 33 + 2r (hi), r < 8 (read by k_agents_fsm)
 };
 constexpr int POOL_FIELDS = 5;  // price, vol, id, seq, meta(bit0 live, bit1 bid)
 constexpr int MAX_GROUPS = 8;
@@ -73,8 +74,15 @@ struct DevArgs {
   const uint32_t* ev_id;
   const uint32_t* ev_price;
   const uint32_t* ev_vol;
+  // split pipeline: per-book step batch written by k_agents_fsm, consumed by k_step_batch
+  uint32_t* batch;
+  uint32_t batch_stride;  // dwords per book: 64 + 160 * R
+  uint32_t pad0;
   Group groups[MAX_GROUPS];
 };
+// step batch layout (dwords): [0] n_ev; [8+2r, 9+2r] placing-agents mask r; [24+2r, 25+2r] bid mask of the
+// placements; [64, 64+32R) shuffled event list (u16 agent indices); then uint2 {price, vol} per agent slot.
+constexpr int BT_NEV = 0, BT_PEND = 8, BT_SIDE = 24, BT_EV = 64;
 
 // ----------------------------------------------------------------------------------
 // wave primitives
@@ -514,6 +522,11 @@ __device__ __forceinline__ void store_book(const Book<R>& B, const Rng& rng, uin
   put(H_TRADE_VOL, B.trade_vol);
   put(H_LAST_NTRADES, last_ntrades);
   put(H_LAST_NEVENTS, last_nevents);
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    put(H_LIVE0 + 2 * r, (uint32_t)B.live[r]);
+    put(H_LIVE0 + 2 * r + 1, (uint32_t)(B.live[r] >> 32));
+  }
   st[lane] = hdr;
 #pragma unroll
   for (int r = 0; r < R; ++r) {
@@ -524,6 +537,37 @@ __device__ __forceinline__ void store_book(const Book<R>& B, const Rng& rng, uin
     p[3 * 64 + lane] = B.seq[r];
     p[4 * 64 + lane] = (lane_bit(B.live[r]) ? 1u : 0u) | (lane_bit(B.bid[r]) ? 2u : 0u);
   }
+}
+
+// ----------------------------------------------------------------------------------
+// Env::step body after the shuffle (env.rs:117-134): process the (already shuffled) event list of
+// agent/slot indices, advance the clock, snapshot, flush trades.  Returns this step's trade count.
+// An event is a New if the slot's pend bit is set, else a Cancellation of the slot's order.
+// ----------------------------------------------------------------------------------
+template <int R>
+__device__ __forceinline__ uint32_t step_from_list(Book<R>& B, const DevArgs& a, uint32_t book, int lane,
+                                                   const uint32_t (&ev)[R], uint32_t n_ev, uint32_t* bins,
+                                                   uint64_t step_index, bool write_last) {
+  const uint64_t step_size = mk64(a.step_lo, a.step_hi);
+  const uint64_t t0 = B.t;
+  B.trade_vol = 0;  // reset_trade_vol (env.rs:118)
+  const uint64_t trades_before = B.n_trades;
+  if ((uint64_t)n_ev >= step_size) B.flags |= FLAG_STEP_SIZE;
+  for (uint32_t k = 0; k < n_ev; ++k) {  // events at t0 + k (env.rs:123-127)
+    const uint32_t n = slot_read<R>(ev, k);
+    if (mask_test<R>(B.pend, n)) {
+      process_new_in_slot<R>(B, a, book, t0, lane, k, n);
+    } else {
+      mask_set<R>(B.live, n, false);  // cancel_order (orderbook.rs:622-644); no-op if filled meanwhile
+    }
+  }
+  B.n_events += n_ev;
+  B.t = t0 + step_size;  // env.rs:129
+  // env.rs:132-134.  Env::level_2_data (the "latest" record) only needs a launch's final snapshot;
+  // with no history buffer every step's record is written there.
+  snapshot<R>(B, a, book, lane, bins, step_index, B.flags, write_last);
+  flush_trades<R>(B, a, book, t0, lane);
+  return (uint32_t)(B.n_trades - trades_before);
 }
 
 constexpr int LDS_DW_PER_WAVE = 4 * 64;  // level bins: 4 * levels dwords, levels <= 64
@@ -546,7 +590,6 @@ __global__ __launch_bounds__(256) void k_run_random(DevArgs a, uint64_t first_st
   Book<R> B;
   Rng rng;
   load_book<R>(B, rng, st, lane);
-  const uint64_t step_size = mk64(a.step_lo, a.step_hi);
   uint32_t last_ntr = 0, last_nev = 0;
   uint32_t ev[R];  // this step's event list: entry k (lane k & 63 of ev[k >> 6]) = agent/slot index
 #pragma unroll
@@ -594,10 +637,6 @@ __global__ __launch_bounds__(256) void k_run_random(DevArgs a, uint64_t first_st
       }
     }
     // ---------------- Env::step -----------------------------------------------------
-    const uint64_t t0 = B.t;
-    B.trade_vol = 0;  // reset_trade_vol (env.rs:118)
-    const uint64_t trades_before = B.n_trades;
-    if ((uint64_t)n_ev >= step_size) B.flags |= FLAG_STEP_SIZE;
     // transactions.shuffle(rng) (env.rs:121; App. B.4)
     for (uint32_t i = n_ev; i-- > 1;) {
       const uint32_t j = rng.below(i + 1);
@@ -605,25 +644,207 @@ __global__ __launch_bounds__(256) void k_run_random(DevArgs a, uint64_t first_st
       slot_write<R>(ev, i, aj);
       slot_write<R>(ev, j, ai);
     }
-    // process events at t0 + k (env.rs:123-127)
-    for (uint32_t k = 0; k < n_ev; ++k) {
-      const uint32_t n = slot_read<R>(ev, k);
-      if (mask_test<R>(B.pend, n)) {
-        process_new_in_slot<R>(B, a, book, t0, lane, k, n);
-      } else {
-        mask_set<R>(B.live, n, false);  // cancel_order (orderbook.rs:622-644); no-op if filled meanwhile
-      }
-    }
-    B.n_events += n_ev;
-    B.t = t0 + step_size;  // env.rs:129
-    // env.rs:132-134.  Env::level_2_data (the "latest" record) only needs the launch's final snapshot;
-    // with no history buffer every step's record is written there.
-    snapshot<R>(B, a, book, lane, bins, first_step + s, B.flags, s + 1 == n_steps || a.hist_cap == 0);
-    flush_trades<R>(B, a, book, t0, lane);
-    last_ntr = (uint32_t)(B.n_trades - trades_before);
+    last_ntr = step_from_list<R>(B, a, book, lane, ev, n_ev, bins, first_step + s,
+                                 s + 1 == n_steps || a.hist_cap == 0);
     last_nev = n_ev;
   }
   store_book<R>(B, rng, st, lane, first_step + n_steps, last_ntr, last_nev);
+}
+
+// ==================================================================================
+// Split pipeline for large batches (the RNG-serial phases dominate the fused kernel's SALU issue):
+//
+//   k_agents_fsm<R>  ONE LANE PER BOOK (64 books per wave).  RandomAgents::update for every group
+//                    (random_agent.rs:85-119) + the Fisher-Yates shuffle of Env::step (env.rs:121), i.e.
+//                    everything that consumes the book's RNG stream, as a per-lane state machine in which
+//                    every iteration performs exactly one next_u32() draw - lanes never wait for each
+//                    other's rejection loops.  Emits a per-book "step batch" (event list + new orders).
+//   k_step_batch<R>  ONE WAVE PER BOOK.  Applies the batch to the register-resident pool and runs the
+//                    event loop / snapshot of Env::step (env.rs:117-134) exactly as the fused kernel.
+// ==================================================================================
+enum Phase : uint32_t { PH_ACT = 0, PH_SIDE = 1, PH_TICK = 2, PH_VOL = 3, PH_SHUF = 4, PH_DONE = 5 };
+constexpr int G_DW = sizeof(Group) / 4;  // dwords per group row in the LDS parameter table
+
+template <int R>
+__global__ __launch_bounds__(64) void k_agents_fsm(DevArgs a) {
+  __shared__ uint16_t list[64 * R * 64];  // event list of lane l: list[k * 64 + l]
+  __shared__ uint32_t gtab[MAX_GROUPS * G_DW];
+  const int lane = threadIdx.x;
+  {
+    const uint32_t* gp = reinterpret_cast<const uint32_t*>(a.groups);
+    for (int i = lane; i < MAX_GROUPS * G_DW; i += 64) gtab[i] = gp[i];
+  }
+  __syncthreads();
+  const uint32_t b = blockIdx.x * 64 + lane;
+  if (b >= a.n_books) return;
+  uint32_t* st = a.state + (size_t)b * a.state_stride;
+  uint32_t* bt = a.batch + (size_t)b * a.batch_stride;
+  const uint32_t total = a.n_agents_total;
+
+  Rng rng;
+  {
+    const uint2 x0 = *reinterpret_cast<const uint2*>(st + H_S0_LO);
+    const uint2 x1 = *reinterpret_cast<const uint2*>(st + H_S1_LO);
+    rng.s0 = mk64(x0.x, x0.y);
+    rng.s1 = mk64(x1.x, x1.y);
+  }
+  uint64_t live[R], pend[R], sidem[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const uint2 x = *reinterpret_cast<const uint2*>(st + H_LIVE0 + 2 * r);
+    live[r] = mk64(x.x, x.y);
+    pend[r] = 0;
+    sidem[r] = 0;
+  }
+  uint2* pv = reinterpret_cast<uint2*>(bt + BT_EV + 32 * R);
+
+  auto gfield = [&](uint32_t g, int f) { return gtab[g * G_DW + f]; };
+  // Group dword fields: 0 n, 1 thr, 2 tick_lo, 3 tick_rng, 4 tick_zone, 5 vol_lo, 6 vol_rng, 7 vol_zone, 8 tick_size
+  uint32_t n = 0, g = 0, gend = 0, thr = 0, n_ev = 0;
+  uint32_t phase = PH_DONE, range = 0, zone = 0, shuf_i = 0, cur_side = 0, cur_price = 0;
+  if (total > 0) {
+    gend = gfield(0, 0);
+    while (n >= gend) {
+      ++g;
+      gend += gfield(g, 0);
+    }
+    thr = gfield(g, 1);
+    phase = PH_ACT;
+  }
+  auto advance = [&]() {  // next agent, or start the shuffle once every agent has been visited
+    ++n;
+    if (n >= total) {
+      if (n_ev >= 2) {
+        phase = PH_SHUF;
+        shuf_i = n_ev - 1;
+        range = n_ev;
+        zone = (range << __builtin_clz(range)) - 1u;
+      } else {
+        phase = PH_DONE;
+      }
+    } else {
+      while (n >= gend) {
+        ++g;
+        gend += gfield(g, 0);
+      }
+      thr = gfield(g, 1);
+      phase = PH_ACT;
+    }
+  };
+
+  while (phase != PH_DONE) {
+    const uint32_t x = rng.next_u32();  // exactly one draw per iteration, whatever the phase
+    if (phase == PH_ACT) {
+      if ((x >> 8) < thr) {  // p = gen::<f32>() < activity_rate (random_agent.rs:91-93)
+        list[n_ev * 64 + lane] = (uint16_t)n;
+        ++n_ev;
+        uint64_t w = live[0];
+#pragma unroll
+        for (int r = 1; r < R; ++r) w = ((n >> 6) == (uint32_t)r) ? live[r] : w;
+        if ((w >> (n & 63)) & 1ull) {
+          advance();  // holds an Active order: its cancellation is queued (:95-97)
+        } else {
+          phase = PH_SIDE;  // [Ask, Bid].choose -> gen_range(0..2)
+          range = 2u;
+          zone = 0x7FFFFFFFu;
+        }
+      } else {
+        advance();
+      }
+    } else {
+      // UniformInt<u32>::sample_single step: accept iff lo(x * range) <= zone
+      const uint64_t m = (uint64_t)x * range;
+      if ((uint32_t)m <= zone) {
+        const uint32_t val = (uint32_t)(m >> 32);
+        if (phase == PH_SIDE) {
+          cur_side = val;  // 0 = Ask, 1 = Bid
+          phase = PH_TICK;
+          range = gfield(g, 3);
+          zone = gfield(g, 4);
+        } else if (phase == PH_TICK) {
+          cur_price = (gfield(g, 2) + val) * gfield(g, 8);
+          phase = PH_VOL;
+          range = gfield(g, 6);
+          zone = gfield(g, 7);
+        } else if (phase == PH_VOL) {
+          pv[n] = make_uint2(cur_price, gfield(g, 5) + val);
+          const uint64_t bit = 1ull << (n & 63);
+#pragma unroll
+          for (int r = 0; r < R; ++r) {
+            if ((n >> 6) == (uint32_t)r) {
+              pend[r] |= bit;
+              if (cur_side) sidem[r] |= bit;
+            }
+          }
+          advance();
+        } else {  // PH_SHUF: swap(i, j), j = val in [0, i]  (rand SliceRandom::shuffle)
+          const uint16_t ai = list[shuf_i * 64 + lane], aj = list[val * 64 + lane];
+          list[shuf_i * 64 + lane] = aj;
+          list[val * 64 + lane] = ai;
+          --shuf_i;
+          if (shuf_i == 0) {
+            phase = PH_DONE;
+          } else {
+            range = shuf_i + 1;
+            zone = (range << __builtin_clz(range)) - 1u;
+          }
+        }
+      }
+    }
+  }
+
+  // publish: RNG state back to the book header, the step batch for k_step_batch
+  *reinterpret_cast<uint2*>(st + H_S0_LO) = make_uint2((uint32_t)rng.s0, (uint32_t)(rng.s0 >> 32));
+  *reinterpret_cast<uint2*>(st + H_S1_LO) = make_uint2((uint32_t)rng.s1, (uint32_t)(rng.s1 >> 32));
+  bt[BT_NEV] = n_ev;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    *reinterpret_cast<uint2*>(bt + BT_PEND + 2 * r) = make_uint2((uint32_t)pend[r], (uint32_t)(pend[r] >> 32));
+    *reinterpret_cast<uint2*>(bt + BT_SIDE + 2 * r) = make_uint2((uint32_t)sidem[r], (uint32_t)(sidem[r] >> 32));
+  }
+  for (uint32_t k = 0; k < n_ev; k += 2) {
+    const uint32_t lo = list[k * 64 + lane];
+    const uint32_t hi = (k + 1 < n_ev) ? list[(k + 1) * 64 + lane] : 0u;
+    bt[BT_EV + (k >> 1)] = lo | (hi << 16);
+  }
+}
+
+template <int R>
+__global__ __launch_bounds__(256) void k_step_batch(DevArgs a, uint64_t step_index, uint32_t write_last) {
+  __shared__ uint32_t lds[4][LDS_DW_PER_WAVE];
+  const int lane = threadIdx.x & 63;
+  const int wv = threadIdx.x >> 6;
+  const uint32_t book = rfl(blockIdx.x * 4 + wv);
+  if (book >= a.n_books) return;
+  uint32_t* st = a.state + (size_t)book * a.state_stride;
+  const uint32_t* bt = a.batch + (size_t)book * a.batch_stride;
+
+  Book<R> B;
+  Rng rng;
+  load_book<R>(B, rng, st, lane);
+  // the step batch: header words, event list (u16), new-order {price, vol} per agent slot
+  const uint32_t bh = bt[lane];
+  const uint32_t n_ev = rdl(bh, BT_NEV);
+  uint32_t ev[R];
+  uint32_t base = B.next_id;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const uint64_t pend = mk64(rdl(bh, BT_PEND + 2 * r), rdl(bh, BT_PEND + 2 * r + 1));
+    const uint64_t side = mk64(rdl(bh, BT_SIDE + 2 * r), rdl(bh, BT_SIDE + 2 * r + 1));
+    ev[r] = reinterpret_cast<const uint16_t*>(bt + BT_EV)[r * 64 + lane];
+    const uint2 pv = reinterpret_cast<const uint2*>(bt + BT_EV + 32 * R)[r * 64 + lane];
+    B.price[r] = sel(pend, pv.x, B.price[r]);
+    B.vol[r] = sel(pend, pv.y, B.vol[r]);
+    // create_order ids: dense, in agent order (orderbook.rs:363): base + #placing agents below this slot
+    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(pend >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pend, 0u));
+    B.id[r] = sel(pend, base + rank, B.id[r]);
+    base += __builtin_popcountll(pend);
+    B.bid[r] = (B.bid[r] & ~pend) | (side & pend);
+    B.pend[r] = pend;
+  }
+  B.next_id = base;
+  const uint32_t ntr = step_from_list<R>(B, a, book, lane, ev, n_ev, lds[wv], step_index, write_last != 0);
+  store_book<R>(B, rng, st, lane, step_index + 1, ntr, n_ev);
 }
 
 // ==================================================================================

@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -105,7 +106,9 @@ struct bk_env {
   int R = 1;
   uint32_t W = 0, stride = 0;
   hipStream_t stream = nullptr;
-  DevBuf<uint32_t> state, l2_last, hist, ev_off, ev_word, ev_id, ev_price, ev_vol;
+  DevBuf<uint32_t> state, l2_last, hist, ev_off, ev_word, ev_id, ev_price, ev_vol, batch;
+  uint32_t batch_stride = 0;
+  int pipeline = 0;  // 0 auto, 1 fused (k_run_random), 2 split (k_agents_fsm + k_step_batch)
   DevBuf<DevTrade> trades;
   DevBuf<DevOrderLog> order_log;
   DevBuf<DevStats> stats;
@@ -117,9 +120,13 @@ struct bk_env {
   size_t ev_capacity = 0;
   // profiling
   bool profile = false;
-  std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
-  double prof_ms = 0.0;
-  uint64_t prof_launches = 0;
+  struct ProfEv {
+    hipEvent_t a, b;
+    int kind;
+  };
+  std::vector<ProfEv> prof_events;
+  double prof_ms[4] = {0, 0, 0, 0};  // per kernel kind: 0 k_run_random, 1 k_agents_fsm, 2 k_step_batch, 3 k_step_events
+  uint64_t prof_launches[4] = {0, 0, 0, 0};
 
   DevArgs args() const {
     DevArgs a{};
@@ -147,6 +154,8 @@ struct bk_env {
     a.ev_id = ev_id.p;
     a.ev_price = ev_price.p;
     a.ev_vol = ev_vol.p;
+    a.batch = batch.p;
+    a.batch_stride = batch_stride;
     for (size_t g = 0; g < groups.size(); ++g) a.groups[g] = groups[g];
     return a;
   }
@@ -161,15 +170,16 @@ int use_device(bk_env* env) {
 
 struct ProfScope {  // HIP events around a launch on the env's stream
   bk_env* env;
+  int kind;
   hipEvent_t a = nullptr, b = nullptr;
-  explicit ProfScope(bk_env* e) : env(e) {
+  ProfScope(bk_env* e, int k) : env(e), kind(k) {
     if (env->profile && hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess)
       (void)hipEventRecord(a, env->stream);
   }
   ~ProfScope() {
     if (a && b) {
       (void)hipEventRecord(b, env->stream);
-      env->prof_events.emplace_back(a, b);
+      env->prof_events.push_back({a, b, kind});
     }
   }
 };
@@ -177,15 +187,34 @@ struct ProfScope {  // HIP events around a launch on the env's stream
 template <int R>
 int launch_run(bk_env* env, const DevArgs& a, uint64_t first_step, uint32_t n_steps) {
   const uint32_t blocks = (env->cfg.n_books + 3) / 4;
-  ProfScope ps(env);
+  ProfScope ps(env, 0);
   hipLaunchKernelGGL(k_run_random<R>, dim3(blocks), dim3(256), 0, env->stream, a, first_step, n_steps);
   HIPCHK(hipGetLastError());
   return BK_OK;
 }
 template <int R>
 int launch_events(bk_env* env, const DevArgs& a, uint64_t step_index) {
-  ProfScope ps(env);
+  ProfScope ps(env, 3);
   hipLaunchKernelGGL(k_step_events<R>, dim3(env->cfg.n_books), dim3(64), 0, env->stream, a, step_index);
+  HIPCHK(hipGetLastError());
+  return BK_OK;
+}
+
+// split pipeline: per step one lane-per-book launch (RNG-serial phases) + one wave-per-book launch (events)
+template <int R>
+int launch_split(bk_env* env, const DevArgs& a, uint64_t first_step, uint32_t n_steps) {
+  const uint32_t B = env->cfg.n_books;
+  for (uint32_t s = 0; s < n_steps; ++s) {
+    {
+      ProfScope ps(env, 1);
+      hipLaunchKernelGGL(k_agents_fsm<R>, dim3((B + 63) / 64), dim3(64), 0, env->stream, a);
+    }
+    {
+      ProfScope ps(env, 2);
+      const uint32_t write_last = (s + 1 == n_steps || a.hist_cap == 0) ? 1u : 0u;
+      hipLaunchKernelGGL(k_step_batch<R>, dim3((B + 3) / 4), dim3(256), 0, env->stream, a, first_step + s, write_last);
+    }
+  }
   HIPCHK(hipGetLastError());
   return BK_OK;
 }
@@ -207,6 +236,21 @@ int refresh_log(bk_env* env, uint32_t book) {
                      n * sizeof(DevOrderLog), hipMemcpyDeviceToHost));
   }
   bh.log_fresh = true;
+  return BK_OK;
+}
+
+int prof_collect(bk_env* env) {
+  HIPCHK(hipStreamSynchronize(env->stream));
+  for (auto& pr : env->prof_events) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, pr.a, pr.b) == hipSuccess) {
+      env->prof_ms[pr.kind] += ms;
+      env->prof_launches[pr.kind] += 1;
+    }
+    (void)hipEventDestroy(pr.a);
+    (void)hipEventDestroy(pr.b);
+  }
+  env->prof_events.clear();
   return BK_OK;
 }
 
@@ -279,6 +323,13 @@ int bk_env_create(const bk_config* cfg, bk_env** out) {
   HIPCHK(env->trades.alloc(B * cfg->trade_capacity));
   HIPCHK(env->order_log.alloc(B * cfg->max_orders));
   HIPCHK(env->stats.alloc(1));
+  env->batch_stride = 64 + 160 * R;
+  HIPCHK(env->batch.alloc(B * env->batch_stride));
+  HIPCHK(hipMemset(env->batch.p, 0, B * env->batch_stride * sizeof(uint32_t)));
+  if (const char* pm = std::getenv("BOURSE_AMD_PIPELINE")) {
+    if (std::strcmp(pm, "fused") == 0) env->pipeline = 1;
+    if (std::strcmp(pm, "split") == 0) env->pipeline = 2;
+  }
   HIPCHK(env->ev_off.alloc(B + 1));
   HIPCHK(hipMemset(env->ev_off.p, 0, (B + 1) * sizeof(uint32_t)));
 
@@ -311,8 +362,8 @@ void bk_env_destroy(bk_env* env) {
   (void)hipSetDevice(env->cfg.device);
   (void)hipStreamSynchronize(env->stream);
   for (auto& pr : env->prof_events) {
-    (void)hipEventDestroy(pr.first);
-    (void)hipEventDestroy(pr.second);
+    (void)hipEventDestroy(pr.a);
+    (void)hipEventDestroy(pr.b);
   }
   delete env;
 }
@@ -550,11 +601,24 @@ int bk_run(bk_env* env, uint64_t n_steps) {
   }
   int rc = BK_OK;
   const uint32_t ns = static_cast<uint32_t>(n_steps);
-  switch (env->R) {
-    case 1: rc = launch_run<1>(env, a, env->steps_done, ns); break;
-    case 2: rc = launch_run<2>(env, a, env->steps_done, ns); break;
-    case 4: rc = launch_run<4>(env, a, env->steps_done, ns); break;
-    default: rc = launch_run<8>(env, a, env->steps_done, ns); break;
+  // The fused kernel keeps a book in registers across all steps of the launch but runs the RNG-serial
+  // phases on the scalar unit of ONE wave per book; the split pipeline runs them one lane per book and needs
+  // >= 64 books per wave to pay off.  auto: split once the batch fills the chip several times over.
+  const bool split = env->pipeline == 2 || (env->pipeline == 0 && env->cfg.n_books >= 16384 && a.n_groups > 0);
+  if (split) {
+    switch (env->R) {
+      case 1: rc = launch_split<1>(env, a, env->steps_done, ns); break;
+      case 2: rc = launch_split<2>(env, a, env->steps_done, ns); break;
+      case 4: rc = launch_split<4>(env, a, env->steps_done, ns); break;
+      default: rc = launch_split<8>(env, a, env->steps_done, ns); break;
+    }
+  } else {
+    switch (env->R) {
+      case 1: rc = launch_run<1>(env, a, env->steps_done, ns); break;
+      case 2: rc = launch_run<2>(env, a, env->steps_done, ns); break;
+      case 4: rc = launch_run<4>(env, a, env->steps_done, ns); break;
+      default: rc = launch_run<8>(env, a, env->steps_done, ns); break;
+    }
   }
   if (rc != BK_OK) return rc;
   env->steps_done += n_steps;
@@ -770,23 +834,34 @@ int bk_profile_enable(bk_env* env, int on) {
 int bk_profile_read(bk_env* env, double* total_ms, uint64_t* n_launches, int reset) {
   if (!env) return fail(BK_INVALID_ARGUMENT, "null env");
   if (int rc = use_device(env)) return rc;
-  HIPCHK(hipStreamSynchronize(env->stream));
-  for (auto& pr : env->prof_events) {
-    float ms = 0.f;
-    if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) {
-      env->prof_ms += ms;
-      env->prof_launches += 1;
+  if (int rc = prof_collect(env)) return rc;
+  double ms = 0;
+  uint64_t n = 0;
+  for (int k = 0; k < 4; ++k) {
+    ms += env->prof_ms[k];
+    n += env->prof_launches[k];
+    if (reset) {
+      env->prof_ms[k] = 0.0;
+      env->prof_launches[k] = 0;
     }
-    (void)hipEventDestroy(pr.first);
-    (void)hipEventDestroy(pr.second);
   }
-  env->prof_events.clear();
-  if (total_ms) *total_ms = env->prof_ms;
-  if (n_launches) *n_launches = env->prof_launches;
-  if (reset) {
-    env->prof_ms = 0.0;
-    env->prof_launches = 0;
-  }
+  if (total_ms) *total_ms = ms;
+  if (n_launches) *n_launches = n;
+  return BK_OK;
+}
+
+int bk_profile_read_kind(bk_env* env, int kind, double* total_ms, uint64_t* n_launches) {
+  if (!env || kind < 0 || kind > 3) return fail(BK_INVALID_ARGUMENT, "bad argument");
+  if (int rc = use_device(env)) return rc;
+  if (int rc = prof_collect(env)) return rc;
+  if (total_ms) *total_ms = env->prof_ms[kind];
+  if (n_launches) *n_launches = env->prof_launches[kind];
+  return BK_OK;
+}
+
+int bk_set_pipeline(bk_env* env, int mode) {
+  if (!env || mode < 0 || mode > 2) return fail(BK_INVALID_ARGUMENT, "pipeline mode must be 0 (auto), 1 (fused) or 2 (split)");
+  env->pipeline = mode;
   return BK_OK;
 }
 

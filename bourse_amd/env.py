@@ -250,6 +250,16 @@ class ManyBookEnv:
         check(self._L.bk_profile_read(self._h, C.byref(ms), C.byref(n), int(reset)))
         return float(ms.value), int(n.value)
 
+    def profile_read_kind(self, kind: int) -> Tuple[float, int]:
+        """kind: 0 k_run_random, 1 k_agents_fsm, 2 k_step_batch, 3 k_step_events (call before profile_read(reset))."""
+        ms, n = C.c_double(0), C.c_uint64(0)
+        check(self._L.bk_profile_read_kind(self._h, int(kind), C.byref(ms), C.byref(n)))
+        return float(ms.value), int(n.value)
+
+    def set_pipeline(self, mode: str):
+        """'auto' | 'fused' | 'split' — kernel pipeline of run(); results are identical."""
+        check(self._L.bk_set_pipeline(self._h, {"auto": 0, "fused": 1, "split": 2}[mode]))
+
     def state_bytes_per_book(self) -> int:
         return int(self._L.bk_state_bytes_per_book(self._h))
 

@@ -181,6 +181,11 @@ int bk_stats_device_ptr(bk_env* env, void** out);
 /* accumulate HIP-event timings of the step kernels launched on the env's stream */
 int bk_profile_enable(bk_env* env, int on);
 int bk_profile_read(bk_env* env, double* total_ms, uint64_t* n_launches, int reset);
+/* per kernel: kind 0 k_run_random (fused), 1 k_agents_fsm, 2 k_step_batch (split pipeline), 3 k_step_events */
+int bk_profile_read_kind(bk_env* env, int kind, double* total_ms, uint64_t* n_launches);
+/* bk_run kernel pipeline: 0 auto, 1 fused (one wave per book, all phases), 2 split (RNG-serial phases one lane per
+ * book + event phase one wave per book).  Results are identical; only speed differs. */
+int bk_set_pipeline(bk_env* env, int mode);
 uint64_t bk_state_bytes_per_book(const bk_env* env);
 
 #ifdef __cplusplus

@@ -43,13 +43,15 @@ def test_dpp_reductions(bk):
 
 
 def _compare_random(bk, oracle, n_books, groups, levels, n_steps, seed=101, tick=2, step_size=100_000, chunks=None,
-                    max_live=None, trade_cap=None):
+                    max_live=None, trade_cap=None, pipeline="fused"):
     n_agents = sum(g[0] for g in groups)
     env = bk.ManyBookEnv(n_books, seed, 0, tick, step_size, True, levels=levels,
                          max_live_orders=max_live or n_agents, trade_capacity=trade_cap or 2 * n_agents * n_steps,
                          history_capacity=n_steps)
     env.set_random_agents(groups)
-    for c in (chunks or [n_steps]):
+    for i, c in enumerate(chunks or [n_steps]):
+        # "mixed": alternate the two kernel pipelines between launches — they share the device state
+        env.set_pipeline(("fused", "split")[i % 2] if pipeline == "mixed" else pipeline)
         env.run(c)
     ref = oracle.ManyBooks(n_books, seed, 0, tick, step_size, True, levels, groups)
     ref.run(n_steps, n_threads=4)
@@ -91,35 +93,50 @@ def _compare_random(bk, oracle, n_books, groups, levels, n_steps, seed=101, tick
     return hist
 
 
-def test_random_agents_c2_shape(bk, oracle):
-    _compare_random(bk, oracle, n_books=96, groups=C2_GROUPS, levels=16, n_steps=40)
+PIPELINES = ["fused", "split"]  # one wave per book for everything / RNG phases one lane per book + event kernel
 
 
-def test_random_agents_c3_shape(bk, oracle):
-    _compare_random(bk, oracle, n_books=64, groups=C3_GROUPS, levels=32, n_steps=40)
+@pytest.mark.parametrize("pipeline", PIPELINES)
+def test_random_agents_c2_shape(bk, oracle, pipeline):
+    _compare_random(bk, oracle, n_books=96, groups=C2_GROUPS, levels=16, n_steps=40, pipeline=pipeline)
 
 
-def test_random_agents_c5_shape_deep_book(bk, oracle):
-    _compare_random(bk, oracle, n_books=8, groups=C5_GROUPS, levels=64, n_steps=12)
+@pytest.mark.parametrize("pipeline", PIPELINES)
+def test_random_agents_c3_shape(bk, oracle, pipeline):
+    _compare_random(bk, oracle, n_books=200, groups=C3_GROUPS, levels=32, n_steps=40, pipeline=pipeline)
 
 
-def test_random_agents_reference_bench_workload(bk, oracle):
+@pytest.mark.parametrize("pipeline", PIPELINES)
+def test_random_agents_c5_shape_deep_book(bk, oracle, pipeline):
+    _compare_random(bk, oracle, n_books=8, groups=C5_GROUPS, levels=64, n_steps=12, pipeline=pipeline)
+
+
+@pytest.mark.parametrize("pipeline", PIPELINES)
+def test_random_agents_reference_bench_workload(bk, oracle, pipeline):
     # the reference's own divan bench parameters scaled down (crates/step_sim/benches/benchmarks.rs:14-23):
     # env tick 1, agents tick 2, two groups with different windows; 10 L2 levels
     groups = [(100, (40, 60), (10, 20), 2, 0.8), (100, (10, 90), (50, 70), 2, 0.2)]
-    _compare_random(bk, oracle, n_books=5, groups=groups, levels=10, n_steps=60, tick=1, step_size=1_000_000)
+    _compare_random(bk, oracle, n_books=5, groups=groups, levels=10, n_steps=60, tick=1, step_size=1_000_000,
+                    pipeline=pipeline)
 
 
-def test_random_agents_edge_shapes(bk, oracle):
-    # single agent, odd counts, rate 0 and rate 1 groups, books not a multiple of the 4 waves per block
+@pytest.mark.parametrize("pipeline", PIPELINES)
+def test_random_agents_edge_shapes(bk, oracle, pipeline):
+    # single agent, odd counts, rate 0 and rate 1 groups, empty group, books not a multiple of 4 or 64
     _compare_random(bk, oracle, n_books=3, groups=[(1, (10, 20), (20, 30), 1, 1.0)], levels=10, n_steps=25, tick=1,
-                    step_size=1000)
+                    step_size=1000, pipeline=pipeline)
     _compare_random(bk, oracle, n_books=7, groups=[(5, (10, 14), (1, 3), 3, 0.0), (37, (10, 14), (1, 3), 3, 1.0),
-                                                   (23, (9, 13), (1, 2), 6, 0.5)], levels=4, n_steps=50, tick=3)
+                                                   (23, (9, 13), (1, 2), 6, 0.5)], levels=4, n_steps=50, tick=3,
+                    pipeline=pipeline)
+    _compare_random(bk, oracle, n_books=67, groups=[(0, (10, 14), (1, 3), 1, 0.5), (2, (10, 12), (1, 2), 1, 0.9),
+                                                    (0, (10, 14), (1, 3), 1, 0.5)], levels=3, n_steps=40, tick=1,
+                    step_size=10, pipeline=pipeline)
 
 
-def test_chunked_launches_equal_one_launch(bk, oracle):
-    a = _compare_random(bk, oracle, n_books=16, groups=C2_GROUPS, levels=16, n_steps=30, chunks=[1, 2, 3, 24])
+@pytest.mark.parametrize("pipeline", PIPELINES + ["mixed"])
+def test_chunked_launches_equal_one_launch(bk, oracle, pipeline):
+    a = _compare_random(bk, oracle, n_books=16, groups=C2_GROUPS, levels=16, n_steps=30, chunks=[1, 2, 3, 24],
+                        pipeline=pipeline)
     b = _compare_random(bk, oracle, n_books=16, groups=C2_GROUPS, levels=16, n_steps=30)
     assert np.array_equal(a, b)
 
