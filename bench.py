@@ -75,6 +75,7 @@ def main():
     ap.add_argument("--steps-per-launch", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-history", action="store_true", help="keep only the latest L2 record (diagnostic)")
+    ap.add_argument("--pipeline", default="auto", choices=["auto", "fused", "split"])
     args = ap.parse_args()
 
     import torch
@@ -109,6 +110,7 @@ def main():
                                  trade_capacity=trade_cap, history_capacity=hist_cap,
                                  book_offset=rank * B, device=local_rank, stream=stream)
     env.set_random_agents(groups)
+    env.set_pipeline(args.pipeline)
     gather = parallel.StatsGather(env, dist) if world > 1 else None
 
     def run_steps(n):
@@ -136,7 +138,10 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
     env.profile(False)
-    kern_ms, n_launch = env.profile_read()
+    per_kind = {k: env.profile_read_kind(i) for i, k in enumerate(("k_run_random", "k_agents_fsm", "k_step_batch", "k_step_events"))}
+    env.profile_read()
+    dominant = max(per_kind, key=lambda k: per_kind[k][0])
+    kern_ms, n_launch = per_kind[dominant]
     if dist is not None:
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -154,15 +159,23 @@ def main():
     S = env.state_bytes_per_book()
     W4 = env.width * 4
     tr_per_bs = n_trades / (B * args.steps)
-    bytes_per_bookstep = 2.0 * S / spl + (W4 if hist_cap else W4) + 32.0 * tr_per_bs
+    ev_per_bs = st["sum_events"] / (B * (args.steps + args.warmup))
+    if dominant == "k_step_batch":
+        # one launch = ONE step of every book: state in + out, the step batch in (header 64 B + 2 B per event +
+        # 8 B per new order, ~0.77 of the events), one L2 record, 32 B per trade
+        steps_per_kernel_launch = 1
+        bytes_per_bookstep = 2.0 * S + 64 + 2.0 * ev_per_bs + 8.0 * 0.77 * ev_per_bs + W4 + 32.0 * tr_per_bs
+    else:
+        steps_per_kernel_launch = spl
+        bytes_per_bookstep = 2.0 * S / spl + W4 + 32.0 * tr_per_bs
     launches = max(n_launch, 1)
     avg_ms = kern_ms / launches
-    achieved = (bytes_per_bookstep * B * spl) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    achieved = (bytes_per_bookstep * B * steps_per_kernel_launch) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
     traffic = None
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc):
         try:
-            traffic = json.load(open(pmc)).get(args.workload, {}).get("hbm_bytes_per_launch")
+            traffic = json.load(open(pmc)).get(args.workload, {}).get(dominant, {}).get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
     out = {
@@ -176,12 +189,14 @@ def main():
             "books_per_gpu": B, "agents_per_book": n_agents, "levels": levels, "steps_per_launch": spl,
             "parallelism": f"independent book shards x{world}, 64 B stats all-gather per launch" if world > 1
             else "single GPU",
-            "trades_per_book_step": tr_per_bs, "events_per_book_step": st["sum_events"] / (B * (args.steps + args.warmup)),
+            "trades_per_book_step": tr_per_bs, "events_per_book_step": ev_per_bs,
+            "pipeline": "split (k_agents_fsm + k_step_batch per step)" if dominant == "k_step_batch" else "fused (k_run_random)",
         },
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "kernel": "k_run_random",
+            "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "kernel": dominant,
             "avg_launch_ms": avg_ms, "launches": n_launch, "bytes_per_book_step": bytes_per_bookstep,
+            "kernel_ms_total": {k: v[0] for k, v in per_kind.items() if v[1]},
         },
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -77,6 +77,7 @@ struct DevArgs {
   // split pipeline: per-book step batch written by k_agents_fsm, consumed by k_step_batch
   uint32_t* batch;
   uint32_t batch_stride;  // dwords per book: 64 + 160 * R
+  uint32_t book_begin, book_end;  // split pipeline: this launch covers books [book_begin, book_end)
   uint32_t pad0;
   Group groups[MAX_GROUPS];
 };
@@ -334,12 +335,11 @@ __device__ __forceinline__ bool match(Book<R>& B, const DevArgs& a, uint32_t boo
       eq[r] = cand[r] & __ballot(B.price[r] == best);
       cnt += __builtin_popcountll(eq[r]);
     }
-    uint32_t pn = 0;  // passive slot index
-    if (cnt == 1) {
-#pragma unroll
-      for (int r = 0; r < R; ++r)
-        if (eq[r]) pn = r * 64 + __builtin_ctzll(eq[r]);
-    } else {
+    // match_orders (orderbook.rs:843-870) on the chosen passive order.  All pool accesses use a
+    // compile-time register index r: the single-candidate case (the common one) is handled inside the
+    // unrolled loop, the multi-candidate case first scans the few candidates' seq stamps.
+    uint32_t pr = 0, pl = 0;
+    if (cnt != 1) {
       uint32_t bs = 0xFFFFFFFFu;
 #pragma unroll
       for (int r = 0; r < R; ++r) {
@@ -347,49 +347,80 @@ __device__ __forceinline__ bool match(Book<R>& B, const DevArgs& a, uint32_t boo
         while (w) {
           const uint32_t l = __builtin_ctzll(w);
           w &= w - 1;
-          const uint32_t s = rdl(B.seq[r], l);
-          if (s < bs) {  // seq stamps are unique per book and < 0xFFFFFFFF
-            bs = s;
-            pn = r * 64 + l;
+          const uint32_t sq = rdl(B.seq[r], l);
+          if (sq < bs) {  // seq stamps are unique per book and < 0xFFFFFFFF
+            bs = sq;
+            pr = r;
+            pl = l;
           }
         }
       }
+#pragma unroll
+      for (int r = 0; r < R; ++r) eq[r] = (pr == (uint32_t)r) ? (1ull << pl) : 0ull;
     }
-    // match_orders
-    uint32_t pv = slot_read<R>(B.vol, pn);
-    const uint32_t pid = slot_read<R>(B.id, pn);
-    const uint32_t tv = v < pv ? v : pv;
+    uint32_t pv = 0, pid = 0, tv = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      if (eq[r]) {  // exactly one r has a (single-bit) mask now
+        const uint32_t l = __builtin_ctzll(eq[r]);
+        pv = rdl(B.vol[r], l);
+        pid = rdl(B.id[r], l);
+        tv = v < pv ? v : pv;
+        pv -= tv;
+        B.vol[r] = wrl(pv, l, B.vol[r]);
+        if (pv == 0) B.live[r] &= ~eq[r];  // passive Filled -> remove_order
+      }
+    }
     v -= tv;
-    pv -= tv;
-    slot_write<R>(B.vol, pn, pv);
     emit_trade(B, a, book, t0, lane, k, !agg_bid, best, tv, agg_id, pid);
     B.trade_vol += tv;
-    if (pv == 0) mask_set<R>(B.live, pn, false);  // passive Filled -> remove_order
     log_fill(lg, B.flags, lane, pid, pv, t0 + k);
     if (v == 0) filled = true;
   }
   return filled;
 }
 
-// place_order for a limit/market order that already sits in slot n with pend set
-// (fused RandomAgents path: slot == agent).  orderbook.rs:583-611
+// One event of the fused/split RandomAgents paths (slot == agent): a New if the slot's pend bit is set
+// (place_order, orderbook.rs:583-611), else the Cancellation of the slot's order (orderbook.rs:622-644; a
+// no-op if the order was filled meanwhile).  The slot's register index is resolved ONCE per stage by a
+// uniform branch so that every pool access inside uses a compile-time register.
 template <int R>
-__device__ __forceinline__ void process_new_in_slot(Book<R>& B, const DevArgs& a, uint32_t book, uint64_t t0, int lane,
-                                                    uint32_t k, uint32_t n) {
+__device__ __forceinline__ void process_slot_event(Book<R>& B, const DevArgs& a, uint32_t book, uint64_t t0, int lane,
+                                                   uint32_t k, uint32_t n) {
   const LogCtx nolog{nullptr, 0};
-  mask_set<R>(B.pend, n, false);
-  const bool is_bid = mask_test<R>(B.bid, n);
-  const uint32_t p = slot_read<R>(B.price, n);
-  uint32_t v = slot_read<R>(B.vol, n);
-  const uint32_t id = slot_read<R>(B.id, n);
+  const uint32_t sl = n & 63;
+  const uint64_t bit = 1ull << sl;
+  bool is_new = false, is_bid = false;
+  uint32_t p = 0, v = 0, id = 0;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    if ((n >> 6) == (uint32_t)r) {
+      is_new = (B.pend[r] & bit) != 0;
+      if (is_new) {
+        B.pend[r] &= ~bit;
+        is_bid = (B.bid[r] & bit) != 0;
+        p = rdl(B.price[r], sl);
+        v = rdl(B.vol[r], sl);
+        id = rdl(B.id[r], sl);
+      } else {
+        B.live[r] &= ~bit;
+      }
+    }
+  }
+  if (!is_new) return;
   const bool market = is_bid ? (p == 0xFFFFFFFFu) : (p == 0u);
   bool filled = false;
   if (B.trading) filled = match<R>(B, a, book, t0, lane, k, is_bid, p, v, id, nolog);
   if (!market && !filled) {  // rest the remainder with a fresh priority stamp
-    slot_write<R>(B.vol, n, v);
-    slot_write<R>(B.seq, n, B.seq_ctr);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      if ((n >> 6) == (uint32_t)r) {
+        B.vol[r] = wrl(v, sl, B.vol[r]);
+        B.seq[r] = wrl(B.seq_ctr, sl, B.seq[r]);
+        B.live[r] |= bit;
+      }
+    }
     B.seq_ctr += 1;
-    mask_set<R>(B.live, n, true);
   }
 }
 
@@ -553,12 +584,12 @@ __device__ __forceinline__ uint32_t step_from_list(Book<R>& B, const DevArgs& a,
   B.trade_vol = 0;  // reset_trade_vol (env.rs:118)
   const uint64_t trades_before = B.n_trades;
   if ((uint64_t)n_ev >= step_size) B.flags |= FLAG_STEP_SIZE;
-  for (uint32_t k = 0; k < n_ev; ++k) {  // events at t0 + k (env.rs:123-127)
-    const uint32_t n = slot_read<R>(ev, k);
-    if (mask_test<R>(B.pend, n)) {
-      process_new_in_slot<R>(B, a, book, t0, lane, k, n);
-    } else {
-      mask_set<R>(B.live, n, false);  // cancel_order (orderbook.rs:622-644); no-op if filled meanwhile
+#pragma unroll
+  for (int re = 0; re < R; ++re) {  // events at t0 + k (env.rs:123-127); entry k lives in lane k & 63 of ev[k >> 6]
+    const uint32_t kb = re * 64;
+    if (n_ev > kb) {
+      const uint32_t cnt = (n_ev - kb) < 64u ? (n_ev - kb) : 64u;
+      for (uint32_t l = 0; l < cnt; ++l) process_slot_event<R>(B, a, book, t0, lane, kb + l, rdl(ev[re], l));
     }
   }
   B.n_events += n_ev;
@@ -675,8 +706,8 @@ __global__ __launch_bounds__(64) void k_agents_fsm(DevArgs a) {
     for (int i = lane; i < MAX_GROUPS * G_DW; i += 64) gtab[i] = gp[i];
   }
   __syncthreads();
-  const uint32_t b = blockIdx.x * 64 + lane;
-  if (b >= a.n_books) return;
+  const uint32_t b = a.book_begin + blockIdx.x * 64 + lane;
+  if (b >= a.book_end) return;
   uint32_t* st = a.state + (size_t)b * a.state_stride;
   uint32_t* bt = a.batch + (size_t)b * a.batch_stride;
   const uint32_t total = a.n_agents_total;
@@ -698,97 +729,93 @@ __global__ __launch_bounds__(64) void k_agents_fsm(DevArgs a) {
   }
   uint2* pv = reinterpret_cast<uint2*>(bt + BT_EV + 32 * R);
 
-  auto gfield = [&](uint32_t g, int f) { return gtab[g * G_DW + f]; };
-  // Group dword fields: 0 n, 1 thr, 2 tick_lo, 3 tick_rng, 4 tick_zone, 5 vol_lo, 6 vol_rng, 7 vol_zone, 8 tick_size
-  uint32_t n = 0, g = 0, gend = 0, thr = 0, n_ev = 0;
+  // Group dword fields: 0 n, 1 thr, 2 tick_lo, 3 tick_rng, 4 tick_zone, 5 vol_lo, 6 vol_rng, 7 vol_zone, 8 tick_size.
+  // The current group's parameters are cached in per-lane registers and re-read from LDS only when a lane
+  // crosses a group boundary (a few times per step), keeping LDS latency out of the per-draw loop.
+  uint32_t n = 0, g = 0, gend = 0, n_ev = 0;
+  uint32_t thr = 0, tick_lo = 0, tick_rng = 1, tick_zone = 0, vol_lo = 0, vol_rng = 1, vol_zone = 0, tick_sz = 0;
   uint32_t phase = PH_DONE, range = 0, zone = 0, shuf_i = 0, cur_side = 0, cur_price = 0;
+  auto load_group = [&]() {
+    const uint32_t* q = gtab + g * G_DW;
+    thr = q[1];
+    tick_lo = q[2];
+    tick_rng = q[3];
+    tick_zone = q[4];
+    vol_lo = q[5];
+    vol_rng = q[6];
+    vol_zone = q[7];
+    tick_sz = q[8];
+  };
   if (total > 0) {
-    gend = gfield(0, 0);
+    gend = gtab[0];
     while (n >= gend) {
       ++g;
-      gend += gfield(g, 0);
+      gend += gtab[g * G_DW];
     }
-    thr = gfield(g, 1);
+    load_group();
     phase = PH_ACT;
   }
-  auto advance = [&]() {  // next agent, or start the shuffle once every agent has been visited
-    ++n;
-    if (n >= total) {
-      if (n_ev >= 2) {
-        phase = PH_SHUF;
+  // One next_u32() draw per iteration.  The body is written select-style (v_cndmask) with four short
+  // predicated blocks (list append, new-order store, shuffle swap, next-agent) so that lanes in different
+  // phases share almost the whole instruction stream.
+  while (phase != PH_DONE) {
+    const uint32_t x = rng.next_u32();
+    const bool is_act = phase == PH_ACT;
+    // ACT: p = gen::<f32>() < activity_rate (random_agent.rs:91-93)
+    const bool hit = is_act & ((x >> 8) < thr);
+    // other phases: UniformInt<u32>::sample_single step: accept iff lo(x * range) <= zone
+    const uint64_t m = (uint64_t)x * range;
+    const bool acc = (!is_act) & ((uint32_t)m <= zone);
+    const uint32_t val = (uint32_t)(m >> 32);
+    if (hit) list[n_ev * 64 + lane] = (uint16_t)n;  // queue an event for agent n
+    n_ev += hit ? 1u : 0u;
+    uint64_t w = live[0];
+#pragma unroll
+    for (int r = 1; r < R; ++r) w = ((n >> 6) == (uint32_t)r) ? live[r] : w;
+    const bool holds_live = (w >> (n & 63)) & 1ull;  // Active order held -> the event is its cancellation (:95-97)
+    const bool acc_side = acc & (phase == PH_SIDE), acc_tick = acc & (phase == PH_TICK);
+    const bool acc_vol = acc & (phase == PH_VOL), acc_shuf = acc & (phase == PH_SHUF);
+    cur_side = acc_side ? val : cur_side;                         // 0 = Ask, 1 = Bid ([Ask, Bid].choose, :99)
+    cur_price = acc_tick ? (tick_lo + val) * tick_sz : cur_price;  // tick * tick_size (:100,:107)
+    if (acc_vol) {                                                 // vol drawn last (:101): the order is complete
+      pv[n] = make_uint2(cur_price, vol_lo + val);
+      const uint64_t bit = 1ull << (n & 63);
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const uint64_t bb = ((n >> 6) == (uint32_t)r) ? bit : 0ull;
+        pend[r] |= bb;
+        sidem[r] |= cur_side ? bb : 0ull;
+      }
+    }
+    if (acc_shuf) {  // swap(i, j), j = val in [0, i]  (rand SliceRandom::shuffle)
+      const uint16_t ai = list[shuf_i * 64 + lane], aj = list[val * 64 + lane];
+      list[shuf_i * 64 + lane] = aj;
+      list[val * 64 + lane] = ai;
+    }
+    shuf_i -= acc_shuf ? 1u : 0u;
+    const uint32_t nr = shuf_i + 1;
+    const uint32_t nz = (nr << __builtin_clz(nr | 1u)) - 1u;
+    const bool to_side = hit & !holds_live;
+    phase = to_side ? PH_SIDE : acc_side ? PH_TICK : acc_tick ? PH_VOL : acc_shuf ? (shuf_i == 0 ? PH_DONE : PH_SHUF) : phase;
+    range = to_side ? 2u : acc_side ? tick_rng : acc_tick ? vol_rng : acc_shuf ? nr : range;
+    zone = to_side ? 0x7FFFFFFFu : acc_side ? tick_zone : acc_tick ? vol_zone : acc_shuf ? nz : zone;
+    if ((is_act & !hit) | (hit & holds_live) | acc_vol) {  // next agent, or start the shuffle after the last one
+      ++n;
+      if (n >= total) {
+        const bool sh = n_ev >= 2;
+        phase = sh ? PH_SHUF : PH_DONE;
         shuf_i = n_ev - 1;
         range = n_ev;
-        zone = (range << __builtin_clz(range)) - 1u;
+        zone = (n_ev << __builtin_clz(n_ev | 1u)) - 1u;
       } else {
-        phase = PH_DONE;
-      }
-    } else {
-      while (n >= gend) {
-        ++g;
-        gend += gfield(g, 0);
-      }
-      thr = gfield(g, 1);
-      phase = PH_ACT;
-    }
-  };
-
-  while (phase != PH_DONE) {
-    const uint32_t x = rng.next_u32();  // exactly one draw per iteration, whatever the phase
-    if (phase == PH_ACT) {
-      if ((x >> 8) < thr) {  // p = gen::<f32>() < activity_rate (random_agent.rs:91-93)
-        list[n_ev * 64 + lane] = (uint16_t)n;
-        ++n_ev;
-        uint64_t w = live[0];
-#pragma unroll
-        for (int r = 1; r < R; ++r) w = ((n >> 6) == (uint32_t)r) ? live[r] : w;
-        if ((w >> (n & 63)) & 1ull) {
-          advance();  // holds an Active order: its cancellation is queued (:95-97)
-        } else {
-          phase = PH_SIDE;  // [Ask, Bid].choose -> gen_range(0..2)
-          range = 2u;
-          zone = 0x7FFFFFFFu;
+        if (n >= gend) {
+          do {
+            ++g;
+            gend += gtab[g * G_DW];
+          } while (n >= gend);
+          load_group();
         }
-      } else {
-        advance();
-      }
-    } else {
-      // UniformInt<u32>::sample_single step: accept iff lo(x * range) <= zone
-      const uint64_t m = (uint64_t)x * range;
-      if ((uint32_t)m <= zone) {
-        const uint32_t val = (uint32_t)(m >> 32);
-        if (phase == PH_SIDE) {
-          cur_side = val;  // 0 = Ask, 1 = Bid
-          phase = PH_TICK;
-          range = gfield(g, 3);
-          zone = gfield(g, 4);
-        } else if (phase == PH_TICK) {
-          cur_price = (gfield(g, 2) + val) * gfield(g, 8);
-          phase = PH_VOL;
-          range = gfield(g, 6);
-          zone = gfield(g, 7);
-        } else if (phase == PH_VOL) {
-          pv[n] = make_uint2(cur_price, gfield(g, 5) + val);
-          const uint64_t bit = 1ull << (n & 63);
-#pragma unroll
-          for (int r = 0; r < R; ++r) {
-            if ((n >> 6) == (uint32_t)r) {
-              pend[r] |= bit;
-              if (cur_side) sidem[r] |= bit;
-            }
-          }
-          advance();
-        } else {  // PH_SHUF: swap(i, j), j = val in [0, i]  (rand SliceRandom::shuffle)
-          const uint16_t ai = list[shuf_i * 64 + lane], aj = list[val * 64 + lane];
-          list[shuf_i * 64 + lane] = aj;
-          list[val * 64 + lane] = ai;
-          --shuf_i;
-          if (shuf_i == 0) {
-            phase = PH_DONE;
-          } else {
-            range = shuf_i + 1;
-            zone = (range << __builtin_clz(range)) - 1u;
-          }
-        }
+        phase = PH_ACT;
       }
     }
   }
@@ -814,8 +841,8 @@ __global__ __launch_bounds__(256) void k_step_batch(DevArgs a, uint64_t step_ind
   __shared__ uint32_t lds[4][LDS_DW_PER_WAVE];
   const int lane = threadIdx.x & 63;
   const int wv = threadIdx.x >> 6;
-  const uint32_t book = rfl(blockIdx.x * 4 + wv);
-  if (book >= a.n_books) return;
+  const uint32_t book = rfl(a.book_begin + blockIdx.x * 4 + wv);
+  if (book >= a.book_end) return;
   uint32_t* st = a.state + (size_t)book * a.state_stride;
   const uint32_t* bt = a.batch + (size_t)book * a.batch_stride;
 

@@ -109,6 +109,13 @@ struct bk_env {
   DevBuf<uint32_t> state, l2_last, hist, ev_off, ev_word, ev_id, ev_price, ev_vol, batch;
   uint32_t batch_stride = 0;
   int pipeline = 0;  // 0 auto, 1 fused (k_run_random), 2 split (k_agents_fsm + k_step_batch)
+  // split pipeline: the batch is cut into n_parts contiguous parts, each on its own stream and started one
+  // k_agents_fsm apart, so the latency-bound lane-per-book kernel of one part runs under the issue-bound
+  // wave-per-book kernel of another.
+  int n_parts = 2;
+  hipStream_t part_stream[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev_fork = nullptr, ev_first[4] = {nullptr, nullptr, nullptr, nullptr},
+             ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
   DevBuf<DevTrade> trades;
   DevBuf<DevOrderLog> order_log;
   DevBuf<DevStats> stats;
@@ -156,6 +163,8 @@ struct bk_env {
     a.ev_vol = ev_vol.p;
     a.batch = batch.p;
     a.batch_stride = batch_stride;
+    a.book_begin = 0;
+    a.book_end = cfg.n_books;
     for (size_t g = 0; g < groups.size(); ++g) a.groups[g] = groups[g];
     return a;
   }
@@ -171,14 +180,15 @@ int use_device(bk_env* env) {
 struct ProfScope {  // HIP events around a launch on the env's stream
   bk_env* env;
   int kind;
+  hipStream_t st;
   hipEvent_t a = nullptr, b = nullptr;
-  ProfScope(bk_env* e, int k) : env(e), kind(k) {
+  ProfScope(bk_env* e, int k, hipStream_t s = nullptr) : env(e), kind(k), st(s ? s : e->stream) {
     if (env->profile && hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess)
-      (void)hipEventRecord(a, env->stream);
+      (void)hipEventRecord(a, st);
   }
   ~ProfScope() {
     if (a && b) {
-      (void)hipEventRecord(b, env->stream);
+      (void)hipEventRecord(b, st);
       env->prof_events.push_back({a, b, kind});
     }
   }
@@ -200,22 +210,51 @@ int launch_events(bk_env* env, const DevArgs& a, uint64_t step_index) {
   return BK_OK;
 }
 
-// split pipeline: per step one lane-per-book launch (RNG-serial phases) + one wave-per-book launch (events)
+// split pipeline: per step and per part one lane-per-book launch (RNG-serial phases) + one wave-per-book launch
 template <int R>
-int launch_split(bk_env* env, const DevArgs& a, uint64_t first_step, uint32_t n_steps) {
+int launch_split(bk_env* env, const DevArgs& a0, uint64_t first_step, uint32_t n_steps) {
   const uint32_t B = env->cfg.n_books;
-  for (uint32_t s = 0; s < n_steps; ++s) {
-    {
-      ProfScope ps(env, 1);
-      hipLaunchKernelGGL(k_agents_fsm<R>, dim3((B + 63) / 64), dim3(64), 0, env->stream, a);
+  int P = env->n_parts;
+  if (B < 4096u * P) P = 1;  // small batches: one part on the caller's stream
+  if (P > 1 && !env->ev_fork) {
+    HIPCHK(hipEventCreateWithFlags(&env->ev_fork, hipEventDisableTiming));
+    for (int i = 0; i < 4; ++i) {
+      HIPCHK(hipStreamCreateWithFlags(&env->part_stream[i], hipStreamNonBlocking));
+      HIPCHK(hipEventCreateWithFlags(&env->ev_first[i], hipEventDisableTiming));
+      HIPCHK(hipEventCreateWithFlags(&env->ev_join[i], hipEventDisableTiming));
     }
-    {
-      ProfScope ps(env, 2);
-      const uint32_t write_last = (s + 1 == n_steps || a.hist_cap == 0) ? 1u : 0u;
-      hipLaunchKernelGGL(k_step_batch<R>, dim3((B + 3) / 4), dim3(256), 0, env->stream, a, first_step + s, write_last);
+  }
+  if (P > 1) {
+    HIPCHK(hipEventRecord(env->ev_fork, env->stream));
+    for (int i = 0; i < P; ++i) HIPCHK(hipStreamWaitEvent(env->part_stream[i], env->ev_fork, 0));
+  }
+  for (uint32_t s = 0; s < n_steps; ++s) {
+    for (int i = 0; i < P; ++i) {
+      DevArgs a = a0;
+      a.book_begin = static_cast<uint32_t>(static_cast<uint64_t>(B) * i / P) & ~3u;
+      a.book_end = (i + 1 == P) ? B : (static_cast<uint32_t>(static_cast<uint64_t>(B) * (i + 1) / P) & ~3u);
+      const uint32_t nb = a.book_end - a.book_begin;
+      hipStream_t st = P > 1 ? env->part_stream[i] : env->stream;
+      if (P > 1 && s == 0 && i > 0) HIPCHK(hipStreamWaitEvent(st, env->ev_first[i - 1], 0));  // stagger the parts
+      {
+        ProfScope ps(env, 1, st);
+        hipLaunchKernelGGL(k_agents_fsm<R>, dim3((nb + 63) / 64), dim3(64), 0, st, a);
+      }
+      if (P > 1 && s == 0) HIPCHK(hipEventRecord(env->ev_first[i], st));
+      {
+        ProfScope ps(env, 2, st);
+        const uint32_t write_last = (s + 1 == n_steps || a.hist_cap == 0) ? 1u : 0u;
+        hipLaunchKernelGGL(k_step_batch<R>, dim3((nb + 3) / 4), dim3(256), 0, st, a, first_step + s, write_last);
+      }
     }
   }
   HIPCHK(hipGetLastError());
+  if (P > 1) {
+    for (int i = 0; i < P; ++i) {
+      HIPCHK(hipEventRecord(env->ev_join[i], env->part_stream[i]));
+      HIPCHK(hipStreamWaitEvent(env->stream, env->ev_join[i], 0));
+    }
+  }
   return BK_OK;
 }
 
@@ -330,6 +369,10 @@ int bk_env_create(const bk_config* cfg, bk_env** out) {
     if (std::strcmp(pm, "fused") == 0) env->pipeline = 1;
     if (std::strcmp(pm, "split") == 0) env->pipeline = 2;
   }
+  if (const char* np = std::getenv("BOURSE_AMD_SPLIT_PARTS")) {
+    const int v = std::atoi(np);
+    if (v >= 1 && v <= 4) env->n_parts = v;
+  }
   HIPCHK(env->ev_off.alloc(B + 1));
   HIPCHK(hipMemset(env->ev_off.p, 0, (B + 1) * sizeof(uint32_t)));
 
@@ -364,6 +407,15 @@ void bk_env_destroy(bk_env* env) {
   for (auto& pr : env->prof_events) {
     (void)hipEventDestroy(pr.a);
     (void)hipEventDestroy(pr.b);
+  }
+  if (env->ev_fork) {
+    (void)hipEventDestroy(env->ev_fork);
+    for (int i = 0; i < 4; ++i) {
+      (void)hipStreamSynchronize(env->part_stream[i]);
+      (void)hipStreamDestroy(env->part_stream[i]);
+      (void)hipEventDestroy(env->ev_first[i]);
+      (void)hipEventDestroy(env->ev_join[i]);
+    }
   }
   delete env;
 }
