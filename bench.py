@@ -90,7 +90,7 @@ def main():
         raise SystemExit("bench.py needs an MI355X: no GPU visible (bourse_amd has no CPU path)")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:  # launched by torch.distributed.run (also with one rank: exercises RCCL path)
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -104,14 +104,14 @@ def main():
     n_agents = sum(g[0] for g in groups)
     spl = max(1, min(args.steps_per_launch, args.steps))
     hist_cap = 0 if args.no_history else spl
-    trade_cap = 64 * spl  # ~35 trades/book-step measured for C3; overflow is flagged and checked below
+    trade_cap = max(64, n_agents // 2 * 3 // 2) * spl  # ~35 trades/book-step measured at C3 (128 agents); overflow is flagged and checked below
     stream = torch.cuda.current_stream().cuda_stream
     env = bourse_amd.ManyBookEnv(B, SEED, 0, TICK, STEP_SIZE, True, levels=levels, max_live_orders=n_agents,
                                  trade_capacity=trade_cap, history_capacity=hist_cap,
                                  book_offset=rank * B, device=local_rank, stream=stream)
     env.set_random_agents(groups)
     env.set_pipeline(args.pipeline)
-    gather = parallel.StatsGather(env, dist) if world > 1 else None
+    gather = parallel.StatsGather(env, dist) if dist is not None else None
 
     def run_steps(n):
         done = 0
@@ -199,6 +199,11 @@ def main():
             "kernel_ms_total": {k: v[0] for k, v in per_kind.items() if v[1]},
         },
     }
+    if gather is not None:
+        g = gather.result()
+        out["config"]["stats_allgather"] = {"zero_copy": gather.zero_copy, "n_books": g["n_books"], "sum_trades": g["sum_trades"]}
+        if g["n_books"] != world * B:
+            raise SystemExit(f"stats all-gather inconsistent: {g}")
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(groups, levels)
     env.close()
