@@ -76,6 +76,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-history", action="store_true", help="keep only the latest L2 record (diagnostic)")
     ap.add_argument("--pipeline", default="auto", choices=["auto", "fused", "split"])
+    ap.add_argument("--profile-every", type=int, default=8, help="HIP-event-time every Nth step's kernels (0 = none)")
     args = ap.parse_args()
 
     import torch
@@ -127,7 +128,7 @@ def main():
     run_steps(args.warmup)
     torch.cuda.synchronize()
     tc0 = int(env.trade_counts().sum())
-    env.profile(True)
+    env.profile(args.profile_every)
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()

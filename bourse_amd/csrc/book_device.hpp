@@ -734,7 +734,7 @@ __global__ __launch_bounds__(64) void k_agents_fsm(DevArgs a) {
   // crosses a group boundary (a few times per step), keeping LDS latency out of the per-draw loop.
   uint32_t n = 0, g = 0, gend = 0, n_ev = 0;
   uint32_t thr = 0, tick_lo = 0, tick_rng = 1, tick_zone = 0, vol_lo = 0, vol_rng = 1, vol_zone = 0, tick_sz = 0;
-  uint32_t phase = PH_DONE, range = 0, zone = 0, shuf_i = 0, cur_side = 0, cur_price = 0;
+  uint32_t phase = PH_DONE, range = 0, zone = 0, cur_side = 0, cur_price = 0;
   auto load_group = [&]() {
     const uint32_t* q = gtab + g * G_DW;
     thr = q[1];
@@ -755,9 +755,10 @@ __global__ __launch_bounds__(64) void k_agents_fsm(DevArgs a) {
     load_group();
     phase = PH_ACT;
   }
-  // One next_u32() draw per iteration.  The body is written select-style (v_cndmask) with four short
-  // predicated blocks (list append, new-order store, shuffle swap, next-agent) so that lanes in different
-  // phases share almost the whole instruction stream.
+
+  // ---- loop 1: agents.update.  One next_u32() draw per iteration, select-style body (v_cndmask) with three
+  // short predicated blocks (list append, new-order store, next-agent) so that lanes in different phases share
+  // almost the whole instruction stream; a lane never waits for another lane's rejection loop.
   while (phase != PH_DONE) {
     const uint32_t x = rng.next_u32();
     const bool is_act = phase == PH_ACT;
@@ -774,7 +775,7 @@ __global__ __launch_bounds__(64) void k_agents_fsm(DevArgs a) {
     for (int r = 1; r < R; ++r) w = ((n >> 6) == (uint32_t)r) ? live[r] : w;
     const bool holds_live = (w >> (n & 63)) & 1ull;  // Active order held -> the event is its cancellation (:95-97)
     const bool acc_side = acc & (phase == PH_SIDE), acc_tick = acc & (phase == PH_TICK);
-    const bool acc_vol = acc & (phase == PH_VOL), acc_shuf = acc & (phase == PH_SHUF);
+    const bool acc_vol = acc & (phase == PH_VOL);
     cur_side = acc_side ? val : cur_side;                         // 0 = Ask, 1 = Bid ([Ask, Bid].choose, :99)
     cur_price = acc_tick ? (tick_lo + val) * tick_sz : cur_price;  // tick * tick_size (:100,:107)
     if (acc_vol) {                                                 // vol drawn last (:101): the order is complete
@@ -787,26 +788,14 @@ __global__ __launch_bounds__(64) void k_agents_fsm(DevArgs a) {
         sidem[r] |= cur_side ? bb : 0ull;
       }
     }
-    if (acc_shuf) {  // swap(i, j), j = val in [0, i]  (rand SliceRandom::shuffle)
-      const uint16_t ai = list[shuf_i * 64 + lane], aj = list[val * 64 + lane];
-      list[shuf_i * 64 + lane] = aj;
-      list[val * 64 + lane] = ai;
-    }
-    shuf_i -= acc_shuf ? 1u : 0u;
-    const uint32_t nr = shuf_i + 1;
-    const uint32_t nz = (nr << __builtin_clz(nr | 1u)) - 1u;
     const bool to_side = hit & !holds_live;
-    phase = to_side ? PH_SIDE : acc_side ? PH_TICK : acc_tick ? PH_VOL : acc_shuf ? (shuf_i == 0 ? PH_DONE : PH_SHUF) : phase;
-    range = to_side ? 2u : acc_side ? tick_rng : acc_tick ? vol_rng : acc_shuf ? nr : range;
-    zone = to_side ? 0x7FFFFFFFu : acc_side ? tick_zone : acc_tick ? vol_zone : acc_shuf ? nz : zone;
-    if ((is_act & !hit) | (hit & holds_live) | acc_vol) {  // next agent, or start the shuffle after the last one
+    phase = to_side ? PH_SIDE : acc_side ? PH_TICK : acc_tick ? PH_VOL : phase;
+    range = to_side ? 2u : acc_side ? tick_rng : acc_tick ? vol_rng : range;
+    zone = to_side ? 0x7FFFFFFFu : acc_side ? tick_zone : acc_tick ? vol_zone : zone;
+    if ((is_act & !hit) | (hit & holds_live) | acc_vol) {  // next agent
       ++n;
       if (n >= total) {
-        const bool sh = n_ev >= 2;
-        phase = sh ? PH_SHUF : PH_DONE;
-        shuf_i = n_ev - 1;
-        range = n_ev;
-        zone = (n_ev << __builtin_clz(n_ev | 1u)) - 1u;
+        phase = PH_DONE;
       } else {
         if (n >= gend) {
           do {
@@ -816,6 +805,27 @@ __global__ __launch_bounds__(64) void k_agents_fsm(DevArgs a) {
           load_group();
         }
         phase = PH_ACT;
+      }
+    }
+  }
+
+  // ---- loop 2: transactions.shuffle(rng) (env.rs:121): for i in (1..n_ev).rev() { swap(i, gen_index(i + 1)) }
+  // (rand SliceRandom::shuffle), again one draw per iteration per lane.
+  {
+    uint32_t i = n_ev > 1 ? n_ev - 1 : 0;
+    uint32_t rg = i + 1;
+    uint32_t zn = (rg << __builtin_clz(rg)) - 1u;
+    while (i != 0) {
+      const uint32_t x = rng.next_u32();
+      const uint64_t m = (uint64_t)x * rg;
+      if ((uint32_t)m <= zn) {
+        const uint32_t j = (uint32_t)(m >> 32);
+        const uint16_t ai = list[i * 64 + lane], aj = list[j * 64 + lane];
+        list[i * 64 + lane] = aj;
+        list[j * 64 + lane] = ai;
+        --i;
+        rg = i + 1;
+        zn = (rg << __builtin_clz(rg)) - 1u;
       }
     }
   }

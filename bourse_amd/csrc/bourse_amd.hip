@@ -126,7 +126,9 @@ struct bk_env {
   uint32_t trading = 1;
   size_t ev_capacity = 0;
   // profiling
-  bool profile = false;
+  int profile = 0;       // 0 off, N: HIP-event-time the kernels of every Nth step
+  uint64_t prof_tick = 0;  // steps seen while profiling
+  bool prof_now = false;
   struct ProfEv {
     hipEvent_t a, b;
     int kind;
@@ -183,7 +185,7 @@ struct ProfScope {  // HIP events around a launch on the env's stream
   hipStream_t st;
   hipEvent_t a = nullptr, b = nullptr;
   ProfScope(bk_env* e, int k, hipStream_t s = nullptr) : env(e), kind(k), st(s ? s : e->stream) {
-    if (env->profile && hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess)
+    if (env->prof_now && hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess)
       (void)hipEventRecord(a, st);
   }
   ~ProfScope() {
@@ -197,6 +199,7 @@ struct ProfScope {  // HIP events around a launch on the env's stream
 template <int R>
 int launch_run(bk_env* env, const DevArgs& a, uint64_t first_step, uint32_t n_steps) {
   const uint32_t blocks = (env->cfg.n_books + 3) / 4;
+  env->prof_now = env->profile > 0;
   ProfScope ps(env, 0);
   hipLaunchKernelGGL(k_run_random<R>, dim3(blocks), dim3(256), 0, env->stream, a, first_step, n_steps);
   HIPCHK(hipGetLastError());
@@ -204,6 +207,7 @@ int launch_run(bk_env* env, const DevArgs& a, uint64_t first_step, uint32_t n_st
 }
 template <int R>
 int launch_events(bk_env* env, const DevArgs& a, uint64_t step_index) {
+  env->prof_now = env->profile > 0;
   ProfScope ps(env, 3);
   hipLaunchKernelGGL(k_step_events<R>, dim3(env->cfg.n_books), dim3(64), 0, env->stream, a, step_index);
   HIPCHK(hipGetLastError());
@@ -229,6 +233,7 @@ int launch_split(bk_env* env, const DevArgs& a0, uint64_t first_step, uint32_t n
     for (int i = 0; i < P; ++i) HIPCHK(hipStreamWaitEvent(env->part_stream[i], env->ev_fork, 0));
   }
   for (uint32_t s = 0; s < n_steps; ++s) {
+    env->prof_now = env->profile > 0 && (env->prof_tick++ % env->profile) == 0;
     for (int i = 0; i < P; ++i) {
       DevArgs a = a0;
       a.book_begin = static_cast<uint32_t>(static_cast<uint64_t>(B) * i / P) & ~3u;
@@ -879,7 +884,9 @@ int bk_stats_device_ptr(bk_env* env, void** out) {
 // ------------------------------------------------------------------ measurement
 int bk_profile_enable(bk_env* env, int on) {
   if (!env) return fail(BK_INVALID_ARGUMENT, "null env");
-  env->profile = on != 0;
+  env->profile = on < 0 ? 0 : on;
+  env->prof_tick = 0;
+  env->prof_now = false;
   return BK_OK;
 }
 

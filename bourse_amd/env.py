@@ -242,8 +242,9 @@ class ManyBookEnv:
         check(self._L.bk_stats_compute(self._h, None))
 
     # ------------------------------------------------------------ measurement
-    def profile(self, on: bool):
-        check(self._L.bk_profile_enable(self._h, int(on)))
+    def profile(self, every: int):
+        """HIP-event timing of the step kernels: 0 off, N >= 1 = time the kernels of every Nth step."""
+        check(self._L.bk_profile_enable(self._h, int(every)))
 
     def profile_read(self, reset: bool = True) -> Tuple[float, int]:
         ms, n = C.c_double(0), C.c_uint64(0)

@@ -178,7 +178,7 @@ int bk_stats_compute(bk_env* env, bk_stats* out_host);
 int bk_stats_device_ptr(bk_env* env, void** out);
 
 /* ------------------------------------------------------------- measurement */
-/* accumulate HIP-event timings of the step kernels launched on the env's stream */
+/* accumulate HIP-event timings of the step kernels: on = 0 off, N >= 1 time the kernels of every Nth step */
 int bk_profile_enable(bk_env* env, int on);
 int bk_profile_read(bk_env* env, double* total_ms, uint64_t* n_launches, int reset);
 /* per kernel: kind 0 k_run_random (fused), 1 k_agents_fsm, 2 k_step_batch (split pipeline), 3 k_step_events */
