@@ -847,11 +847,13 @@ __global__ __launch_bounds__(64) void k_agents_fsm(DevArgs a) {
 }
 
 template <int R>
-__global__ __launch_bounds__(256) void k_step_batch(DevArgs a, uint64_t step_index, uint32_t write_last) {
-  __shared__ uint32_t lds[4][LDS_DW_PER_WAVE];
-  const int lane = threadIdx.x & 63;
-  const int wv = threadIdx.x >> 6;
-  const uint32_t book = rfl(a.book_begin + blockIdx.x * 4 + wv);
+__global__ __launch_bounds__(64) void k_step_batch(DevArgs a, uint64_t step_index, uint32_t write_last) {
+  // one-wave workgroups: the dispatcher places every wave independently, so the wave slots left beside the
+  // co-running k_agents_fsm waves are all usable (4-wave workgroups needed a free slot on every SIMD)
+  __shared__ uint32_t lds[1][LDS_DW_PER_WAVE];
+  const int lane = threadIdx.x;
+  const int wv = 0;
+  const uint32_t book = a.book_begin + blockIdx.x;
   if (book >= a.book_end) return;
   uint32_t* st = a.state + (size_t)book * a.state_stride;
   const uint32_t* bt = a.batch + (size_t)book * a.batch_stride;

@@ -249,7 +249,7 @@ int launch_split(bk_env* env, const DevArgs& a0, uint64_t first_step, uint32_t n
       {
         ProfScope ps(env, 2, st);
         const uint32_t write_last = (s + 1 == n_steps || a.hist_cap == 0) ? 1u : 0u;
-        hipLaunchKernelGGL(k_step_batch<R>, dim3((nb + 3) / 4), dim3(256), 0, st, a, first_step + s, write_last);
+        hipLaunchKernelGGL(k_step_batch<R>, dim3(nb), dim3(64), 0, st, a, first_step + s, write_last);
       }
     }
   }
