@@ -161,22 +161,24 @@ def main():
     W4 = env.width * 4
     tr_per_bs = n_trades / (B * args.steps)
     ev_per_bs = st["sum_events"] / (B * (args.steps + args.warmup))
+    pipe, parts = env.pipeline()
     if dominant == "k_step_batch":
-        # one launch = ONE step of every book: state in + out, the step batch in (header 64 B + 2 B per event +
-        # 8 B per new order, ~0.77 of the events), one L2 record, 32 B per trade
-        steps_per_kernel_launch = 1
+        # one launch = ONE step of ONE part (B / parts books): state in + out, the step batch in (header 64 B +
+        # 2 B per event + 8 B per new order, ~0.77 of the events), one L2 record, 32 B per trade
+        book_steps_per_launch = B / parts
         bytes_per_bookstep = 2.0 * S + 64 + 2.0 * ev_per_bs + 8.0 * 0.77 * ev_per_bs + W4 + 32.0 * tr_per_bs
     else:
-        steps_per_kernel_launch = spl
+        book_steps_per_launch = B * spl
         bytes_per_bookstep = 2.0 * S / spl + W4 + 32.0 * tr_per_bs
     launches = max(n_launch, 1)
     avg_ms = kern_ms / launches
-    achieved = (bytes_per_bookstep * B * steps_per_kernel_launch) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    achieved = (bytes_per_bookstep * book_steps_per_launch) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
     traffic = None
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc):
         try:
-            traffic = json.load(open(pmc)).get(args.workload, {}).get(dominant, {}).get("hbm_bytes_per_launch")
+            per_bs = json.load(open(pmc)).get(args.workload, {}).get(dominant, {}).get("hbm_bytes_per_book_step")
+            traffic = per_bs * book_steps_per_launch if per_bs is not None else None
         except Exception:
             traffic = None
     out = {
@@ -191,12 +193,14 @@ def main():
             "parallelism": f"independent book shards x{world}, 64 B stats all-gather per launch" if world > 1
             else "single GPU",
             "trades_per_book_step": tr_per_bs, "events_per_book_step": ev_per_bs,
-            "pipeline": "split (k_agents_fsm + k_step_batch per step)" if dominant == "k_step_batch" else "fused (k_run_random)",
+            "pipeline": f"split (k_agents_fsm + k_step_batch per step, {parts} book parts on separate streams)"
+            if pipe == "split" else "fused (k_run_random)",
         },
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "kernel": dominant,
             "avg_launch_ms": avg_ms, "launches": n_launch, "bytes_per_book_step": bytes_per_bookstep,
+            "book_steps_per_launch": book_steps_per_launch,
             "kernel_ms_total": {k: v[0] for k, v in per_kind.items() if v[1]},
         },
     }

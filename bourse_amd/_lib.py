@@ -96,6 +96,7 @@ SIGNATURES = {
     "bk_get_trades": (_i32, [_vp, _u32, _u64, _u64, _vp]),
     "bk_clear_trades": (_i32, [_vp]),
     "bk_time": (_i32, [_vp, _u32, _p64]),
+    "bk_set_time": (_i32, [_vp, _u32, _u64]),
     "bk_trade_vol": (_i32, [_vp, _u32, _p32]),
     "bk_steps_done": (_i32, [_vp, _p64]),
     "bk_book_flags": (_i32, [_vp, _p32]),
@@ -107,6 +108,7 @@ SIGNATURES = {
     "bk_profile_read": (_i32, [_vp, C.POINTER(C.c_double), _p64, _i32]),
     "bk_profile_read_kind": (_i32, [_vp, _i32, C.POINTER(C.c_double), _p64]),
     "bk_set_pipeline": (_i32, [_vp, _i32]),
+    "bk_get_pipeline": (_i32, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "bk_state_bytes_per_book": (_u64, [_vp]),
 }
 

@@ -2,6 +2,7 @@
 
 * ``StepEnv``      <- rust/src/step_sim.rs:55-607
 * ``StepEnvNumpy`` <- rust/src/step_sim_numpy.rs:66-516
+* ``OrderBook``    <- rust/src/order_book.rs:30-380 (immediate mode; no JSON snapshot)
 
 Same constructor, method and property names, dtypes and array layouts (the CODE's layouts:
 see SURVEY §8b for the two places where the reference's docstrings disagree with its code), so
@@ -153,6 +154,86 @@ class StepEnv(_EnvBase):
 
     def level_2_data_array(self):
         return self._l2()
+
+
+class OrderBook:
+    """``bourse.core.OrderBook(start_time, tick_size, trading=True)`` — immediate-mode book
+    (ref rust/src/order_book.rs:30-380) on the GPU: every call is one event processed at the book's current
+    time (``Env::step`` with a one-event queue and step_size 0), so ``set_time`` is the caller's job exactly as in
+    the reference.  Orders placed at the SAME time keep strict FIFO priority here (the reference's
+    ``(price, t)`` key would overwrite).  JSON snapshots are out of scope."""
+
+    def __init__(self, start_time, tick_size, trading=True, *, max_live_orders=512, max_orders=1 << 16,
+                 trade_capacity=1 << 16, device=0):
+        self._env = ManyBookEnv(1, 0, start_time, tick_size, 0, trading, levels=LEVELS,
+                                max_live_orders=max_live_orders, max_orders=max_orders,
+                                trade_capacity=trade_capacity, history_capacity=0, device=device)
+
+    def _l2(self):
+        return self._env.level2(0, 1)[0]
+
+    def set_time(self, t):
+        self._env.set_time(0, t)
+
+    def enable_trading(self):
+        self._env.enable_trading()
+
+    def disable_trading(self):
+        self._env.disable_trading()
+
+    def ask_vol(self):
+        return int(self._l2()[3])
+
+    def best_ask_vol(self):
+        return int(self._l2()[7])
+
+    def best_ask_vol_and_orders(self):
+        l2 = self._l2()
+        return int(l2[7]), int(l2[8])
+
+    def bid_vol(self):
+        return int(self._l2()[4])
+
+    def best_bid_vol(self):
+        return int(self._l2()[5])
+
+    def best_bid_vol_and_orders(self):
+        l2 = self._l2()
+        return int(l2[5]), int(l2[6])
+
+    def bid_ask(self):
+        l2 = self._l2()
+        return int(l2[1]), int(l2[2])
+
+    def order_status(self, order_id):
+        return self._env.order_status(0, order_id)
+
+    def place_order(self, bid, vol, trader_id, price=None):
+        """``create_and_place_order`` (ref orderbook.rs:411-421)."""
+        oid = self._env.place_order(0, bid, vol, trader_id, price)
+        self._env.step()
+        return oid
+
+    def cancel_order(self, order_id):
+        self._env.cancel_order(0, order_id)
+        self._env.step()
+
+    def modify_order(self, order_id, new_price=None, new_vol=None):
+        self._env.modify_order(0, order_id, new_price, new_vol)
+        self._env.step()
+
+    def get_trades(self):
+        return [
+            (int(r["t"]), bool(r["side"]), int(r["price"]), int(r["vol"]), int(r["active_id"]), int(r["passive_id"]))
+            for r in self._env.trades(0, first=0)
+        ]
+
+    def get_orders(self):
+        return [
+            (bool(r["side"]), int(r["status"]), int(r["arr_time"]), int(r["end_time"]), int(r["vol"]),
+             int(r["start_vol"]), int(r["price"]), int(r["trader_id"]), int(r["order_id"]))
+            for r in self._env.orders(0)
+        ]
 
 
 class StepEnvNumpy(_EnvBase):

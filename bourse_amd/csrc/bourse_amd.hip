@@ -80,6 +80,7 @@ struct BookHost {
   std::vector<HostEvent> queue;
   std::vector<DevOrderLog> log_cache;
   uint64_t n_uploaded = 0;  // orders whose New event has reached the device
+  uint64_t time_offset = 0;  // set by bk_set_time: book time = start_time + steps_done * step_size + time_offset (wrapping)
   bool log_fresh = false;
 };
 
@@ -449,7 +450,7 @@ int bk_place_order(bk_env* env, uint32_t book, int bid, uint32_t vol, uint32_t t
   const uint64_t id = bh.orders.size();  // current_order_id, orderbook.rs:327-329
   if (id >= 0xFFFFFFFFull) return fail(BK_CAPACITY, "order id space exhausted");
   const uint32_t p = has_price ? price : (bid ? 0xFFFFFFFFu : 0u);  // market sentinels, types.rs:168,221
-  const uint64_t now = env->cfg.start_time + env->steps_done * env->cfg.step_size;
+  const uint64_t now = env->cfg.start_time + env->steps_done * env->cfg.step_size + bh.time_offset;
   bh.orders.push_back(HostOrder{static_cast<uint8_t>(bid ? 1 : 0), vol, p, trader_id, now});
   bh.queue.push_back(HostEvent{0u | (bid ? 1u << 8 : 0u), static_cast<uint32_t>(id), p, vol});
   if (out_order_id) *out_order_id = id;
@@ -786,6 +787,17 @@ int bk_clear_trades(bk_env* env) {
   return BK_OK;
 }
 
+// OrderBook::set_time (crates/order_book/src/orderbook.rs:183-185) for one book (host-driven path)
+int bk_set_time(bk_env* env, uint32_t book, uint64_t t) {
+  if (int rc = check_book(env, book)) return rc;
+  if (int rc = use_device(env)) return rc;
+  HIPCHK(hipStreamSynchronize(env->stream));
+  const uint32_t w[2] = {static_cast<uint32_t>(t), static_cast<uint32_t>(t >> 32)};
+  HIPCHK(hipMemcpy(env->state.p + static_cast<size_t>(book) * env->stride + H_T_LO, w, 8, hipMemcpyHostToDevice));
+  env->books[book].time_offset = t - (env->cfg.start_time + env->steps_done * env->cfg.step_size);
+  return BK_OK;
+}
+
 int bk_time(bk_env* env, uint32_t book, uint64_t* out) {
   if (int rc = check_book(env, book)) return rc;
   uint32_t h[2];
@@ -915,6 +927,16 @@ int bk_profile_read_kind(bk_env* env, int kind, double* total_ms, uint64_t* n_la
   if (int rc = prof_collect(env)) return rc;
   if (total_ms) *total_ms = env->prof_ms[kind];
   if (n_launches) *n_launches = env->prof_launches[kind];
+  return BK_OK;
+}
+
+int bk_get_pipeline(bk_env* env, int* split, int* n_parts) {
+  if (!env) return fail(BK_INVALID_ARGUMENT, "null env");
+  const bool sp = env->pipeline == 2 || (env->pipeline == 0 && env->cfg.n_books >= 16384 && !env->groups.empty());
+  int P = env->n_parts;
+  if (env->cfg.n_books < 4096u * P) P = 1;
+  if (split) *split = sp ? 1 : 0;
+  if (n_parts) *n_parts = sp ? P : 1;
   return BK_OK;
 }
 

@@ -201,6 +201,10 @@ class ManyBookEnv:
         check(self._L.bk_time(self._h, book, C.byref(out)))
         return int(out.value)
 
+    def set_time(self, book: int, t: int):
+        """``OrderBook::set_time`` (orderbook.rs:183-185) — host-driven path."""
+        check(self._L.bk_set_time(self._h, book, int(t)))
+
     def trade_vol(self, book: int = 0) -> int:
         out = C.c_uint32(0)
         check(self._L.bk_trade_vol(self._h, book, C.byref(out)))
@@ -260,6 +264,12 @@ class ManyBookEnv:
     def set_pipeline(self, mode: str):
         """'auto' | 'fused' | 'split' — kernel pipeline of run(); results are identical."""
         check(self._L.bk_set_pipeline(self._h, {"auto": 0, "fused": 1, "split": 2}[mode]))
+
+    def pipeline(self) -> Tuple[str, int]:
+        """('fused' | 'split', number of book parts launched on separate streams) that run() will use."""
+        a, b = C.c_int(0), C.c_int(1)
+        check(self._L.bk_get_pipeline(self._h, C.byref(a), C.byref(b)))
+        return ("split" if a.value else "fused"), int(b.value)
 
     def state_bytes_per_book(self) -> int:
         return int(self._L.bk_state_bytes_per_book(self._h))

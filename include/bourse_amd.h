@@ -164,6 +164,7 @@ int bk_trade_counts(bk_env* env, uint64_t* totals /* [n_books] */);
 int bk_get_trades(bk_env* env, uint32_t book, uint64_t first, uint64_t n, bk_trade* out);
 int bk_clear_trades(bk_env* env);
 int bk_time(bk_env* env, uint32_t book, uint64_t* out);          /* OrderBook::get_time */
+int bk_set_time(bk_env* env, uint32_t book, uint64_t t);         /* OrderBook::set_time, orderbook.rs:183-185 */
 int bk_trade_vol(bk_env* env, uint32_t book, uint32_t* out);     /* OrderBook::get_trade_vol (live) */
 int bk_steps_done(bk_env* env, uint64_t* out);
 int bk_book_flags(bk_env* env, uint32_t* out /* [n_books] */);   /* sticky BK_FLAG_* bits */
@@ -186,6 +187,8 @@ int bk_profile_read_kind(bk_env* env, int kind, double* total_ms, uint64_t* n_la
 /* bk_run kernel pipeline: 0 auto, 1 fused (one wave per book, all phases), 2 split (RNG-serial phases one lane per
  * book + event phase one wave per book).  Results are identical; only speed differs. */
 int bk_set_pipeline(bk_env* env, int mode);
+/* the pipeline bk_run will use: *split = 0/1; *n_parts = contiguous book parts launched on separate streams */
+int bk_get_pipeline(bk_env* env, int* split, int* n_parts);
 uint64_t bk_state_bytes_per_book(const bk_env* env);
 
 #ifdef __cplusplus

@@ -440,3 +440,132 @@ def test_full_size_invariants_c3(bk):
     assert np.array_equal(small.history(), h[:, :64])
     st = env.stats()
     assert st["n_books"] == B and st["sum_trades"] == int(tc.sum()) and st["sum_trade_vol"] == int(h[-1, :, 0].sum())
+
+
+# ------------------------------------------------------------------- immediate-mode OrderBook on the GPU
+def test_order_book_python_suite_on_gpu(bk):
+    """The reference's tests/test_order_book.py vectors on bourse_amd.core.OrderBook."""
+    MAXP = bk.MAX_PRICE
+    ob = bk.core.OrderBook(0, 1)                                          # test_order_book_init :6-15
+    assert ob.bid_ask() == (0, MAXP) and (ob.bid_vol(), ob.ask_vol()) == (0, 0)
+    assert ob.best_bid_vol_and_orders() == (0, 0) and ob.best_ask_vol_and_orders() == (0, 0)
+    ob.place_order(True, 10, 11, price=50)                                # test_place_order :18-42
+    ob.place_order(False, 20, 12, price=60)
+    assert ob.bid_ask() == (50, 60) and (ob.bid_vol(), ob.ask_vol()) == (10, 20)
+    assert ob.best_bid_vol_and_orders() == (10, 1) and ob.best_ask_vol_and_orders() == (20, 1)
+    ob.place_order(True, 10, 11, price=55)
+    ob.place_order(False, 20, 12, price=65)
+    assert ob.bid_ask() == (55, 60) and (ob.bid_vol(), ob.ask_vol()) == (20, 40)
+    assert (ob.best_bid_vol(), ob.best_ask_vol()) == (10, 20)
+    bad = bk.core.OrderBook(0, 2)                                         # test_incorrect_order_price :45-52
+    with pytest.raises(ValueError):
+        bad.place_order(True, 10, 101, price=11)
+
+    ob = bk.core.OrderBook(0, 1)                                          # test_cancel_order :54-88
+    ids = [ob.place_order(True, 10, 11, price=50), ob.place_order(False, 20, 12, price=60),
+           ob.place_order(True, 10, 11, price=55), ob.place_order(False, 20, 12, price=65)]
+    ob.cancel_order(ids[2])
+    ob.cancel_order(ids[3])
+    assert ob.order_status(ids[2]) == 3 and ob.order_status(ids[3]) == 3
+    assert ob.bid_ask() == (50, 60) and (ob.bid_vol(), ob.ask_vol()) == (10, 20)
+    ob.cancel_order(ids[0])
+    ob.cancel_order(ids[1])
+    assert ob.bid_ask() == (0, MAXP) and ob.best_bid_vol_and_orders() == (0, 0) and ob.best_ask_vol_and_orders() == (0, 0)
+
+    ob = bk.core.OrderBook(0, 1)                                          # test_trades :91-135 (C.14)
+    ob.place_order(True, 10, 11, price=50)
+    id1 = ob.place_order(False, 20, 12, price=60)
+    id2 = ob.place_order(True, 10, 11, price=55)
+    id3 = ob.place_order(False, 20, 12, price=65)
+    ob.set_time(10)
+    id4 = ob.place_order(True, 30, 11)
+    assert ob.order_status(id4) == 2 and ob.order_status(id1) == 2
+    assert ob.bid_ask() == (55, 65) and (ob.bid_vol(), ob.ask_vol()) == (20, 10)
+    ob.set_time(20)
+    id5 = ob.place_order(False, 20, 12, price=55)
+    assert ob.order_status(id5) == 1 and ob.order_status(id2) == 2
+    assert ob.bid_ask() == (50, 55) and (ob.bid_vol(), ob.ask_vol()) == (10, 20)
+    tr = ob.get_trades()
+    assert [t[0] for t in tr] == [10, 10, 20] and [t[2] for t in tr] == [60, 65, 55] and [t[3] for t in tr] == [20, 10, 10]
+    assert [t[4] for t in tr] == [id4, id4, id5] and [t[5] for t in tr] == [id1, id3, id2]
+
+    ob = bk.core.OrderBook(0, 1)                                          # test_mod_order_volume :138-154
+    ob.place_order(True, 10, 11, price=50)
+    i1 = ob.place_order(True, 10, 11, price=55)
+    i2 = ob.place_order(False, 20, 12, price=65)
+    ob.place_order(False, 20, 12, price=60)
+    ob.modify_order(i1, new_vol=5)
+    ob.modify_order(i2, new_vol=10)
+    assert ob.bid_ask() == (55, 60) and (ob.bid_vol(), ob.ask_vol()) == (15, 30) and (ob.best_bid_vol(), ob.best_ask_vol()) == (5, 20)
+    ob = bk.core.OrderBook(0, 1)                                          # test_modify_order :157-169
+    a = ob.place_order(True, 10, 11, price=50)
+    ob.place_order(False, 30, 11, price=60)
+    ob.modify_order(a, new_price=45, new_vol=20)
+    assert ob.bid_ask() == (45, 60) and (ob.bid_vol(), ob.ask_vol()) == (20, 30) and ob.order_status(a) == 1
+    o = ob.get_orders()                                                   # test_get_orders :172-187 (tuple layout)
+    assert [x[0] for x in o] == [True, False] and [x[8] for x in o] == [0, 1] and [x[6] for x in o] == [45, 60]
+
+
+def test_order_book_rust_kats_on_gpu(bk):
+    """orderbook.rs unit vectors needing immediate mode: C.7 crossing modify, C.8 sweep, C.9 market edge cases."""
+    MAXP = bk.MAX_PRICE
+    b = bk.core.OrderBook(0, 1)                                           # C.7 orderbook.rs:1145-1168
+    b.place_order(False, 10, 0, 100)
+    b.place_order(True, 10, 0, 50)
+    b.modify_order(1, 100, 20)
+    assert (b.ask_vol(), b.best_ask_vol_and_orders()) == (0, (0, 0)) and (b.bid_vol(), b.best_bid_vol_and_orders()) == (10, (10, 1))
+    assert b.bid_ask() == (100, MAXP)
+    t = b.get_trades()
+    assert len(t) == 1 and (t[0][2], t[0][3]) == (100, 10)
+    b = bk.core.OrderBook(0, 1)                                           # C.8 orderbook.rs:1171-1214
+    for t_, (bid, vol, price) in enumerate([(False, 101, 20), (False, 101, 18), (True, 202, 12), (True, 202, 14)]):
+        b.set_time(t_)
+        b.place_order(bid, vol, 101, price)
+    b.set_time(4)
+    b.place_order(True, 102, 101, None)
+    assert b.ask_vol() == 100 and b.bid_ask() == (14, 20)
+    tr = b.get_trades()
+    assert [(x[2], x[3]) for x in tr] == [(18, 101), (20, 1)]
+    b.place_order(False, 204, 101, 14)
+    assert (b.bid_vol(), b.ask_vol()) == (202, 102) and b.best_bid_vol_and_orders() == (202, 1) and b.best_ask_vol_and_orders() == (2, 1)
+    assert b.bid_ask() == (12, 14)
+    tr = b.get_trades()
+    assert (tr[2][2], tr[2][3]) == (14, 202) and [x[4] for x in tr] == [4, 4, 5] and [x[5] for x in tr] == [1, 0, 3]
+    b = bk.core.OrderBook(0, 1, False)                                    # C.9 orderbook.rs:1217-1227
+    b.place_order(True, 101, 101, None)
+    assert b.bid_ask() == (0, MAXP) and b.order_status(0) == 4
+    b = bk.core.OrderBook(0, 1)                                           # C.9 orderbook.rs:1230-1242
+    b.place_order(False, 10, 101, 50)
+    b.place_order(True, 20, 101, None)
+    assert b.bid_ask() == (0, MAXP) and (b.bid_vol(), b.ask_vol()) == (0, 0) and b.order_status(1) == 3
+
+
+def test_host_driven_many_books_match_oracle(bk, oracle):
+    """B > 1 on the host-driven path: every book gets its own instruction stream and its own shuffle RNG."""
+    B, T = 5, 25
+    env = bk.ManyBookEnv(B, 77, 0, 1, 1000, levels=10, max_live_orders=256, max_orders=4096, trade_capacity=4096,
+                         history_capacity=T)
+    refs = [oracle.StepEnv(77 + b, 0, 1, 1000) for b in range(B)]
+    rng = np.random.default_rng(9)
+    for _ in range(T):
+        for b in range(B):
+            for _k in range(int(rng.integers(0, 12))):
+                bid, vol, price = bool(rng.integers(0, 2)), int(rng.integers(1, 30)), int(rng.integers(90, 110))
+                assert env.place_order(b, bid, vol, b, price) == refs[b].place_order(bid, vol, b, price)
+            n = refs[b].book.n_orders()
+            if n and rng.random() < 0.5:
+                i = int(rng.integers(0, n))
+                env.cancel_order(b, i)
+                refs[b].cancel_order(i)
+        env.step()
+        for r in refs:
+            r.step()
+    h = env.history()
+    for b in range(B):
+        assert np.array_equal(h[:, b], refs[b].history()), b
+        got, exp = env.trades(b, first=0), refs[b].book.trades_array()
+        for f in got.dtype.names:
+            assert np.array_equal(got[f], exp[f]), (b, f)
+        go, eo = env.orders(b), refs[b].book.orders_array()
+        for f in go.dtype.names:
+            assert np.array_equal(go[f], eo[f]), (b, f)
