@@ -110,6 +110,9 @@ SIGNATURES = {
     "bk_set_pipeline": (_i32, [_vp, _i32]),
     "bk_get_pipeline": (_i32, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "bk_state_bytes_per_book": (_u64, [_vp]),
+    "bk_checkpoint_bytes": (_u64, [_vp]),
+    "bk_checkpoint_save": (_i32, [_vp, _vp, _u64]),
+    "bk_checkpoint_load": (_i32, [_vp, _vp, _u64]),
 }
 
 _lib = None

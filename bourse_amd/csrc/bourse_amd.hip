@@ -946,6 +946,46 @@ int bk_set_pipeline(bk_env* env, int mode) {
   return BK_OK;
 }
 
+// ---------------------------------------------------------------- checkpoint / resume (on-device order flow)
+// The reference cannot resume a running simulation (Env, agents and RNG are not serialisable);
+// here the whole simulation state IS the per-book device block (pool, clock, counters, RNG), so a checkpoint
+// is one device-to-host copy.  Host-driven envs (order log + host order table) are not covered.
+uint64_t bk_checkpoint_bytes(const bk_env* env) {
+  return env ? 16 + static_cast<uint64_t>(env->cfg.n_books) * env->stride * 4 : 0;
+}
+
+int bk_checkpoint_save(bk_env* env, void* out, uint64_t nbytes) {
+  if (!env || !out) return fail(BK_INVALID_ARGUMENT, "null argument");
+  if (nbytes < bk_checkpoint_bytes(env)) return fail(BK_INVALID_ARGUMENT, "checkpoint buffer too small");
+  for (const BookHost& bh : env->books)
+    if (!bh.orders.empty()) return fail(BK_INVALID_ARGUMENT, "checkpointing a host-driven env is not supported");
+  if (int rc = use_device(env)) return rc;
+  HIPCHK(hipStreamSynchronize(env->stream));
+  uint64_t* h = static_cast<uint64_t*>(out);
+  h[0] = env->steps_done;
+  h[1] = (static_cast<uint64_t>(env->cfg.n_books) << 32) | env->stride;
+  HIPCHK(hipMemcpy(h + 2, env->state.p, static_cast<size_t>(env->cfg.n_books) * env->stride * 4, hipMemcpyDeviceToHost));
+  return BK_OK;
+}
+
+int bk_checkpoint_load(bk_env* env, const void* in, uint64_t nbytes) {
+  if (!env || !in) return fail(BK_INVALID_ARGUMENT, "null argument");
+  const uint64_t* h = static_cast<const uint64_t*>(in);
+  if (nbytes < bk_checkpoint_bytes(env) || h[1] != ((static_cast<uint64_t>(env->cfg.n_books) << 32) | env->stride))
+    return fail(BK_INVALID_ARGUMENT, "checkpoint does not match this env (n_books / pool size)");
+  if (int rc = use_device(env)) return rc;
+  HIPCHK(hipStreamSynchronize(env->stream));
+  HIPCHK(hipMemcpy(env->state.p, h + 2, static_cast<size_t>(env->cfg.n_books) * env->stride * 4, hipMemcpyHostToDevice));
+  env->steps_done = h[0];
+  env->hist_base = h[0];  // retained history/trade records restart at the restored step
+  const uint32_t B = env->cfg.n_books;
+  hipLaunchKernelGGL(k_book_service, dim3((B + 255) / 256), dim3(256), 0, env->stream, env->state.p, env->stride, B, 0,
+                     0u);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(env->stream));
+  return BK_OK;
+}
+
 uint64_t bk_state_bytes_per_book(const bk_env* env) { return env ? static_cast<uint64_t>(env->stride) * 4 : 0; }
 
 // DPP reduction self-test (tests only): in[n_waves*64] -> out[n_waves*4] = {min, max, sum, sel-sum}

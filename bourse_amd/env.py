@@ -271,6 +271,18 @@ class ManyBookEnv:
         check(self._L.bk_get_pipeline(self._h, C.byref(a), C.byref(b)))
         return ("split" if a.value else "fused"), int(b.value)
 
+    def checkpoint(self) -> np.ndarray:
+        """Complete simulation state (pool, clock, counters, RNG of every book) as a byte array."""
+        n = int(self._L.bk_checkpoint_bytes(self._h))
+        buf = np.zeros(n, dtype=np.uint8)
+        check(self._L.bk_checkpoint_save(self._h, buf.ctypes.data_as(C.c_void_p), n))
+        return buf
+
+    def restore(self, buf: np.ndarray):
+        """Load a checkpoint taken from an env of the same shape; the run continues bit-identically."""
+        buf = np.ascontiguousarray(buf, dtype=np.uint8)
+        check(self._L.bk_checkpoint_load(self._h, buf.ctypes.data_as(C.c_void_p), buf.nbytes))
+
     def state_bytes_per_book(self) -> int:
         return int(self._L.bk_state_bytes_per_book(self._h))
 

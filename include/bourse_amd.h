@@ -191,6 +191,14 @@ int bk_set_pipeline(bk_env* env, int mode);
 int bk_get_pipeline(bk_env* env, int* split, int* n_parts);
 uint64_t bk_state_bytes_per_book(const bk_env* env);
 
+/* ------------------------------------------------------ checkpoint / resume */
+/* Dump / restore the complete simulation state of an on-device-order-flow env (pool, clock, counters, per-book
+ * RNG).  The reference has no counterpart: its Env/agents/RNG are not serialisable (only OrderBook JSON snapshots,
+ * crates/order_book/src/orderbook.rs:811-832).  A restored env continues bit-identically. */
+uint64_t bk_checkpoint_bytes(const bk_env* env);
+int bk_checkpoint_save(bk_env* env, void* out, uint64_t nbytes);
+int bk_checkpoint_load(bk_env* env, const void* in, uint64_t nbytes);
+
 #ifdef __cplusplus
 }
 #endif

@@ -569,3 +569,27 @@ def test_host_driven_many_books_match_oracle(bk, oracle):
         go, eo = env.orders(b), refs[b].book.orders_array()
         for f in go.dtype.names:
             assert np.array_equal(go[f], eo[f]), (b, f)
+
+
+def test_checkpoint_restore_continues_bit_identically(bk):
+    def mk():
+        e = bk.ManyBookEnv(48, 5, 0, 2, 100_000, levels=16, max_live_orders=64, trade_capacity=8192, history_capacity=40)
+        e.set_random_agents(C2_GROUPS)
+        return e
+
+    a = mk()
+    a.run(15)
+    ck = a.checkpoint()
+    a.run(25)
+    b = mk()
+    b.restore(ck)
+    assert b.steps_done() == 15
+    b.set_pipeline("split")
+    b.run(25)
+    assert np.array_equal(a.history()[15:], b.history())
+    assert np.array_equal(a.trade_counts(), b.trade_counts())
+    assert [a.rng_state(i) for i in range(48)] == [b.rng_state(i) for i in range(48)]
+    ta, tb = a.trades(3, first=0), b.trades(3)
+    assert np.array_equal(ta[len(ta) - len(tb):], tb)
+    with pytest.raises(bk.BourseError):
+        bk.ManyBookEnv(4, 5, 0, 2, 100_000, levels=16, max_live_orders=64).restore(ck)
