@@ -6,6 +6,7 @@
 #include <thread>
 
 #include "bourse_oracle.hpp"
+#include "bourse_oracle_agents.hpp"
 
 using namespace orc;
 
@@ -18,9 +19,41 @@ struct OrcEnv {  // mirrors the PyO3 pyclass: Env + its own RNG (ref rust/src/st
       : env(start, tick, step, trading, levels), rng(Rng::seed_from_u64(seed)) {}
 };
 
-struct OrcAgents {  // an AgentSet: groups updated in declaration order (ref crates/macros/src/lib.rs:57-73)
-  std::vector<RandomAgents> groups;
+struct OrcAgents {  // an AgentSet: members updated in declaration order (ref crates/macros/src/lib.rs:57-73)
+  std::vector<std::unique_ptr<AgentBase>> groups;
+  void update(Env& env, Rng& rng) {
+    for (auto& g : groups) g->update(env, rng);
+  }
 };
+
+struct OrcAgentDesc {  // one AgentSet member; mirrored by pyoracle.AGENT_DESC_DTYPE (96 bytes)
+  uint32_t type;       // 0 RandomAgents, 1 NoiseAgent, 2 MomentumAgent
+  uint32_t n;
+  uint32_t tick_lo, tick_hi, vol_lo, vol_hi;  // RandomAgents ranges
+  uint32_t tick_size;
+  float rate;          // RandomAgents activity_rate
+  uint32_t trader_start;
+  float p_limit, p_market, p_cancel;
+  uint32_t trade_vol;
+  uint32_t pad;
+  double mu, sigma, decay, demand, scale, order_ratio;
+};
+static_assert(sizeof(OrcAgentDesc) == 104, "layout");
+
+void add_from_desc(OrcAgents& a, const OrcAgentDesc& d) {
+  if (d.type == 0) {
+    a.groups.push_back(std::make_unique<RandomAgentsBox>(
+        RandomAgents(d.n, d.tick_lo, d.tick_hi, d.vol_lo, d.vol_hi, d.tick_size, d.rate)));
+  } else if (d.type == 1) {
+    a.groups.push_back(std::make_unique<NoiseAgent>(
+        d.trader_start, static_cast<uint16_t>(d.n),
+        NoiseAgentParams{d.tick_size, d.p_limit, d.p_market, d.p_cancel, d.trade_vol, d.mu, d.sigma}));
+  } else {
+    a.groups.push_back(std::make_unique<MomentumAgent>(
+        d.trader_start, static_cast<uint16_t>(d.n),
+        MomentumParams{d.tick_size, d.p_cancel, d.trade_vol, d.decay, d.demand, d.scale, d.order_ratio, d.mu, d.sigma}));
+  }
+}
 
 struct OrcOrderRec {  // PyOrder layout, ref rust/src/types.rs:17-31
   uint8_t side_is_bid;
@@ -343,17 +376,39 @@ void* orc_agents_new() { return new OrcAgents(); }
 void orc_agents_free(void* a) { delete static_cast<OrcAgents*>(a); }
 void orc_agents_add_random(void* a, uint64_t n, uint32_t tick_lo, uint32_t tick_hi, uint32_t vol_lo,
                            uint32_t vol_hi, uint32_t tick_size, float rate) {
-  static_cast<OrcAgents*>(a)->groups.emplace_back(n, tick_lo, tick_hi, vol_lo, vol_hi, tick_size, rate);
+  static_cast<OrcAgents*>(a)->groups.push_back(
+      std::make_unique<RandomAgentsBox>(RandomAgents(n, tick_lo, tick_hi, vol_lo, vol_hi, tick_size, rate)));
+}
+void orc_agents_add_desc(void* a, const void* desc) {
+  add_from_desc(*static_cast<OrcAgents*>(a), *static_cast<const OrcAgentDesc*>(desc));
+}
+// mutate a NoiseAgent's probabilities (the reference's tests do `agents.params.p_limit = 0.0`): which 0 p_limit, 1 p_market, 2 p_cancel
+void orc_agents_set_noise_prob(void* a, int g, int which, float v) {
+  auto* n = dynamic_cast<NoiseAgent*>(static_cast<OrcAgents*>(a)->groups[g].get());
+  if (!n) return;
+  if (which == 0) n->params.p_limit = v;
+  if (which == 1) n->params.p_market = v;
+  if (which == 2) n->params.p_cancel = v;
+}
+// ids currently held by a Noise/Momentum member (its `orders` list)
+uint64_t orc_agents_order_list(void* a, int g, uint64_t* out, uint64_t cap) {
+  AgentBase* b = static_cast<OrcAgents*>(a)->groups[g].get();
+  const std::vector<OrderId>* v = nullptr;
+  if (auto* n = dynamic_cast<NoiseAgent*>(b)) v = &n->orders;
+  if (auto* m = dynamic_cast<MomentumAgent*>(b)) v = &m->orders;
+  if (!v) return 0;
+  for (size_t i = 0; i < v->size() && i < cap; ++i) out[i] = (*v)[i];
+  return v->size();
 }
 // held ids of group g: out[i] = id or u64::MAX for None
 void orc_agents_held_ids(void* a, int g, uint64_t* out) {
-  auto& grp = static_cast<OrcAgents*>(a)->groups[g];
+  auto& grp = dynamic_cast<RandomAgentsBox&>(*static_cast<OrcAgents*>(a)->groups[g]).inner;
   for (size_t i = 0; i < grp.orders.size(); ++i) out[i] = grp.orders[i].value_or(ORDER_ID_MAX);
 }
 // agents.update(env, rng) with the env's own RNG — one call of the AgentSet
 void orc_agents_update(void* a, void* e) {
   auto* x = static_cast<OrcEnv*>(e);
-  for (auto& g : static_cast<OrcAgents*>(a)->groups) g.update(x->env, x->rng);
+  static_cast<OrcAgents*>(a)->update(x->env, x->rng);
 }
 // sim_runner body (ref runner.rs:53-68) continuing from an explicit RNG state;
 // st = seed_from_u64(seed) for a fresh run.  The env's own RNG is not touched.
@@ -363,7 +418,7 @@ int orc_sim_run(void* e, void* a, uint64_t* st, uint64_t n_steps) {
   Rng rng{st[0], st[1]};
   int rc = ORC_OK;
   for (uint64_t s = 0; s < n_steps; ++s) {
-    for (auto& g : ag->groups) g.update(x->env, rng);
+    ag->update(x->env, rng);
     int r = x->env.step(rng);
     if (r != ORC_OK) rc = r;
   }
@@ -386,8 +441,23 @@ void* orc_many_new(uint32_t n_books, uint64_t seed_base, uint64_t start, uint32_
       const uint32_t* r = groups + 7 * g;
       float rate;
       std::memcpy(&rate, &r[6], 4);
-      bk->agents.groups.emplace_back(r[0], r[1], r[2], r[3], r[4], r[5], rate);
+      bk->agents.groups.push_back(
+          std::make_unique<RandomAgentsBox>(RandomAgents(r[0], r[1], r[2], r[3], r[4], r[5], rate)));
     }
+    m->books.push_back(std::move(bk));
+  }
+  return m;
+}
+// same with an arbitrary AgentSet given as n_desc OrcAgentDesc records
+void* orc_many_new_mixed(uint32_t n_books, uint64_t seed_base, uint64_t start, uint32_t tick, uint64_t step,
+                         int trading, int levels, int n_desc, const void* descs) {
+  auto* m = new OrcMany();
+  m->levels = levels;
+  m->books.reserve(n_books);
+  const OrcAgentDesc* d = static_cast<const OrcAgentDesc*>(descs);
+  for (uint32_t b = 0; b < n_books; ++b) {
+    auto bk = std::make_unique<ManyBook>(start, tick, step, trading != 0, levels, seed_base + b);
+    for (int g = 0; g < n_desc; ++g) add_from_desc(bk->agents, d[g]);
     m->books.push_back(std::move(bk));
   }
   return m;
@@ -405,7 +475,7 @@ int orc_many_run(void* mp, uint64_t n_steps, int n_threads) {
     for (size_t b = lo; b < hi; ++b) {
       ManyBook& k = *m->books[b];
       for (uint64_t s = 0; s < n_steps; ++s) {
-        for (auto& g : k.agents.groups) g.update(k.env, k.rng);
+        k.agents.update(k.env, k.rng);
         int r = k.env.step(k.rng);
         if (r != ORC_OK) rc = r;
       }
@@ -468,6 +538,34 @@ void orc_many_order_counts(void* mp, uint64_t* out) {
   for (size_t b = 0; b < m->books.size(); ++b) out[b] = m->books[b]->env.order_book.orders.size();
 }
 
-int orc_version() { return 1; }
+// ---- sampling and portable-math hooks for unit tests
+double orc_rng_f64(uint64_t* st) {
+  Rng r{st[0], st[1]};
+  double v = gen_f64(r);
+  st[0] = r.s0;
+  st[1] = r.s1;
+  return v;
+}
+double orc_rng_std_normal(uint64_t* st) {
+  Rng r{st[0], st[1]};
+  double v = sample_standard_normal(r);
+  st[0] = r.s0;
+  st[1] = r.s1;
+  return v;
+}
+double orc_rng_lognormal(uint64_t* st, double mu, double sigma) {
+  Rng r{st[0], st[1]};
+  double v = LogNormal{mu, sigma}.sample(r);
+  st[0] = r.s0;
+  st[1] = r.s1;
+  return v;
+}
+double orc_pm_exp(double x) { return pm::exp(x); }
+double orc_pm_log(double x) { return pm::log(x); }
+double orc_pm_tanh(double x) { return pm::tanh(x); }
+uint32_t orc_round_price_up(double p, double tick) { return round_price_up(p, tick); }
+uint32_t orc_round_price_down(double p, double tick) { return round_price_down(p, tick); }
+
+int orc_version() { return 2; }
 
 }  // extern "C"

@@ -48,7 +48,9 @@ TRADE_DTYPE = np.dtype(
 
 def build(force: bool = False) -> str:
     """Compile the oracle with g++ (seconds).  Returns the library path."""
-    srcs = [os.path.join(_HERE, f) for f in ("bourse_oracle.cpp", "bourse_oracle_capi.cpp", "bourse_oracle.hpp")]
+    srcs = [os.path.join(_HERE, f) for f in ("bourse_oracle.cpp", "bourse_oracle_capi.cpp", "bourse_oracle.hpp",
+                                             "bourse_oracle_agents.cpp", "bourse_oracle_agents.hpp", "pm_math.hpp",
+                                             "zig_norm_tables.inc")]
     stale = force or not os.path.exists(_LIB_PATH) or any(
         os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in srcs
     )
@@ -146,6 +148,19 @@ def lib() -> C.CDLL:
     sig("orc_many_history", None, vp, u64, u64, p32)
     sig("orc_many_trade_counts", None, vp, p64)
     sig("orc_many_order_counts", None, vp, p64)
+    dbl = C.c_double
+    sig("orc_agents_add_desc", None, vp, vp)
+    sig("orc_agents_order_list", u64, vp, i32, p64, u64)
+    sig("orc_agents_set_noise_prob", None, vp, i32, i32, f32)
+    sig("orc_many_new_mixed", vp, u32, u64, u64, u32, u64, i32, i32, i32, vp)
+    sig("orc_rng_f64", dbl, p64)
+    sig("orc_rng_std_normal", dbl, p64)
+    sig("orc_rng_lognormal", dbl, p64, dbl, dbl)
+    sig("orc_pm_exp", dbl, dbl)
+    sig("orc_pm_log", dbl, dbl)
+    sig("orc_pm_tanh", dbl, dbl)
+    sig("orc_round_price_up", u32, dbl, dbl)
+    sig("orc_round_price_down", u32, dbl, dbl)
     sig("orc_version", i32)
     _lib = L
     return L
@@ -186,6 +201,15 @@ class Rng:
 
     def gen_range(self, lo, hi):
         return int(lib().orc_rng_range(_p64(self.st), lo, hi))
+
+    def gen_f64(self):
+        return float(lib().orc_rng_f64(_p64(self.st)))
+
+    def std_normal(self):
+        return float(lib().orc_rng_std_normal(_p64(self.st)))
+
+    def lognormal(self, mu, sigma):
+        return float(lib().orc_rng_lognormal(_p64(self.st), mu, sigma))
 
     def shuffle(self, arr):
         a = np.ascontiguousarray(arr, dtype=np.uint32)
@@ -651,6 +675,69 @@ class StepEnvNumpy(_EnvBase):
 
 
 # ---------------------------------------------------------------------- agents
+AGENT_DESC_DTYPE = np.dtype([
+    ("type", "<u4"), ("n", "<u4"), ("tick_lo", "<u4"), ("tick_hi", "<u4"), ("vol_lo", "<u4"), ("vol_hi", "<u4"),
+    ("tick_size", "<u4"), ("rate", "<f4"), ("trader_start", "<u4"), ("p_limit", "<f4"), ("p_market", "<f4"),
+    ("p_cancel", "<f4"), ("trade_vol", "<u4"), ("pad", "<u4"), ("mu", "<f8"), ("sigma", "<f8"), ("decay", "<f8"),
+    ("demand", "<f8"), ("scale", "<f8"), ("order_ratio", "<f8"),
+])
+assert AGENT_DESC_DTYPE.itemsize == 104
+
+
+def agent_descs(members):
+    """members: list of tuples
+       ("random", n, (tick_lo, tick_hi), (vol_lo, vol_hi), tick_size, activity_rate)          RandomAgents::new
+       ("noise", trader_start, n, dict(tick_size, p_limit, p_market, p_cancel, trade_vol, price_dist_mu, price_dist_sigma))
+       ("momentum", trader_start, n, dict(tick_size, p_cancel, trade_vol, decay, demand, scale, order_ratio,
+                                          price_dist_mu, price_dist_sigma))"""
+    d = np.zeros(len(members), dtype=AGENT_DESC_DTYPE)
+    for i, m in enumerate(members):
+        if m[0] == "random":
+            _, n, tr, vr, ts, rate = m
+            d[i]["type"], d[i]["n"], d[i]["tick_size"], d[i]["rate"] = 0, n, ts, np.float32(rate)
+            d[i]["tick_lo"], d[i]["tick_hi"], d[i]["vol_lo"], d[i]["vol_hi"] = tr[0], tr[1], vr[0], vr[1]
+        else:
+            kind, start, n, p = m
+            d[i]["type"] = 1 if kind == "noise" else 2
+            d[i]["trader_start"], d[i]["n"], d[i]["tick_size"] = start, n, p["tick_size"]
+            d[i]["p_cancel"], d[i]["trade_vol"] = np.float32(p["p_cancel"]), p["trade_vol"]
+            d[i]["mu"], d[i]["sigma"] = p["price_dist_mu"], p["price_dist_sigma"]
+            if kind == "noise":
+                d[i]["p_limit"], d[i]["p_market"] = np.float32(p["p_limit"]), np.float32(p["p_market"])
+            else:
+                for k in ("decay", "demand", "scale", "order_ratio"):
+                    d[i][k] = p[k]
+    return d
+
+
+class AgentSet:
+    """A derive(AgentSet) struct: members of any built-in type, updated in declaration order."""
+
+    def __init__(self, members):
+        self._a = lib().orc_agents_new()
+        self.members = list(members)
+        self._descs = agent_descs(self.members)
+        for i in range(len(self._descs)):
+            lib().orc_agents_add_desc(self._a, self._descs[i:i + 1].ctypes.data_as(C.c_void_p))
+
+    def __del__(self):
+        if getattr(self, "_a", None):
+            lib().orc_agents_free(self._a)
+            self._a = None
+
+    def update(self, env):
+        lib().orc_agents_update(self._a, env._e)
+
+    def set_noise_prob(self, g, which, value):
+        lib().orc_agents_set_noise_prob(self._a, g, {"p_limit": 0, "p_market": 1, "p_cancel": 2}[which],
+                                        C.c_float(float(np.float32(value))))
+
+    def order_list(self, g):
+        out = np.zeros(65536, dtype=np.uint64)
+        n = int(lib().orc_agents_order_list(self._a, g, _p64(out), len(out)))
+        return out[:n].copy()
+
+
 class RandomAgentSet:
     """An AgentSet of RandomAgents groups, updated in declaration order."""
 
@@ -693,12 +780,18 @@ def sim_runner(env, agents, seed, n_steps, rng_state=None):
 class ManyBooks:
     """B independent (Env, RandomAgents groups, RNG) simulations; book b seeded seed + b."""
 
-    def __init__(self, n_books, seed, start_time, tick_size, step_size, trading, levels, groups):
+    def __init__(self, n_books, seed, start_time, tick_size, step_size, trading, levels, groups=None, members=None):
+        self.n_books, self.levels, self.tick = int(n_books), int(levels), int(tick_size)
+        if members is not None:  # arbitrary AgentSet (see agent_descs)
+            d = agent_descs(members)
+            self._m = lib().orc_many_new_mixed(self.n_books, int(seed), int(start_time), int(tick_size),
+                                                int(step_size), int(bool(trading)), self.levels, len(d),
+                                                d.ctypes.data_as(C.c_void_p))
+            return
         g = np.zeros((len(groups), 7), dtype=np.uint32)
         for i, (n, tr, vr, ts, rate) in enumerate(groups):
             g[i, :6] = (n, tr[0], tr[1], vr[0], vr[1], ts)
             g[i, 6] = np.float32(rate).view(np.uint32)
-        self.n_books, self.levels, self.tick = int(n_books), int(levels), int(tick_size)
         self._m = lib().orc_many_new(self.n_books, int(seed), int(start_time), int(tick_size), int(step_size),
                                      int(bool(trading)), self.levels, len(groups), _p32(g))
 
