@@ -6,7 +6,9 @@ behind a C ABI (include/bourse_amd.h).  See DESIGN.md / INTEGRATION.md.
 """
 from . import _lib, core, step_sim
 from ._lib import BourseError, CapacityError, NoDeviceError
-from .env import MAX_PRICE, ManyBookEnv, RandomAgents, sim_runner
+from .env import (MAX_PRICE, ManyBookEnv, MomentumAgent, MomentumParams, NoiseAgent, NoiseAgentParams, RandomAgents,
+                  sim_runner)
 
-__all__ = ["core", "step_sim", "ManyBookEnv", "RandomAgents", "sim_runner", "MAX_PRICE", "BourseError",
+__all__ = ["core", "step_sim", "ManyBookEnv", "RandomAgents", "NoiseAgent", "NoiseAgentParams", "MomentumAgent",
+           "MomentumParams", "sim_runner", "MAX_PRICE", "BourseError",
            "CapacityError", "NoDeviceError"]

@@ -49,6 +49,17 @@ class RandomAgentsCfg(C.Structure):
     ]
 
 
+class AgentDesc(C.Structure):
+    _fields_ = [
+        ("type", C.c_uint32), ("n_agents", C.c_uint32), ("tick_lo", C.c_uint32), ("tick_hi", C.c_uint32),
+        ("vol_lo", C.c_uint32), ("vol_hi", C.c_uint32), ("tick_size", C.c_uint32), ("activity_rate", C.c_float),
+        ("agent_id_start", C.c_uint32), ("p_limit", C.c_float), ("p_market", C.c_float), ("p_cancel", C.c_float),
+        ("trade_vol", C.c_uint32), ("reserved", C.c_uint32), ("price_dist_mu", C.c_double),
+        ("price_dist_sigma", C.c_double), ("decay", C.c_double), ("demand", C.c_double), ("scale", C.c_double),
+        ("order_ratio", C.c_double),
+    ]
+
+
 class Stats(C.Structure):
     _fields_ = [
         ("n_books", C.c_uint64), ("sum_trade_vol", C.c_uint64), ("sum_trades", C.c_uint64),
@@ -85,6 +96,7 @@ SIGNATURES = {
     "bk_order_count": (_i32, [_vp, _u32, _p64]),
     "bk_get_orders": (_i32, [_vp, _u32, _u64, _u64, _vp]),
     "bk_set_random_agents": (_i32, [_vp, _u32, C.POINTER(RandomAgentsCfg)]),
+    "bk_set_agents": (_i32, [_vp, _u32, C.POINTER(AgentDesc)]),
     "bk_run": (_i32, [_vp, _u64]),
     "bk_l2_width": (_u32, [_vp]),
     "bk_level2": (_i32, [_vp, _u32, _u32, _p32]),

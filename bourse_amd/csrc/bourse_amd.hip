@@ -17,6 +17,7 @@
 
 #include "../../include/bourse_amd.h"
 #include "book_device.hpp"
+#include "mixed_agents.hpp"
 
 using namespace bkd;
 
@@ -24,6 +25,7 @@ static_assert(sizeof(DevStats) == sizeof(bk_stats), "bk_stats layout");
 static_assert(sizeof(bk_config) == 72 && sizeof(bk_random_agents) == 28 && sizeof(bk_trade) == 40 &&
                   sizeof(bk_order) == 48,
               "C ABI struct layout (mirrored by bourse_amd/_lib.py)");
+static_assert(sizeof(bk_agent_desc) == 104, "bk_agent_desc layout (mirrored by bourse_amd/_lib.py)");
 static_assert(sizeof(DevTrade) == 32 && sizeof(DevOrderLog) == 32, "device record layout");
 
 namespace {
@@ -120,6 +122,8 @@ struct bk_env {
   DevBuf<DevTrade> trades;
   DevBuf<DevOrderLog> order_log;
   DevBuf<DevStats> stats;
+  DevBuf<MixedDesc> mixed_descs;  // AgentSets with Noise/Momentum members (k_run_mixed)
+  uint32_t n_mixed = 0, n_fixed = 0;
   std::vector<BookHost> books;
   std::vector<Group> groups;
   uint32_t n_agents_total = 0;
@@ -211,6 +215,17 @@ int launch_events(bk_env* env, const DevArgs& a, uint64_t step_index) {
   env->prof_now = env->profile > 0;
   ProfScope ps(env, 3);
   hipLaunchKernelGGL(k_step_events<R>, dim3(env->cfg.n_books), dim3(64), 0, env->stream, a, step_index);
+  HIPCHK(hipGetLastError());
+  return BK_OK;
+}
+
+template <int R>
+int launch_mixed(bk_env* env, const DevArgs& a, uint64_t first_step, uint32_t n_steps) {
+  const uint32_t blocks = (env->cfg.n_books + 3) / 4;
+  env->prof_now = env->profile > 0;
+  ProfScope ps(env, 0);
+  MixedArgs ma{env->mixed_descs.p, env->n_mixed, env->n_fixed};
+  hipLaunchKernelGGL(k_run_mixed<R>, dim3(blocks), dim3(256), 0, env->stream, a, ma, first_step, n_steps);
   HIPCHK(hipGetLastError());
   return BK_OK;
 }
@@ -639,6 +654,81 @@ int bk_set_random_agents(bk_env* env, uint32_t n_groups, const bk_random_agents*
     return fail(BK_CAPACITY, "sum of n_agents exceeds max_live_orders (one pool slot per agent)");
   env->groups = gs;
   env->n_agents_total = static_cast<uint32_t>(total);
+  env->n_mixed = 0;
+  return BK_OK;
+}
+
+int bk_set_agents(bk_env* env, uint32_t n_members, const bk_agent_desc* members) {
+  if (!env || (!members && n_members)) return fail(BK_INVALID_ARGUMENT, "null argument");
+  bool all_random = true;
+  for (uint32_t i = 0; i < n_members; ++i) all_random = all_random && members[i].type == BK_AGENT_RANDOM;
+  if (all_random) {
+    std::vector<bk_random_agents> g(n_members);
+    for (uint32_t i = 0; i < n_members; ++i)
+      g[i] = bk_random_agents{members[i].n_agents, members[i].tick_lo, members[i].tick_hi, members[i].vol_lo,
+                              members[i].vol_hi, members[i].tick_size, members[i].activity_rate};
+    return bk_set_random_agents(env, n_members, g.data());
+  }
+  if (n_members > MAX_MEMBERS) return fail(BK_INVALID_ARGUMENT, "at most 4 members in a set with Noise/Momentum agents");
+  if (int rc = use_device(env)) return rc;
+  std::vector<MixedDesc> ds(n_members);
+  uint32_t fixed = 0;
+  for (uint32_t i = 0; i < n_members; ++i) {
+    const bk_agent_desc& m = members[i];
+    MixedDesc& D = ds[i];
+    std::memset(&D, 0, sizeof(D));
+    D.type = m.type;
+    D.n = m.n_agents;
+    if (m.tick_size == 0 || m.tick_size % env->cfg.tick_size != 0)
+      return fail(BK_PRICE_NOT_TICK_MULTIPLE, "member tick_size must be a non-zero multiple of the env tick_size");
+    if (m.type == BK_AGENT_RANDOM) {
+      if (m.tick_lo >= m.tick_hi || m.vol_lo >= m.vol_hi || m.tick_lo == 0 ||
+          static_cast<uint64_t>(m.tick_hi - 1) * m.tick_size >= 0xFFFFFFFFull)
+        return fail(BK_INVALID_ARGUMENT, "bad RandomAgents ranges");
+      D.thr = activity_threshold(m.activity_rate);
+      D.tick_lo = m.tick_lo;
+      D.tick_rng = m.tick_hi - m.tick_lo;
+      D.tick_zone = sample_zone(D.tick_rng);
+      D.vol_lo = m.vol_lo;
+      D.vol_rng = m.vol_hi - m.vol_lo;
+      D.vol_zone = sample_zone(D.vol_rng);
+      D.tick_size = m.tick_size;
+      D.slot_base = fixed;
+      fixed += m.n_agents;
+    } else if (m.type == BK_AGENT_NOISE || m.type == BK_AGENT_MOMENTUM) {
+      if (m.n_agents > 0xFFFFu) return fail(BK_INVALID_ARGUMENT, "n_agents is a u16 in the reference");
+      if (!(m.price_dist_sigma >= 0.0) || !std::isfinite(m.price_dist_sigma) || !std::isfinite(m.price_dist_mu))
+        return fail(BK_INVALID_ARGUMENT, "LogNormal::new(mu, sigma) needs finite mu and sigma >= 0");  // .unwrap()
+      D.thr_limit = activity_threshold(m.p_limit);
+      D.thr_market = activity_threshold(m.p_market);
+      // keep iff gen::<f32>() > p_cancel: k * 2^-24 > p  <=>  k > floor(p * 2^24)
+      if (m.p_cancel != m.p_cancel) {
+        D.keep_thr = 1 << 24;  // NaN: never kept
+      } else {
+        const double y = std::floor(static_cast<double>(m.p_cancel) * 16777216.0);
+        D.keep_thr = y < 0.0 ? -1 : (y > 16777216.0 ? (1 << 24) : static_cast<int32_t>(y));
+      }
+      D.trade_vol = m.trade_vol;
+      D.mu = m.price_dist_mu;
+      D.sigma = m.price_dist_sigma;
+      D.decay = m.decay;
+      D.demand = m.demand;
+      D.scale = m.scale;
+      D.order_ratio = m.order_ratio;
+      D.n_f = static_cast<double>(m.n_agents);
+      D.tick_f = static_cast<double>(m.tick_size);
+    } else {
+      return fail(BK_INVALID_ARGUMENT, "unknown agent type");
+    }
+  }
+  if (fixed >= env->cfg.max_live_orders)
+    return fail(BK_CAPACITY, "RandomAgents members leave no pool slots for the other members' orders");
+  HIPCHK(env->mixed_descs.alloc(n_members));
+  HIPCHK(hipMemcpy(env->mixed_descs.p, ds.data(), ds.size() * sizeof(MixedDesc), hipMemcpyHostToDevice));
+  env->n_mixed = n_members;
+  env->n_fixed = fixed;
+  env->groups.clear();
+  env->n_agents_total = 0;
   return BK_OK;
 }
 
@@ -659,6 +749,17 @@ int bk_run(bk_env* env, uint64_t n_steps) {
   }
   int rc = BK_OK;
   const uint32_t ns = static_cast<uint32_t>(n_steps);
+  if (env->n_mixed) {
+    switch (env->R) {
+      case 1: rc = launch_mixed<1>(env, a, env->steps_done, ns); break;
+      case 2: rc = launch_mixed<2>(env, a, env->steps_done, ns); break;
+      case 4: rc = launch_mixed<4>(env, a, env->steps_done, ns); break;
+      default: rc = launch_mixed<8>(env, a, env->steps_done, ns); break;
+    }
+    if (rc != BK_OK) return rc;
+    env->steps_done += n_steps;
+    return BK_OK;
+  }
   // The fused kernel keeps a book in registers across all steps of the launch but runs the RNG-serial
   // phases on the scalar unit of ONE wave per book; the split pipeline runs them one lane per book and needs
   // >= 64 books per wave to pay off.  auto: split once the batch fills the chip several times over.

@@ -1,0 +1,354 @@
+// mixed_agents.hpp — gfx950 kernel for AgentSets that contain NoiseAgent / MomentumAgent members
+// (SURVEY §8f rank 1), alone or together with RandomAgents groups, in declaration order.
+//
+//   k_run_mixed<R>: one wave per book, n_steps x { every member's update(env, rng); Env::step(rng) } with the
+//   book in registers across the launch (like k_run_random).  The members' logic is strictly sequential in the
+//   book's RNG stream, so it runs as wave-uniform control flow; the f64 price arithmetic (log-normal offsets around
+//   the mid, rounding to ticks, tanh of the momentum) is evaluated redundantly on every lane.
+//
+// Restated semantics (paths relative to the reference repo):
+//   agents::common::{cancel_live_orders, place_*_limit_order, round_price_*}  crates/step_sim/src/agents/common.rs:21-141
+//   NoiseAgent::update      crates/step_sim/src/agents/noise_agent.rs:127-176
+//   MomentumAgent::update   crates/step_sim/src/agents/momentum_agent.rs:146-208
+//   rand / rand_distr sampling (Standard f64, Bernoulli(0.5), Open01, StandardNormal ziggurat, LogNormal): third-party,
+//   restated — PARITY UNPINNED against Rust; exp/ln/tanh from pm_math.hpp so that the CPU oracle, which uses the
+//   same restatement, can be matched bit-for-bit.
+//
+// Device representation: every order a member creates gets a pool slot at creation (pending until its New event is
+// processed; released again if it never rests), RandomAgents members keep their fixed slot == agent mapping in
+// [0, n_fixed); a member's `orders` list is "live slots tagged with the member", iterated in ascending order id
+// (= the list's insertion order).
+#pragma once
+#include "book_device.hpp"
+#include "pm_math.hpp"
+
+// every f64 expression below must round exactly like the oracle's (no FMA contraction): file-scope switch
+#pragma clang fp contract(off)
+
+namespace bkd {
+
+constexpr int MAX_MEMBERS = 4;
+constexpr int H_GFLAGS = 30;  // bit j: member j has a last_price
+constexpr int H_GST = 48;     // member j: dwords 48+4j.. = momentum (lo, hi), last_price (lo, hi)
+
+struct MixedDesc {
+  uint32_t type;  // 0 RandomAgents, 1 NoiseAgent, 2 MomentumAgent
+  uint32_t n;
+  uint32_t thr, tick_lo, tick_rng, tick_zone, vol_lo, vol_rng, vol_zone, tick_size;  // RandomAgents (see Group)
+  uint32_t thr_limit, thr_market;  // NoiseAgent: (u32 >> 8) < thr  <=>  gen::<f32>() < p
+  int32_t keep_thr;                // cancel_live_orders keeps an order iff (u32 >> 8) > keep_thr  <=>  gen::<f32>() > p_cancel
+  uint32_t trade_vol;
+  uint32_t slot_base;              // RandomAgents: first fixed slot
+  uint32_t pad;
+  double mu, sigma, decay, demand, scale, order_ratio, n_f, tick_f;
+};
+static_assert(sizeof(MixedDesc) == 128, "MixedDesc layout");
+
+struct MixedArgs {
+  const MixedDesc* descs;
+  uint32_t n_desc;
+  uint32_t n_fixed;  // pool slots reserved for RandomAgents members
+};
+
+#define ZIG_TABLE_BEGIN(name) __constant__ const double name[257] = {
+#define ZIG_TABLE_END };
+#include "zig_norm_tables.inc"
+#undef ZIG_TABLE_BEGIN
+#undef ZIG_TABLE_END
+
+__device__ __forceinline__ uint64_t next_u64(Rng& rng) {
+  uint64_t r = rng.s0 * 5ull;
+  r = (r << 7) | (r >> 57);
+  r *= 9ull;
+  const uint64_t t1 = rng.s1 ^ rng.s0;
+  rng.s0 = ((rng.s0 << 24) | (rng.s0 >> 40)) ^ t1 ^ (t1 << 16);
+  rng.s1 = (t1 << 37) | (t1 >> 27);
+  return r;
+}
+// wave-uniform double out of the VALU back into scalar registers (keeps later control flow uniform)
+__device__ __forceinline__ double uni(double x) {
+  const uint64_t b = pm::to_bits(x);
+  return pm::from_bits(mk64(rfl((uint32_t)b), rfl((uint32_t)(b >> 32))));
+}
+__device__ __forceinline__ double gen_f64(Rng& rng) {  // rand Standard f64
+  return static_cast<double>(next_u64(rng) >> 11) * (1.0 / 9007199254740992.0);
+}
+__device__ __forceinline__ double gen_open01(Rng& rng) {  // rand Open01 f64
+  const double v = pm::from_bits(0x3FF0000000000000ull | (next_u64(rng) >> 12));
+  return v - (1.0 - 2.220446049250313e-16 / 2.0);
+}
+// rand_distr StandardNormal: 256-layer ziggurat (utils.rs ziggurat, symmetric)
+__device__ __forceinline__ double sample_standard_normal(Rng& rng) {
+  for (;;) {
+    const uint64_t bits = next_u64(rng);
+    const uint32_t i = (uint32_t)bits & 0xffu;
+    const double u = pm::from_bits(0x4000000000000000ull | (bits >> 12)) - 3.0;
+    const double x = uni(u * ZIG_NORM_X[i]);
+    if (pm::fabs_(x) < ZIG_NORM_X[i + 1]) return x;
+    if (i == 0) {
+      const double R = 3.654152885361008796;
+      double xx = 1.0, yy = 0.0;
+      while (-2.0 * yy < xx * xx) {
+        const double x_ = gen_open01(rng);
+        const double y_ = gen_open01(rng);
+        xx = uni(pm::log(x_) / R);
+        yy = uni(pm::log(y_));
+      }
+      return (u < 0.0) ? xx - R : R - xx;
+    }
+    const double lhs = uni(ZIG_NORM_F[i + 1] + (ZIG_NORM_F[i] - ZIG_NORM_F[i + 1]) * gen_f64(rng));
+    if (lhs < uni(pm::exp(-x * x / 2.0))) return x;
+  }
+}
+__device__ __forceinline__ uint32_t price_from_f64(double p) {  // clamp(0, u32::MAX) as u32 (NaN -> 0)
+  if (!(p == p)) return 0u;
+  if (p < 0.0) p = 0.0;
+  if (p > 4294967295.0) p = 4294967295.0;
+  return static_cast<uint32_t>(p);
+}
+__device__ __forceinline__ uint32_t round_price_up(double p, double tick) {  // common.rs:21-25
+  return price_from_f64(pm::ceil_(p / tick) * tick);
+}
+__device__ __forceinline__ uint32_t round_price_down(double p, double tick) {  // common.rs:36-40
+  return price_from_f64(pm::floor_(p / tick) * tick);
+}
+// `gen::<f64>() < p` as an integer threshold on the 53 random bits: k * 2^-53 < p  <=>  k < ceil(p * 2^53)
+__device__ __forceinline__ uint64_t thr53(double p) {
+  if (!(p > 0.0)) return 0ull;
+  if (p >= 1.0) return 9007199254740992ull;
+  return static_cast<uint64_t>(static_cast<int64_t>(pm::ceil_(p * 9007199254740992.0)));
+}
+
+template <int R>
+struct MixedCtx {
+  uint32_t ev[R];     // event list (slot indices)
+  uint32_t owner[R];  // member index + 1 of the limit order resting / pending in the slot, 0 = none
+  uint64_t dyn[R];    // slots available for dynamic allocation (index >= n_fixed)
+  uint32_t n_ev;
+};
+
+// Env::place_order from a member: id assignment + New event; the order is parked in a free pool slot
+template <int R>
+__device__ __forceinline__ void mixed_create(Book<R>& B, MixedCtx<R>& C, int lane, bool is_bid, uint32_t price,
+                                             uint32_t vol, uint32_t owner_tag) {
+  const uint32_t id = B.next_id;
+  B.next_id += 1;  // create_order consumes the id (orderbook.rs:363)
+  int slot = -1;
+#pragma unroll
+  for (int r = R - 1; r >= 0; --r) {
+    const uint64_t fr = ~(B.live[r] | B.pend[r]) & C.dyn[r];
+    if (fr) slot = r * 64 + (int)__builtin_ctzll(fr);
+  }
+  if (slot < 0) {
+    B.flags |= FLAG_POOL_OVERFLOW;  // reported, never silent: the order (and its event) is dropped
+    return;
+  }
+  slot_write<R>(B.price, slot, price);
+  slot_write<R>(B.vol, slot, vol);
+  slot_write<R>(B.id, slot, id);
+  slot_write<R>(C.owner, slot, owner_tag);
+  mask_set<R>(B.bid, slot, is_bid);
+  mask_set<R>(B.pend, slot, true);
+  slot_write<R>(C.ev, C.n_ev, (uint32_t)slot);
+  C.n_ev += 1;
+  (void)lane;
+}
+
+// common::cancel_live_orders (common.rs:54-76): the member's Active orders in list (= id) order, one f32 draw each;
+// `draw > p_cancel` keeps the order, otherwise its cancellation is queued
+template <int R>
+__device__ __forceinline__ void mixed_cancel_live(Book<R>& B, MixedCtx<R>& C, Rng& rng, int lane, uint32_t tag,
+                                                  int32_t keep_thr) {
+  uint64_t mask[R];
+  uint64_t any = 0;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    mask[r] = B.live[r] & __ballot(C.owner[r] == tag);
+    any |= mask[r];
+  }
+  while (any) {
+    uint32_t m = 0xFFFFFFFFu;
+#pragma unroll
+    for (int r = 0; r < R; ++r) m = min(m, sel(mask[r], B.id[r], 0xFFFFFFFFu));
+    const uint32_t idmin = wave_umin(m);
+    int slot = 0;
+    any = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const uint64_t hit = mask[r] & __ballot(B.id[r] == idmin);
+      if (hit) slot = r * 64 + (int)__builtin_ctzll(hit);
+      mask[r] &= ~hit;
+      any |= mask[r];
+    }
+    const uint32_t x = rng.next_u32();
+    if (!((int32_t)(x >> 8) > keep_thr)) {  // not kept -> env.cancel_order(id)
+      slot_write<R>(C.ev, C.n_ev, (uint32_t)slot);
+      C.n_ev += 1;
+    }
+  }
+  (void)lane;
+}
+
+template <int R>
+__global__ __launch_bounds__(256) void k_run_mixed(DevArgs a, MixedArgs ma, uint64_t first_step, uint32_t n_steps) {
+  __shared__ uint32_t lds[4][LDS_DW_PER_WAVE];
+  const int lane = threadIdx.x & 63;
+  const int wv = threadIdx.x >> 6;
+  const uint32_t book = rfl(blockIdx.x * 4 + wv);
+  if (book >= a.n_books) return;
+  uint32_t* st = a.state + (size_t)book * a.state_stride;
+
+  Book<R> B;
+  Rng rng;
+  load_book<R>(B, rng, st, lane);
+  MixedCtx<R> C;
+  const uint32_t hdr = st[lane];
+  uint32_t gflags = rdl(hdr, H_GFLAGS);
+  double g_mom[MAX_MEMBERS], g_last[MAX_MEMBERS];
+#pragma unroll
+  for (int j = 0; j < MAX_MEMBERS; ++j) {
+    g_mom[j] = pm::from_bits(mk64(rdl(hdr, H_GST + 4 * j), rdl(hdr, H_GST + 4 * j + 1)));
+    g_last[j] = pm::from_bits(mk64(rdl(hdr, H_GST + 4 * j + 2), rdl(hdr, H_GST + 4 * j + 3)));
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    C.ev[r] = 0;
+    C.owner[r] = (st[HDR_DW + r * POOL_FIELDS * 64 + 4 * 64 + lane] >> 8) & 0xFFu;
+    C.dyn[r] = __ballot((uint32_t)(r * 64 + lane) >= ma.n_fixed);
+  }
+  uint32_t last_ntr = 0, last_nev = 0;
+
+  for (uint32_t s = 0; s < n_steps; ++s) {
+    C.n_ev = 0;
+    // OrderBook::mid_price (orderbook.rs:272-276) of the book as the agents see it (updates only queue events)
+    double mid;
+    {
+      uint32_t mb = 0u, mk = 0xFFFFFFFFu;
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        mb = max(mb, sel(B.live[r] & B.bid[r], B.price[r], 0u));
+        mk = min(mk, sel(B.live[r] & ~B.bid[r], B.price[r], 0xFFFFFFFFu));
+      }
+      const uint32_t bid = wave_umax(mb), ask = wave_umin(mk);
+          mid = static_cast<double>(bid) + 0.5 * static_cast<double>(ask - bid);
+    }
+    for (uint32_t j = 0; j < ma.n_desc; ++j) {  // members in declaration order (crates/macros/src/lib.rs:57-73)
+      const MixedDesc D = ma.descs[j];
+      if (D.type == 0) {
+        // ---- RandomAgents::update (random_agent.rs:85-119), fixed slots [slot_base, slot_base + n)
+        for (uint32_t i = 0; i < D.n; ++i) {
+          const uint32_t n = D.slot_base + i;
+          const uint32_t x = rng.next_u32();
+          if ((x >> 8) < D.thr) {
+            slot_write<R>(C.ev, C.n_ev, n);
+            C.n_ev += 1;
+            if (!mask_test<R>(B.live, n)) {
+              const uint32_t side = rng.below(2u, 0x7FFFFFFFu);
+              const uint32_t tick = D.tick_lo + rng.below(D.tick_rng, D.tick_zone);
+              const uint32_t vol = D.vol_lo + rng.below(D.vol_rng, D.vol_zone);
+              slot_write<R>(B.price, n, tick * D.tick_size);
+              slot_write<R>(B.vol, n, vol);
+              slot_write<R>(B.id, n, B.next_id);
+              B.next_id += 1;
+              mask_set<R>(B.bid, n, side != 0);
+              mask_set<R>(B.pend, n, true);
+            }
+          }
+        }
+      } else {
+        const uint32_t tag = j + 1;
+        mixed_cancel_live<R>(B, C, rng, lane, tag, D.keep_thr);
+        if (D.type == 1) {
+          // ---- NoiseAgent::update (noise_agent.rs:127-176)
+          for (uint32_t t = 0; t < D.n; ++t) {
+            if ((rng.next_u32() >> 8) < D.thr_limit) {                // gen::<f32>() < p_limit
+              const bool buy = next_u64(rng) < 0x8000000000000000ull;  // gen_bool(0.5)
+                          const double dist = pm::fabs_(uni(pm::exp(D.mu + D.sigma * sample_standard_normal(rng))));
+              const uint32_t price = rfl(buy ? round_price_down(mid - dist, D.tick_f) : round_price_up(mid + dist, D.tick_f));
+              mixed_create<R>(B, C, lane, buy, price, D.trade_vol, tag);
+            }
+            if ((rng.next_u32() >> 8) < D.thr_market) {                // gen::<f32>() < p_market
+              const bool buy = next_u64(rng) < 0x8000000000000000ull;
+              mixed_create<R>(B, C, lane, buy, buy ? 0xFFFFFFFFu : 0u, D.trade_vol, 0u);
+            }
+          }
+        } else {
+          // ---- MomentumAgent::update (momentum_agent.rs:146-208)
+          double m = 0.0, p_market = 0.0;
+          {
+                      if ((gflags >> j) & 1u) {
+              double gm = g_mom[0], gl = g_last[0];
+#pragma unroll
+              for (int q = 1; q < MAX_MEMBERS; ++q) {
+                gm = ((uint32_t)q == j) ? g_mom[q] : gm;
+                gl = ((uint32_t)q == j) ? g_last[q] : gl;
+              }
+              m = uni(gm * (1.0 - D.decay) + D.decay * (mid - gl));
+              p_market = uni(D.demand * pm::tanh(D.scale * m) / D.n_f);
+            }
+          }
+          uint64_t thr_l, thr_m;
+          {
+                      const double p_limit = D.order_ratio * p_market;
+            thr_l = thr53(p_limit);
+            thr_m = thr53(p_market);
+            thr_l = mk64(rfl((uint32_t)thr_l), rfl((uint32_t)(thr_l >> 32)));
+            thr_m = mk64(rfl((uint32_t)thr_m), rfl((uint32_t)(thr_m >> 32)));
+          }
+          const int sgn = (m > 0.0) ? 1 : ((m < 0.0) ? -1 : 0);
+          for (uint32_t t = 0; t < D.n; ++t) {
+            if ((next_u64(rng) >> 11) < thr_l) {  // gen::<f64>() < p_limit
+              if (sgn != 0) {
+                              const double dist = pm::fabs_(uni(pm::exp(D.mu + D.sigma * sample_standard_normal(rng))));
+                const uint32_t price = rfl(sgn > 0 ? round_price_down(mid - dist, D.tick_f) : round_price_up(mid + dist, D.tick_f));
+                mixed_create<R>(B, C, lane, sgn > 0, price, D.trade_vol, tag);
+              }
+            }
+            if ((next_u64(rng) >> 11) < thr_m) {  // gen::<f64>() < p_market
+              if (sgn != 0) mixed_create<R>(B, C, lane, sgn > 0, sgn > 0 ? 0xFFFFFFFFu : 0u, D.trade_vol, 0u);
+            }
+          }
+#pragma unroll
+          for (int q = 0; q < MAX_MEMBERS; ++q) {
+            if ((uint32_t)q == j) {
+              g_mom[q] = m;
+              g_last[q] = mid;
+            }
+          }
+          gflags |= 1u << j;
+        }
+      }
+    }
+    // ---- Env::step: shuffle (env.rs:121) then the shared event loop / snapshot
+    for (uint32_t i = C.n_ev; i-- > 1;) {
+      const uint32_t jx = rng.below(i + 1);
+      const uint32_t ai = slot_read<R>(C.ev, i), aj = slot_read<R>(C.ev, jx);
+      slot_write<R>(C.ev, i, aj);
+      slot_write<R>(C.ev, jx, ai);
+    }
+    last_ntr = step_from_list<R>(B, a, book, lane, C.ev, C.n_ev, lds[wv], first_step + s,
+                                 s + 1 == n_steps || a.hist_cap == 0);
+    last_nev = C.n_ev;
+  }
+  store_book<R>(B, rng, st, lane, first_step + n_steps, last_ntr, last_nev);
+  // member state and owner tags
+  uint32_t h2 = st[lane];
+  auto put = [&](int idx, uint32_t v) { h2 = (lane == idx) ? v : h2; };
+  put(H_GFLAGS, gflags);
+#pragma unroll
+  for (int j = 0; j < MAX_MEMBERS; ++j) {
+    const uint64_t mb = pm::to_bits(g_mom[j]), lb = pm::to_bits(g_last[j]);
+    put(H_GST + 4 * j, (uint32_t)mb);
+    put(H_GST + 4 * j + 1, (uint32_t)(mb >> 32));
+    put(H_GST + 4 * j + 2, (uint32_t)lb);
+    put(H_GST + 4 * j + 3, (uint32_t)(lb >> 32));
+  }
+  st[lane] = h2;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    uint32_t* p = st + HDR_DW + r * POOL_FIELDS * 64 + 4 * 64;
+    p[lane] = (lane_bit(B.live[r]) ? 1u : 0u) | (lane_bit(B.bid[r]) ? 2u : 0u) | (C.owner[r] << 8);
+  }
+}
+
+}  // namespace bkd

@@ -15,7 +15,7 @@ from typing import Iterable, Optional, Sequence, Tuple
 import numpy as np
 
 from . import _lib
-from ._lib import Config, RandomAgentsCfg, Stats, check
+from ._lib import AgentDesc, Config, RandomAgentsCfg, Stats, check
 
 MAX_PRICE = 2**32 - 1
 
@@ -33,6 +33,58 @@ class RandomAgents:
 
     def as_tuple(self):
         return (self.n_agents, tuple(self.tick_range), tuple(self.vol_range), self.tick_size, self.activity_rate)
+
+
+@dataclass(frozen=True)
+class NoiseAgentParams:
+    """ref crates/step_sim/src/agents/noise_agent.rs:24-46"""
+
+    tick_size: int
+    p_limit: float
+    p_market: float
+    p_cancel: float
+    trade_vol: int
+    price_dist_mu: float
+    price_dist_sigma: float
+
+
+@dataclass(frozen=True)
+class NoiseAgent:
+    """``NoiseAgent::new(agent_id_start, n_agents, params)`` (ref noise_agent.rs:110-123)."""
+
+    agent_id_start: int
+    n_agents: int
+    params: NoiseAgentParams
+
+    def as_tuple(self):
+        return ("noise", self.agent_id_start, self.n_agents, dict(self.params.__dict__))
+
+
+@dataclass(frozen=True)
+class MomentumParams:
+    """ref crates/step_sim/src/agents/momentum_agent.rs:24-60"""
+
+    tick_size: int
+    p_cancel: float
+    trade_vol: int
+    decay: float
+    demand: float
+    scale: float
+    order_ratio: float
+    price_dist_mu: float
+    price_dist_sigma: float
+
+
+@dataclass(frozen=True)
+class MomentumAgent:
+    """``MomentumAgent::new(agent_id_start, n_agents, params)`` (ref momentum_agent.rs:128-142)."""
+
+    agent_id_start: int
+    n_agents: int
+    params: MomentumParams
+
+    def as_tuple(self):
+        return ("momentum", self.agent_id_start, self.n_agents, dict(self.params.__dict__))
 
 
 class ManyBookEnv:
@@ -136,6 +188,39 @@ class ManyBookEnv:
             arr[i].activity_rate = float(np.float32(rate))
         check(self._L.bk_set_random_agents(self._h, len(gs), arr))
         self.groups = gs
+
+    def set_agents(self, members):
+        """A ``#[derive(AgentSet)]`` struct: members updated in declaration order (ref crates/macros/src/lib.rs:57-73).
+        Each member is a RandomAgents / NoiseAgent / MomentumAgent instance or the equivalent tuple
+        ``("random", n, tick_range, vol_range, tick_size, rate)`` / ``("noise"|"momentum", id_start, n, params_dict)``."""
+        ms = []
+        for m in members:
+            if isinstance(m, RandomAgents):
+                ms.append(("random",) + m.as_tuple())
+            elif isinstance(m, (NoiseAgent, MomentumAgent)):
+                ms.append(m.as_tuple())
+            else:
+                ms.append(tuple(m))
+        arr = (AgentDesc * max(len(ms), 1))()
+        for i, m in enumerate(ms):
+            d = arr[i]
+            if m[0] == "random":
+                _, n, tr, vr, ts, rate = m
+                d.type, d.n_agents, d.tick_size, d.activity_rate = 0, int(n), int(ts), float(np.float32(rate))
+                d.tick_lo, d.tick_hi, d.vol_lo, d.vol_hi = int(tr[0]), int(tr[1]), int(vr[0]), int(vr[1])
+            else:
+                kind, start, n, p = m
+                d.type = 1 if kind == "noise" else 2
+                d.agent_id_start, d.n_agents, d.tick_size = int(start), int(n), int(p["tick_size"])
+                d.p_cancel, d.trade_vol = float(np.float32(p["p_cancel"])), int(p["trade_vol"])
+                d.price_dist_mu, d.price_dist_sigma = float(p["price_dist_mu"]), float(p["price_dist_sigma"])
+                if kind == "noise":
+                    d.p_limit, d.p_market = float(np.float32(p["p_limit"])), float(np.float32(p["p_market"]))
+                else:
+                    d.decay, d.demand = float(p["decay"]), float(p["demand"])
+                    d.scale, d.order_ratio = float(p["scale"]), float(p["order_ratio"])
+        check(self._L.bk_set_agents(self._h, len(ms), arr))
+        self.members = ms
 
     def run(self, n_steps: int, sync: bool = True):
         """``sim_runner``'s loop body ``n_steps`` times in ONE kernel launch (runner.rs:53-68)."""

@@ -70,6 +70,26 @@ typedef struct bk_random_agents {
   float activity_rate;
 } bk_random_agents;
 
+/* One member of a derive(AgentSet) struct (crates/macros/src/lib.rs:57-73): RandomAgents, NoiseAgent
+ * (NoiseAgent::new(agent_id_start, n_agents, NoiseAgentParams), crates/step_sim/src/agents/noise_agent.rs:24-123) or
+ * MomentumAgent (MomentumAgent::new(agent_id_start, n_agents, MomentumParams), momentum_agent.rs:24-142). */
+enum bk_agent_type { BK_AGENT_RANDOM = 0, BK_AGENT_NOISE = 1, BK_AGENT_MOMENTUM = 2 };
+typedef struct bk_agent_desc {
+  uint32_t type;             /* bk_agent_type */
+  uint32_t n_agents;
+  uint32_t tick_lo, tick_hi; /* RandomAgents tick_range */
+  uint32_t vol_lo, vol_hi;   /* RandomAgents vol_range */
+  uint32_t tick_size;        /* the member's tick_size parameter */
+  float activity_rate;       /* RandomAgents */
+  uint32_t agent_id_start;   /* Noise/Momentum: first trader id */
+  float p_limit, p_market;   /* NoiseAgentParams */
+  float p_cancel;            /* Noise/Momentum */
+  uint32_t trade_vol;        /* Noise/Momentum */
+  uint32_t reserved;
+  double price_dist_mu, price_dist_sigma;       /* Noise/Momentum: LogNormal(mu, sigma) */
+  double decay, demand, scale, order_ratio;     /* MomentumParams */
+} bk_agent_desc;
+
 /* Trade — crates/order_book/src/types.rs:103-118; tuple order of PyTrade, rust/src/types.rs:4-15 */
 typedef struct bk_trade {
   uint64_t t;
@@ -142,6 +162,10 @@ int bk_get_orders(bk_env* env, uint32_t book, uint64_t first, uint64_t n, bk_ord
 /* An AgentSet of RandomAgents groups, identical for every book, updated in declaration order
  * (crates/macros/src/lib.rs:57-73).  Sum of n_agents <= max_live_orders. */
 int bk_set_random_agents(bk_env* env, uint32_t n_groups, const bk_random_agents* groups);
+/* Any mix of built-in members (at most 4 when a Noise/Momentum member is present), identical for every book.
+ * Noise/Momentum members price orders with f64 log-normal offsets: their outputs match the CPU oracle bit for bit
+ * but only statistically match a Rust build (third-party sampling + libm). */
+int bk_set_agents(bk_env* env, uint32_t n_members, const bk_agent_desc* members);
 /* sim_runner's loop body n_steps times for every book: agents.update(env, rng); env.step(rng)
  * (crates/step_sim/src/runner.rs:53-68), sharing each book's RNG between agents and shuffle. */
 int bk_run(bk_env* env, uint64_t n_steps);

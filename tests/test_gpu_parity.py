@@ -593,3 +593,67 @@ def test_checkpoint_restore_continues_bit_identically(bk):
     assert np.array_equal(ta[len(ta) - len(tb):], tb)
     with pytest.raises(bk.BourseError):
         bk.ManyBookEnv(4, 5, 0, 2, 100_000, levels=16, max_live_orders=64).restore(ck)
+
+
+# ------------------------------------------------------------------- NoiseAgent / MomentumAgent on the device (§8f rank 1)
+NOISE_P = dict(tick_size=2, p_limit=0.2, p_market=0.2, p_cancel=0.1, trade_vol=100, price_dist_mu=0.0, price_dist_sigma=1.0)
+MOM_P = dict(tick_size=2, p_cancel=0.1, trade_vol=100, decay=1.0, demand=5.0, scale=0.5, order_ratio=1.0,
+             price_dist_mu=0.0, price_dist_sigma=10.0)  # the reference's doc example, crates/step_sim/src/lib.rs:53-73
+
+
+def _compare_members(bk, oracle, n_books, members, levels, n_steps, tick=1, step_size=1_000_000, seed=101, pool=256,
+                     chunks=None):
+    env = bk.ManyBookEnv(n_books, seed, 0, tick, step_size, True, levels=levels, max_live_orders=pool,
+                         trade_capacity=64 * n_steps * 8, history_capacity=n_steps)
+    env.set_agents(members)
+    for c in (chunks or [n_steps]):
+        env.run(c)
+    ref = oracle.ManyBooks(n_books, seed, 0, tick, step_size, True, levels, members=members)
+    ref.run(n_steps, 2)
+    assert not env.flags().any(), np.unique(env.flags())
+    hist, want = env.history(), ref.history()
+    if not np.array_equal(hist, want):
+        bad = np.argwhere(hist != want)[0]
+        raise AssertionError(f"L2 history differs first at (step, book, word) = {bad}: {hist[tuple(bad)]} vs {want[tuple(bad)]}")
+    assert np.array_equal(env.trade_counts(), ref.trade_counts())
+    want_rng = ref.rng_states()
+    for b in range(n_books):
+        assert env.rng_state(b) == (int(want_rng[b, 0]), int(want_rng[b, 1])), b
+    for b in (0, n_books - 1):
+        got, exp = env.trades(b, first=0), ref.book(b).trades_array()
+        for f in got.dtype.names:
+            assert np.array_equal(got[f], exp[f]), (b, f)
+        live = env.live_orders(b)
+        o = ref.book(b).orders_array()
+        act = o[o["status"] == 1]
+        assert set(zip(live["order_id"].tolist(), live["price"].tolist(), live["vol"].tolist(), live["side"].tolist())) == \
+            set(zip(act["order_id"].tolist(), act["price"].tolist(), act["vol"].tolist(), act["side"].tolist()))
+    assert int(ref.trade_counts().sum()) > 0
+    env.close()
+    return hist
+
+
+def test_noise_agents_on_device(bk, oracle):
+    _compare_members(bk, oracle, 24, [("noise", 0, 20, NOISE_P)], levels=10, n_steps=80)
+    _compare_members(bk, oracle, 5, [("noise", 3, 50, dict(NOISE_P, p_limit=0.6, p_market=0.1, p_cancel=0.3, price_dist_sigma=2.5,
+                                                           price_dist_mu=1.0, tick_size=4))], levels=16, n_steps=60, tick=2)
+
+
+def test_momentum_and_noise_doc_example_on_device(bk, oracle):
+    # crates/step_sim/src/lib.rs:37-88: MomentumAgent(0, 10) + NoiseAgent(10, 20), Env::new(0, 1, 1_000_000, true), seed 101
+    members = [("momentum", 0, 10, MOM_P), ("noise", 10, 20, NOISE_P)]
+    a = _compare_members(bk, oracle, 16, members, levels=10, n_steps=50)
+    b = _compare_members(bk, oracle, 16, members, levels=10, n_steps=50, chunks=[7, 1, 42])
+    assert np.array_equal(a, b)
+
+
+def test_mixed_random_noise_momentum_set_on_device(bk, oracle):
+    members = [("random", 40, (1073741800, 1073741840), (10, 20), 2, 0.5), ("noise", 0, 30, dict(NOISE_P, p_limit=0.4)),
+               ("momentum", 100, 25, dict(MOM_P, demand=8.0, scale=0.01, decay=0.5)), ("noise", 200, 10, dict(NOISE_P, price_dist_sigma=3.0))]
+    _compare_members(bk, oracle, 12, members, levels=32, n_steps=60, tick=2, pool=512)
+
+
+def test_c5_as_written_momentum_plus_noise_512_agents(bk, oracle):
+    # BASELINE configs[4]: 512 momentum + "market-maker" (= NoiseAgent, the reference has no market maker) agents, 64 levels
+    members = [("momentum", 0, 256, dict(MOM_P, demand=20.0)), ("noise", 256, 256, dict(NOISE_P, p_limit=0.3, p_cancel=0.2))]
+    _compare_members(bk, oracle, 6, members, levels=64, n_steps=40, pool=512)
