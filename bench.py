@@ -35,10 +35,22 @@ WORKLOADS = {
     "C3": (65536, 32, [(64, (32, 64), (10, 20), 2, 0.8), (64, (32, 64), (50, 70), 2, 0.2)]),
     "C5": (8192, 64, [(256, (100, 164), (10, 20), 2, 0.8), (256, (100, 164), (50, 70), 2, 0.2)]),
 }
+# BASELINE configs[4] as written: momentum + "market-maker" agents (the reference's only liquidity provider is NoiseAgent;
+# it has no market-maker type), doc-example parameters (ref crates/step_sim/src/lib.rs:53-73) scaled to 512 agents
+MOM_P = dict(tick_size=2, p_cancel=0.1, trade_vol=100, decay=1.0, demand=20.0, scale=0.5, order_ratio=1.0,
+             price_dist_mu=0.0, price_dist_sigma=10.0)
+NOISE_P = dict(tick_size=2, p_limit=0.3, p_market=0.2, p_cancel=0.2, trade_vol=100, price_dist_mu=0.0, price_dist_sigma=1.0)
+WORKLOADS["C5M"] = (8192, 64, [("momentum", 0, 256, MOM_P), ("noise", 256, 256, NOISE_P)])
 TICK, STEP_SIZE, SEED = 2, 100_000, 101
 
 
 def cpu_baseline(groups, levels, budget_s=15.0):
+    if any(isinstance(g[0], str) for g in groups):
+        return _cpu_baseline(dict(members=groups), levels, budget_s)
+    return _cpu_baseline(dict(groups=groups), levels, budget_s)
+
+
+def _cpu_baseline(agents_kw, levels, budget_s=15.0):
     """Time the CPU oracle (kind "port": C++ restatement of the reference algorithm, ordered maps per
     side, one Env per book) on all host cores, on a bounded sample of the same workload."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -47,12 +59,12 @@ def cpu_baseline(groups, levels, budget_s=15.0):
     cores = os.cpu_count() or 1
     warm, steps = 20, 40
     # size the sample from a quick single-thread probe so the leg takes ~budget_s
-    probe = pyoracle.ManyBooks(64, SEED, 0, TICK, STEP_SIZE, True, levels, groups)
+    probe = pyoracle.ManyBooks(64, SEED, 0, TICK, STEP_SIZE, True, levels, **agents_kw)
     t = time.perf_counter()
     probe.run(warm + 10, 1)
     rate1 = 64 * (warm + 10) / (time.perf_counter() - t)
     books = int(max(cores * 8, min(8192, rate1 * cores * 0.5 * budget_s / (warm + steps))))
-    many = pyoracle.ManyBooks(books, SEED, 0, TICK, STEP_SIZE, True, levels, groups)
+    many = pyoracle.ManyBooks(books, SEED, 0, TICK, STEP_SIZE, True, levels, **agents_kw)
     many.run(warm, cores)
     t = time.perf_counter()
     many.run(steps, cores)
@@ -102,15 +114,20 @@ def main():
 
     books_default, levels, groups = WORKLOADS[args.workload]
     B = args.books or books_default
-    n_agents = sum(g[0] for g in groups)
+    mixed = any(isinstance(g[0], str) for g in groups)
+    n_agents = sum(g[2] if isinstance(g[0], str) and g[0] != "random" else (g[1] if isinstance(g[0], str) else g[0])
+                   for g in groups)
     spl = max(1, min(args.steps_per_launch, args.steps))
     hist_cap = 0 if args.no_history else spl
     trade_cap = max(64, n_agents // 2 * 3 // 2) * spl  # ~35 trades/book-step measured at C3 (128 agents); overflow is flagged and checked below
     stream = torch.cuda.current_stream().cuda_stream
-    env = bourse_amd.ManyBookEnv(B, SEED, 0, TICK, STEP_SIZE, True, levels=levels, max_live_orders=n_agents,
+    env = bourse_amd.ManyBookEnv(B, SEED, 0, TICK, STEP_SIZE, True, levels=levels, max_live_orders=min(n_agents, 512),
                                  trade_capacity=trade_cap, history_capacity=hist_cap,
                                  book_offset=rank * B, device=local_rank, stream=stream)
-    env.set_random_agents(groups)
+    if mixed:
+        env.set_agents(groups)
+    else:
+        env.set_random_agents(groups)
     env.set_pipeline(args.pipeline)
     gather = parallel.StatsGather(env, dist) if dist is not None else None
 
@@ -139,7 +156,8 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
     env.profile(False)
-    per_kind = {k: env.profile_read_kind(i) for i, k in enumerate(("k_run_random", "k_agents_fsm", "k_step_batch", "k_step_events"))}
+    kind0 = "k_run_mixed" if mixed else "k_run_random"
+    per_kind = {k: env.profile_read_kind(i) for i, k in enumerate((kind0, "k_agents_fsm", "k_step_batch", "k_step_events"))}
     env.profile_read()
     dominant = max(per_kind, key=lambda k: per_kind[k][0])
     kern_ms, n_launch = per_kind[dominant]
@@ -186,15 +204,15 @@ def main():
         "warmup": args.warmup, "ms_per_step": dt * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "u32", "data": "synthetic",
         "config": {
-            "workload": f"{args.workload}: {B} books/GPU x {n_agents} on-device RandomAgents "
-                        f"({len(groups)} groups), {levels} levels/side, tick {TICK}, step_size {STEP_SIZE}, "
+            "workload": f"{args.workload}: {B} books/GPU x {n_agents} on-device agents "
+                        f"({len(groups)} {'members: ' + '+'.join(g[0] for g in groups) if mixed else 'groups'}), {levels} levels/side, tick {TICK}, step_size {STEP_SIZE}, "
                         f"seed {SEED}+book",
             "books_per_gpu": B, "agents_per_book": n_agents, "levels": levels, "steps_per_launch": spl,
             "parallelism": f"independent book shards x{world}, 64 B stats all-gather per launch" if world > 1
             else "single GPU",
             "trades_per_book_step": tr_per_bs, "events_per_book_step": ev_per_bs,
             "pipeline": f"split (k_agents_fsm + k_step_batch per step, {parts} book parts on separate streams)"
-            if pipe == "split" else "fused (k_run_random)",
+            if pipe == "split" else f"fused ({kind0})",
         },
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
