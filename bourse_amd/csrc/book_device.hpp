@@ -745,6 +745,10 @@ __global__ __launch_bounds__(64) void k_agents_fsm(DevArgs a) {
     vol_rng = q[6];
     vol_zone = q[7];
     tick_sz = q[8];
+    // pin the LDS loads' completion HERE (rare path): otherwise the compiler parks their s_waitcnt lgkmcnt(0) at the
+    // loop's join block, where every iteration then also waits for its own list-append ds_write to drain
+    asm volatile("" : "+v"(thr), "+v"(tick_lo), "+v"(tick_rng), "+v"(tick_zone));
+    asm volatile("" : "+v"(vol_lo), "+v"(vol_rng), "+v"(vol_zone), "+v"(tick_sz));
   };
   if (total > 0) {
     gend = gtab[0];
