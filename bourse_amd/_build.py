@@ -29,8 +29,12 @@ def is_stale() -> bool:
 def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not is_stale():
         return LIB
-    cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-o", LIB, os.path.join(CSRC, "bourse_amd.hip")]
+    # The step kernels are dominated by wave-UNIFORM control flow (scalar branches).  By default LLVM's StructurizeCFG
+    # pass also rewrites uniform regions, which costs ~9 % extra scalar instructions (flag registers + s_andn2/vccnz
+    # branches) on the SALU-bound k_step_batch: skip it for uniform regions (+7 % book-steps/s, parity tests green).
+    extra = os.environ.get("BOURSE_AMD_HIPCC_FLAGS", "-mllvm -structurizecfg-skip-uniform-regions=1").split()
+    cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared"] + extra + [
+        "-o", LIB, os.path.join(CSRC, "bourse_amd.hip")]
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
     res = subprocess.run(cmd, cwd=CSRC, capture_output=True, text=True)
