@@ -213,7 +213,8 @@ __device__ __forceinline__ void mask_set(uint64_t (&m)[R], uint32_t n, bool on) 
 template <int R>
 __device__ __forceinline__ void flush_trades(Book<R>& B, const DevArgs& a, uint32_t book, uint64_t t0, int lane) {
   if (B.tr_n == 0) return;
-  const uint64_t first = B.n_trades - B.tr_n;  // global index of lane 0's record
+  const uint64_t first = B.n_trades;  // global index of lane 0's record (n_trades counts flushed records)
+  B.n_trades += B.tr_n;
   const uint64_t pos0 = first - B.trade_base;
   if ((uint32_t)lane < B.tr_n) {
     const uint64_t pos = pos0 + (uint32_t)lane;
@@ -250,7 +251,6 @@ __device__ __forceinline__ void emit_trade(Book<R>& B, const DevArgs& a, uint32_
   B.tr_act = wrl(active, l, B.tr_act);
   B.tr_pas = wrl(passive, l, B.tr_pas);
   B.tr_n = l + 1;
-  B.n_trades += 1;
 }
 
 // ----------------------------------------------------------------------------------

@@ -115,7 +115,7 @@ struct bk_env {
   // split pipeline: the batch is cut into n_parts contiguous parts, each on its own stream and started one
   // k_agents_fsm apart, so the latency-bound lane-per-book kernel of one part runs under the issue-bound
   // wave-per-book kernel of another.
-  int n_parts = 2;
+  int n_parts = 3;
   hipStream_t part_stream[4] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev_fork = nullptr, ev_first[4] = {nullptr, nullptr, nullptr, nullptr},
              ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
