@@ -763,7 +763,7 @@ int bk_run(bk_env* env, uint64_t n_steps) {
   // The fused kernel keeps a book in registers across all steps of the launch but runs the RNG-serial
   // phases on the scalar unit of ONE wave per book; the split pipeline runs them one lane per book and needs
   // >= 64 books per wave to pay off.  auto: split once the batch fills the chip several times over.
-  const bool split = env->pipeline == 2 || (env->pipeline == 0 && env->cfg.n_books >= 16384 && a.n_groups > 0);
+  const bool split = env->pipeline == 2 || (env->pipeline == 0 && env->cfg.n_books >= 8192 && a.n_groups > 0);
   if (split) {
     switch (env->R) {
       case 1: rc = launch_split<1>(env, a, env->steps_done, ns); break;
@@ -1033,7 +1033,7 @@ int bk_profile_read_kind(bk_env* env, int kind, double* total_ms, uint64_t* n_la
 
 int bk_get_pipeline(bk_env* env, int* split, int* n_parts) {
   if (!env) return fail(BK_INVALID_ARGUMENT, "null env");
-  const bool sp = env->pipeline == 2 || (env->pipeline == 0 && env->cfg.n_books >= 16384 && !env->groups.empty());
+  const bool sp = env->pipeline == 2 || (env->pipeline == 0 && env->cfg.n_books >= 8192 && !env->groups.empty());
   int P = env->n_parts;
   if (env->cfg.n_books < 4096u * P) P = 1;
   if (split) *split = sp ? 1 : 0;
