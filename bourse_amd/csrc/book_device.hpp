@@ -390,45 +390,48 @@ __device__ __forceinline__ bool match(Book<R>& B, const DevArgs& a, uint32_t boo
 
 // One event of the fused/split RandomAgents paths (slot == agent): a New if the slot's pend bit is set
 // (place_order, orderbook.rs:583-611), else the Cancellation of the slot's order (orderbook.rs:622-644; a
-// no-op if the order was filled meanwhile).  The slot's register index is resolved ONCE per stage by a
-// uniform branch so that every pool access inside uses a compile-time register.
-template <int R>
+// no-op if the order was filled meanwhile).  The whole handler is instantiated per pool register RS and selected by
+// ONE uniform branch on the slot index, so every pool access inside uses a compile-time register and no flag has to
+// survive between stages (scalar instructions are the scarce resource of this kernel).
+template <int R, int RS>
+__device__ __forceinline__ void slot_event_at(Book<R>& B, const DevArgs& a, uint32_t book, uint64_t t0, int lane,
+                                              uint32_t k, uint32_t sl) {
+  const LogCtx nolog{nullptr, 0};
+  const uint64_t bit = 1ull << sl;
+  if (!(B.pend[RS] & bit)) {
+    B.live[RS] &= ~bit;  // Cancellation
+    return;
+  }
+  B.pend[RS] &= ~bit;
+  const uint32_t p = rdl(B.price[RS], sl);
+  uint32_t v = rdl(B.vol[RS], sl);
+  const uint32_t id = rdl(B.id[RS], sl);
+  bool filled = false, market;
+  if (B.bid[RS] & bit) {
+    market = p == 0xFFFFFFFFu;
+    if (B.trading) filled = match_side<R, true>(B, a, book, t0, lane, k, p, v, id, nolog);
+  } else {
+    market = p == 0u;
+    if (B.trading) filled = match_side<R, false>(B, a, book, t0, lane, k, p, v, id, nolog);
+  }
+  if (!market && !filled) {  // rest the remainder with a fresh priority stamp
+    B.vol[RS] = wrl(v, sl, B.vol[RS]);
+    B.seq[RS] = wrl(B.seq_ctr, sl, B.seq[RS]);
+    B.live[RS] |= bit;
+    B.seq_ctr += 1;
+  }
+}
+
+template <int R, int RS = 0>
 __device__ __forceinline__ void process_slot_event(Book<R>& B, const DevArgs& a, uint32_t book, uint64_t t0, int lane,
                                                    uint32_t k, uint32_t n) {
-  const LogCtx nolog{nullptr, 0};
-  const uint32_t sl = n & 63;
-  const uint64_t bit = 1ull << sl;
-  bool is_new = false, is_bid = false;
-  uint32_t p = 0, v = 0, id = 0;
-#pragma unroll
-  for (int r = 0; r < R; ++r) {
-    if ((n >> 6) == (uint32_t)r) {
-      is_new = (B.pend[r] & bit) != 0;
-      if (is_new) {
-        B.pend[r] &= ~bit;
-        is_bid = (B.bid[r] & bit) != 0;
-        p = rdl(B.price[r], sl);
-        v = rdl(B.vol[r], sl);
-        id = rdl(B.id[r], sl);
-      } else {
-        B.live[r] &= ~bit;
-      }
-    }
-  }
-  if (!is_new) return;
-  const bool market = is_bid ? (p == 0xFFFFFFFFu) : (p == 0u);
-  bool filled = false;
-  if (B.trading) filled = match<R>(B, a, book, t0, lane, k, is_bid, p, v, id, nolog);
-  if (!market && !filled) {  // rest the remainder with a fresh priority stamp
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      if ((n >> 6) == (uint32_t)r) {
-        B.vol[r] = wrl(v, sl, B.vol[r]);
-        B.seq[r] = wrl(B.seq_ctr, sl, B.seq[r]);
-        B.live[r] |= bit;
-      }
-    }
-    B.seq_ctr += 1;
+  if constexpr (RS + 1 < R) {
+    if ((n >> 6) == (uint32_t)RS)
+      slot_event_at<R, RS>(B, a, book, t0, lane, k, n & 63);
+    else
+      process_slot_event<R, RS + 1>(B, a, book, t0, lane, k, n);
+  } else {
+    slot_event_at<R, RS>(B, a, book, t0, lane, k, n & 63);
   }
 }
 
