@@ -705,23 +705,15 @@ __global__ __launch_bounds__(256) void k_run_random(DevArgs a, uint64_t first_st
 //                    event loop / snapshot of Env::step (env.rs:117-134) exactly as the fused kernel.
 // ==================================================================================
 enum Phase : uint32_t { PH_ACT = 0, PH_SIDE = 1, PH_TICK = 2, PH_VOL = 3, PH_SHUF = 4, PH_DONE = 5 };
-constexpr int G_DW = sizeof(Group) / 4;  // dwords per group row in the LDS parameter table
 
 template <int R>
 __global__ __launch_bounds__(64) void k_agents_fsm(DevArgs a) {
   __shared__ uint16_t list[64 * R * 64];  // event list of lane l: list[k * 64 + l]
-  __shared__ uint32_t gtab[MAX_GROUPS * G_DW];
   const int lane = threadIdx.x;
-  {
-    const uint32_t* gp = reinterpret_cast<const uint32_t*>(a.groups);
-    for (int i = lane; i < MAX_GROUPS * G_DW; i += 64) gtab[i] = gp[i];
-  }
-  __syncthreads();
   const uint32_t b = a.book_begin + blockIdx.x * 64 + lane;
   if (b >= a.book_end) return;
   uint32_t* st = a.state + (size_t)b * a.state_stride;
   uint32_t* bt = a.batch + (size_t)b * a.batch_stride;
-  const uint32_t total = a.n_agents_total;
 
   Rng rng;
   {
@@ -740,86 +732,53 @@ __global__ __launch_bounds__(64) void k_agents_fsm(DevArgs a) {
   }
   uint2* pv = reinterpret_cast<uint2*>(bt + BT_EV + 32 * R);
 
-  // Group dword fields: 0 n, 1 thr, 2 tick_lo, 3 tick_rng, 4 tick_zone, 5 vol_lo, 6 vol_rng, 7 vol_zone, 8 tick_size.
-  // The current group's parameters are cached in per-lane registers and re-read from LDS only when a lane
-  // crosses a group boundary (a few times per step), keeping LDS latency out of the per-draw loop.
-  uint32_t n = 0, g = 0, gend = 0, n_ev = 0;
-  uint32_t thr = 0, tick_lo = 0, tick_rng = 1, tick_zone = 0, vol_lo = 0, vol_rng = 1, vol_zone = 0, tick_sz = 0;
-  uint32_t phase = PH_DONE, range = 0, zone = 0, cur_side = 0, cur_price = 0;
-  auto load_group = [&]() {
-    const uint32_t* q = gtab + g * G_DW;
-    thr = q[1];
-    tick_lo = q[2];
-    tick_rng = q[3];
-    tick_zone = q[4];
-    vol_lo = q[5];
-    vol_rng = q[6];
-    vol_zone = q[7];
-    tick_sz = q[8];
-    // pin the LDS loads' completion HERE (rare path): otherwise the compiler parks their s_waitcnt lgkmcnt(0) at the
-    // loop's join block, where every iteration then also waits for its own list-append ds_write to drain
-    asm volatile("" : "+v"(thr), "+v"(tick_lo), "+v"(tick_rng), "+v"(tick_zone));
-    asm volatile("" : "+v"(vol_lo), "+v"(vol_rng), "+v"(vol_zone), "+v"(tick_sz));
-  };
-  if (total > 0) {
-    gend = gtab[0];
-    while (n >= gend) {
-      ++g;
-      gend += gtab[g * G_DW];
-    }
-    load_group();
-    phase = PH_ACT;
-  }
-
-  // ---- loop 1: agents.update.  One next_u32() draw per iteration, select-style body (v_cndmask) with three
-  // short predicated blocks (list append, new-order store, next-agent) so that lanes in different phases share
-  // almost the whole instruction stream; a lane never waits for another lane's rejection loop.
-  while (phase != PH_DONE) {
-    const uint32_t x = rng.next_u32();
-    const bool is_act = phase == PH_ACT;
-    // ACT: p = gen::<f32>() < activity_rate (random_agent.rs:91-93)
-    const bool hit = is_act & ((x >> 8) < thr);
-    // other phases: UniformInt<u32>::sample_single step: accept iff lo(x * range) <= zone
-    const uint64_t m = (uint64_t)x * range;
-    const bool acc = (!is_act) & ((uint32_t)m <= zone);
-    const uint32_t val = (uint32_t)(m >> 32);
-    if (hit) list[n_ev * 64 + lane] = (uint16_t)n;  // queue an event for agent n
-    n_ev += hit ? 1u : 0u;
-    uint64_t w = live[0];
+  // ---- loop 1: agents.update, group by group (declaration order).  Inside a group every lane runs a state
+  // machine that performs exactly ONE next_u32() draw per iteration (a lane never waits for another lane's rejection
+  // loop); the group's parameters are wave-uniform (SGPRs).  Lanes re-converge at each group boundary.
+  // Select-style body (v_cndmask) with three short predicated blocks: list append, new-order store, next agent.
+  uint32_t n = 0, n_ev = 0, gbase = 0;
+  for (uint32_t g = 0; g < a.n_groups; ++g) {
+    const Group G = a.groups[g];
+    const uint32_t gend = gbase + G.n;
+    gbase = gend;
+    if (G.n == 0) continue;
+    uint32_t phase = PH_ACT, range = 0, zone = 0, cur_side = 0, cur_price = 0;
+    while (phase != PH_DONE) {
+      const uint32_t x = rng.next_u32();
+      const bool is_act = phase == PH_ACT;
+      // ACT: p = gen::<f32>() < activity_rate (random_agent.rs:91-93)
+      const bool hit = is_act & ((x >> 8) < G.thr);
+      // other phases: UniformInt<u32>::sample_single step: accept iff lo(x * range) <= zone
+      const uint64_t m = (uint64_t)x * range;
+      const bool acc = (!is_act) & ((uint32_t)m <= zone);
+      const uint32_t val = (uint32_t)(m >> 32);
+      if (hit) list[n_ev * 64 + lane] = (uint16_t)n;  // queue an event for agent n
+      n_ev += hit ? 1u : 0u;
+      uint64_t w = live[0];
 #pragma unroll
-    for (int r = 1; r < R; ++r) w = ((n >> 6) == (uint32_t)r) ? live[r] : w;
-    const bool holds_live = (w >> (n & 63)) & 1ull;  // Active order held -> the event is its cancellation (:95-97)
-    const bool acc_side = acc & (phase == PH_SIDE), acc_tick = acc & (phase == PH_TICK);
-    const bool acc_vol = acc & (phase == PH_VOL);
-    cur_side = acc_side ? val : cur_side;                         // 0 = Ask, 1 = Bid ([Ask, Bid].choose, :99)
-    cur_price = acc_tick ? (tick_lo + val) * tick_sz : cur_price;  // tick * tick_size (:100,:107)
-    if (acc_vol) {                                                 // vol drawn last (:101): the order is complete
-      pv[n] = make_uint2(cur_price, vol_lo + val);
-      const uint64_t bit = 1ull << (n & 63);
+      for (int r = 1; r < R; ++r) w = ((n >> 6) == (uint32_t)r) ? live[r] : w;
+      const bool holds_live = (w >> (n & 63)) & 1ull;  // Active order held -> the event is its cancellation (:95-97)
+      const bool acc_side = acc & (phase == PH_SIDE), acc_tick = acc & (phase == PH_TICK);
+      const bool acc_vol = acc & (phase == PH_VOL);
+      cur_side = acc_side ? val : cur_side;                             // 0 = Ask, 1 = Bid ([Ask, Bid].choose, :99)
+      cur_price = acc_tick ? (G.tick_lo + val) * G.tick_size : cur_price;  // tick * tick_size (:100,:107)
+      if (acc_vol) {                                                    // vol drawn last (:101): the order is complete
+        pv[n] = make_uint2(cur_price, G.vol_lo + val);
+        const uint64_t bit = 1ull << (n & 63);
 #pragma unroll
-      for (int r = 0; r < R; ++r) {
-        const uint64_t bb = ((n >> 6) == (uint32_t)r) ? bit : 0ull;
-        pend[r] |= bb;
-        sidem[r] |= cur_side ? bb : 0ull;
-      }
-    }
-    const bool to_side = hit & !holds_live;
-    phase = to_side ? PH_SIDE : acc_side ? PH_TICK : acc_tick ? PH_VOL : phase;
-    range = to_side ? 2u : acc_side ? tick_rng : acc_tick ? vol_rng : range;
-    zone = to_side ? 0x7FFFFFFFu : acc_side ? tick_zone : acc_tick ? vol_zone : zone;
-    if ((is_act & !hit) | (hit & holds_live) | acc_vol) {  // next agent
-      ++n;
-      if (n >= total) {
-        phase = PH_DONE;
-      } else {
-        if (n >= gend) {
-          do {
-            ++g;
-            gend += gtab[g * G_DW];
-          } while (n >= gend);
-          load_group();
+        for (int r = 0; r < R; ++r) {
+          const uint64_t bb = ((n >> 6) == (uint32_t)r) ? bit : 0ull;
+          pend[r] |= bb;
+          sidem[r] |= cur_side ? bb : 0ull;
         }
-        phase = PH_ACT;
+      }
+      const bool to_side = hit & !holds_live;
+      phase = to_side ? PH_SIDE : acc_side ? PH_TICK : acc_tick ? PH_VOL : phase;
+      range = to_side ? 2u : acc_side ? G.tick_rng : acc_tick ? G.vol_rng : range;
+      zone = to_side ? 0x7FFFFFFFu : acc_side ? G.tick_zone : acc_tick ? G.vol_zone : zone;
+      if ((is_act & !hit) | (hit & holds_live) | acc_vol) {  // next agent of the group, or done with the group
+        ++n;
+        phase = (n >= gend) ? PH_DONE : PH_ACT;
       }
     }
   }
