@@ -709,6 +709,9 @@ enum Phase : uint32_t { PH_ACT = 0, PH_SIDE = 1, PH_TICK = 2, PH_VOL = 3, PH_SHU
 template <int R>
 __global__ __launch_bounds__(64) void k_agents_fsm(DevArgs a) {
   __shared__ uint16_t list[64 * R * 64];  // event list of lane l: list[k * 64 + l]
+  // placing-agents / bid-side bit masks of lane l, 32-bit word w: pmask[w * 64 + l], smask[w * 64 + l]
+  // (one ds_or per new order instead of ~20 VALU of per-lane 64-bit mask arithmetic in the hot loop)
+  __shared__ uint32_t pmask[2 * R * 64], smask[2 * R * 64];
   const int lane = threadIdx.x;
   const uint32_t b = a.book_begin + blockIdx.x * 64 + lane;
   if (b >= a.book_end) return;
@@ -722,13 +725,15 @@ __global__ __launch_bounds__(64) void k_agents_fsm(DevArgs a) {
     rng.s0 = mk64(x0.x, x0.y);
     rng.s1 = mk64(x1.x, x1.y);
   }
-  uint64_t live[R], pend[R], sidem[R];
+  uint64_t live[R];
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     const uint2 x = *reinterpret_cast<const uint2*>(st + H_LIVE0 + 2 * r);
     live[r] = mk64(x.x, x.y);
-    pend[r] = 0;
-    sidem[r] = 0;
+    pmask[(2 * r) * 64 + lane] = 0;
+    pmask[(2 * r + 1) * 64 + lane] = 0;
+    smask[(2 * r) * 64 + lane] = 0;
+    smask[(2 * r + 1) * 64 + lane] = 0;
   }
   uint2* pv = reinterpret_cast<uint2*>(bt + BT_EV + 32 * R);
 
@@ -764,13 +769,9 @@ __global__ __launch_bounds__(64) void k_agents_fsm(DevArgs a) {
       cur_price = acc_tick ? (G.tick_lo + val) * G.tick_size : cur_price;  // tick * tick_size (:100,:107)
       if (acc_vol) {                                                    // vol drawn last (:101): the order is complete
         pv[n] = make_uint2(cur_price, G.vol_lo + val);
-        const uint64_t bit = 1ull << (n & 63);
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-          const uint64_t bb = ((n >> 6) == (uint32_t)r) ? bit : 0ull;
-          pend[r] |= bb;
-          sidem[r] |= cur_side ? bb : 0ull;
-        }
+        const uint32_t wi = (n >> 5) * 64 + lane;
+        atomicOr(&pmask[wi], 1u << (n & 31));
+        atomicOr(&smask[wi], cur_side << (n & 31));
       }
       const bool to_side = hit & !holds_live;
       phase = to_side ? PH_SIDE : acc_side ? PH_TICK : acc_tick ? PH_VOL : phase;
@@ -810,8 +811,8 @@ __global__ __launch_bounds__(64) void k_agents_fsm(DevArgs a) {
   bt[BT_NEV] = n_ev;
 #pragma unroll
   for (int r = 0; r < R; ++r) {
-    *reinterpret_cast<uint2*>(bt + BT_PEND + 2 * r) = make_uint2((uint32_t)pend[r], (uint32_t)(pend[r] >> 32));
-    *reinterpret_cast<uint2*>(bt + BT_SIDE + 2 * r) = make_uint2((uint32_t)sidem[r], (uint32_t)(sidem[r] >> 32));
+    *reinterpret_cast<uint2*>(bt + BT_PEND + 2 * r) = make_uint2(pmask[(2 * r) * 64 + lane], pmask[(2 * r + 1) * 64 + lane]);
+    *reinterpret_cast<uint2*>(bt + BT_SIDE + 2 * r) = make_uint2(smask[(2 * r) * 64 + lane], smask[(2 * r + 1) * 64 + lane]);
   }
   for (uint32_t k = 0; k < n_ev; k += 2) {
     const uint32_t lo = list[k * 64 + lane];
