@@ -340,25 +340,15 @@ __device__ __forceinline__ bool match_side(Book<R>& B, const DevArgs& a, uint32_
     // match_orders (orderbook.rs:843-870) on the chosen passive order.  All pool accesses use a
     // compile-time register index r: the single-candidate case (the common one) is handled inside the
     // unrolled loop, the multi-candidate case first scans the few candidates' seq stamps.
-    uint32_t pr = 0, pl = 0;
     if (cnt != 1) {
-      uint32_t bs = 0xFFFFFFFFu;
+      // several orders rest at the touch: the oldest (min seq stamp, unique per book) is next in the queue.
+      // A second DPP reduction instead of a scalar scan of the candidates: the VALU has slack, the SALU does not.
+      uint32_t sm = 0xFFFFFFFFu;
 #pragma unroll
-      for (int r = 0; r < R; ++r) {
-        uint64_t w = eq[r];
-        while (w) {
-          const uint32_t l = __builtin_ctzll(w);
-          w &= w - 1;
-          const uint32_t sq = rdl(B.seq[r], l);
-          if (sq < bs) {  // seq stamps are unique per book and < 0xFFFFFFFF
-            bs = sq;
-            pr = r;
-            pl = l;
-          }
-        }
-      }
+      for (int r = 0; r < R; ++r) sm = min(sm, sel(eq[r], B.seq[r], 0xFFFFFFFFu));
+      const uint32_t bs = wave_umin(sm);
 #pragma unroll
-      for (int r = 0; r < R; ++r) eq[r] = (pr == (uint32_t)r) ? (1ull << pl) : 0ull;
+      for (int r = 0; r < R; ++r) eq[r] &= __ballot(B.seq[r] == bs);
     }
     uint32_t pv = 0, pid = 0, tv = 0;
 #pragma unroll
