@@ -45,6 +45,8 @@ def test_dpp_reductions(bk):
 def _compare_random(bk, oracle, n_books, groups, levels, n_steps, seed=101, tick=2, step_size=100_000, chunks=None,
                     max_live=None, trade_cap=None, pipeline="fused"):
     n_agents = sum(g[0] for g in groups)
+    if chunks:
+        n_steps = sum(chunks)
     env = bk.ManyBookEnv(n_books, seed, 0, tick, step_size, True, levels=levels,
                          max_live_orders=max_live or n_agents, trade_capacity=trade_cap or 2 * n_agents * n_steps,
                          history_capacity=n_steps)
@@ -657,3 +659,31 @@ def test_c5_as_written_momentum_plus_noise_512_agents(bk, oracle):
     # BASELINE configs[4]: 512 momentum + "market-maker" (= NoiseAgent, the reference has no market maker) agents, 64 levels
     members = [("momentum", 0, 256, dict(MOM_P, demand=20.0)), ("noise", 256, 256, dict(NOISE_P, p_limit=0.3, p_cancel=0.2))]
     _compare_members(bk, oracle, 6, members, levels=64, n_steps=40, pool=512)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_fuzz_random_agent_configs_vs_oracle(bk, oracle, seed):
+    """Randomly drawn RandomAgents sets (group counts/sizes, windows, volumes incl. tiny ranges, rates incl. 0/1, ticks,
+    level depth, batch size) on a randomly chosen pipeline, against the oracle."""
+    rng = np.random.default_rng(1000 + seed)
+    tick = int(rng.choice([1, 2, 5]))
+    n_groups = int(rng.integers(1, 5))
+    groups, total = [], 0
+    for _ in range(n_groups):
+        n = int(rng.integers(0, 90))
+        lo = int(rng.integers(1, 200))
+        w = int(rng.integers(1, 40))
+        vlo = int(rng.integers(1, 100))
+        vw = int(rng.integers(1, 60))
+        rate = float(rng.choice([0.0, 1.0, rng.random()]))
+        groups.append((n, (lo, lo + w), (vlo, vlo + vw), tick * int(rng.integers(1, 4)), rate))
+        total += n
+    if total == 0:
+        groups[0] = (7,) + groups[0][1:]
+        total = 7
+    n_books = int(rng.integers(1, 150))
+    levels = int(rng.integers(1, 65))
+    _compare_random(bk, oracle, n_books=n_books, groups=groups, levels=levels, n_steps=int(rng.integers(5, 40)),
+                    tick=tick, step_size=int(rng.choice([300, 100_000])), seed=int(rng.integers(0, 2**40)),
+                    pipeline=str(rng.choice(["fused", "split", "mixed"])), chunks=None if rng.random() < 0.5 else [3, 1, 1],
+                    max_live=max(64, total))
