@@ -57,7 +57,7 @@ def _cpu_baseline(agents_kw, levels, budget_s=15.0):
     import pyoracle
 
     cores = os.cpu_count() or 1
-    warm, steps = 20, 40
+    warm, steps = 20, 100
     # size the sample from a quick single-thread probe so the leg takes ~budget_s
     probe = pyoracle.ManyBooks(64, SEED, 0, TICK, STEP_SIZE, True, levels, **agents_kw)
     t = time.perf_counter()

@@ -737,6 +737,10 @@ __global__ __launch_bounds__(64) void k_agents_fsm(DevArgs a) {
     const uint32_t gend = gbase + G.n;
     gbase = gend;
     if (G.n == 0) continue;
+    // complete the scalar loads of the group's parameters HERE: a wait parked inside the loop would be
+    // s_waitcnt lgkmcnt(0), which also waits for the iteration's own LDS writes (list append, ds_or) to drain
+    asm volatile("" ::"s"(G.thr), "s"(G.tick_lo), "s"(G.tick_rng), "s"(G.tick_zone));
+    asm volatile("" ::"s"(G.vol_lo), "s"(G.vol_rng), "s"(G.vol_zone), "s"(G.tick_size));
     uint32_t phase = PH_ACT, range = 0, zone = 0, cur_side = 0, cur_price = 0;
     while (phase != PH_DONE) {
       const uint32_t x = rng.next_u32();

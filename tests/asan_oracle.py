@@ -1,5 +1,5 @@
 """Run the CPU oracle's main workloads under AddressSanitizer + UBSan (CPU only; GPU ASan is unavailable on this pool).
-Usage: make -C oracle asan && LD_PRELOAD=$(gcc -print-file-name=libasan.so) ASAN_OPTIONS=detect_leaks=0 python tools/asan_oracle.py"""
+Usage: make -C oracle asan && LD_PRELOAD=$(gcc -print-file-name=libasan.so) ASAN_OPTIONS=detect_leaks=0 python tests/asan_oracle.py"""
 import sys, os, ctypes
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'oracle'))
 import pyoracle
