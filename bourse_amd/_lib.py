@@ -103,6 +103,12 @@ SIGNATURES = {
     "bk_history_len": (_i32, [_vp, _p64, _p64]),
     "bk_history": (_i32, [_vp, _u64, _u64, _u32, _u32, _p32]),
     "bk_clear_history": (_i32, [_vp]),
+    "bk_history_copy_async": (_i32, [_vp, _u64, _u64, _u32, _u32, _p32, _vp]),
+    "bk_stream_create": (_i32, [C.POINTER(_vp)]),
+    "bk_stream_sync": (_i32, [_vp]),
+    "bk_stream_destroy": (_i32, [_vp]),
+    "bk_pinned_alloc": (_i32, [_u64, C.POINTER(_vp)]),
+    "bk_pinned_free": (_i32, [_vp]),
     "bk_trade_count": (_i32, [_vp, _u32, _p64, _p64]),
     "bk_trade_counts": (_i32, [_vp, _p64]),
     "bk_get_trades": (_i32, [_vp, _u32, _u64, _u64, _vp]),

@@ -61,7 +61,7 @@ struct DevArgs {
   uint32_t state_stride;        // dwords per book
   uint32_t l2_width;            // 5 + 4*levels
   uint32_t trade_cap, hist_cap;
-  uint32_t hist_base_lo, hist_base_hi;  // step index stored in history slot 0
+  uint32_t hist_slot0, hist_pad;  // history is a ring of hist_cap steps: slot of the launch's first step
   uint32_t n_agents_total, log_cap;
   uint32_t* state;
   uint32_t* l2_last;
@@ -430,7 +430,7 @@ __device__ __forceinline__ void process_slot_event(Book<R>& B, const DevArgs& a,
 // ----------------------------------------------------------------------------------
 template <int R>
 __device__ __forceinline__ void snapshot(const Book<R>& B, const DevArgs& a, uint32_t book, int lane,
-                                         uint32_t* __restrict__ bins /* LDS, >= 4*levels */, uint64_t step_index,
+                                         uint32_t* __restrict__ bins /* LDS, >= 4*levels */, uint32_t hist_slot,
                                          uint32_t& flags, bool write_last) {
   const uint32_t L = a.levels;
   uint32_t mb = 0u, ma = 0xFFFFFFFFu, sb = 0u, sa = 0u;
@@ -470,13 +470,8 @@ __device__ __forceinline__ void snapshot(const Book<R>& B, const DevArgs& a, uin
   const uint32_t W = a.l2_width;
   uint32_t* last = a.l2_last + (size_t)book * W;
   uint32_t* hist = nullptr;
-  if (a.hist_cap) {
-    const uint64_t slot = step_index - mk64(a.hist_base_lo, a.hist_base_hi);
-    if (slot < a.hist_cap)
-      hist = a.hist + ((size_t)slot * a.n_books + book) * W;
-    else
-      flags |= FLAG_HIST_OVERFLOW;
-  }
+  if (a.hist_cap) hist = a.hist + ((size_t)hist_slot * a.n_books + book) * W;  // ring: the oldest record is overwritten
+  (void)flags;
   uint32_t h = 0;
   h = lane == 0 ? B.trade_vol : h;
   h = lane == 1 ? bid_best : h;
@@ -579,7 +574,7 @@ __device__ __forceinline__ void store_book(const Book<R>& B, const Rng& rng, uin
 template <int R>
 __device__ __forceinline__ uint32_t step_from_list(Book<R>& B, const DevArgs& a, uint32_t book, int lane,
                                                    const uint32_t (&ev)[R], uint32_t n_ev, uint32_t* bins,
-                                                   uint64_t step_index, bool write_last) {
+                                                   uint32_t hist_slot, bool write_last) {
   const uint64_t step_size = mk64(a.step_lo, a.step_hi);
   const uint64_t t0 = B.t;
   B.trade_vol = 0;  // reset_trade_vol (env.rs:118)
@@ -597,7 +592,7 @@ __device__ __forceinline__ uint32_t step_from_list(Book<R>& B, const DevArgs& a,
   B.t = t0 + step_size;  // env.rs:129
   // env.rs:132-134.  Env::level_2_data (the "latest" record) only needs a launch's final snapshot;
   // with no history buffer every step's record is written there.
-  snapshot<R>(B, a, book, lane, bins, step_index, B.flags, write_last);
+  snapshot<R>(B, a, book, lane, bins, hist_slot, B.flags, write_last);
   flush_trades<R>(B, a, book, t0, lane);
   return (uint32_t)(B.n_trades - trades_before);
 }
@@ -676,7 +671,7 @@ __global__ __launch_bounds__(256) void k_run_random(DevArgs a, uint64_t first_st
       slot_write<R>(ev, i, aj);
       slot_write<R>(ev, j, ai);
     }
-    last_ntr = step_from_list<R>(B, a, book, lane, ev, n_ev, bins, first_step + s,
+    last_ntr = step_from_list<R>(B, a, book, lane, ev, n_ev, bins, a.hist_cap ? (a.hist_slot0 + s) % a.hist_cap : 0u,
                                  s + 1 == n_steps || a.hist_cap == 0);
     last_nev = n_ev;
   }
@@ -851,7 +846,7 @@ __global__ __launch_bounds__(64) void k_step_batch(DevArgs a, uint64_t step_inde
     B.pend[r] = pend;
   }
   B.next_id = base;
-  const uint32_t ntr = step_from_list<R>(B, a, book, lane, ev, n_ev, lds[wv], step_index, write_last != 0);
+  const uint32_t ntr = step_from_list<R>(B, a, book, lane, ev, n_ev, lds[wv], a.hist_slot0, write_last != 0);
   store_book<R>(B, rng, st, lane, step_index + 1, ntr, n_ev);
 }
 
@@ -1002,7 +997,7 @@ __global__ __launch_bounds__(64) void k_step_events(DevArgs a, uint64_t step_ind
   }
   B.n_events += n_ev;
   B.t = t0 + step_size;
-  snapshot<R>(B, a, book, lane, bins, step_index, B.flags, true);
+  snapshot<R>(B, a, book, lane, bins, a.hist_slot0, B.flags, true);
   flush_trades<R>(B, a, book, t0, lane);
   store_book<R>(B, rng, st, lane, step_index + 1, (uint32_t)(B.n_trades - trades_before), n_ev);
 }

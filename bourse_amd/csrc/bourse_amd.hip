@@ -154,8 +154,8 @@ struct bk_env {
     a.l2_width = W;
     a.trade_cap = cfg.trade_capacity;
     a.hist_cap = cfg.history_capacity;
-    a.hist_base_lo = static_cast<uint32_t>(hist_base);
-    a.hist_base_hi = static_cast<uint32_t>(hist_base >> 32);
+    a.hist_slot0 = cfg.history_capacity ? static_cast<uint32_t>(steps_done % cfg.history_capacity) : 0u;
+    a.hist_pad = 0;
     a.n_agents_total = n_agents_total;
     a.log_cap = cfg.max_orders;
     a.state = state.p;
@@ -254,6 +254,7 @@ int launch_split(bk_env* env, const DevArgs& a0, uint64_t first_step, uint32_t n
       DevArgs a = a0;
       a.book_begin = static_cast<uint32_t>(static_cast<uint64_t>(B) * i / P) & ~3u;
       a.book_end = (i + 1 == P) ? B : (static_cast<uint32_t>(static_cast<uint64_t>(B) * (i + 1) / P) & ~3u);
+      a.hist_slot0 = a.hist_cap ? static_cast<uint32_t>((first_step + s) % a.hist_cap) : 0u;
       const uint32_t nb = a.book_end - a.book_begin;
       hipStream_t st = P > 1 ? env->part_stream[i] : env->stream;
       if (P > 1 && s == 0 && i > 0) HIPCHK(hipStreamWaitEvent(st, env->ev_first[i - 1], 0));  // stagger the parts
@@ -524,8 +525,6 @@ int bk_step(bk_env* env) {
   if (!env) return fail(BK_INVALID_ARGUMENT, "null env");
   if (int rc = use_device(env)) return rc;
   const size_t B = env->cfg.n_books;
-  if (env->cfg.history_capacity && env->steps_done - env->hist_base >= env->cfg.history_capacity)
-    return fail(BK_CAPACITY, "L2 history buffer full: call bk_clear_history() or raise history_capacity");
   // validate + flatten the queues (CSR)
   std::vector<uint32_t> off(B + 1, 0u);
   size_t total = 0;
@@ -740,8 +739,6 @@ int bk_run(bk_env* env, uint64_t n_steps) {
   for (const BookHost& bh : env->books)
     if (!bh.queue.empty() || !bh.orders.empty())
       return fail(BK_INVALID_ARGUMENT, "bk_run cannot be mixed with host-driven orders on the same env");
-  if (env->cfg.history_capacity && env->steps_done - env->hist_base + n_steps > env->cfg.history_capacity)
-    return fail(BK_CAPACITY, "L2 history buffer too small for this run: bk_clear_history() or raise history_capacity");
   DevArgs a = env->args();
   if (a.n_groups == 0) {  // no agents: plain steps
     a.groups[0] = Group{};
@@ -798,26 +795,96 @@ int bk_level2(bk_env* env, uint32_t first_book, uint32_t n_books, uint32_t* out)
   return BK_OK;
 }
 
+// first retained step of the history ring: the last history_capacity steps, or since the last bk_clear_history()
+static uint64_t hist_first(const bk_env* env) {
+  const uint64_t cap = env->cfg.history_capacity;
+  const uint64_t lo = env->steps_done > cap ? env->steps_done - cap : 0;
+  return std::max(lo, env->hist_base);
+}
+
 int bk_history_len(bk_env* env, uint64_t* first_step, uint64_t* n_steps) {
   if (!env) return fail(BK_INVALID_ARGUMENT, "null env");
-  if (first_step) *first_step = env->hist_base;
-  if (n_steps) *n_steps = env->cfg.history_capacity ? env->steps_done - env->hist_base : 0;
+  const uint64_t f = hist_first(env);
+  if (first_step) *first_step = f;
+  if (n_steps) *n_steps = env->cfg.history_capacity ? env->steps_done - f : 0;
+  return BK_OK;
+}
+
+// copy steps [first_step, first_step + n_steps) of the ring to `out` (handles the wrap); async if cs != nullptr
+static int hist_copy(bk_env* env, uint64_t first_step, uint64_t n_steps, uint32_t first_book, uint32_t n_books,
+                     uint32_t* out, hipStream_t cs, bool async) {
+  if (!env || !out) return fail(BK_INVALID_ARGUMENT, "null argument");
+  if (!env->cfg.history_capacity || first_step < hist_first(env) || first_step + n_steps > env->steps_done)
+    return fail(BK_INVALID_ARGUMENT, "step range not retained (history is a ring of history_capacity steps)");
+  if (static_cast<uint64_t>(first_book) + n_books > env->cfg.n_books)
+    return fail(BK_INVALID_ARGUMENT, "book range out of bounds");
+  if (int rc = use_device(env)) return rc;
+  const size_t W = env->W, B = env->cfg.n_books, cap = env->cfg.history_capacity;
+  const size_t row = static_cast<size_t>(n_books) * W * 4;
+  uint64_t done = 0;
+  while (done < n_steps) {
+    const uint64_t slot = (first_step + done) % cap;
+    const uint64_t n = std::min<uint64_t>(n_steps - done, cap - slot);
+    const uint32_t* src = env->hist.p + (slot * B + first_book) * W;
+    uint32_t* dst = out + done * static_cast<size_t>(n_books) * W;
+    if (async && n_books == B)  // whole rows are contiguous: one linear copy
+      HIPCHK(hipMemcpyAsync(dst, src, row * n, hipMemcpyDeviceToHost, cs));
+    else if (async)
+      HIPCHK(hipMemcpy2DAsync(dst, row, src, B * W * 4, row, n, hipMemcpyDeviceToHost, cs));
+    else
+      HIPCHK(hipMemcpy2D(dst, row, src, B * W * 4, row, n, hipMemcpyDeviceToHost));
+    done += n;
+  }
   return BK_OK;
 }
 
 int bk_history(bk_env* env, uint64_t first_step, uint64_t n_steps, uint32_t first_book, uint32_t n_books,
                uint32_t* out) {
-  if (!env || !out) return fail(BK_INVALID_ARGUMENT, "null argument");
-  if (first_step < env->hist_base || first_step + n_steps > env->steps_done || !env->cfg.history_capacity)
-    return fail(BK_INVALID_ARGUMENT, "step range not retained");
-  if (static_cast<uint64_t>(first_book) + n_books > env->cfg.n_books)
-    return fail(BK_INVALID_ARGUMENT, "book range out of bounds");
+  if (!env) return fail(BK_INVALID_ARGUMENT, "null env");
   if (int rc = use_device(env)) return rc;
   HIPCHK(hipStreamSynchronize(env->stream));
-  const size_t W = env->W, B = env->cfg.n_books;
-  const uint32_t* src = env->hist.p + ((first_step - env->hist_base) * B + first_book) * W;
-  HIPCHK(hipMemcpy2D(out, static_cast<size_t>(n_books) * W * 4, src, B * W * 4, static_cast<size_t>(n_books) * W * 4,
-                     n_steps, hipMemcpyDeviceToHost));
+  return hist_copy(env, first_step, n_steps, first_book, n_books, out, nullptr, false);
+}
+
+// Egress overlapped with stepping: the copy is ordered after the work queued on the env's stream so far and runs on
+// `copy_stream`; the caller keeps stepping and must not let the ring wrap onto the steps being copied
+// (history_capacity >= 2 x chunk), then waits with bk_stream_sync(copy_stream).  `out` should be pinned
+// (bk_pinned_alloc) for the copy to be truly asynchronous.
+int bk_history_copy_async(bk_env* env, uint64_t first_step, uint64_t n_steps, uint32_t first_book, uint32_t n_books,
+                          uint32_t* out, void* copy_stream) {
+  if (!env || !copy_stream) return fail(BK_INVALID_ARGUMENT, "null argument");
+  if (int rc = use_device(env)) return rc;
+  hipStream_t cs = static_cast<hipStream_t>(copy_stream);
+  hipEvent_t ev;
+  HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  HIPCHK(hipEventRecord(ev, env->stream));
+  HIPCHK(hipStreamWaitEvent(cs, ev, 0));
+  HIPCHK(hipEventDestroy(ev));
+  return hist_copy(env, first_step, n_steps, first_book, n_books, out, cs, true);
+}
+
+int bk_stream_create(void** out) {
+  if (!out) return fail(BK_INVALID_ARGUMENT, "null argument");
+  hipStream_t s;
+  HIPCHK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  *out = s;
+  return BK_OK;
+}
+int bk_stream_sync(void* stream) {
+  HIPCHK(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+  return BK_OK;
+}
+int bk_stream_destroy(void* stream) {
+  HIPCHK(hipStreamDestroy(static_cast<hipStream_t>(stream)));
+  return BK_OK;
+}
+int bk_pinned_alloc(uint64_t nbytes, void** out) {
+  if (!out) return fail(BK_INVALID_ARGUMENT, "null argument");
+  HIPCHK(hipHostMalloc(out, nbytes, hipHostMallocDefault));
+  return BK_OK;
+}
+int bk_pinned_free(void* p) {
+  HIPCHK(hipHostFree(p));
   return BK_OK;
 }
 

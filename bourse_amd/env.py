@@ -100,6 +100,7 @@ class ManyBookEnv:
         cfg.trading, cfg.seed, cfg.book_offset = int(bool(trading)), int(seed) & (2**64 - 1), int(book_offset)
         cfg.max_live_orders, cfg.max_orders = int(max_live_orders), int(max_orders)
         cfg.trade_capacity, cfg.history_capacity, cfg.device = int(trade_capacity), int(history_capacity), int(device)
+        self.history_capacity = int(history_capacity)
         self._h = C.c_void_p()
         self.n_books, self.levels, self.tick_size = int(n_books), int(levels), int(tick_size)
         self.step_size, self.start_time = int(step_size), int(start_time)
@@ -255,6 +256,57 @@ class ManyBookEnv:
         if n_steps and nb:
             check(self._L.bk_history(self._h, first_step, n_steps, first_book, nb, _lib.p32(out)))
         return out
+
+    def stream_history(self, n_steps: int, chunk: int, on_chunk=None) -> dict:
+        """Run ``n_steps`` in chunks while the previous chunk's L2 records stream to pinned host memory on a copy
+        stream (double-buffered; needs history_capacity >= 2 * chunk).  ``on_chunk(first_step, array[chunk, B, W])`` is
+        called once a chunk has landed (the array is reused two chunks later).  Returns timing figures."""
+        import time
+
+        if chunk < 1 or self.history_capacity < 2 * chunk:
+            raise ValueError("stream_history needs history_capacity >= 2 * chunk")
+        L, W, B = self._L, self.width, self.n_books
+        out_t = C.POINTER(C.c_uint32)
+        streams, bufs = [], []
+        for _ in range(2):  # chunk k uses stream/buffer k % 2: copy k overlaps run k+1, and is awaited before run k+2
+            cs, p = C.c_void_p(), C.c_void_p()
+            check(L.bk_stream_create(C.byref(cs)))
+            check(L.bk_pinned_alloc(chunk * B * W * 4, C.byref(p)))
+            streams.append(cs)
+            bufs.append((p, np.ctypeslib.as_array(C.cast(p, out_t), shape=(chunk, B, W))))
+        inflight = [None, None]  # per buffer: (first_step, n_steps)
+
+        def land(i):
+            if inflight[i] is not None:
+                check(L.bk_stream_sync(streams[i]))
+                if on_chunk is not None:
+                    on_chunk(inflight[i][0], bufs[i][1][: inflight[i][1]])
+                inflight[i] = None
+
+        done, k, nbytes = 0, 0, 0
+        t0 = time.perf_counter()
+        try:
+            while done < n_steps:
+                c = min(chunk, n_steps - done)
+                i = k % 2
+                land(i)  # chunk k-2 has left the ring and its host buffer has been consumed
+                first = self.steps_done()
+                self.run(c, sync=False)
+                check(L.bk_history_copy_async(self._h, first, c, 0, B, C.cast(bufs[i][0], out_t), streams[i]))
+                inflight[i] = (first, c)
+                nbytes += c * B * W * 4
+                done += c
+                k += 1
+            land(k % 2)
+            land((k + 1) % 2)
+            self.sync()
+            dt = time.perf_counter() - t0
+        finally:
+            for cs, (p, _) in zip(streams, bufs):
+                L.bk_stream_sync(cs)
+                L.bk_pinned_free(p)
+                L.bk_stream_destroy(cs)
+        return {"seconds": dt, "book_steps_per_s": B * n_steps / dt, "d2h_gb_per_s": nbytes / dt / 1e9, "bytes": nbytes}
 
     def clear_history(self):
         check(self._L.bk_clear_history(self._h))

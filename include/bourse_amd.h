@@ -37,7 +37,7 @@ enum bk_status {
 #define BK_FLAG_STEP_SIZE 4u       /* a step queued >= step_size events */
 #define BK_FLAG_ORDER_LOG_FULL 8u  /* order id beyond the order-log capacity */
 #define BK_FLAG_UNKNOWN_ORDER 16u  /* cancel/modify of an id that was never created */
-#define BK_FLAG_HIST_OVERFLOW 32u  /* L2 history buffer full: records dropped */
+#define BK_FLAG_HIST_OVERFLOW 32u  /* (unused: the L2 history is a ring; reading a step that was overwritten is an error) */
 
 typedef struct bk_env bk_env;
 
@@ -55,7 +55,7 @@ typedef struct bk_config {
   uint32_t max_live_orders; /* live-order pool per book, rounded up to a multiple of 64 (<= 1024) */
   uint32_t max_orders;      /* order-log capacity per book for the host-driven path (0 = no log) */
   uint32_t trade_capacity;  /* trade records retained per book between bk_clear_trades() calls */
-  uint32_t history_capacity;/* L2 records (steps) retained between bk_clear_history() calls; 0 = keep only the latest */
+  uint32_t history_capacity;/* L2 history ring: the last N steps are retained (0 = keep only the latest record) */
   int32_t device;           /* HIP device ordinal */
   uint32_t reserved;
 } bk_config;
@@ -182,6 +182,17 @@ int bk_history_len(bk_env* env, uint64_t* first_step, uint64_t* n_steps);
 int bk_history(bk_env* env, uint64_t first_step, uint64_t n_steps, uint32_t first_book, uint32_t n_books,
                uint32_t* out);
 int bk_clear_history(bk_env* env);
+/* Streaming egress: the history buffer is a ring of history_capacity steps; this queues the
+ * device-to-host copy of retained steps on `copy_stream`, ordered after the work queued on the env so far, and returns
+ * at once, so the next bk_run() overlaps the copy.  Keep history_capacity >= 2 x the chunk being copied; `out` should
+ * come from bk_pinned_alloc().  Wait with bk_stream_sync(copy_stream). */
+int bk_history_copy_async(bk_env* env, uint64_t first_step, uint64_t n_steps, uint32_t first_book, uint32_t n_books,
+                          uint32_t* out, void* copy_stream);
+int bk_stream_create(void** out);
+int bk_stream_sync(void* stream);
+int bk_stream_destroy(void* stream);
+int bk_pinned_alloc(uint64_t nbytes, void** out);
+int bk_pinned_free(void* p);
 /* OrderBook::get_trades, orderbook.rs:800-802 */
 int bk_trade_count(bk_env* env, uint32_t book, uint64_t* total, uint64_t* first_retained);
 int bk_trade_counts(bk_env* env, uint64_t* totals /* [n_books] */);

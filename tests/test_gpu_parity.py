@@ -168,8 +168,11 @@ def test_trade_capacity_overflow_is_flagged_not_silent(bk):
     with pytest.raises(bk.CapacityError):
         env.trades(0, first=0)
     assert len(env.trades(0, first=0, n=8)) == 8
-    with pytest.raises(bk.CapacityError):
-        env.run(1)  # history buffer full: reported before launching
+    env.run(5)  # the L2 history is a ring of the last 30 steps: stepping on is fine ...
+    first, n = env.history_len()
+    assert (first, n) == (5, 30)
+    with pytest.raises(bk.BourseError):
+        env.history(first_step=0, n_steps=3)  # ... reading a step that was overwritten is an error, never stale data
 
 
 # ------------------------------------------------------------------- host-driven path (C ABI Env methods)
@@ -687,3 +690,26 @@ def test_fuzz_random_agent_configs_vs_oracle(bk, oracle, seed):
                     tick=tick, step_size=int(rng.choice([300, 100_000])), seed=int(rng.integers(0, 2**40)),
                     pipeline=str(rng.choice(["fused", "split", "mixed"])), chunks=None if rng.random() < 0.5 else [3, 1, 1],
                     max_live=max(64, total))
+
+
+def test_history_ring_and_streaming_egress(bk, oracle):
+    """History ring: the last N steps are retained across launches and pipelines; streamed chunks equal the oracle."""
+    B, T, chunk = 40, 36, 6
+    env = bk.ManyBookEnv(B, 9, 0, 2, 100_000, levels=16, max_live_orders=64, trade_capacity=64 * T, history_capacity=2 * chunk)
+    env.set_random_agents(C2_GROUPS)
+    ref = oracle.ManyBooks(B, 9, 0, 2, 100_000, True, 16, C2_GROUPS)
+    ref.run(T, 2)
+    want = ref.history()
+    got = {}
+    env.set_pipeline("split")
+    stats = env.stream_history(T, chunk, on_chunk=lambda first, arr: got.__setitem__(first, arr.copy()))
+    assert sorted(got) == list(range(0, T, chunk)) and stats["bytes"] == T * B * env.width * 4
+    for first, arr in got.items():
+        assert np.array_equal(arr, want[first:first + chunk]), first
+    first, n = env.history_len()
+    assert (first, n) == (T - 2 * chunk, 2 * chunk)
+    assert np.array_equal(env.history(), want[T - 2 * chunk:])  # wrapped read of the ring
+    env.set_pipeline("fused")
+    env.run(5)
+    ref.run(5, 1)
+    assert np.array_equal(env.history(), ref.history()[T + 5 - 2 * chunk:])
