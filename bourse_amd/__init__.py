@@ -6,9 +6,9 @@ behind a C ABI (include/bourse_amd.h).  See DESIGN.md / INTEGRATION.md.
 """
 from . import _lib, core, step_sim
 from ._lib import BourseError, CapacityError, NoDeviceError
-from .env import (MAX_PRICE, ManyBookEnv, MomentumAgent, MomentumParams, NoiseAgent, NoiseAgentParams, RandomAgents,
-                  sim_runner)
+from .env import (MAX_PRICE, ManyBookEnv, ManyMarketEnv, MomentumAgent, MomentumParams, NoiseAgent, NoiseAgentParams,
+                  RandomAgents, RandomMarketAgents, market_sim_runner, sim_runner)
 
 __all__ = ["core", "step_sim", "ManyBookEnv", "RandomAgents", "NoiseAgent", "NoiseAgentParams", "MomentumAgent",
-           "MomentumParams", "sim_runner", "MAX_PRICE", "BourseError",
+           "MomentumParams", "sim_runner", "ManyMarketEnv", "RandomMarketAgents", "market_sim_runner", "MAX_PRICE", "BourseError",
            "CapacityError", "NoDeviceError"]

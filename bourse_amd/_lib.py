@@ -37,7 +37,7 @@ class Config(C.Structure):
         ("tick_size", C.c_uint32), ("trading", C.c_uint32), ("step_size", C.c_uint64),
         ("seed", C.c_uint64), ("book_offset", C.c_uint64), ("max_live_orders", C.c_uint32),
         ("max_orders", C.c_uint32), ("trade_capacity", C.c_uint32), ("history_capacity", C.c_uint32),
-        ("device", C.c_int32), ("reserved", C.c_uint32),
+        ("device", C.c_int32), ("assets", C.c_uint32),
     ]
 
 
@@ -96,6 +96,8 @@ SIGNATURES = {
     "bk_order_count": (_i32, [_vp, _u32, _p64]),
     "bk_get_orders": (_i32, [_vp, _u32, _u64, _u64, _vp]),
     "bk_set_random_agents": (_i32, [_vp, _u32, C.POINTER(RandomAgentsCfg)]),
+    "bk_set_tick_sizes": (_i32, [_vp, _u32, _p32]),
+    "bk_set_random_market_agents": (_i32, [_vp, _u32, C.POINTER(RandomAgentsCfg), _p32]),
     "bk_set_agents": (_i32, [_vp, _u32, C.POINTER(AgentDesc)]),
     "bk_run": (_i32, [_vp, _u64]),
     "bk_l2_width": (_u32, [_vp]),

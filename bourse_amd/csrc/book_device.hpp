@@ -33,6 +33,7 @@ enum Hdr : int {
 };
 constexpr int POOL_FIELDS = 5;  // price, vol, id, seq, meta(bit0 live, bit1 bid)
 constexpr int MAX_GROUPS = 8;
+constexpr int MAX_ASSETS = 8;  // books per market (MarketEnv<ASSETS>)
 
 constexpr uint32_t FLAG_POOL_OVERFLOW = 1u, FLAG_TRADE_OVERFLOW = 2u, FLAG_STEP_SIZE = 4u,
                    FLAG_ORDER_LOG_FULL = 8u, FLAG_UNKNOWN_ORDER = 16u, FLAG_HIST_OVERFLOW = 32u;
@@ -43,7 +44,8 @@ struct Group {  // RandomAgents::new, host-preprocessed
   uint32_t tick_lo, tick_rng, tick_zone;
   uint32_t vol_lo, vol_rng, vol_zone;
   uint32_t tick_size;  // the agents' tick size
-  uint32_t pad[3];
+  uint32_t asset;      // RandomMarketAgents: the asset (book of the market) the group trades
+  uint32_t pad[2];
 };
 
 struct DevTrade {  // 32 B device trade record
@@ -77,8 +79,11 @@ struct DevArgs {
   // split pipeline: per-book step batch written by k_agents_fsm, consumed by k_step_batch
   uint32_t* batch;
   uint32_t batch_stride;  // dwords per book: 64 + 160 * R
-  uint32_t book_begin, book_end;  // split pipeline: this launch covers books [book_begin, book_end)
-  uint32_t pad0;
+  uint32_t book_begin, book_end;  // split pipeline: this launch covers books (markets if assets > 1) [begin, end)
+  // MarketEnv mode (market_env.rs): `assets` consecutive books form a market sharing one clock, one RNG stream and one
+  // shuffled event queue; 1 = independent books.  asset_tick = the books' tick sizes (market.rs:74-81).
+  uint32_t assets;
+  uint32_t asset_tick[MAX_ASSETS];
   Group groups[MAX_GROUPS];
 };
 // step batch layout (dwords): [0] n_ev; [8+2r, 9+2r] placing-agents mask r; [24+2r, 25+2r] bid mask of the
@@ -155,6 +160,25 @@ struct Rng {
   __device__ __forceinline__ uint32_t below(uint32_t range) {
     uint32_t zone = (range << __builtin_clz(range)) - 1u;
     return below(range, zone);
+  }
+};
+
+// The same generator for the lane-per-book kernel, on 32-bit halves (s0 = a1:a0, s1 = b1:b0): full-rate VALU only
+// (v_alignbit / v_lshl_add / v_xor3) instead of 64-bit shifts and quarter-rate 32x32 multiplies.
+struct RngLane {
+  uint32_t a0, a1, b0, b1;
+  __device__ __forceinline__ uint32_t next_u32() {
+    const uint32_t lo5 = (a0 << 2) + a0;                                   // (s0 * 5) bits 0..31
+    const uint32_t hi5 = (a1 << 2) + a1 + (a0 >> 30) + (lo5 < a0 ? 1u : 0u);  // bits 32..63
+    const uint32_t r = __builtin_amdgcn_alignbit(lo5, hi5, 25);            // low word of rotl(s0 * 5, 7)
+    const uint32_t t0 = b0 ^ a0, t1 = b1 ^ a1;
+    const uint32_t n0 = __builtin_amdgcn_alignbit(a0, a1, 8) ^ t0 ^ (t0 << 16);  // rotl(s0, 24) ^ t ^ (t << 16)
+    const uint32_t n1 = __builtin_amdgcn_alignbit(a1, a0, 8) ^ t1 ^ __builtin_amdgcn_alignbit(t1, t0, 16);
+    a0 = n0;
+    a1 = n1;
+    b0 = __builtin_amdgcn_alignbit(t1, t0, 27);  // rotl(t, 37)
+    b1 = __builtin_amdgcn_alignbit(t0, t1, 27);
+    return (r << 3) + r;
   }
 };
 
@@ -431,7 +455,7 @@ __device__ __forceinline__ void process_slot_event(Book<R>& B, const DevArgs& a,
 template <int R>
 __device__ __forceinline__ void snapshot(const Book<R>& B, const DevArgs& a, uint32_t book, int lane,
                                          uint32_t* __restrict__ bins /* LDS, >= 4*levels */, uint32_t hist_slot,
-                                         uint32_t& flags, bool write_last) {
+                                         uint32_t& flags, bool write_last, uint32_t tick) {
   const uint32_t L = a.levels;
   uint32_t mb = 0u, ma = 0xFFFFFFFFu, sb = 0u, sa = 0u;
 #pragma unroll
@@ -449,7 +473,6 @@ __device__ __forceinline__ void snapshot(const Book<R>& B, const DevArgs& a, uin
   for (uint32_t j = lane; j < 4 * L; j += 64) bins[j] = 0;
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
-  const uint32_t tick = a.tick_size;
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     const bool is_live = lane_bit(B.live[r]);
@@ -571,10 +594,13 @@ __device__ __forceinline__ void store_book(const Book<R>& B, const Rng& rng, uin
 // agent/slot indices, advance the clock, snapshot, flush trades.  Returns this step's trade count.
 // An event is a New if the slot's pend bit is set, else a Cancellation of the slot's order.
 // ----------------------------------------------------------------------------------
-template <int R>
+// MKT: the list is the MARKET's queue (market_env.rs:110-121); this book processes the events of its own agents'
+// slots (`mine`) at their global positions t0 + k and skips the rest.  Returns trades; `n_own` = events processed.
+template <int R, bool MKT = false>
 __device__ __forceinline__ uint32_t step_from_list(Book<R>& B, const DevArgs& a, uint32_t book, int lane,
                                                    const uint32_t (&ev)[R], uint32_t n_ev, uint32_t* bins,
-                                                   uint32_t hist_slot, bool write_last) {
+                                                   uint32_t hist_slot, bool write_last, uint32_t tick,
+                                                   const uint64_t (&mine)[R], uint32_t& n_own) {
   const uint64_t step_size = mk64(a.step_lo, a.step_hi);
   const uint64_t t0 = B.t;
   B.trade_vol = 0;  // reset_trade_vol (env.rs:118)
@@ -585,14 +611,22 @@ __device__ __forceinline__ uint32_t step_from_list(Book<R>& B, const DevArgs& a,
     const uint32_t kb = re * 64;
     if (n_ev > kb) {
       const uint32_t cnt = (n_ev - kb) < 64u ? (n_ev - kb) : 64u;
-      for (uint32_t l = 0; l < cnt; ++l) process_slot_event<R>(B, a, book, t0, lane, kb + l, rdl(ev[re], l));
+      for (uint32_t l = 0; l < cnt; ++l) {
+        const uint32_t slot = rdl(ev[re], l);
+        if (MKT) {
+          if (!mask_test<R>(mine, slot)) continue;
+          ++n_own;
+        }
+        process_slot_event<R>(B, a, book, t0, lane, kb + l, slot);
+      }
     }
   }
-  B.n_events += n_ev;
+  if (!MKT) n_own = n_ev;
+  B.n_events += n_own;
   B.t = t0 + step_size;  // env.rs:129
   // env.rs:132-134.  Env::level_2_data (the "latest" record) only needs a launch's final snapshot;
   // with no history buffer every step's record is written there.
-  snapshot<R>(B, a, book, lane, bins, hist_slot, B.flags, write_last);
+  snapshot<R>(B, a, book, lane, bins, hist_slot, B.flags, write_last, tick);
   flush_trades<R>(B, a, book, t0, lane);
   return (uint32_t)(B.n_trades - trades_before);
 }
@@ -672,8 +706,7 @@ __global__ __launch_bounds__(256) void k_run_random(DevArgs a, uint64_t first_st
       slot_write<R>(ev, j, ai);
     }
     last_ntr = step_from_list<R>(B, a, book, lane, ev, n_ev, bins, a.hist_cap ? (a.hist_slot0 + s) % a.hist_cap : 0u,
-                                 s + 1 == n_steps || a.hist_cap == 0);
-    last_nev = n_ev;
+                                 s + 1 == n_steps || a.hist_cap == 0, a.tick_size, B.pend, last_nev);
   }
   store_book<R>(B, rng, st, lane, first_step + n_steps, last_ntr, last_nev);
 }
@@ -698,22 +731,30 @@ __global__ __launch_bounds__(64) void k_agents_fsm(DevArgs a) {
   // (one ds_or per new order instead of ~20 VALU of per-lane 64-bit mask arithmetic in the hot loop)
   __shared__ uint32_t pmask[2 * R * 64], smask[2 * R * 64];
   const int lane = threadIdx.x;
+  // MarketEnv mode (assets = M > 1): the lane owns a MARKET = books [b*M, b*M + M) with one RNG stream and one event
+  // queue (market_env.rs:110-121, runner.rs:108-131); RandomMarketAgents::update is RandomAgents::update addressed to
+  // the group's asset (random_agent.rs:204-247), so the state machine below is unchanged.
+  const uint32_t M = a.assets;
   const uint32_t b = a.book_begin + blockIdx.x * 64 + lane;
   if (b >= a.book_end) return;
-  uint32_t* st = a.state + (size_t)b * a.state_stride;
-  uint32_t* bt = a.batch + (size_t)b * a.batch_stride;
+  uint32_t* st = a.state + (size_t)b * M * a.state_stride;
+  uint32_t* bt = a.batch + (size_t)b * M * a.batch_stride;
 
-  Rng rng;
+  RngLane rng;
   {
     const uint2 x0 = *reinterpret_cast<const uint2*>(st + H_S0_LO);
     const uint2 x1 = *reinterpret_cast<const uint2*>(st + H_S1_LO);
-    rng.s0 = mk64(x0.x, x0.y);
-    rng.s1 = mk64(x1.x, x1.y);
+    rng.a0 = x0.x, rng.a1 = x0.y, rng.b0 = x1.x, rng.b1 = x1.y;
   }
   uint64_t live[R];
 #pragma unroll
   for (int r = 0; r < R; ++r) {
-    const uint2 x = *reinterpret_cast<const uint2*>(st + H_LIVE0 + 2 * r);
+    uint2 x = *reinterpret_cast<const uint2*>(st + H_LIVE0 + 2 * r);
+    for (uint32_t as = 1; as < M; ++as) {  // slot = agent index in every book of the market: the masks are disjoint
+      const uint2 y = *reinterpret_cast<const uint2*>(st + (size_t)as * a.state_stride + H_LIVE0 + 2 * r);
+      x.x |= y.x;
+      x.y |= y.y;
+    }
     live[r] = mk64(x.x, x.y);
     pmask[(2 * r) * 64 + lane] = 0;
     pmask[(2 * r + 1) * 64 + lane] = 0;
@@ -795,8 +836,10 @@ __global__ __launch_bounds__(64) void k_agents_fsm(DevArgs a) {
   }
 
   // publish: RNG state back to the book header, the step batch for k_step_batch
-  *reinterpret_cast<uint2*>(st + H_S0_LO) = make_uint2((uint32_t)rng.s0, (uint32_t)(rng.s0 >> 32));
-  *reinterpret_cast<uint2*>(st + H_S1_LO) = make_uint2((uint32_t)rng.s1, (uint32_t)(rng.s1 >> 32));
+  for (uint32_t as = 0; as < M; ++as) {  // every book of a market carries a copy of the market's RNG state
+    *reinterpret_cast<uint2*>(st + (size_t)as * a.state_stride + H_S0_LO) = make_uint2(rng.a0, rng.a1);
+    *reinterpret_cast<uint2*>(st + (size_t)as * a.state_stride + H_S1_LO) = make_uint2(rng.b0, rng.b1);
+  }
   bt[BT_NEV] = n_ev;
 #pragma unroll
   for (int r = 0; r < R; ++r) {
@@ -810,17 +853,37 @@ __global__ __launch_bounds__(64) void k_agents_fsm(DevArgs a) {
   }
 }
 
-template <int R>
+template <int R, bool MKT>
 __global__ __launch_bounds__(64) void k_step_batch(DevArgs a, uint64_t step_index, uint32_t write_last) {
   // one-wave workgroups: the dispatcher places every wave independently, so the wave slots left beside the
   // co-running k_agents_fsm waves are all usable (4-wave workgroups needed a free slot on every SIMD)
   __shared__ uint32_t lds[1][LDS_DW_PER_WAVE];
   const int lane = threadIdx.x;
   const int wv = 0;
-  const uint32_t book = a.book_begin + blockIdx.x;
-  if (book >= a.book_end) return;
+  // MKT: book = market * assets + asset; the step batch is the market's (stored at the market's first book)
+  const uint32_t book = MKT ? a.book_begin * a.assets + blockIdx.x : a.book_begin + blockIdx.x;
+  if (book >= (MKT ? a.book_end * a.assets : a.book_end)) return;
+  const uint32_t mkt_book0 = MKT ? (book / a.assets) * a.assets : book;
+  const uint32_t asset = book - mkt_book0;
   uint32_t* st = a.state + (size_t)book * a.state_stride;
-  const uint32_t* bt = a.batch + (size_t)book * a.batch_stride;
+  const uint32_t* bt = a.batch + (size_t)mkt_book0 * a.batch_stride;
+  uint64_t mine[R];  // MKT: the pool slots (= agent indices) of the groups trading this asset
+#pragma unroll
+  for (int r = 0; r < R; ++r) mine[r] = MKT ? 0ull : ~0ull;
+  if (MKT) {
+    uint32_t gb = 0;
+    for (uint32_t g = 0; g < a.n_groups; ++g) {
+      const uint32_t ge = gb + a.groups[g].n;
+      if (a.groups[g].asset == asset) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const uint32_t lo = gb > 64u * r ? gb : 64u * r, hi = ge < 64u * r + 64u ? ge : 64u * r + 64u;
+          if (lo < hi) mine[r] |= ((hi - lo) == 64u ? ~0ull : ((1ull << (hi - lo)) - 1ull)) << (lo - 64u * r);
+        }
+      }
+      gb = ge;
+    }
+  }
 
   Book<R> B;
   Rng rng;
@@ -832,7 +895,7 @@ __global__ __launch_bounds__(64) void k_step_batch(DevArgs a, uint64_t step_inde
   uint32_t base = B.next_id;
 #pragma unroll
   for (int r = 0; r < R; ++r) {
-    const uint64_t pend = mk64(rdl(bh, BT_PEND + 2 * r), rdl(bh, BT_PEND + 2 * r + 1));
+    const uint64_t pend = mk64(rdl(bh, BT_PEND + 2 * r), rdl(bh, BT_PEND + 2 * r + 1)) & mine[r];
     const uint64_t side = mk64(rdl(bh, BT_SIDE + 2 * r), rdl(bh, BT_SIDE + 2 * r + 1));
     ev[r] = reinterpret_cast<const uint16_t*>(bt + BT_EV)[r * 64 + lane];
     const uint2 pv = reinterpret_cast<const uint2*>(bt + BT_EV + 32 * R)[r * 64 + lane];
@@ -846,8 +909,10 @@ __global__ __launch_bounds__(64) void k_step_batch(DevArgs a, uint64_t step_inde
     B.pend[r] = pend;
   }
   B.next_id = base;
-  const uint32_t ntr = step_from_list<R>(B, a, book, lane, ev, n_ev, lds[wv], a.hist_slot0, write_last != 0);
-  store_book<R>(B, rng, st, lane, step_index + 1, ntr, n_ev);
+  uint32_t n_own = 0;
+  const uint32_t ntr = step_from_list<R, MKT>(B, a, book, lane, ev, n_ev, lds[wv], a.hist_slot0, write_last != 0,
+                                              MKT ? a.asset_tick[asset] : a.tick_size, mine, n_own);
+  store_book<R>(B, rng, st, lane, step_index + 1, ntr, n_own);
 }
 
 // ==================================================================================
@@ -882,13 +947,18 @@ __global__ __launch_bounds__(64) void k_step_events(DevArgs a, uint64_t step_ind
   __shared__ uint16_t perm[EV_LDS_CAP];
   const int lane = threadIdx.x;
   const uint32_t book = blockIdx.x;
+  // MarketEnv mode: the event queue belongs to the MARKET (book / assets); every book of the market shuffles it with
+  // its copy of the market's RNG stream (identical results) and processes its own asset's events at their global
+  // positions t0 + k (market_env.rs:110-121).  assets == 1: market == book.
+  const uint32_t mkt = book / a.assets, asset = book - mkt * a.assets;
   uint32_t* st = a.state + (size_t)book * a.state_stride;
   Book<R> B;
   Rng rng;
   load_book<R>(B, rng, st, lane);
   const uint64_t step_size = mk64(a.step_lo, a.step_hi);
-  const uint32_t e0 = a.ev_off[book];
-  const uint32_t n_ev = a.ev_off[book + 1] - e0;
+  const uint32_t e0 = a.ev_off[mkt];
+  const uint32_t n_ev = a.ev_off[mkt + 1] - e0;
+  uint32_t n_own = 0;
   LogCtx lg{a.order_log ? a.order_log + (size_t)book * a.log_cap : nullptr, a.log_cap};
 
   const uint64_t t0 = B.t;
@@ -911,6 +981,8 @@ __global__ __launch_bounds__(64) void k_step_events(DevArgs a, uint64_t step_ind
   for (uint32_t k = 0; k < n_ev; ++k) {
     const uint32_t e = e0 + rfl(perm[k]);
     const uint32_t w = rfl(a.ev_word[e]);
+    if (((w >> 16) & 0xFFu) != asset) continue;  // another asset's event
+    ++n_own;
     const uint32_t id = rfl(a.ev_id[e]);
     const uint32_t ep = rfl(a.ev_price[e]);
     const uint32_t evv = rfl(a.ev_vol[e]);
@@ -995,11 +1067,11 @@ __global__ __launch_bounds__(64) void k_step_events(DevArgs a, uint64_t step_ind
       }
     }
   }
-  B.n_events += n_ev;
+  B.n_events += n_own;
   B.t = t0 + step_size;
-  snapshot<R>(B, a, book, lane, bins, a.hist_slot0, B.flags, true);
+  snapshot<R>(B, a, book, lane, bins, a.hist_slot0, B.flags, true, a.asset_tick[asset]);
   flush_trades<R>(B, a, book, t0, lane);
-  store_book<R>(B, rng, st, lane, step_index + 1, (uint32_t)(B.n_trades - trades_before), n_ev);
+  store_book<R>(B, rng, st, lane, step_index + 1, (uint32_t)(B.n_trades - trades_before), n_own);
 }
 
 // ==================================================================================

@@ -107,6 +107,8 @@ struct DevBuf {
 struct bk_env {
   bk_config cfg{};
   int R = 1;
+  uint32_t M = 1;  // books per market (MarketEnv<ASSETS>): cfg.assets, 1 = independent books
+  uint32_t asset_tick[MAX_ASSETS] = {0, 0, 0, 0, 0, 0, 0, 0};
   uint32_t W = 0, stride = 0;
   hipStream_t stream = nullptr;
   DevBuf<uint32_t> state, l2_last, hist, ev_off, ev_word, ev_id, ev_price, ev_vol, batch;
@@ -171,7 +173,9 @@ struct bk_env {
     a.batch = batch.p;
     a.batch_stride = batch_stride;
     a.book_begin = 0;
-    a.book_end = cfg.n_books;
+    a.book_end = cfg.n_books / M;
+    a.assets = M;
+    for (int i = 0; i < MAX_ASSETS; ++i) a.asset_tick[i] = asset_tick[i];
     for (size_t g = 0; g < groups.size(); ++g) a.groups[g] = groups[g];
     return a;
   }
@@ -233,9 +237,10 @@ int launch_mixed(bk_env* env, const DevArgs& a, uint64_t first_step, uint32_t n_
 // split pipeline: per step and per part one lane-per-book launch (RNG-serial phases) + one wave-per-book launch
 template <int R>
 int launch_split(bk_env* env, const DevArgs& a0, uint64_t first_step, uint32_t n_steps) {
-  const uint32_t B = env->cfg.n_books;
+  const uint32_t M = env->M;
+  const uint32_t B = env->cfg.n_books / M;  // units the parts are cut in: books, or markets of M books
   int P = env->n_parts;
-  if (B < 4096u * P) P = 1;  // small batches: one part on the caller's stream
+  if (env->cfg.n_books < 4096u * P) P = 1;  // small batches: one part on the caller's stream
   if (P > 1 && !env->ev_fork) {
     HIPCHK(hipEventCreateWithFlags(&env->ev_fork, hipEventDisableTiming));
     for (int i = 0; i < 4; ++i) {
@@ -266,7 +271,10 @@ int launch_split(bk_env* env, const DevArgs& a0, uint64_t first_step, uint32_t n
       {
         ProfScope ps(env, 2, st);
         const uint32_t write_last = (s + 1 == n_steps || a.hist_cap == 0) ? 1u : 0u;
-        hipLaunchKernelGGL(k_step_batch<R>, dim3(nb), dim3(64), 0, st, a, first_step + s, write_last);
+        if (M > 1)
+          hipLaunchKernelGGL((k_step_batch<R, true>), dim3(nb * M), dim3(64), 0, st, a, first_step + s, write_last);
+        else
+          hipLaunchKernelGGL((k_step_batch<R, false>), dim3(nb), dim3(64), 0, st, a, first_step + s, write_last);
       }
     }
   }
@@ -359,6 +367,9 @@ int bk_env_create(const bk_config* cfg, bk_env** out) {
   if (cfg->n_books == 0) return fail(BK_INVALID_ARGUMENT, "n_books must be >= 1");
   if (cfg->tick_size == 0) return fail(BK_INVALID_ARGUMENT, "tick_size must be > 0");  // orderbook.rs:159
   if (cfg->levels == 0 || cfg->levels > 64) return fail(BK_INVALID_ARGUMENT, "levels must be in 1..64");
+  const uint32_t M = cfg->assets ? cfg->assets : 1u;
+  if (M > MAX_ASSETS || cfg->n_books % M != 0)
+    return fail(BK_INVALID_ARGUMENT, "assets must be <= 8 and divide n_books");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
     return fail(BK_NO_DEVICE, "no HIP device available: bourse_amd has no CPU execution path");
@@ -366,6 +377,8 @@ int bk_env_create(const bk_config* cfg, bk_env** out) {
 
   std::unique_ptr<bk_env> env(new bk_env());
   env->cfg = *cfg;
+  env->M = M;
+  for (uint32_t i = 0; i < MAX_ASSETS; ++i) env->asset_tick[i] = cfg->tick_size;
   uint32_t pool = cfg->max_live_orders ? cfg->max_live_orders : 128;
   int R = 1;
   while (R * 64u < pool) R *= 2;
@@ -403,7 +416,7 @@ int bk_env_create(const bk_config* cfg, bk_env** out) {
   for (size_t b = 0; b < B; ++b) {
     uint32_t* h = st.data() + b * env->stride;
     uint64_t s0, s1;
-    seed_from_u64(cfg->seed + cfg->book_offset + b, s0, s1);
+    seed_from_u64(cfg->seed + cfg->book_offset + b / M, s0, s1);  // one stream per market (runner.rs:115)
     h[H_T_LO] = static_cast<uint32_t>(cfg->start_time);
     h[H_T_HI] = static_cast<uint32_t>(cfg->start_time >> 32);
     h[H_S0_LO] = static_cast<uint32_t>(s0);
@@ -459,16 +472,18 @@ int bk_env_sync(bk_env* env) {
 int bk_place_order(bk_env* env, uint32_t book, int bid, uint32_t vol, uint32_t trader_id, int has_price,
                    uint32_t price, uint64_t* out_order_id) {
   if (int rc = check_book(env, book)) return rc;
-  if (has_price && price % env->cfg.tick_size != 0)  // create_order's tick check, orderbook.rs:367-382
-    return fail(BK_PRICE_NOT_TICK_MULTIPLE, "Price " + std::to_string(price) + " was not a multiple of tick-size " +
-                                                std::to_string(env->cfg.tick_size));
+  const uint32_t asset = book % env->M, tick = env->asset_tick[asset];
+  if (has_price && price % tick != 0)  // create_order's tick check, orderbook.rs:367-382
+    return fail(BK_PRICE_NOT_TICK_MULTIPLE,
+                "Price " + std::to_string(price) + " was not a multiple of tick-size " + std::to_string(tick));
   BookHost& bh = env->books[book];
+  BookHost& qh = env->books[book - asset];  // the queue is the market's (market_env.rs:58)
   const uint64_t id = bh.orders.size();  // current_order_id, orderbook.rs:327-329
   if (id >= 0xFFFFFFFFull) return fail(BK_CAPACITY, "order id space exhausted");
   const uint32_t p = has_price ? price : (bid ? 0xFFFFFFFFu : 0u);  // market sentinels, types.rs:168,221
   const uint64_t now = env->cfg.start_time + env->steps_done * env->cfg.step_size + bh.time_offset;
   bh.orders.push_back(HostOrder{static_cast<uint8_t>(bid ? 1 : 0), vol, p, trader_id, now});
-  bh.queue.push_back(HostEvent{0u | (bid ? 1u << 8 : 0u), static_cast<uint32_t>(id), p, vol});
+  qh.queue.push_back(HostEvent{0u | (bid ? 1u << 8 : 0u) | (asset << 16), static_cast<uint32_t>(id), p, vol});
   if (out_order_id) *out_order_id = id;
   return BK_OK;
 }
@@ -476,16 +491,18 @@ int bk_place_order(bk_env* env, uint32_t book, int bid, uint32_t vol, uint32_t t
 int bk_cancel_order(bk_env* env, uint32_t book, uint64_t order_id) {
   if (int rc = check_book(env, book)) return rc;
   // an id that was never created panics only when the event is PROCESSED (orderbook.rs:642): checked in bk_step
-  env->books[book].queue.push_back(
-      HostEvent{1u, static_cast<uint32_t>(std::min<uint64_t>(order_id, 0xFFFFFFFFull)), 0u, 0u});
+  const uint32_t asset = book % env->M;
+  env->books[book - asset].queue.push_back(
+      HostEvent{1u | (asset << 16), static_cast<uint32_t>(std::min<uint64_t>(order_id, 0xFFFFFFFFull)), 0u, 0u});
   return BK_OK;
 }
 
 int bk_modify_order(bk_env* env, uint32_t book, uint64_t order_id, int has_price, uint32_t new_price, int has_vol,
                     uint32_t new_vol) {
   if (int rc = check_book(env, book)) return rc;
-  const uint32_t w = 2u | (has_price ? 1u << 9 : 0u) | (has_vol ? 1u << 10 : 0u);
-  env->books[book].queue.push_back(
+  const uint32_t asset = book % env->M;
+  const uint32_t w = 2u | (has_price ? 1u << 9 : 0u) | (has_vol ? 1u << 10 : 0u) | (asset << 16);
+  env->books[book - asset].queue.push_back(
       HostEvent{w, static_cast<uint32_t>(std::min<uint64_t>(order_id, 0xFFFFFFFFull)), new_price, new_vol});
   return BK_OK;
 }
@@ -524,25 +541,25 @@ int bk_enable_trading(bk_env* env, int enabled) {
 int bk_step(bk_env* env) {
   if (!env) return fail(BK_INVALID_ARGUMENT, "null env");
   if (int rc = use_device(env)) return rc;
-  const size_t B = env->cfg.n_books;
-  // validate + flatten the queues (CSR)
-  std::vector<uint32_t> off(B + 1, 0u);
+  const size_t B = env->cfg.n_books, M = env->M, NM = B / M;
+  // validate + flatten the queues (CSR, one row per market; a market of one book when assets == 1)
+  std::vector<uint32_t> off(NM + 1, 0u);
   size_t total = 0;
-  for (size_t b = 0; b < B; ++b) {
-    const BookHost& bh = env->books[b];
-    if (bh.queue.size() > EV_LDS_CAP)
-      return fail(BK_CAPACITY, "more than 8192 events queued for one book in one step");
-    for (const HostEvent& e : bh.queue)
-      if ((e.word & 0xFFu) != 0 && e.id >= bh.orders.size())
+  for (size_t m = 0; m < NM; ++m) {
+    const BookHost& qh = env->books[m * M];
+    if (qh.queue.size() > EV_LDS_CAP)
+      return fail(BK_CAPACITY, "more than 8192 events queued for one book (market) in one step");
+    for (const HostEvent& e : qh.queue)
+      if ((e.word & 0xFFu) != 0 && e.id >= env->books[m * M + ((e.word >> 16) & 0xFFu)].orders.size())
         return fail(BK_UNKNOWN_ORDER_ID, "No order with id " + std::to_string(e.id) + " exists");
-    off[b] = static_cast<uint32_t>(total);
-    total += bh.queue.size();
+    off[m] = static_cast<uint32_t>(total);
+    total += qh.queue.size();
   }
-  off[B] = static_cast<uint32_t>(total);
+  off[NM] = static_cast<uint32_t>(total);
   std::vector<uint32_t> w(total), id(total), pr(total), vo(total);
   size_t k = 0;
-  for (size_t b = 0; b < B; ++b)
-    for (const HostEvent& e : env->books[b].queue) {
+  for (size_t m = 0; m < NM; ++m)
+    for (const HostEvent& e : env->books[m * M].queue) {
       w[k] = e.word;
       id[k] = e.id;
       pr[k] = e.price;
@@ -558,7 +575,7 @@ int bk_step(bk_env* env) {
     HIPCHK(env->ev_vol.alloc(cap));
     env->ev_capacity = cap;
   }
-  HIPCHK(hipMemcpyAsync(env->ev_off.p, off.data(), (B + 1) * 4, hipMemcpyHostToDevice, env->stream));
+  HIPCHK(hipMemcpyAsync(env->ev_off.p, off.data(), (NM + 1) * 4, hipMemcpyHostToDevice, env->stream));
   if (total) {
     HIPCHK(hipMemcpyAsync(env->ev_word.p, w.data(), total * 4, hipMemcpyHostToDevice, env->stream));
     HIPCHK(hipMemcpyAsync(env->ev_id.p, id.data(), total * 4, hipMemcpyHostToDevice, env->stream));
@@ -621,7 +638,8 @@ int bk_get_orders(bk_env* env, uint32_t book, uint64_t first, uint64_t n, bk_ord
 }
 
 // ------------------------------------------------------------------ on-device order flow
-int bk_set_random_agents(bk_env* env, uint32_t n_groups, const bk_random_agents* groups) {
+int bk_set_random_market_agents(bk_env* env, uint32_t n_groups, const bk_random_agents* groups,
+                                const uint32_t* assets) {
   if (!env || (!groups && n_groups)) return fail(BK_INVALID_ARGUMENT, "null argument");
   if (n_groups > MAX_GROUPS) return fail(BK_INVALID_ARGUMENT, "at most 8 agent groups");
   std::vector<Group> gs;
@@ -632,7 +650,9 @@ int bk_set_random_agents(bk_env* env, uint32_t n_groups, const bk_random_agents*
       return fail(BK_INVALID_ARGUMENT, "empty tick/vol range");  // gen_range asserts low < high
     // every sampled price tick * tick_size must pass create_order's tick check (else `.unwrap()` panics,
     // random_agent.rs:103-110)
-    if (r.tick_size % env->cfg.tick_size != 0)
+    const uint32_t asset = assets ? assets[g] : 0u;
+    if (asset >= env->M) return fail(BK_INVALID_ARGUMENT, "group asset index out of range");
+    if (r.tick_size % env->asset_tick[asset] != 0)
       return fail(BK_PRICE_NOT_TICK_MULTIPLE, "agent tick_size must be a multiple of the env tick_size");
     if (static_cast<uint64_t>(r.tick_hi - 1) * r.tick_size >= 0xFFFFFFFFull || r.tick_lo == 0)
       return fail(BK_INVALID_ARGUMENT, "limit prices must lie in (0, u32::MAX)");
@@ -646,6 +666,7 @@ int bk_set_random_agents(bk_env* env, uint32_t n_groups, const bk_random_agents*
     G.vol_rng = r.vol_hi - r.vol_lo;
     G.vol_zone = sample_zone(G.vol_rng);
     G.tick_size = r.tick_size;
+    G.asset = asset;
     total += r.n_agents;
     gs.push_back(G);
   }
@@ -654,6 +675,22 @@ int bk_set_random_agents(bk_env* env, uint32_t n_groups, const bk_random_agents*
   env->groups = gs;
   env->n_agents_total = static_cast<uint32_t>(total);
   env->n_mixed = 0;
+  return BK_OK;
+}
+
+int bk_set_random_agents(bk_env* env, uint32_t n_groups, const bk_random_agents* groups) {
+  return bk_set_random_market_agents(env, n_groups, groups, nullptr);  // every group on asset 0
+}
+
+int bk_set_tick_sizes(bk_env* env, uint32_t n, const uint32_t* tick_sizes) {
+  if (!env || !tick_sizes) return fail(BK_INVALID_ARGUMENT, "null argument");
+  if (n != env->M) return fail(BK_INVALID_ARGUMENT, "one tick size per asset");
+  if (env->steps_done || !env->groups.empty()) return fail(BK_INVALID_ARGUMENT, "set the tick sizes before anything else");
+  for (const BookHost& bh : env->books)
+    if (!bh.orders.empty()) return fail(BK_INVALID_ARGUMENT, "set the tick sizes before anything else");
+  for (uint32_t i = 0; i < n; ++i)
+    if (tick_sizes[i] == 0) return fail(BK_INVALID_ARGUMENT, "tick_size must be > 0");  // orderbook.rs:159
+  for (uint32_t i = 0; i < n; ++i) env->asset_tick[i] = tick_sizes[i];
   return BK_OK;
 }
 
@@ -669,6 +706,7 @@ int bk_set_agents(bk_env* env, uint32_t n_members, const bk_agent_desc* members)
     return bk_set_random_agents(env, n_members, g.data());
   }
   if (n_members > MAX_MEMBERS) return fail(BK_INVALID_ARGUMENT, "at most 4 members in a set with Noise/Momentum agents");
+  if (env->M > 1) return fail(BK_INVALID_ARGUMENT, "markets (assets > 1) run RandomMarketAgents only");
   if (int rc = use_device(env)) return rc;
   std::vector<MixedDesc> ds(n_members);
   uint32_t fixed = 0;
@@ -760,7 +798,9 @@ int bk_run(bk_env* env, uint64_t n_steps) {
   // The fused kernel keeps a book in registers across all steps of the launch but runs the RNG-serial
   // phases on the scalar unit of ONE wave per book; the split pipeline runs them one lane per book and needs
   // >= 64 books per wave to pay off.  auto: split once the batch fills the chip several times over.
-  const bool split = env->pipeline == 2 || (env->pipeline == 0 && env->cfg.n_books >= 8192 && a.n_groups > 0);
+  // Markets always take the split pipeline: the market's RNG-serial phase is one lane, its books are M waves.
+  const bool split = env->pipeline == 2 || env->M > 1 ||
+                     (env->pipeline == 0 && env->cfg.n_books >= 8192 && a.n_groups > 0);
   if (split) {
     switch (env->R) {
       case 1: rc = launch_split<1>(env, a, env->steps_done, ns); break;

@@ -36,6 +36,23 @@ class RandomAgents:
 
 
 @dataclass(frozen=True)
+class RandomMarketAgents:
+    """``RandomMarketAgents::new(asset, n_agents, tick_range, vol_range, tick_size, activity_rate)``
+    (ref agents/random_agent.rs:185-201): a RandomAgents group trading one asset of a market."""
+
+    asset: int
+    n_agents: int
+    tick_range: Tuple[int, int]
+    vol_range: Tuple[int, int]
+    tick_size: int
+    activity_rate: float
+
+    def as_tuple(self):
+        return (self.asset, self.n_agents, tuple(self.tick_range), tuple(self.vol_range), self.tick_size,
+                self.activity_rate)
+
+
+@dataclass(frozen=True)
 class NoiseAgentParams:
     """ref crates/step_sim/src/agents/noise_agent.rs:24-46"""
 
@@ -92,9 +109,12 @@ class ManyBookEnv:
 
     def __init__(self, n_books: int, seed: int, start_time: int, tick_size: int, step_size: int, trading: bool = True,
                  levels: int = 10, max_live_orders: int = 128, max_orders: int = 0, trade_capacity: int = 4096,
-                 history_capacity: int = 0, book_offset: int = 0, device: int = 0, stream: Optional[int] = None):
+                 history_capacity: int = 0, book_offset: int = 0, device: int = 0, stream: Optional[int] = None,
+                 assets: int = 1, tick_sizes: Optional[Sequence[int]] = None):
         self._L = _lib.load()
         cfg = Config()
+        cfg.assets = int(assets)
+        self.assets = max(1, int(assets))
         cfg.n_books, cfg.levels = int(n_books), int(levels)
         cfg.start_time, cfg.tick_size, cfg.step_size = int(start_time), int(tick_size), int(step_size)
         cfg.trading, cfg.seed, cfg.book_offset = int(bool(trading)), int(seed) & (2**64 - 1), int(book_offset)
@@ -108,6 +128,9 @@ class ManyBookEnv:
         self.width = int(self._L.bk_l2_width(self._h))
         if stream is not None:
             check(self._L.bk_env_set_stream(self._h, C.c_void_p(stream)))
+        if tick_sizes is not None:
+            tk = np.asarray(list(tick_sizes), dtype=np.uint32)
+            check(self._L.bk_set_tick_sizes(self._h, len(tk), _lib.p32(tk)))
 
     def close(self):
         if getattr(self, "_h", None) and self._h.value:
@@ -188,6 +211,20 @@ class ManyBookEnv:
             arr[i].vol_lo, arr[i].vol_hi, arr[i].tick_size = int(vr[0]), int(vr[1]), int(ts)
             arr[i].activity_rate = float(np.float32(rate))
         check(self._L.bk_set_random_agents(self._h, len(gs), arr))
+        self.groups = gs
+
+    def set_random_market_agents(self, groups: Iterable["RandomMarketAgents | tuple"]):
+        """A ``MarketAgentSet`` of ``RandomMarketAgents`` groups ``(asset, n, tick_range, vol_range, tick_size, rate)``,
+        identical for every market (needs ``assets > 1`` books per market)."""
+        gs = [g.as_tuple() if isinstance(g, RandomMarketAgents) else g for g in groups]
+        arr = (RandomAgentsCfg * max(len(gs), 1))()
+        assets = np.zeros(max(len(gs), 1), dtype=np.uint32)
+        for i, (asset, n, tr, vr, ts, rate) in enumerate(gs):
+            assets[i] = int(asset)
+            arr[i].n_agents, arr[i].tick_lo, arr[i].tick_hi = int(n), int(tr[0]), int(tr[1])
+            arr[i].vol_lo, arr[i].vol_hi, arr[i].tick_size = int(vr[0]), int(vr[1]), int(ts)
+            arr[i].activity_rate = float(np.float32(rate))
+        check(self._L.bk_set_random_market_agents(self._h, len(gs), arr, _lib.p32(assets)))
         self.groups = gs
 
     def set_agents(self, members):
@@ -430,4 +467,40 @@ def sim_runner(env: ManyBookEnv, agents: Sequence[RandomAgents | tuple], n_steps
     The seed is the env's (book b: seed + book_offset + b): in the reference the RNG is a local of
     ``sim_runner``; here it is part of the device state so runs can be continued."""
     env.set_random_agents(agents)
+    env.run(n_steps)
+
+
+class ManyMarketEnv(ManyBookEnv):
+    """``n_markets`` independent ``MarketEnv<ASSETS>`` (ref crates/step_sim/src/market_env.rs:46-340) in lockstep: the
+    ``len(tick_sizes)`` books of a market share one clock, one RNG stream (market m: seed + market_offset + m) and one
+    shuffled event queue.  Every ``ManyBookEnv`` reader works on the flat book index ``market * assets + asset``
+    (``book()``); the mutators below take ``(market, asset)`` like ``MarketEnv``'s take ``asset`` / ``MarketOrderId``."""
+
+    def __init__(self, n_markets: int, seed: int, start_time: int, tick_sizes: Sequence[int], step_size: int,
+                 trading: bool = True, market_offset: int = 0, **kw):
+        tick_sizes = [int(t) for t in tick_sizes]
+        super().__init__(int(n_markets) * len(tick_sizes), seed, start_time, tick_sizes[0], step_size, trading,
+                         book_offset=market_offset, assets=len(tick_sizes), tick_sizes=tick_sizes, **kw)
+        self.n_markets, self.tick_sizes = int(n_markets), tick_sizes
+
+    def book(self, market: int, asset: int) -> int:
+        if not (0 <= market < self.n_markets and 0 <= asset < self.assets):
+            raise IndexError("market / asset out of range")
+        return market * self.assets + asset
+
+    def place_order(self, market: int, asset: int, bid: bool, vol: int, trader_id: int, price: Optional[int] = None):
+        """``MarketEnv::place_order(asset, side, vol, trader_id, price)`` (market_env.rs:163-176) -> per-asset order id"""
+        return super().place_order(self.book(market, asset), bid, vol, trader_id, price)
+
+    def cancel_order(self, market: int, asset: int, order_id: int):
+        super().cancel_order(self.book(market, asset), order_id)
+
+    def modify_order(self, market: int, asset: int, order_id: int, new_price: Optional[int] = None,
+                     new_vol: Optional[int] = None):
+        super().modify_order(self.book(market, asset), order_id, new_price, new_vol)
+
+
+def market_sim_runner(env: ManyMarketEnv, agents: Sequence[RandomMarketAgents | tuple], n_steps: int):
+    """``market_sim_runner(env, agents, seed, n_steps, _)`` (ref runner.rs:108-131) for every market of ``env``."""
+    env.set_random_market_agents(agents)
     env.run(n_steps)

@@ -57,7 +57,10 @@ typedef struct bk_config {
   uint32_t trade_capacity;  /* trade records retained per book between bk_clear_trades() calls */
   uint32_t history_capacity;/* L2 history ring: the last N steps are retained (0 = keep only the latest record) */
   int32_t device;           /* HIP device ordinal */
-  uint32_t reserved;
+  uint32_t assets;          /* MarketEnv<ASSETS> mode (crates/step_sim/src/market_env.rs:46-132): `assets` consecutive books
+                             * form a market sharing one clock, ONE RNG stream and ONE shuffled event queue; book =
+                             * market * assets + asset; market m is seeded seed + book_offset + m (book_offset counted in
+                             * markets).  0 or 1 = independent books (Env).  <= 8, must divide n_books. */
 } bk_config;
 
 /* RandomAgents::new(n_agents, tick_range, vol_range, tick_size, activity_rate)
@@ -162,6 +165,16 @@ int bk_get_orders(bk_env* env, uint32_t book, uint64_t first, uint64_t n, bk_ord
 /* An AgentSet of RandomAgents groups, identical for every book, updated in declaration order
  * (crates/macros/src/lib.rs:57-73).  Sum of n_agents <= max_live_orders. */
 int bk_set_random_agents(bk_env* env, uint32_t n_groups, const bk_random_agents* groups);
+/* Market mode.  Market::new(start_time, tick_size: [Price; ASSETS], trading) — crates/order_book/src/market.rs:74-81:
+ * per-asset tick sizes (default: cfg.tick_size for every asset); call before anything else. */
+int bk_set_tick_sizes(bk_env* env, uint32_t n_assets, const uint32_t* tick_sizes);
+/* A MarketAgentSet of RandomMarketAgents groups (RandomMarketAgents::new(asset, n_agents, tick_range, vol_range,
+ * tick_size, activity_rate), random_agent.rs:185-201), identical for every market, updated in declaration order with
+ * the market's RNG (market_sim_runner, runner.rs:108-131).  assets[g] = the asset group g trades (NULL: all 0).
+ * Sum of n_agents <= max_live_orders.  bk_run() then steps every market; host-driven orders use the per-book calls with
+ * book = market * assets + asset (MarketEnv::place_order / cancel_order / modify_order, market_env.rs:163-218). */
+int bk_set_random_market_agents(bk_env* env, uint32_t n_groups, const bk_random_agents* groups,
+                                const uint32_t* assets);
 /* Any mix of built-in members (at most 4 when a Noise/Momentum member is present), identical for every book.
  * Noise/Momentum members price orders with f64 log-normal offsets: their outputs match the CPU oracle bit for bit
  * but only statistically match a Rust build (third-party sampling + libm). */

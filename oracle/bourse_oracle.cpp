@@ -505,4 +505,101 @@ void RandomAgents::update(Env& env, Rng& rng) {  // random_agent.rs:85-119
   }
 }
 
+// ---------------------------------------------------------------------------
+// Market / MarketEnv / RandomMarketAgents
+// ---------------------------------------------------------------------------
+Market::Market(Nanos start_time, const std::vector<Price>& tick_sizes, bool trading, int levels) {  // market.rs:74-81
+  for (Price tk : tick_sizes) order_books.emplace_back(start_time, tk, trading, levels);
+}
+void Market::set_time(Nanos t) {
+  for (OrderBook& b : order_books) b.t = t;
+}
+void Market::set_trading(bool on) {
+  for (OrderBook& b : order_books) b.trading = on;
+}
+void Market::reset_trade_vols() {
+  for (OrderBook& b : order_books) b.trade_vol = 0;
+}
+int Market::process_event(const MarketEvent& e) {  // market.rs:343-354: dispatch on order_id.0
+  OrderBook& b = order_books[e.asset];
+  return b.process_event(Event{e.kind, e.order_id, e.new_price, e.new_vol});
+}
+
+MarketEnv::MarketEnv(Nanos start_time, const std::vector<Price>& tick_sizes, Nanos step_size_, bool trading, int levels)
+    : step_size(step_size_), market(start_time, tick_sizes, trading, levels), trade_vols(tick_sizes.size()) {
+  for (const OrderBook& b : market.order_books) {  // market_env.rs:84-94
+    level_2_data.push_back(b.level_2_data());
+    level_2_data_records.emplace_back(levels);
+  }
+}
+
+int MarketEnv::step(Rng& rng) {  // market_env.rs:110-132
+  const Nanos start_time = market.get_time();
+  market.reset_trade_vols();
+  std::vector<MarketEvent> txs;
+  txs.swap(transactions);
+  shuffle(txs, rng);  // ONE shuffle over the events of all assets (:114)
+  int rc = ORC_OK;
+  for (size_t i = 0; i < txs.size(); ++i) {
+    market.set_time(start_time + static_cast<Nanos>(i));  // every book's clock (:117-118)
+    const int r = market.process_event(txs[i]);
+    if (r != ORC_OK) {
+      rc = r;
+      break;
+    }
+  }
+  market.set_time(start_time + step_size);
+  for (size_t a = 0; a < market.order_books.size(); ++a) {  // :124-131
+    level_2_data[a] = market.order_books[a].level_2_data();
+    level_2_data_records[a].append_record(level_2_data[a]);
+    trade_vols[a].push_back(market.order_books[a].trade_vol);
+  }
+  return rc;
+}
+
+int MarketEnv::place_order(uint32_t asset, Side side, Vol vol, TraderId trader, std::optional<Price> price,
+                           OrderId* out_id) {  // market_env.rs:163-176
+  OrderId id = 0;
+  const int rc = market.order_books[asset].create_order(side, vol, trader, price, &id);
+  if (rc != ORC_OK) return rc;
+  transactions.push_back(MarketEvent{Event::NewOrder, asset, id, std::nullopt, std::nullopt});
+  if (out_id) *out_id = id;
+  return ORC_OK;
+}
+void MarketEnv::cancel_order(uint32_t asset, OrderId id) {  // :189-191
+  transactions.push_back(MarketEvent{Event::Cancellation, asset, id, std::nullopt, std::nullopt});
+}
+void MarketEnv::modify_order(uint32_t asset, OrderId id, std::optional<Price> new_price,
+                             std::optional<Vol> new_vol) {  // :207-218
+  transactions.push_back(MarketEvent{Event::Modify, asset, id, new_price, new_vol});
+}
+
+RandomMarketAgents::RandomMarketAgents(uint32_t asset_, size_t n, Price tlo, Price thi, Vol vlo, Vol vhi, Price tick,
+                                       float rate)
+    : asset(asset_), orders(n), tick_lo(tlo), tick_hi(thi), vol_lo(vlo), vol_hi(vhi), tick_size(tick),
+      activity_rate(rate) {}
+
+void RandomMarketAgents::update(MarketEnv& env, Rng& rng) {  // random_agent.rs:204-247: RandomAgents on one asset
+  for (size_t n = 0; n < orders.size(); ++n) {
+    std::optional<OrderId>& slot = orders[n];
+    const float p = rng.gen_f32();  // :215
+    if (p < activity_rate) {
+      if (slot.has_value() &&
+          env.market.order_books[asset].orders[*slot].order.status == Status::Active) {  // :219
+        env.cancel_order(asset, *slot);
+        slot = std::nullopt;
+      } else {
+        const Side side = rng.gen_index(2) == 0 ? Side::Ask : Side::Bid;  // :223
+        const Price tick = rng.gen_range_u32(tick_lo, tick_hi);           // :224
+        const Vol vol = rng.gen_range_u32(vol_lo, vol_hi);                // :225
+        OrderId id = 0;
+        const int rc = env.place_order(asset, side, vol, static_cast<TraderId>(n), tick * tick_size, &id);
+        assert(rc == ORC_OK);  // .unwrap() :235
+        (void)rc;
+        slot = id;
+      }
+    }
+  }
+}
+
 }  // namespace orc

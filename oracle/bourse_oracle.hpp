@@ -246,4 +246,58 @@ struct RandomAgents {
   void update(Env& env, Rng& rng);
 };
 
+// ---------------------------------------------------------------------------
+// Market — ref: crates/order_book/src/market.rs:59-356.  ASSETS order books sharing one clock; an order is
+// addressed by MarketOrderId = (asset, per-book order id) (types.rs:20-22).
+// ---------------------------------------------------------------------------
+struct MarketEvent {  // Event<MarketOrderId>
+  Event::Kind kind;
+  uint32_t asset;
+  OrderId order_id;
+  std::optional<Price> new_price;
+  std::optional<Vol> new_vol;
+};
+
+struct Market {
+  std::vector<OrderBook> order_books;
+  Market(Nanos start_time, const std::vector<Price>& tick_sizes, bool trading, int levels);  // market.rs:74-81
+  Nanos get_time() const { return order_books[0].t; }                                        // :103-105
+  void set_time(Nanos t);                                                                     // :113-117
+  void set_trading(bool on);                                                                  // :120-134
+  void reset_trade_vols();                                                                    // :142-146
+  int process_event(const MarketEvent& e);                                                    // :343-354
+};
+
+// ---------------------------------------------------------------------------
+// MarketEnv — ref: crates/step_sim/src/market_env.rs:46-340
+// ---------------------------------------------------------------------------
+struct MarketEnv {
+  Nanos step_size;
+  Market market;
+  std::vector<std::vector<Vol>> trade_vols;  // per asset
+  std::vector<MarketEvent> transactions;     // ONE queue for all assets
+  std::vector<Level2Data> level_2_data;
+  std::vector<Level2DataRecords> level_2_data_records;
+
+  MarketEnv(Nanos start_time, const std::vector<Price>& tick_sizes, Nanos step_size_, bool trading, int levels);
+  int step(Rng& rng);  // market_env.rs:110-132
+  int place_order(uint32_t asset, Side side, Vol vol, TraderId trader, std::optional<Price> price, OrderId* out_id);
+  void cancel_order(uint32_t asset, OrderId id);
+  void modify_order(uint32_t asset, OrderId id, std::optional<Price> new_price, std::optional<Vol> new_vol);
+};
+
+// ---------------------------------------------------------------------------
+// RandomMarketAgents — ref: crates/step_sim/src/agents/random_agent.rs:164-248
+// ---------------------------------------------------------------------------
+struct RandomMarketAgents {
+  uint32_t asset;
+  std::vector<std::optional<OrderId>> orders;
+  Price tick_lo, tick_hi;
+  Vol vol_lo, vol_hi;
+  Price tick_size;
+  float activity_rate;
+  RandomMarketAgents(uint32_t asset_, size_t n, Price tlo, Price thi, Vol vlo, Vol vhi, Price tick, float rate);
+  void update(MarketEnv& env, Rng& rng);
+};
+
 }  // namespace orc

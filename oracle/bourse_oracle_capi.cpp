@@ -538,6 +538,125 @@ void orc_many_order_counts(void* mp, uint64_t* out) {
   for (size_t b = 0; b < m->books.size(); ++b) out[b] = m->books[b]->env.order_book.orders.size();
 }
 
+// ---------------------------------------------- many independent MARKETS -----
+// n_markets x (MarketEnv, RandomMarketAgents groups, RNG) as market_sim_runner owns them (runner.rs:108-131);
+// market m seeded seed_base + m.  groups: rows of {asset, n, tick_lo, tick_hi, vol_lo, vol_hi, tick_size, rate_bits}
+struct OneMarket {
+  MarketEnv env;
+  std::vector<RandomMarketAgents> agents;
+  Rng rng;
+  OneMarket(Nanos start, const std::vector<Price>& ticks, Nanos step, bool trading, int levels, uint64_t seed)
+      : env(start, ticks, step, trading, levels), rng(Rng::seed_from_u64(seed)) {}
+};
+struct OrcMarkets {
+  int levels, assets;
+  std::vector<std::unique_ptr<OneMarket>> mk;
+};
+
+void* orc_mkts_new(uint32_t n_markets, uint64_t seed_base, uint64_t start, uint32_t assets, const uint32_t* tick_sizes,
+                   uint64_t step, int trading, int levels, int n_groups, const uint32_t* groups) {
+  auto* m = new OrcMarkets();
+  m->levels = levels;
+  m->assets = static_cast<int>(assets);
+  const std::vector<Price> ticks(tick_sizes, tick_sizes + assets);
+  for (uint32_t i = 0; i < n_markets; ++i) {
+    auto k = std::make_unique<OneMarket>(start, ticks, step, trading != 0, levels, seed_base + i);
+    for (int g = 0; g < n_groups; ++g) {
+      const uint32_t* r = groups + 8 * g;
+      float rate;
+      std::memcpy(&rate, &r[7], 4);
+      k->agents.emplace_back(r[0], r[1], r[2], r[3], r[4], r[5], r[6], rate);
+    }
+    m->mk.push_back(std::move(k));
+  }
+  return m;
+}
+void orc_mkts_free(void* m) { delete static_cast<OrcMarkets*>(m); }
+int orc_mkts_run(void* mp, uint64_t n_steps, int n_threads) {
+  auto* m = static_cast<OrcMarkets*>(mp);
+  const size_t B = m->mk.size();
+  if (n_threads < 1) n_threads = 1;
+  std::atomic<int> rc{ORC_OK};
+  auto work = [&](size_t lo, size_t hi) {
+    for (size_t b = lo; b < hi; ++b) {
+      OneMarket& k = *m->mk[b];
+      for (uint64_t s = 0; s < n_steps; ++s) {
+        for (RandomMarketAgents& a : k.agents) a.update(k.env, k.rng);  // MarketAgentSet: fields in order
+        int r = k.env.step(k.rng);
+        if (r != ORC_OK) rc = r;
+      }
+    }
+  };
+  std::vector<std::thread> th;
+  for (int t = 0; t < n_threads; ++t) th.emplace_back(work, B * t / n_threads, B * (t + 1) / n_threads);
+  for (auto& t : th) t.join();
+  return rc;
+}
+// host-driven MarketEnv calls on market `mi`
+int orc_mkts_place(void* mp, uint32_t mi, uint32_t asset, int bid, uint32_t vol, uint32_t trader, int has_price,
+                   uint32_t price, uint64_t* out_id) {
+  OrderId id = 0;
+  const int rc = static_cast<OrcMarkets*>(mp)->mk[mi]->env.place_order(
+      asset, side_from_bool(bid != 0), vol, trader, has_price ? std::optional<Price>(price) : std::nullopt, &id);
+  if (out_id) *out_id = id;
+  return rc;
+}
+void orc_mkts_cancel(void* mp, uint32_t mi, uint32_t asset, uint64_t id) {
+  static_cast<OrcMarkets*>(mp)->mk[mi]->env.cancel_order(asset, id);
+}
+void orc_mkts_modify(void* mp, uint32_t mi, uint32_t asset, uint64_t id, int has_p, uint32_t p, int has_v, uint32_t v) {
+  static_cast<OrcMarkets*>(mp)->mk[mi]->env.modify_order(asset, id, has_p ? std::optional<Price>(p) : std::nullopt,
+                                                         has_v ? std::optional<Vol>(v) : std::nullopt);
+}
+int orc_mkts_step(void* mp) {  // one MarketEnv::step on every market, each with its own RNG
+  int rc = ORC_OK;
+  for (auto& k : static_cast<OrcMarkets*>(mp)->mk) {
+    const int r = k->env.step(k->rng);
+    if (r != ORC_OK) rc = r;
+  }
+  return rc;
+}
+void orc_mkts_set_trading(void* mp, int on) {
+  for (auto& k : static_cast<OrcMarkets*>(mp)->mk) k->env.market.set_trading(on != 0);
+}
+uint64_t orc_mkts_n_steps(void* mp) {
+  auto* m = static_cast<OrcMarkets*>(mp);
+  return m->mk.empty() ? 0 : m->mk[0]->env.trade_vols[0].size();
+}
+void* orc_mkts_book(void* mp, uint32_t mi, uint32_t asset) {
+  return &static_cast<OrcMarkets*>(mp)->mk[mi]->env.market.order_books[asset];
+}
+void orc_mkts_rng_state(void* mp, uint32_t mi, uint64_t* st) {
+  auto& k = *static_cast<OrcMarkets*>(mp)->mk[mi];
+  st[0] = k.rng.s0;
+  st[1] = k.rng.s1;
+}
+// out[step - first_step][market * assets + asset][5+4L]
+void orc_mkts_history(void* mp, uint64_t first_step, uint64_t n, uint32_t* out) {
+  auto* m = static_cast<OrcMarkets*>(mp);
+  const int L = m->levels;
+  const size_t W = 5 + 4 * static_cast<size_t>(L), A = m->assets, B = m->mk.size() * A;
+  for (size_t b = 0; b < B; ++b) {
+    const MarketEnv& env = m->mk[b / A]->env;
+    const auto& r = env.level_2_data_records[b % A];
+    for (uint64_t s = 0; s < n; ++s) {
+      const size_t ss = first_step + s;
+      uint32_t* o = out + (s * B + b) * W;
+      o[0] = env.trade_vols[b % A][ss];
+      o[1] = r.bid_prices[ss];
+      o[2] = r.ask_prices[ss];
+      o[3] = r.ask_vols[ss];
+      o[4] = r.bid_vols[ss];
+      for (int i = 0; i < L; ++i) {
+        o[5 + 4 * i + 0] = r.bid_vols_at_levels[i][ss];
+        o[5 + 4 * i + 1] = r.bid_orders_at_levels[i][ss];
+        o[5 + 4 * i + 2] = r.ask_vols_at_levels[i][ss];
+        o[5 + 4 * i + 3] = r.ask_orders_at_levels[i][ss];
+      }
+    }
+  }
+}
+
 // ---- sampling and portable-math hooks for unit tests
 double orc_rng_f64(uint64_t* st) {
   Rng r{st[0], st[1]};
@@ -566,6 +685,6 @@ double orc_pm_tanh(double x) { return pm::tanh(x); }
 uint32_t orc_round_price_up(double p, double tick) { return round_price_up(p, tick); }
 uint32_t orc_round_price_down(double p, double tick) { return round_price_down(p, tick); }
 
-int orc_version() { return 2; }
+int orc_version() { return 3; }
 
 }  // extern "C"

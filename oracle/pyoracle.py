@@ -162,6 +162,18 @@ def lib() -> C.CDLL:
     sig("orc_round_price_up", u32, dbl, dbl)
     sig("orc_round_price_down", u32, dbl, dbl)
     sig("orc_version", i32)
+    sig("orc_mkts_new", vp, u32, u64, u64, u32, p32, u64, i32, i32, i32, p32)
+    sig("orc_mkts_free", None, vp)
+    sig("orc_mkts_run", i32, vp, u64, i32)
+    sig("orc_mkts_place", i32, vp, u32, u32, i32, u32, u32, i32, u32, p64)
+    sig("orc_mkts_cancel", None, vp, u32, u32, u64)
+    sig("orc_mkts_modify", None, vp, u32, u32, u64, i32, u32, i32, u32)
+    sig("orc_mkts_step", i32, vp)
+    sig("orc_mkts_set_trading", None, vp, i32)
+    sig("orc_mkts_n_steps", u64, vp)
+    sig("orc_mkts_book", vp, vp, u32, u32)
+    sig("orc_mkts_rng_state", None, vp, u32, p64)
+    sig("orc_mkts_history", None, vp, u64, u64, p32)
     _lib = L
     return L
 
@@ -834,4 +846,76 @@ class ManyBooks:
     def order_counts(self):
         out = np.zeros(self.n_books, dtype=np.uint64)
         lib().orc_many_order_counts(self._m, _p64(out))
+        return out
+
+
+class ManyMarkets:
+    """n_markets independent (MarketEnv<assets>, RandomMarketAgents groups, RNG) simulations (ref
+    crates/step_sim/src/market_env.rs, runner.rs:108-131); market m seeded seed + m.  Books are addressed flat as
+    market * assets + asset.  groups: (asset, n, (tick_lo, tick_hi), (vol_lo, vol_hi), tick_size, rate)."""
+
+    def __init__(self, n_markets, seed, start_time, tick_sizes, step_size, trading, levels, groups=()):
+        self.n_markets, self.assets, self.levels = int(n_markets), len(tick_sizes), int(levels)
+        self.n_books = self.n_markets * self.assets
+        self.ticks = [int(t) for t in tick_sizes]
+        g = np.zeros((max(len(groups), 1), 8), dtype=np.uint32)
+        for i, (asset, n, tr, vr, ts, rate) in enumerate(groups):
+            g[i, :7] = (asset, n, tr[0], tr[1], vr[0], vr[1], ts)
+            g[i, 7] = np.float32(rate).view(np.uint32)
+        tk = np.asarray(self.ticks, dtype=np.uint32)
+        self._m = lib().orc_mkts_new(self.n_markets, int(seed), int(start_time), self.assets, _p32(tk), int(step_size),
+                                     int(bool(trading)), self.levels, len(groups), _p32(g))
+
+    def __del__(self):
+        if getattr(self, "_m", None):
+            lib().orc_mkts_free(self._m)
+            self._m = None
+
+    def run(self, n_steps, n_threads=1):
+        rc = lib().orc_mkts_run(self._m, int(n_steps), int(n_threads))
+        if rc != 0:
+            raise RuntimeError(f"oracle mkts_run status {rc}")
+
+    def place_order(self, market, asset, bid, vol, trader_id, price=None):
+        out = C.c_uint64(0)
+        rc = lib().orc_mkts_place(self._m, int(market), int(asset), int(bool(bid)), int(vol), int(trader_id),
+                                  int(price is not None), int(price or 0), C.byref(out))
+        if rc == 1:
+            raise ValueError(f"Price {price} was not a multiple of tick-size {self.ticks[asset]}")
+        return int(out.value)
+
+    def cancel_order(self, market, asset, order_id):
+        lib().orc_mkts_cancel(self._m, int(market), int(asset), int(order_id))
+
+    def modify_order(self, market, asset, order_id, new_price=None, new_vol=None):
+        lib().orc_mkts_modify(self._m, int(market), int(asset), int(order_id), int(new_price is not None),
+                              int(new_price or 0), int(new_vol is not None), int(new_vol or 0))
+
+    def step(self):
+        rc = lib().orc_mkts_step(self._m)
+        if rc != 0:
+            raise RuntimeError(f"oracle mkts_step status {rc}")
+
+    def set_trading(self, on):
+        lib().orc_mkts_set_trading(self._m, int(bool(on)))
+
+    def n_steps(self):
+        return int(lib().orc_mkts_n_steps(self._m))
+
+    def history(self, first_step=0, n=None):
+        """u32[n, n_markets * assets, 5+4L]"""
+        if n is None:
+            n = self.n_steps() - first_step
+        o = np.zeros((n, self.n_books, 5 + 4 * self.levels), dtype=np.uint32)
+        if n:
+            lib().orc_mkts_history(self._m, int(first_step), int(n), _p32(o))
+        return o
+
+    def book(self, market, asset):
+        return _BookView(lib().orc_mkts_book(self._m, int(market), int(asset)), self.levels, self.ticks[asset])
+
+    def rng_states(self):
+        out = np.zeros((self.n_markets, 2), dtype=np.uint64)
+        for b in range(self.n_markets):
+            lib().orc_mkts_rng_state(self._m, b, _p64(out[b]))
         return out

@@ -713,3 +713,138 @@ def test_history_ring_and_streaming_egress(bk, oracle):
     env.run(5)
     ref.run(5, 1)
     assert np.array_equal(env.history(), ref.history()[T + 5 - 2 * chunk:])
+
+
+# ------------------------------------------------------------------ MarketEnv mode
+def test_kat_market_env_on_gpu(bk):  # ref crates/step_sim/src/market_env.rs:342-407
+    MAXP = 2**32 - 1
+    env = bk.ManyMarketEnv(1, 101, 0, [1, 1], 1000, levels=10, max_live_orders=64, max_orders=64, trade_capacity=64,
+                           history_capacity=8)
+    env.place_order(0, 0, True, 10, 101, 10)
+    env.place_order(0, 0, False, 20, 101, 20)
+    env.step()
+    l2 = env.level2()
+    assert (l2[0, 1], l2[0, 2]) == (10, 20) and (l2[1, 1], l2[1, 2]) == (0, MAXP)
+    o = env.orders(0)
+    assert len(o) == 2 and list(o["status"]) == [1, 1]
+    assert env.time(0) == env.time(1) == 1000
+    env.place_order(0, 0, True, 10, 101, 11)
+    env.place_order(0, 0, False, 20, 101, 21)
+    env.step()
+    l2 = env.level2()
+    assert (l2[0, 1], l2[0, 2]) == (11, 20) and (l2[1, 1], l2[1, 2]) == (0, MAXP)
+    assert len(env.orders(0)) == 4 and env.time(1) == 2000
+    env.place_order(0, 0, True, 30, 101, None)
+    env.step()
+    l2 = env.level2()
+    assert (l2[0, 1], l2[0, 2]) == (11, 21) and (l2[0, 3], l2[1, 3]) == (10, 0)
+    o = env.orders(0)
+    assert len(o) == 5 and o["status"][1] == 2 and o["status"][4] == 2
+    assert len(env.trades(0, first=0)) == 2 and len(env.trades(1, first=0)) == 0
+    h = env.history()[:, 0]
+    assert list(h[:, 1]) == [10, 11, 11] and list(h[:, 2]) == [20, 20, 21]   # prices
+    assert list(h[:, 4]) == [10, 20, 20] and list(h[:, 3]) == [20, 40, 10]   # volumes
+    assert list(h[:, 5]) == [10, 10, 10] and list(h[:, 7]) == [20, 20, 10]   # touch volumes
+    assert list(h[:, 6]) == [1, 1, 1] and list(h[:, 8]) == [1, 1, 1]         # touch order counts
+    assert list(h[:, 0]) == [0, 0, 30]                                       # trade vols
+    with pytest.raises(ValueError):
+        bk.ManyMarketEnv(1, 1, 0, [1, 3], 1000, max_orders=8).place_order(0, 1, True, 1, 0, 10)  # tick of asset 1
+
+
+def _compare_markets(bk, oracle, n_markets, ticks, groups, levels, n_steps, seed=101, step_size=100_000, chunks=None):
+    A = len(ticks)
+    n_agents = sum(g[1] for g in groups)
+    env = bk.ManyMarketEnv(n_markets, seed, 0, ticks, step_size, True, levels=levels, max_live_orders=n_agents,
+                           trade_capacity=2 * n_agents * n_steps, history_capacity=n_steps)
+    env.set_random_market_agents(groups)
+    for c in (chunks or [n_steps]):
+        env.run(c)
+    ref = oracle.ManyMarkets(n_markets, seed, 0, ticks, step_size, True, levels, groups)
+    ref.run(n_steps, n_threads=4)
+    assert not env.flags().any(), np.unique(env.flags())
+    hist, want = env.history(), ref.history()
+    if not np.array_equal(hist, want):
+        bad = np.argwhere(hist != want)[0]
+        raise AssertionError(f"L2 history differs first at (step, book, word) = {bad}: {hist[tuple(bad)]} vs {want[tuple(bad)]}")
+    assert np.array_equal(env.level2(), want[-1])
+    want_rng = ref.rng_states()
+    for m in sorted(set([0, 1, n_markets // 2, n_markets - 1])):
+        for a in range(A):
+            b = env.book(m, a)
+            assert env.rng_state(b) == (int(want_rng[m, 0]), int(want_rng[m, 1])), (m, a)
+            assert env.time(b) == n_steps * step_size
+            got, exp = env.trades(b, first=0), ref.book(m, a).trades_array()
+            assert len(got) == len(exp), (m, a)
+            for f in ("t", "side", "price", "vol", "active_id", "passive_id"):
+                assert np.array_equal(got[f], exp[f]), (m, a, f)
+            live, o = env.live_orders(b), ref.book(m, a).orders_array()
+            act = o[o["status"] == 1]
+            assert set(zip(live["order_id"].tolist(), live["price"].tolist(), live["vol"].tolist(), live["side"].tolist())) == \
+                set(zip(act["order_id"].tolist(), act["price"].tolist(), act["vol"].tolist(), act["side"].tolist()))
+    env.close()
+
+
+def test_random_market_agents_doc_example(bk, oracle):  # ref agents/random_agent.rs:146-162 (two assets, tick 1 / agents' 2)
+    groups = [(0, 10, (40, 60), (10, 20), 2, 0.8), (1, 10, (40, 60), (10, 20), 2, 0.8)]
+    _compare_markets(bk, oracle, 64, [1, 1], groups, 10, 40, step_size=1_000_000)
+
+
+def test_random_market_agents_three_assets_mixed_ticks(bk, oracle):
+    # several groups per asset, an asset nobody trades, per-asset tick sizes, launches in chunks
+    groups = [(0, 40, (30, 50), (10, 20), 4, 0.7), (2, 33, (20, 40), (5, 9), 3, 0.9), (0, 20, (30, 50), (50, 70), 2, 0.3),
+              (2, 35, (22, 38), (1, 4), 6, 0.5)]
+    _compare_markets(bk, oracle, 70, [2, 5, 3], groups, 16, 30, chunks=[1, 12, 17])
+
+
+def test_random_market_agents_large_batch_parts(bk, oracle):
+    # enough books for the three-part staggered launch (>= 12 288 books)
+    groups = [(0, 24, (40, 56), (10, 20), 2, 0.8), (1, 24, (40, 56), (10, 20), 2, 0.8), (1, 16, (40, 56), (50, 70), 2, 0.2)]
+    _compare_markets(bk, oracle, 6200, [2, 2], groups, 16, 12)
+
+
+@pytest.mark.parametrize("seed", [4, 5])
+def test_market_host_driven_random_stream(bk, oracle, seed):
+    """MarketEnv::place/cancel/modify across assets: ONE shuffled queue per market, events stamped t0 + global index."""
+    NM, A, T = 3, 3, 20
+    ticks = [1, 2, 5]
+    env = bk.ManyMarketEnv(NM, 50 + seed, 0, ticks, 1000, levels=10, max_live_orders=256, max_orders=4096,
+                           trade_capacity=4096, history_capacity=T)
+    ref = oracle.ManyMarkets(NM, 50 + seed, 0, ticks, 1000, True, 10)
+    rng = np.random.default_rng(seed)
+    for _ in range(T):
+        for m in range(NM):
+            for _k in range(int(rng.integers(0, 25))):
+                a = int(rng.integers(0, A))
+                kind = rng.random()
+                n = ref.book(m, a).n_orders()
+                if kind < 0.65 or n == 0:
+                    bid, vol = bool(rng.integers(0, 2)), int(rng.integers(1, 30))
+                    price = None if rng.random() < 0.1 else int(rng.integers(18, 24)) * 5 * ticks[a]
+                    assert env.place_order(m, a, bid, vol, 7, price) == ref.place_order(m, a, bid, vol, 7, price)
+                elif kind < 0.85:
+                    i = int(rng.integers(0, n))
+                    env.cancel_order(m, a, i)
+                    ref.cancel_order(m, a, i)
+                else:
+                    i = int(rng.integers(0, n))
+                    np_ = None if rng.random() < 0.5 else int(rng.integers(18, 24)) * 5 * ticks[a]
+                    nv = None if rng.random() < 0.4 else int(rng.integers(1, 30))
+                    env.modify_order(m, a, i, np_, nv)
+                    ref.modify_order(m, a, i, np_, nv)
+        env.step()
+        ref.step()
+    h, want = env.history(), ref.history()
+    assert np.array_equal(h, want)
+    for m in range(NM):
+        for a in range(A):
+            b = env.book(m, a)
+            got, exp = env.trades(b, first=0), ref.book(m, a).trades_array()
+            for f in got.dtype.names:
+                assert np.array_equal(got[f], exp[f]), (m, a, f)
+            go, eo = env.orders(b), ref.book(m, a).orders_array()
+            for f in go.dtype.names:
+                assert np.array_equal(go[f], eo[f]), (m, a, f)
+    want_rng = ref.rng_states()
+    for m in range(NM):
+        for a in range(A):
+            assert env.rng_state(env.book(m, a)) == (int(want_rng[m, 0]), int(want_rng[m, 1]))

@@ -362,3 +362,53 @@ def test_python_numpy_api(oracle):  # C.13 tests/test_step_sim/test_numpy_api.py
     with pytest.raises(ValueError):
         bad.submit_limit_orders((sides[:2], vols[:2], tr[:2], np.array([20, 21], dtype=np.uint32)))
     assert bad.n_transactions() == 1  # first element stayed created + queued (step_sim_numpy.rs:167-177)
+
+
+def test_market_env_three_steps(oracle):  # crates/step_sim/src/market_env.rs:342-407 (MarketEnv<2>, one queue for both assets)
+    MAXP = 2**32 - 1
+    m = oracle.ManyMarkets(1, 101, 0, [1, 1], 1000, True, 10)
+    m.place_order(0, 0, True, 10, 101, 10)
+    m.place_order(0, 0, False, 20, 101, 20)
+    m.step()
+    assert m.book(0, 0).bid_ask() == (10, 20) and m.book(0, 1).bid_ask() == (0, MAXP)
+    o = m.book(0, 0).orders_array()
+    assert len(o) == 2 and o["status"].tolist() == [1, 1]
+    m.place_order(0, 0, True, 10, 101, 11)
+    m.place_order(0, 0, False, 20, 101, 21)
+    m.step()
+    assert m.book(0, 0).bid_ask() == (11, 20) and m.book(0, 0).n_orders() == 4
+    m.place_order(0, 0, True, 30, 101, None)
+    m.step()
+    assert m.book(0, 0).bid_ask() == (11, 21) and (m.book(0, 0).ask_vol(), m.book(0, 1).ask_vol()) == (10, 0)
+    o = m.book(0, 0).orders_array()
+    assert len(o) == 5 and o["status"][1] == 2 and o["status"][4] == 2
+    assert len(m.book(0, 0).trades_array()) == 2
+    h = m.history()[:, 0]
+    assert h[:, 1].tolist() == [10, 11, 11] and h[:, 2].tolist() == [20, 20, 21]
+    assert h[:, 4].tolist() == [10, 20, 20] and h[:, 3].tolist() == [20, 40, 10]
+    assert h[:, 5].tolist() == [10, 10, 10] and h[:, 7].tolist() == [20, 20, 10]
+    assert h[:, 6].tolist() == [1, 1, 1] and h[:, 8].tolist() == [1, 1, 1]
+    assert h[:, 0].tolist() == [0, 0, 30]
+    assert m.history()[:, 1, :5].tolist() == [[0, 0, MAXP, 0, 0]] * 3
+
+
+def test_market_shares_one_queue_and_clock(oracle):
+    """market_env.rs:110-121: one shuffle over all assets' events, event i stamped t0 + i on EVERY book's clock."""
+    m = oracle.ManyMarkets(1, 3, 0, [1, 2], 1000, True, 4)
+    for k in range(6):
+        m.place_order(0, k % 2, True, 5, 0, 10 + 2 * k)
+    m.step()
+    t = sorted(m.book(0, 0).orders_array()["arr_time"].tolist() + m.book(0, 1).orders_array()["arr_time"].tolist())
+    assert t == [0, 1, 2, 3, 4, 5]  # a permutation of the global positions, split between the two books
+    with pytest.raises(ValueError):
+        m.place_order(0, 1, True, 5, 0, 11)  # asset 1 has tick 2 (Market::new(_, [1, 2], _), market.rs:74-81)
+
+
+def test_random_market_agents_equal_single_book_agents(oracle):
+    """RandomMarketAgents on a one-asset market == RandomAgents on an Env (random_agent.rs:84-120 vs :204-247)."""
+    g = [(12, (40, 60), (10, 20), 2, 0.8), (7, (45, 55), (1, 5), 2, 0.4)]
+    a = oracle.ManyBooks(3, 11, 0, 2, 100_000, True, 8, g)
+    b = oracle.ManyMarkets(3, 11, 0, [2], 100_000, True, 8, [(0,) + x for x in g])
+    a.run(30)
+    b.run(30)
+    assert np.array_equal(a.history(), b.history()) and np.array_equal(a.rng_states(), b.rng_states())
