@@ -95,6 +95,8 @@ SIGNATURES = {
     "bk_order_status": (_i32, [_vp, _u32, _u64, _p8]),
     "bk_order_count": (_i32, [_vp, _u32, _p64]),
     "bk_get_orders": (_i32, [_vp, _u32, _u64, _u64, _vp]),
+    "bk_get_order_keys": (_i32, [_vp, _u32, _u64, _u64, _p32, _p64]),
+    "bk_load_book": (_i32, [_vp, _u32, _u64, _u32, _u64, _vp, _p32, _p64, _u64, _vp]),
     "bk_set_random_agents": (_i32, [_vp, _u32, C.POINTER(RandomAgentsCfg)]),
     "bk_set_tick_sizes": (_i32, [_vp, _u32, _p32]),
     "bk_set_random_market_agents": (_i32, [_vp, _u32, C.POINTER(RandomAgentsCfg), _p32]),

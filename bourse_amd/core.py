@@ -161,13 +161,39 @@ class OrderBook:
     (ref rust/src/order_book.rs:30-380) on the GPU: every call is one event processed at the book's current
     time (``Env::step`` with a one-event queue and step_size 0), so ``set_time`` is the caller's job exactly as in
     the reference.  Orders placed at the SAME time keep strict FIFO priority here (the reference's
-    ``(price, t)`` key would overwrite).  JSON snapshots are out of scope."""
+    ``(price, t)`` key would overwrite).  ``save_json_snapshot`` / ``order_book_from_json`` use the
+    reference's serde layout (orderbook.rs:93-112, 811-918)."""
 
     def __init__(self, start_time, tick_size, trading=True, *, max_live_orders=512, max_orders=1 << 16,
                  trade_capacity=1 << 16, device=0):
         self._env = ManyBookEnv(1, 0, start_time, tick_size, 0, trading, levels=LEVELS,
                                 max_live_orders=max_live_orders, max_orders=max_orders,
                                 trade_capacity=trade_capacity, history_capacity=0, device=device)
+        self._trading = bool(trading)
+        self._trade_vol0 = 0  # OrderBook.trade_vol is never reset by this class: base + volume of all trades
+
+    def trade_vol(self):
+        """Cumulative traded volume (``OrderBook::get_trade_vol``, orderbook.rs:314-316), wrapping u32."""
+        return (self._trade_vol0 + int(self._env.trades(0, first=0)["vol"].sum(dtype=np.uint64))) & 0xFFFFFFFF
+
+    def save_json_snapshot(self, path, pretty=False):
+        """``OrderBook::save_json`` (orderbook.rs:811-819; rust/src/order_book.rs:364-380)."""
+        import json
+
+        state = self._env.book_state(0, trading=self._trading, trade_vol=self.trade_vol())
+        with open(path, "w") as f:
+            if pretty:
+                json.dump(state, f, indent=2)
+            else:
+                json.dump(state, f, separators=(",", ":"))
+
+    @classmethod
+    def _from_state(cls, state, **kw):
+        ob = cls(int(state["t"]), int(state["tick_size"]), bool(state["trading"]), **kw)
+        ob._env.load_book_state(0, state)
+        vols = sum(int(t["vol"]) for t in state["trades"])
+        ob._trade_vol0 = (int(state["trade_vol"]) - vols) & 0xFFFFFFFF
+        return ob
 
     def _l2(self):
         return self._env.level2(0, 1)[0]
@@ -177,9 +203,11 @@ class OrderBook:
 
     def enable_trading(self):
         self._env.enable_trading()
+        self._trading = True
 
     def disable_trading(self):
         self._env.disable_trading()
+        self._trading = False
 
     def ask_vol(self):
         return int(self._l2()[3])
@@ -234,6 +262,15 @@ class OrderBook:
              int(r["start_vol"]), int(r["price"]), int(r["trader_id"]), int(r["order_id"]))
             for r in self._env.orders(0)
         ]
+
+
+def order_book_from_json(path, **kw):
+    """``bourse.core.order_book_from_json(path)`` (rust/src/order_book.rs:383-398): a book on the GPU initialised from a
+    snapshot written by ``save_json_snapshot`` here or by the reference's ``OrderBook::save_json``."""
+    import json
+
+    with open(path) as f:
+        return OrderBook._from_state(json.load(f), **kw)
 
 
 class StepEnvNumpy(_EnvBase):

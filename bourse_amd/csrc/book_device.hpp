@@ -52,9 +52,11 @@ struct DevTrade {  // 32 B device trade record
   uint32_t t_lo, t_hi, price, vol, active, passive, side_is_bid, pad;
 };
 
-struct DevOrderLog {  // 32 B mutable part of an order (host keeps the immutable part)
-  uint32_t status, vol, price, pad;
+struct DevOrderLog {  // 48 B mutable part of an order (host keeps the immutable part)
+  uint32_t status, vol, price;
+  uint32_t key_price;  // OrderEntry.key (orderbook.rs:34-39): the price and time the priority key was last set with
   uint32_t arr_lo, arr_hi, end_lo, end_hi;
+  uint32_t key_lo, key_hi, pad[2];
 };
 
 struct DevArgs {
@@ -286,7 +288,7 @@ struct LogCtx {
 };
 __device__ __forceinline__ void log_write(const LogCtx& lg, uint32_t& flags, int lane, uint32_t id, uint32_t status,
                                           uint32_t vol, uint32_t price, uint64_t arr, uint64_t end,
-                                          bool set_arr) {
+                                          bool set_arr, bool set_key = false, uint64_t key_t = 0) {
   if (!lg.base) return;
   if (id >= lg.cap) {
     flags |= FLAG_ORDER_LOG_FULL;
@@ -303,6 +305,11 @@ __device__ __forceinline__ void log_write(const LogCtx& lg, uint32_t& flags, int
     }
     e->end_lo = (uint32_t)end;
     e->end_hi = (uint32_t)(end >> 32);
+    if (set_key) {  // key = (side, price_key(price), key_t): create (t = 0), rest on placement / replace (t = now)
+      e->key_price = price;
+      e->key_lo = (uint32_t)key_t;
+      e->key_hi = (uint32_t)(key_t >> 32);
+    }
   }
 }
 // passive order touched by a fill: vol / status / end_time only
@@ -1024,7 +1031,8 @@ __global__ __launch_bounds__(64) void k_step_events(DevArgs a, uint64_t step_ind
           mask_set<R>(B.live, n, true);
         }
       }
-      log_write(lg, B.flags, lane, id, status, v, p, tk, end, true);
+      // key: provisional (price, 0) from create_order (orderbook.rs:388-391) unless the order rests (:501-505)
+      log_write(lg, B.flags, lane, id, status, v, p, tk, end, true, true, status == 1 ? tk : 0ull);
     } else if (kind == 1) {
       // ---- Cancellation (orderbook.rs:622-644): only an Active order changes
       const int n = find_live_by_id<R>(B, id);
@@ -1059,7 +1067,7 @@ __global__ __launch_bounds__(64) void k_step_events(DevArgs a, uint64_t step_ind
             slot_write<R>(B.seq, n, B.seq_ctr);
             B.seq_ctr += 1;
             mask_set<R>(B.live, n, true);
-            log_write(lg, B.flags, lane, id, 1, nv, np, 0, ~0ull, false);
+            log_write(lg, B.flags, lane, id, 1, nv, np, 0, ~0ull, false, true, tk);  // re-keyed (orderbook.rs:699-721)
           } else {
             log_write(lg, B.flags, lane, id, 2, 0, np, 0, tk, false);
           }

@@ -26,7 +26,7 @@ static_assert(sizeof(bk_config) == 72 && sizeof(bk_random_agents) == 28 && sizeo
                   sizeof(bk_order) == 48,
               "C ABI struct layout (mirrored by bourse_amd/_lib.py)");
 static_assert(sizeof(bk_agent_desc) == 104, "bk_agent_desc layout (mirrored by bourse_amd/_lib.py)");
-static_assert(sizeof(DevTrade) == 32 && sizeof(DevOrderLog) == 32, "device record layout");
+static_assert(sizeof(DevTrade) == 32 && sizeof(DevOrderLog) == 48, "device record layout");
 
 namespace {
 
@@ -992,6 +992,146 @@ int bk_clear_trades(bk_env* env) {
   hipLaunchKernelGGL(k_book_service, dim3((B + 255) / 256), dim3(256), 0, env->stream, env->state.p, env->stride, B, 0,
                      0u);
   HIPCHK(hipGetLastError());
+  return BK_OK;
+}
+
+// OrderEntry.key of orders [first, first + n) (orderbook.rs:34-39): the price and time the order's priority key was
+// last set with.  key = (side, price_key(key_price), key_time); price_key = u32::MAX - price for bids (side.rs:300-302).
+int bk_get_order_keys(bk_env* env, uint32_t book, uint64_t first, uint64_t n, uint32_t* key_price,
+                      uint64_t* key_time) {
+  if (int rc = check_book(env, book)) return rc;
+  BookHost& bh = env->books[book];
+  if (first + n > bh.orders.size()) return fail(BK_INVALID_ARGUMENT, "order range out of bounds");
+  if (env->cfg.max_orders == 0) return fail(BK_INVALID_ARGUMENT, "order log disabled (max_orders == 0)");
+  if (bh.n_uploaded > env->cfg.max_orders) return fail(BK_CAPACITY, "order log capacity exceeded");
+  if (int rc = use_device(env)) return rc;
+  if (int rc = refresh_log(env, book)) return rc;
+  for (uint64_t i = 0; i < n; ++i) {
+    const uint64_t id = first + i;
+    if (id < bh.n_uploaded && id < bh.log_cache.size()) {
+      const DevOrderLog& d = bh.log_cache[id];
+      if (key_price) key_price[i] = d.key_price;
+      if (key_time) key_time[i] = (static_cast<uint64_t>(d.key_hi) << 32) | d.key_lo;
+    } else {  // created, New event still queued: provisional key (orderbook.rs:388-391)
+      if (key_price) key_price[i] = bh.orders[id].price;
+      if (key_time) key_time[i] = 0;
+    }
+  }
+  return BK_OK;
+}
+
+// Replace one book's state with a snapshot (OrderBook::load_json -> TryFrom<OrderBookState>, orderbook.rs:827-918):
+// clock, per-step trade volume, every order ever created (with its key) and every trade.  Active orders go back into
+// the pool in key order, the level-2 record is rebuilt from them.  The book must have no queued events.
+int bk_load_book(bk_env* env, uint32_t book, uint64_t t, uint32_t trade_vol, uint64_t n_orders, const bk_order* orders,
+                 const uint32_t* key_price, const uint64_t* key_time, uint64_t n_trades, const bk_trade* trades) {
+  if (int rc = check_book(env, book)) return rc;
+  if ((n_orders && (!orders || !key_price || !key_time)) || (n_trades && !trades))
+    return fail(BK_INVALID_ARGUMENT, "null argument");
+  if (env->M > 1) return fail(BK_INVALID_ARGUMENT, "bk_load_book: independent books only");
+  BookHost& bh = env->books[book];
+  if (!bh.queue.empty()) return fail(BK_INVALID_ARGUMENT, "events are queued for this book");
+  if (n_orders > env->cfg.max_orders) return fail(BK_CAPACITY, "snapshot holds more orders than max_orders");
+  if (n_trades > env->cfg.trade_capacity) return fail(BK_CAPACITY, "snapshot holds more trades than trade_capacity");
+  if (n_orders >= 0xFFFFFFFFull) return fail(BK_CAPACITY, "order id space exhausted");
+  std::vector<uint64_t> act;  // Active orders, to be ranked by key time (price-time priority within a price)
+  for (uint64_t i = 0; i < n_orders; ++i) {
+    if (orders[i].order_id != i) return fail(BK_INVALID_ARGUMENT, "orders must be listed by id");
+    if (orders[i].status > 4) return fail(BK_INVALID_ARGUMENT, "bad order status");
+    if (orders[i].status == 1) act.push_back(i);
+  }
+  const uint32_t pool = static_cast<uint32_t>(env->R) * 64u;
+  if (act.size() > pool) return fail(BK_CAPACITY, "snapshot holds more Active orders than max_live_orders");
+  if (int rc = use_device(env)) return rc;
+  HIPCHK(hipStreamSynchronize(env->stream));
+  std::stable_sort(act.begin(), act.end(), [&](uint64_t a, uint64_t b) { return key_time[a] < key_time[b]; });
+
+  const uint32_t L = env->cfg.levels, W = env->W, tick = env->asset_tick[0];
+  std::vector<uint32_t> st(env->stride, 0u), l2(W, 0u);
+  uint32_t* hdr = st.data();
+  HIPCHK(hipMemcpy(hdr, env->state.p + static_cast<size_t>(book) * env->stride, HDR_DW * 4, hipMemcpyDeviceToHost));
+  hdr[H_T_LO] = static_cast<uint32_t>(t);
+  hdr[H_T_HI] = static_cast<uint32_t>(t >> 32);
+  hdr[H_NEXT_ID] = static_cast<uint32_t>(n_orders);
+  hdr[H_SEQ] = static_cast<uint32_t>(act.size());
+  hdr[H_TRADES_LO] = static_cast<uint32_t>(n_trades);
+  hdr[H_TRADES_HI] = static_cast<uint32_t>(n_trades >> 32);
+  hdr[H_TRADE_BASE_LO] = hdr[H_TRADE_BASE_HI] = 0;
+  hdr[H_FLAGS] = 0;
+  hdr[H_TRADE_VOL] = trade_vol;
+  hdr[H_LAST_NTRADES] = hdr[H_LAST_NEVENTS] = 0;
+  for (int r = 0; r < 8; ++r) hdr[H_LIVE0 + 2 * r] = hdr[H_LIVE0 + 2 * r + 1] = 0;
+  uint32_t bid_best = 0, ask_best = 0xFFFFFFFFu, bid_vol = 0, ask_vol = 0;
+  for (size_t k = 0; k < act.size(); ++k) {
+    const bk_order& o = orders[act[k]];
+    const uint32_t r = static_cast<uint32_t>(k) / 64u, lane = static_cast<uint32_t>(k) % 64u;
+    uint32_t* p = st.data() + HDR_DW + r * POOL_FIELDS * 64;
+    p[0 * 64 + lane] = o.price;
+    p[1 * 64 + lane] = o.vol;
+    p[2 * 64 + lane] = static_cast<uint32_t>(o.order_id);
+    p[3 * 64 + lane] = static_cast<uint32_t>(k);  // seq: rank in key-time order
+    p[4 * 64 + lane] = 1u | (o.side_is_bid ? 2u : 0u);
+    hdr[H_LIVE0 + 2 * r + (lane >> 5)] |= 1u << (lane & 31);
+    if (o.side_is_bid) {
+      bid_best = std::max(bid_best, o.price);
+      bid_vol += o.vol;
+    } else {
+      ask_best = std::min(ask_best, o.price);
+      ask_vol += o.vol;
+    }
+  }
+  // level-2 record of the loaded book (orderbook.rs:229-264): [trade_vol, bid, ask, ask_vol, bid_vol, levels...]
+  l2[0] = trade_vol;
+  l2[1] = bid_best;
+  l2[2] = ask_best;
+  l2[3] = ask_vol;
+  l2[4] = bid_vol;
+  for (uint64_t i : act) {
+    const bk_order& o = orders[i];
+    const uint32_t d = o.side_is_bid ? bid_best - o.price : o.price - ask_best;
+    if (d % tick == 0 && d / tick < L) {
+      l2[5 + 4 * (d / tick) + (o.side_is_bid ? 0 : 2)] += o.vol;
+      l2[5 + 4 * (d / tick) + (o.side_is_bid ? 1 : 3)] += 1;
+    }
+  }
+  std::vector<DevOrderLog> log(n_orders);
+  bh.orders.clear();
+  for (uint64_t i = 0; i < n_orders; ++i) {
+    const bk_order& o = orders[i];
+    bh.orders.push_back(HostOrder{static_cast<uint8_t>(o.side_is_bid ? 1 : 0), o.start_vol, o.price, o.trader_id,
+                                  o.arr_time});
+    DevOrderLog& d = log[i];
+    std::memset(&d, 0, sizeof(d));
+    d.status = o.status;
+    d.vol = o.vol;
+    d.price = o.price;
+    d.key_price = key_price[i];
+    d.arr_lo = static_cast<uint32_t>(o.arr_time);
+    d.arr_hi = static_cast<uint32_t>(o.arr_time >> 32);
+    d.end_lo = static_cast<uint32_t>(o.end_time);
+    d.end_hi = static_cast<uint32_t>(o.end_time >> 32);
+    d.key_lo = static_cast<uint32_t>(key_time[i]);
+    d.key_hi = static_cast<uint32_t>(key_time[i] >> 32);
+  }
+  std::vector<DevTrade> tr(n_trades);
+  for (uint64_t i = 0; i < n_trades; ++i) {
+    const bk_trade& x = trades[i];
+    tr[i] = DevTrade{static_cast<uint32_t>(x.t), static_cast<uint32_t>(x.t >> 32), x.price, x.vol,
+                     static_cast<uint32_t>(x.active_order_id), static_cast<uint32_t>(x.passive_order_id),
+                     x.side_is_bid ? 1u : 0u, 0u};
+  }
+  HIPCHK(hipMemcpy(env->state.p + static_cast<size_t>(book) * env->stride, st.data(), st.size() * 4,
+                   hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(env->l2_last.p + static_cast<size_t>(book) * W, l2.data(), W * 4, hipMemcpyHostToDevice));
+  if (n_orders)
+    HIPCHK(hipMemcpy(env->order_log.p + static_cast<size_t>(book) * env->cfg.max_orders, log.data(),
+                     n_orders * sizeof(DevOrderLog), hipMemcpyHostToDevice));
+  if (n_trades)
+    HIPCHK(hipMemcpy(env->trades.p + static_cast<size_t>(book) * env->cfg.trade_capacity, tr.data(),
+                     n_trades * sizeof(DevTrade), hipMemcpyHostToDevice));
+  bh.n_uploaded = n_orders;
+  bh.log_fresh = false;
+  bh.time_offset = t - (env->cfg.start_time + env->steps_done * env->cfg.step_size);
   return BK_OK;
 }
 

@@ -202,6 +202,61 @@ class ManyBookEnv:
             check(self._L.bk_get_orders(self._h, book, 0, n, a.ctypes.data_as(C.c_void_p)))
         return a
 
+    def order_keys(self, book: int) -> Tuple[np.ndarray, np.ndarray]:
+        """``OrderEntry.key`` of every order (orderbook.rs:34-39) as (key price, key time)."""
+        n = self.order_count(book)
+        kp, kt = np.zeros(n, dtype=np.uint32), np.zeros(n, dtype=np.uint64)
+        if n:
+            check(self._L.bk_get_order_keys(self._h, book, 0, n, _lib.p32(kp), _lib.p64(kt)))
+        return kp, kt
+
+    # ------------------------------------------------------------ JSON snapshots (serde layout of the reference)
+    def book_state(self, book: int, trading: bool = True, trade_vol: Optional[int] = None) -> dict:
+        """The book as ``serde_json`` serialises ``OrderBook`` (orderbook.rs:93-112: t, tick_size, trade_vol, orders
+        [{order, key}], trades, trading; ask_side / bid_side are skipped and rebuilt on load, :891-918)."""
+        side = {1: "Bid", 0: "Ask"}
+        status = ["New", "Active", "Filled", "Cancelled", "Rejected"]  # types.rs:51-63
+        o, (kp, kt) = self.orders(book), self.order_keys(book)
+        orders = []
+        for r, p, t in zip(o, kp.tolist(), kt.tolist()):
+            bid = int(r["side"])
+            orders.append({
+                "order": {"side": side[bid], "status": status[int(r["status"])], "arr_time": int(r["arr_time"]),
+                          "end_time": int(r["end_time"]), "vol": int(r["vol"]), "start_vol": int(r["start_vol"]),
+                          "price": int(r["price"]), "trader_id": int(r["trader_id"]), "order_id": int(r["order_id"])},
+                "key": [side[bid], (MAX_PRICE - p) if bid else p, t],  # price_key, side.rs:300-313
+            })
+        trades = [{"t": int(r["t"]), "side": side[int(r["side"])], "price": int(r["price"]), "vol": int(r["vol"]),
+                   "active_order_id": int(r["active_id"]), "passive_order_id": int(r["passive_id"])}
+                  for r in self.trades(book, first=0)]
+        tick = self.tick_sizes[book % self.assets] if hasattr(self, "tick_sizes") else self.tick_size
+        return {"t": self.time(book), "tick_size": int(tick),
+                "trade_vol": self.trade_vol(book) if trade_vol is None else int(trade_vol), "orders": orders,
+                "trades": trades, "trading": bool(trading)}
+
+    def load_book_state(self, book: int, state: dict):
+        """``TryFrom<OrderBookState>`` (orderbook.rs:891-918) for one book of this env (same tick size)."""
+        side = {"Bid": 1, "Ask": 0}
+        status = {"New": 0, "Active": 1, "Filled": 2, "Cancelled": 3, "Rejected": 4}
+        if int(state["tick_size"]) != self.tick_size:
+            raise ValueError("snapshot tick_size differs from the env's")
+        n = len(state["orders"])
+        o = np.zeros(n, dtype=_lib.ORDER_DTYPE)
+        kp, kt = np.zeros(max(n, 1), dtype=np.uint32), np.zeros(max(n, 1), dtype=np.uint64)
+        for i, e in enumerate(state["orders"]):
+            r, k = e["order"], e["key"]
+            bid = side[r["side"]]
+            o[i] = (bid, status[r["status"]], r["arr_time"], r["end_time"], r["vol"], r["start_vol"], r["price"],
+                    r["trader_id"], r["order_id"])
+            kp[i] = (MAX_PRICE - k[1]) if side[k[0]] else k[1]
+            kt[i] = k[2]
+        t = np.zeros(len(state["trades"]), dtype=_lib.TRADE_DTYPE)
+        for i, r in enumerate(state["trades"]):
+            t[i] = (r["t"], side[r["side"]], r["price"], r["vol"], r["active_order_id"], r["passive_order_id"])
+        check(self._L.bk_load_book(self._h, book, int(state["t"]), int(state["trade_vol"]), n,
+                                   o.ctypes.data_as(C.c_void_p), _lib.p32(kp), _lib.p64(kt), len(t),
+                                   t.ctypes.data_as(C.c_void_p)))
+
     # ------------------------------------------------------------ on-device flow
     def set_random_agents(self, groups: Iterable[RandomAgents | tuple]):
         gs = [g.as_tuple() if isinstance(g, RandomAgents) else g for g in groups]

@@ -160,6 +160,14 @@ int bk_step(bk_env* env);
 int bk_order_status(bk_env* env, uint32_t book, uint64_t order_id, uint8_t* out_status);
 int bk_order_count(bk_env* env, uint32_t book, uint64_t* out);
 int bk_get_orders(bk_env* env, uint32_t book, uint64_t first, uint64_t n, bk_order* out); /* Env::get_orders */
+/* OrderEntry.key (crates/order_book/src/orderbook.rs:34-39) of orders [first, first+n): the price and the time the
+ * order's priority key (side, price_key, t) was last set with — what OrderBook::save_json serialises beside each order. */
+int bk_get_order_keys(bk_env* env, uint32_t book, uint64_t first, uint64_t n, uint32_t* key_price, uint64_t* key_time);
+/* OrderBook::load_json -> TryFrom<OrderBookState> (orderbook.rs:827-918): replace one book's state with a snapshot
+ * (clock, trade volume, all orders listed by id with their keys, all trades); Active orders re-enter the book in key
+ * order and the level-2 record is rebuilt.  Independent books only; nothing may be queued for the book. */
+int bk_load_book(bk_env* env, uint32_t book, uint64_t t, uint32_t trade_vol, uint64_t n_orders, const bk_order* orders,
+                 const uint32_t* key_price, const uint64_t* key_time, uint64_t n_trades, const bk_trade* trades);
 
 /* ---------------------------------------------------- on-device order flow */
 /* An AgentSet of RandomAgents groups, identical for every book, updated in declaration order

@@ -312,6 +312,43 @@ void orc_book_get_trades(void* b, void* out, uint64_t first, uint64_t n) {
   for (uint64_t i = 0; i < n; ++i) fill_trade(ob->trades[first + i], r + i);
 }
 
+// OrderEntry.key of orders [first, first+n) (orderbook.rs:34-39): side (1 = Bid), price_key, t
+void orc_book_get_keys(void* b, uint64_t first, uint64_t n, uint8_t* side_is_bid, uint32_t* price_key, uint64_t* t) {
+  auto* ob = static_cast<OrderBook*>(b);
+  for (uint64_t i = 0; i < n; ++i) {
+    const OrderKey& k = ob->orders[first + i].key;
+    side_is_bid[i] = side_to_bool(k.side);
+    price_key[i] = k.price_key;
+    t[i] = k.t;
+  }
+}
+// TryFrom<OrderBookState> (orderbook.rs:891-918): orders + keys + trades copied as given, the two sides rebuilt by
+// inserting every Active order under its stored key.
+void* orc_book_from_state(uint64_t t, uint32_t tick, uint32_t trade_vol, int trading, int levels, uint64_t n_orders,
+                          const void* orders, const uint8_t* key_bid, const uint32_t* key_price, const uint64_t* key_t,
+                          uint64_t n_trades, const void* trades) {
+  auto* ob = new OrderBook(t, tick, trading != 0, levels);
+  ob->trade_vol = trade_vol;
+  const auto* ro = static_cast<const OrcOrderRec*>(orders);
+  for (uint64_t i = 0; i < n_orders; ++i) {
+    Order o{side_from_bool(ro[i].side_is_bid != 0), static_cast<Status>(ro[i].status), ro[i].arr_time, ro[i].end_time,
+            ro[i].vol, ro[i].start_vol, ro[i].price, ro[i].trader_id, ro[i].order_id};
+    OrderKey k{side_from_bool(key_bid[i] != 0), key_price[i], key_t[i]};
+    ob->orders.push_back(OrderEntry{o, k});
+    if (o.status == Status::Active) {
+      if (o.side == Side::Bid)
+        ob->bid_side.s.insert_order(k, o.order_id, o.vol);
+      else
+        ob->ask_side.s.insert_order(k, o.order_id, o.vol);
+    }
+  }
+  const auto* rt = static_cast<const OrcTradeRec*>(trades);
+  for (uint64_t i = 0; i < n_trades; ++i)
+    ob->trades.push_back(Trade{rt[i].t, side_from_bool(rt[i].side_is_bid != 0), rt[i].price, rt[i].vol, rt[i].active_id,
+                               rt[i].passive_id});
+  return ob;
+}
+
 // ---------------------------------------------------------------- Env ------
 void* orc_env_new(uint64_t seed, uint64_t start, uint32_t tick, uint64_t step, int trading, int levels) {
   return new OrcEnv(seed, start, tick, step, trading != 0, levels);

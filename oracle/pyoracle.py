@@ -117,6 +117,8 @@ def lib() -> C.CDLL:
     sig("orc_book_order_status", i32, vp, u64, p8)
     sig("orc_book_get_orders", None, vp, vp, u64, u64)
     sig("orc_book_get_trades", None, vp, vp, u64, u64)
+    sig("orc_book_get_keys", None, vp, u64, u64, p8, p32, p64)
+    sig("orc_book_from_state", vp, u64, u32, u32, i32, i32, u64, vp, p8, p32, p64, u64, vp)
 
     sig("orc_env_new", vp, u64, u64, u32, u64, i32, i32)
     sig("orc_env_free", None, vp)
@@ -426,61 +428,66 @@ class OrderBook(_BookView):
         if rc != 0:
             raise IndexError(order_id)
 
-    # JSON snapshot: OUT OF SCOPE for the HIP path; the oracle keeps
-    # a minimal own-format round trip so the reference's Python test-suite can run.
+    # JSON snapshot in the reference's serde layout (orderbook.rs:93-112: t, tick_size, trade_vol, orders [{order,
+    # key}], trades, trading; unit enum variants as strings, OrderKey as a 3-array; the sides are not serialised).
+    def state(self):
+        side = {1: "Bid", 0: "Ask"}
+        status = ["New", "Active", "Filled", "Cancelled", "Rejected"]
+        o = self.orders_array()
+        n = len(o)
+        kb, kp, kt = np.zeros(max(n, 1), np.uint8), np.zeros(max(n, 1), np.uint32), np.zeros(max(n, 1), np.uint64)
+        if n:
+            lib().orc_book_get_keys(self._b, 0, n, kb.ctypes.data_as(C.POINTER(C.c_uint8)), _p32(kp), _p64(kt))
+        orders = [{
+            "order": {"side": side[int(r["side"])], "status": status[int(r["status"])], "arr_time": int(r["arr_time"]),
+                      "end_time": int(r["end_time"]), "vol": int(r["vol"]), "start_vol": int(r["start_vol"]),
+                      "price": int(r["price"]), "trader_id": int(r["trader_id"]), "order_id": int(r["order_id"])},
+            "key": [side[int(kb[i])], int(kp[i]), int(kt[i])],
+        } for i, r in enumerate(o)]
+        trades = [{"t": int(r["t"]), "side": side[int(r["side"])], "price": int(r["price"]), "vol": int(r["vol"]),
+                   "active_order_id": int(r["active_id"]), "passive_order_id": int(r["passive_id"])}
+                  for r in self.trades_array()]
+        return {"t": self.get_time(), "tick_size": self._tick, "trade_vol": self.trade_vol(), "orders": orders,
+                "trades": trades, "trading": self._trading}
+
     def save_json_snapshot(self, path, pretty=False):
-        state = {
-            "t": self.get_time(), "tick_size": self._tick, "trading": self._trading, "levels": self._levels,
-            "trade_vol": self.trade_vol(), "orders": self.get_orders(), "trades": self.get_trades(),
-        }
         with open(path, "w") as f:
-            json.dump(state, f, indent=2 if pretty else None)
+            if pretty:
+                json.dump(self.state(), f, indent=2)
+            else:
+                json.dump(self.state(), f, separators=(",", ":"))
+
+
+def order_book_from_state(s, levels=10):
+    """``TryFrom<OrderBookState>`` (orderbook.rs:891-918)."""
+    side = {"Bid": 1, "Ask": 0}
+    status = {"New": 0, "Active": 1, "Filled": 2, "Cancelled": 3, "Rejected": 4}
+    n = len(s["orders"])
+    o = np.zeros(n, dtype=ORDER_DTYPE)
+    kb, kp, kt = np.zeros(max(n, 1), np.uint8), np.zeros(max(n, 1), np.uint32), np.zeros(max(n, 1), np.uint64)
+    for i, e in enumerate(s["orders"]):
+        r, k = e["order"], e["key"]
+        o[i] = (side[r["side"]], status[r["status"]], r["arr_time"], r["end_time"], r["vol"], r["start_vol"],
+                r["price"], r["trader_id"], r["order_id"])
+        kb[i], kp[i], kt[i] = side[k[0]], k[1], k[2]
+    t = np.zeros(len(s["trades"]), dtype=TRADE_DTYPE)
+    for i, r in enumerate(s["trades"]):
+        t[i] = (r["t"], side[r["side"]], r["price"], r["vol"], r["active_order_id"], r["passive_order_id"])
+    ob = OrderBook.__new__(OrderBook)
+    ptr = lib().orc_book_from_state(int(s["t"]), int(s["tick_size"]), int(s["trade_vol"]), int(bool(s["trading"])),
+                                    int(levels), n, o.ctypes.data_as(C.c_void_p),
+                                    kb.ctypes.data_as(C.POINTER(C.c_uint8)), _p32(kp), _p64(kt), len(t),
+                                    t.ctypes.data_as(C.c_void_p))
+    _BookView.__init__(ob, ptr, levels, int(s["tick_size"]))
+    ob._trading, ob._own = bool(s["trading"]), True
+    return ob
 
 
 def order_book_from_json(path):
     with open(path) as f:
-        s = json.load(f)
-    ob = _LoadedBook(s)
-    return ob
+        return order_book_from_state(json.load(f))
 
 
-class _LoadedBook:
-    """Snapshot view: aggregates rebuilt from Active orders (ref orderbook.rs:891-918)."""
-
-    def __init__(self, s):
-        self._s = s
-        self._orders = [tuple(o) for o in s["orders"]]
-        self._trades = [tuple(t) for t in s["trades"]]
-
-    def _side(self, bid):
-        return [o for o in self._orders if o[1] == 1 and o[0] == bid]
-
-    def bid_ask(self):
-        b, a = self._side(True), self._side(False)
-        return (max(o[6] for o in b) if b else 0, min(o[6] for o in a) if a else MAX_PRICE)
-
-    def best_bid_vol_and_orders(self):
-        b = self._side(True)
-        if not b:
-            return (0, 0)
-        p = max(o[6] for o in b)
-        return (sum(o[4] for o in b if o[6] == p), sum(1 for o in b if o[6] == p))
-
-    def best_ask_vol_and_orders(self):
-        a = self._side(False)
-        if not a:
-            return (0, 0)
-        p = min(o[6] for o in a)
-        return (sum(o[4] for o in a if o[6] == p), sum(1 for o in a if o[6] == p))
-
-    def get_orders(self):
-        return list(self._orders)
-
-    def get_trades(self):
-        return list(self._trades)
-
-
-# ------------------------------------------------------------------------- Env
 class _EnvBase:
     LEVELS = 10
 

@@ -101,7 +101,35 @@ def rust_random_agents():
     print("oracle c2x4:", m.history().shape, m.trade_counts())
 
 
+def orderbook_snapshot():
+    # a serde-layout OrderBook snapshot (orderbook.rs:93-112) with every order status, re-keyed and reduced orders
+    import pyoracle
+
+    rng = np.random.default_rng(7)
+    ob = pyoracle.OrderBook(100, 2)
+    t = 100
+    for _ in range(60):
+        t += int(rng.integers(1, 4))
+        ob.set_time(t)
+        n, kind = ob.n_orders(), rng.random()
+        if kind < 0.6 or n == 0:
+            ob.place_order(bool(rng.integers(0, 2)), int(rng.integers(1, 40)), int(rng.integers(0, 9)),
+                           None if rng.random() < 0.1 else int(rng.integers(45, 56)) * 2)
+        elif kind < 0.8:
+            ob.cancel_order(int(rng.integers(0, n)))
+        else:
+            ob.modify_order(int(rng.integers(0, n)), None if rng.random() < 0.4 else int(rng.integers(45, 56)) * 2,
+                            None if rng.random() < 0.4 else int(rng.integers(1, 40)))
+    ob.disable_trading()
+    ob.set_time(t + 1)
+    ob.place_order(True, 5, 1, None)  # Rejected
+    ob.enable_trading()
+    ob.save_json_snapshot(os.path.join(HERE, "orderbook_snapshot.json"))
+    print("orderbook snapshot:", ob.n_orders(), "orders", len(ob.trades_array()), "trades", ob.bid_ask())
+
+
 if __name__ == "__main__":
+    orderbook_snapshot()
     c1_random_trades()
     numpy_agents()
     rust_random_agents()

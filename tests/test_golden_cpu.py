@@ -94,3 +94,12 @@ def test_many_books_equals_single_env_sim_runner(oracle):
         assert np.array_equal(env.history(), m.history()[:, b])
         assert tuple(st) == tuple(m.rng_states()[b])
         assert env.get_trades() == m.book(b).get_trades()
+
+
+def test_golden_orderbook_snapshot_round_trips_through_the_oracle(oracle):
+    import json
+    path = os.path.join(G, "orderbook_snapshot.json")
+    s = json.load(open(path))
+    ob = oracle.order_book_from_json(path)
+    assert ob.state() == s
+    assert {e["order"]["status"] for e in s["orders"]} == {"Active", "Filled", "Cancelled", "Rejected"}

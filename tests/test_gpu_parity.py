@@ -5,6 +5,8 @@ sides: book b's RNG is ``seed_from_u64(seed + b)``; outputs compared: level-2 hi
 (every step, every book), trade records (order, times, prices, vols, fill ids), RNG state,
 order/trade counts and the resting orders in priority order.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -848,3 +850,89 @@ def test_market_host_driven_random_stream(bk, oracle, seed):
     for m in range(NM):
         for a in range(A):
             assert env.rng_state(env.book(m, a)) == (int(want_rng[m, 0]), int(want_rng[m, 1]))
+
+
+# ------------------------------------------------------------------ JSON snapshots (serde layout of the reference)
+def _random_book_ops(rng, books, t0, n_ops):
+    """The same random immediate-mode operations on every book in ``books`` (distinct times: SURVEY App. A.9)."""
+    t = t0
+    for _ in range(n_ops):
+        t += int(rng.integers(1, 5))
+        for b in books:
+            b.set_time(t)
+        n = len(books[0].get_orders())
+        kind = rng.random()
+        if kind < 0.6 or n == 0:
+            args = (bool(rng.integers(0, 2)), int(rng.integers(1, 40)), int(rng.integers(0, 9)),
+                    None if rng.random() < 0.1 else int(rng.integers(45, 56)) * 2)
+            ids = {b.place_order(*args) for b in books}
+            assert len(ids) == 1
+        elif kind < 0.8:
+            i = int(rng.integers(0, n))
+            for b in books:
+                b.cancel_order(i)
+        else:
+            i = int(rng.integers(0, n))
+            np_ = None if rng.random() < 0.4 else int(rng.integers(45, 56)) * 2
+            nv = None if rng.random() < 0.4 else int(rng.integers(1, 40))
+            for b in books:
+                b.modify_order(i, np_, nv)
+    return t
+
+
+def test_json_snapshot_matches_oracle_and_round_trips(bk, oracle, tmp_path):
+    import json
+    rng = np.random.default_rng(12)
+    g, o = bk.core.OrderBook(0, 2), oracle.OrderBook(0, 2)
+    t = _random_book_ops(rng, [g, o], 0, 150)
+    # the device's serde state (orders WITH their priority keys, trades, clock, trade_vol) equals the oracle's
+    gp, op = tmp_path / "gpu.json", tmp_path / "orc.json"
+    g.save_json_snapshot(str(gp))
+    o.save_json_snapshot(str(op))
+    assert json.loads(gp.read_text()) == json.loads(op.read_text())
+    assert gp.read_text() == op.read_text()
+    g.save_json_snapshot(str(tmp_path / "pretty.json"), pretty=True)
+    assert json.loads((tmp_path / "pretty.json").read_text()) == json.loads(op.read_text())
+    # cross-load: a snapshot written by either side continues identically on both
+    g2 = bk.core.order_book_from_json(str(op))
+    o2 = oracle.order_book_from_json(str(gp))
+    for x in (g2, o2):
+        assert x.bid_ask() == o.bid_ask() and x.get_orders() == o.get_orders() and x.get_trades() == o.get_trades()
+        assert x.best_bid_vol_and_orders() == o.best_bid_vol_and_orders()
+        assert x.best_ask_vol_and_orders() == o.best_ask_vol_and_orders()
+        assert (x.bid_vol(), x.ask_vol()) == (o.bid_vol(), o.ask_vol())
+    _random_book_ops(rng, [g, o, g2, o2], t, 120)
+    want = o.state()
+    assert o2.state() == want
+    for x in (g, g2):
+        x.save_json_snapshot(str(gp))
+        assert json.loads(gp.read_text()) == want
+
+
+def test_json_snapshot_python_reference_test(bk, tmp_path):  # ref tests/test_order_book.py:189-210
+    ob = bk.core.OrderBook(0, 1)
+    ob.place_order(True, 100, 101, price=50)
+    ob.place_order(False, 100, 101, price=60)
+    ob.place_order(True, 10, 11, price=55)
+    ob.place_order(False, 20, 12, price=65)
+    path = str(tmp_path / "foo.json")
+    ob.save_json_snapshot(path)
+    loaded_ob = bk.core.order_book_from_json(path)
+    assert ob.bid_ask() == loaded_ob.bid_ask()
+    assert ob.best_ask_vol_and_orders() == loaded_ob.best_ask_vol_and_orders()
+    assert ob.best_bid_vol_and_orders() == loaded_ob.best_bid_vol_and_orders()
+    assert ob.get_orders() == loaded_ob.get_orders()
+    assert ob.get_trades() == loaded_ob.get_trades()
+
+
+def test_json_golden_snapshot_loads_on_gpu(bk):
+    """tests/golden/orderbook_snapshot.json: written by the oracle in the build container (make_golden.py)."""
+    import json
+    path = os.path.join(os.path.dirname(__file__), "golden", "orderbook_snapshot.json")
+    s = json.load(open(path))
+    ob = bk.core.order_book_from_json(path)
+    assert ob._env.book_state(0, trading=s["trading"], trade_vol=ob.trade_vol()) == s
+    act = [e["order"] for e in s["orders"] if e["order"]["status"] == "Active"]
+    bids = [x["price"] for x in act if x["side"] == "Bid"]
+    asks = [x["price"] for x in act if x["side"] == "Ask"]
+    assert ob.bid_ask() == (max(bids, default=0), min(asks, default=2**32 - 1))

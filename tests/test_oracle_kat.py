@@ -412,3 +412,28 @@ def test_random_market_agents_equal_single_book_agents(oracle):
     a.run(30)
     b.run(30)
     assert np.array_equal(a.history(), b.history()) and np.array_equal(a.rng_states(), b.rng_states())
+
+
+def test_json_snapshot_serde_layout(oracle, tmp_path):
+    """serde_json layout of OrderBook (orderbook.rs:93-112, OrderEntry :33-39, Order types.rs:78-99, Trade :104-118,
+    unit enums as strings, OrderKey = (Side, u32, u64) as an array; ask_side/bid_side skipped): written out by hand."""
+    ob = oracle.OrderBook(5, 1)
+    ob.place_order(True, 10, 7, 50)      # id 0 rests: key (Bid, u32::MAX - 50, 5)
+    ob.set_time(6)
+    ob.place_order(False, 4, 8, None)    # id 1 market sell, fills 4 @ 50: key stays provisional (Ask, 0, 0)
+    p = tmp_path / "s.json"
+    ob.save_json_snapshot(str(p))
+    assert p.read_text() == (
+        '{"t":6,"tick_size":1,"trade_vol":4,"orders":['
+        '{"order":{"side":"Bid","status":"Active","arr_time":5,"end_time":18446744073709551615,"vol":6,"start_vol":10,'
+        '"price":50,"trader_id":7,"order_id":0},"key":["Bid",4294967245,5]},'
+        '{"order":{"side":"Ask","status":"Filled","arr_time":6,"end_time":6,"vol":0,"start_vol":4,'
+        '"price":0,"trader_id":8,"order_id":1},"key":["Ask",0,0]}],'
+        '"trades":[{"t":6,"side":"Bid","price":50,"vol":4,"active_order_id":1,"passive_order_id":0}],"trading":true}')
+    lb = oracle.order_book_from_json(str(p))  # TryFrom<OrderBookState>, orderbook.rs:891-918
+    assert lb.state() == ob.state() and lb.bid_ask() == ob.bid_ask() == (50, 2**32 - 1)
+    assert lb.best_bid_vol_and_orders() == (6, 1)
+    lb.set_time(7)
+    ob.set_time(7)
+    assert lb.place_order(False, 6, 9, 50) == ob.place_order(False, 6, 9, 50) == 2
+    assert lb.state() == ob.state()
