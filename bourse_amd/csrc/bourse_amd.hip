@@ -1028,9 +1028,9 @@ int bk_load_book(bk_env* env, uint32_t book, uint64_t t, uint32_t trade_vol, uin
   if (int rc = check_book(env, book)) return rc;
   if ((n_orders && (!orders || !key_price || !key_time)) || (n_trades && !trades))
     return fail(BK_INVALID_ARGUMENT, "null argument");
-  if (env->M > 1) return fail(BK_INVALID_ARGUMENT, "bk_load_book: independent books only");
   BookHost& bh = env->books[book];
-  if (!bh.queue.empty()) return fail(BK_INVALID_ARGUMENT, "events are queued for this book");
+  if (!env->books[book - book % env->M].queue.empty())
+    return fail(BK_INVALID_ARGUMENT, "events are queued for this book (market)");
   if (n_orders > env->cfg.max_orders) return fail(BK_CAPACITY, "snapshot holds more orders than max_orders");
   if (n_trades > env->cfg.trade_capacity) return fail(BK_CAPACITY, "snapshot holds more trades than trade_capacity");
   if (n_orders >= 0xFFFFFFFFull) return fail(BK_CAPACITY, "order id space exhausted");
@@ -1046,7 +1046,7 @@ int bk_load_book(bk_env* env, uint32_t book, uint64_t t, uint32_t trade_vol, uin
   HIPCHK(hipStreamSynchronize(env->stream));
   std::stable_sort(act.begin(), act.end(), [&](uint64_t a, uint64_t b) { return key_time[a] < key_time[b]; });
 
-  const uint32_t L = env->cfg.levels, W = env->W, tick = env->asset_tick[0];
+  const uint32_t L = env->cfg.levels, W = env->W, tick = env->asset_tick[book % env->M];
   std::vector<uint32_t> st(env->stride, 0u), l2(W, 0u);
   uint32_t* hdr = st.data();
   HIPCHK(hipMemcpy(hdr, env->state.p + static_cast<size_t>(book) * env->stride, HDR_DW * 4, hipMemcpyDeviceToHost));

@@ -238,8 +238,9 @@ class ManyBookEnv:
         """``TryFrom<OrderBookState>`` (orderbook.rs:891-918) for one book of this env (same tick size)."""
         side = {"Bid": 1, "Ask": 0}
         status = {"New": 0, "Active": 1, "Filled": 2, "Cancelled": 3, "Rejected": 4}
-        if int(state["tick_size"]) != self.tick_size:
-            raise ValueError("snapshot tick_size differs from the env's")
+        tick = self.tick_sizes[book % self.assets] if hasattr(self, "tick_sizes") else self.tick_size
+        if int(state["tick_size"]) != tick:
+            raise ValueError("snapshot tick_size differs from the book's")
         n = len(state["orders"])
         o = np.zeros(n, dtype=_lib.ORDER_DTYPE)
         kp, kt = np.zeros(max(n, 1), dtype=np.uint32), np.zeros(max(n, 1), dtype=np.uint64)
@@ -553,6 +554,29 @@ class ManyMarketEnv(ManyBookEnv):
     def modify_order(self, market: int, asset: int, order_id: int, new_price: Optional[int] = None,
                      new_vol: Optional[int] = None):
         super().modify_order(self.book(market, asset), order_id, new_price, new_vol)
+
+
+    # Market::save_json / load_json (market.rs:367-390): {"order_books": [OrderBook; ASSETS]}
+    def market_state(self, market: int, trading: bool = True) -> dict:
+        return {"order_books": [self.book_state(self.book(market, a), trading) for a in range(self.assets)]}
+
+    def load_market_state(self, market: int, state: dict):
+        if len(state["order_books"]) != self.assets:
+            raise ValueError("snapshot holds a different number of assets")
+        for a, s in enumerate(state["order_books"]):
+            self.load_book_state(self.book(market, a), s)
+
+    def save_json(self, market: int, path: str, pretty: bool = False, trading: bool = True):
+        import json
+
+        with open(path, "w") as f:
+            json.dump(self.market_state(market, trading), f, **({"indent": 2} if pretty else {"separators": (",", ":")}))
+
+    def load_json(self, market: int, path: str):
+        import json
+
+        with open(path) as f:
+            self.load_market_state(market, json.load(f))
 
 
 def market_sim_runner(env: ManyMarketEnv, agents: Sequence[RandomMarketAgents | tuple], n_steps: int):

@@ -165,7 +165,7 @@ int bk_get_orders(bk_env* env, uint32_t book, uint64_t first, uint64_t n, bk_ord
 int bk_get_order_keys(bk_env* env, uint32_t book, uint64_t first, uint64_t n, uint32_t* key_price, uint64_t* key_time);
 /* OrderBook::load_json -> TryFrom<OrderBookState> (orderbook.rs:827-918): replace one book's state with a snapshot
  * (clock, trade volume, all orders listed by id with their keys, all trades); Active orders re-enter the book in key
- * order and the level-2 record is rebuilt.  Independent books only; nothing may be queued for the book. */
+ * order and the level-2 record is rebuilt.  Nothing may be queued for the book (its market). */
 int bk_load_book(bk_env* env, uint32_t book, uint64_t t, uint32_t trade_vol, uint64_t n_orders, const bk_order* orders,
                  const uint32_t* key_price, const uint64_t* key_time, uint64_t n_trades, const bk_trade* trades);
 

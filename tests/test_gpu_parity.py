@@ -850,6 +850,15 @@ def test_market_host_driven_random_stream(bk, oracle, seed):
     for m in range(NM):
         for a in range(A):
             assert env.rng_state(env.book(m, a)) == (int(want_rng[m, 0]), int(want_rng[m, 1]))
+    # Market::save_json layout (market.rs:367-377): {"order_books": [...]}; load into another market and carry on
+    st = env.market_state(1)
+    for a in range(A):
+        v = ref.book(1, a)
+        v._trading = True
+        assert st["order_books"][a] == oracle.OrderBook.state(v), a
+    env.load_market_state(0, st)
+    assert env.market_state(0) == st
+    assert np.array_equal(env.level2()[0:A], env.level2()[A:2 * A])
 
 
 # ------------------------------------------------------------------ JSON snapshots (serde layout of the reference)
