@@ -5,7 +5,7 @@ sys.path.insert(0, ROOT)
 import bourse_amd
 T, L = 50, 32
 groups = [(64, (32, 64), (10, 20), 2, 0.8), (64, (32, 64), (50, 70), 2, 0.2)]
-for B in (8192, 32768, 65536, 131072):
+for B in (32768, 65536, 131072):
     row = []
     for pipe in ("fused", "split"):
         env = bourse_amd.ManyBookEnv(B, 101, 0, 2, 100_000, levels=L, max_live_orders=128, trade_capacity=64 * T, history_capacity=T)
