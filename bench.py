@@ -28,6 +28,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
+N_CU, CLOCK_GHZ = 256, 2.4  # same guide: 256 CUs, 2.4 GHz peak engine clock
 
 WORKLOADS = {
     # name: (books_per_gpu, levels, groups)                                   SURVEY §8d
@@ -210,6 +211,19 @@ def main():
     K = kernels[dominant]
     achieved, avg_ms, n_launch, traffic = K["achieved"], K["avg_launch_ms"], K["launches"], K["traffic"]
     bytes_per_bookstep, book_steps_per_launch = K["bytes_per_book_step"], K["book_steps_per_launch"]
+    # What actually bounds the path: instruction ISSUE, not bytes.  Per CU and clock the sequencer issues
+    # at most one scalar and one vector instruction; the counts per book-step are PMC figures committed under profiles/.
+    issue = None
+    ins = {k: pmc.get(k, {}).get("insts_per_book_step") for k in kernels}
+    if all(ins.values()) and ins:
+        salu = sum(v["salu"] for v in ins.values())
+        valu = sum(v["valu"] for v in ins.values())
+        peak = N_CU * CLOCK_GHZ * 1e9  # instructions/s of one type, whole GPU
+        per_gpu = value / world
+        issue = {"bound": "scalar/vector issue (1 SALU + 1 VALU per CU per clock)", "salu_per_book_step": salu,
+                 "valu_per_book_step": valu, "peak_insts_per_s": peak, "salu_frac": salu * per_gpu / peak,
+                 "valu_frac": valu * per_gpu / peak, "events_per_s_per_cu": ev_per_bs * per_gpu / N_CU,
+                 "assumed_clock_ghz": CLOCK_GHZ, "n_cu": N_CU}
     out = {
         "metric": "book-steps/sec", "value": value, "unit": "book-steps/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": dt * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
@@ -231,6 +245,7 @@ def main():
             "avg_launch_ms": avg_ms, "launches": n_launch, "bytes_per_book_step": bytes_per_bookstep,
             "book_steps_per_launch": book_steps_per_launch,
             "kernels": kernels,
+            "issue": issue,
         },
     }
     if gather is not None:
