@@ -117,6 +117,8 @@ SIGNATURES = {
     "bk_trade_counts": (_i32, [_vp, _p64]),
     "bk_get_trades": (_i32, [_vp, _u32, _u64, _u64, _vp]),
     "bk_clear_trades": (_i32, [_vp]),
+    "bk_trades_compact": (_i32, [_vp, _p64]),
+    "bk_trades_compact_copy_async": (_i32, [_vp, _vp, _p64, _vp]),
     "bk_time": (_i32, [_vp, _u32, _p64]),
     "bk_set_time": (_i32, [_vp, _u32, _u64]),
     "bk_trade_vol": (_i32, [_vp, _u32, _p32]),

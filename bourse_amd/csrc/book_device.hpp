@@ -1137,6 +1137,74 @@ __global__ void k_stats(const uint32_t* state, uint32_t stride, const uint32_t* 
   if (blockIdx.x == 0 && threadIdx.x == 0) out->n_books = n_books;
 }
 
+// ---- trade egress: compact every book's retained records into one dense stream ----
+struct OutTrade {  // == bk_trade (40 B), the record layout of the C ABI
+  uint64_t t;
+  uint32_t side_is_bid, price, vol, reserved;
+  uint64_t active, passive;
+};
+// counts[b] = records retained for book b (since trade_base, at most trade_cap); then an exclusive scan by ONE
+// workgroup: off[b] = sum of counts[0..b), off[n_books] = total.  B <= a few 10^5: a single 1024-thread block suffices.
+__global__ __launch_bounds__(1024) void k_trade_scan(const uint32_t* state, uint32_t stride, uint32_t n_books,
+                                                     uint32_t trade_cap, unsigned long long* off) {
+  __shared__ unsigned long long part[1024];
+  __shared__ unsigned long long carry;
+  const uint32_t tid = threadIdx.x;
+  if (tid == 0) carry = 0;
+  __syncthreads();
+  for (uint32_t base = 0; base < n_books; base += 1024) {
+    const uint32_t b = base + tid;
+    unsigned long long c = 0;
+    if (b < n_books) {
+      const uint32_t* h = state + (size_t)b * stride;
+      const uint64_t n = mk64(h[H_TRADES_LO], h[H_TRADES_HI]) - mk64(h[H_TRADE_BASE_LO], h[H_TRADE_BASE_HI]);
+      c = n < trade_cap ? n : trade_cap;
+    }
+    part[tid] = c;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024; d <<= 1) {  // Hillis-Steele inclusive scan
+      const unsigned long long v = tid >= d ? part[tid - d] : 0ull;
+      __syncthreads();
+      part[tid] += v;
+      __syncthreads();
+    }
+    if (b < n_books) off[b] = carry + part[tid] - c;
+    __syncthreads();
+    if (tid == 1023) carry += part[1023];
+    __syncthreads();
+  }
+  if (tid == 0) off[n_books] = carry;
+}
+// one wave per book: copy its retained records to dense[off[b] ...] in the C ABI layout, then mark them consumed
+// (trade_base = n_trades, as bk_clear_trades does)
+__global__ __launch_bounds__(256) void k_trade_gather(uint32_t* state, uint32_t stride, uint32_t n_books,
+                                                      uint32_t trade_cap, const DevTrade* trades,
+                                                      const unsigned long long* off, OutTrade* dense) {
+  const int lane = threadIdx.x & 63;
+  const uint32_t b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= n_books) return;
+  uint32_t* h = state + (size_t)b * stride;
+  const uint32_t cnt = (uint32_t)(off[b + 1] - off[b]);
+  const DevTrade* src = trades + (size_t)b * trade_cap;
+  OutTrade* dst = dense + off[b];
+  for (uint32_t i = lane; i < cnt; i += 64) {
+    const DevTrade d = src[i];
+    OutTrade o;
+    o.t = mk64(d.t_lo, d.t_hi);
+    o.side_is_bid = d.side_is_bid;
+    o.price = d.price;
+    o.vol = d.vol;
+    o.reserved = 0;
+    o.active = d.active;
+    o.passive = d.passive;
+    dst[i] = o;
+  }
+  if (lane == 0) {
+    h[H_TRADE_BASE_LO] = h[H_TRADES_LO];
+    h[H_TRADE_BASE_HI] = h[H_TRADES_HI];
+  }
+}
+
 // self-test of the DPP reductions (used by tests on the GPU box)
 __global__ void k_selftest_reduce(const uint32_t* in, uint32_t* out) {
   const int lane = threadIdx.x & 63;

@@ -22,6 +22,7 @@
 using namespace bkd;
 
 static_assert(sizeof(DevStats) == sizeof(bk_stats), "bk_stats layout");
+static_assert(sizeof(OutTrade) == sizeof(bk_trade), "bk_trade layout");
 static_assert(sizeof(bk_config) == 72 && sizeof(bk_random_agents) == 28 && sizeof(bk_trade) == 40 &&
                   sizeof(bk_order) == 48,
               "C ABI struct layout (mirrored by bourse_amd/_lib.py)");
@@ -124,6 +125,9 @@ struct bk_env {
   DevBuf<DevTrade> trades;
   DevBuf<DevOrderLog> order_log;
   DevBuf<DevStats> stats;
+  DevBuf<OutTrade> tr_dense;           // bk_trades_compact: dense record stream + CSR offsets
+  DevBuf<unsigned long long> tr_off;
+  uint64_t tr_total = 0;
   DevBuf<MixedDesc> mixed_descs;  // AgentSets with Noise/Momentum members (k_run_mixed)
   uint32_t n_mixed = 0, n_fixed = 0;
   std::vector<BookHost> books;
@@ -982,6 +986,51 @@ int bk_get_trades(bk_env* env, uint32_t book, uint64_t first, uint64_t n, bk_tra
     t.active_order_id = d.active;
     t.passive_order_id = d.passive;
   }
+  return BK_OK;
+}
+
+// Trade egress at scale (Env::get_trades for every book at once): gather every book's retained
+// records into ONE dense device buffer in the bk_trade layout with CSR offsets (book b owns [off[b], off[b+1])), and mark
+// them consumed (as bk_clear_trades).  Returns the number of records; fetch them with bk_trades_compact_copy_async.
+int bk_trades_compact(bk_env* env, uint64_t* out_total) {
+  if (!env) return fail(BK_INVALID_ARGUMENT, "null env");
+  if (int rc = use_device(env)) return rc;
+  const uint32_t B = env->cfg.n_books;
+  if (!env->tr_off.p) HIPCHK(env->tr_off.alloc(static_cast<size_t>(B) + 1));
+  hipLaunchKernelGGL(k_trade_scan, dim3(1), dim3(1024), 0, env->stream, env->state.p, env->stride, B,
+                     env->cfg.trade_capacity, env->tr_off.p);
+  HIPCHK(hipGetLastError());
+  unsigned long long total = 0;
+  HIPCHK(hipMemcpyAsync(&total, env->tr_off.p + B, 8, hipMemcpyDeviceToHost, env->stream));
+  HIPCHK(hipStreamSynchronize(env->stream));
+  if (total > env->tr_dense.n) HIPCHK(env->tr_dense.alloc(std::max<size_t>(total + total / 4, 1024)));
+  hipLaunchKernelGGL(k_trade_gather, dim3((B + 3) / 4), dim3(256), 0, env->stream, env->state.p, env->stride, B,
+                     env->cfg.trade_capacity, env->trades.p, env->tr_off.p, env->tr_dense.p);
+  HIPCHK(hipGetLastError());
+  env->tr_total = total;
+  if (out_total) *out_total = total;
+  return BK_OK;
+}
+
+// Copy the stream made by the last bk_trades_compact: `records` (tr_total x bk_trade) and `offsets` (n_books + 1) to
+// host memory on `copy_stream` (ordered after the compaction; NULL = the env's stream, synchronous).  Pinned
+// destinations (bk_pinned_alloc) make the copy overlap the next bk_run.
+int bk_trades_compact_copy_async(bk_env* env, bk_trade* records, uint64_t* offsets, void* copy_stream) {
+  if (!env || !offsets || (env->tr_total && !records)) return fail(BK_INVALID_ARGUMENT, "null argument");
+  if (!env->tr_off.p) return fail(BK_INVALID_ARGUMENT, "call bk_trades_compact first");
+  if (int rc = use_device(env)) return rc;
+  hipStream_t cs = copy_stream ? static_cast<hipStream_t>(copy_stream) : env->stream;
+  if (copy_stream) {
+    hipEvent_t ev;
+    HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    HIPCHK(hipEventRecord(ev, env->stream));
+    HIPCHK(hipStreamWaitEvent(cs, ev, 0));
+    HIPCHK(hipEventDestroy(ev));
+  }
+  HIPCHK(hipMemcpyAsync(offsets, env->tr_off.p, (static_cast<size_t>(env->cfg.n_books) + 1) * 8, hipMemcpyDeviceToHost, cs));
+  if (env->tr_total)
+    HIPCHK(hipMemcpyAsync(records, env->tr_dense.p, env->tr_total * sizeof(bk_trade), hipMemcpyDeviceToHost, cs));
+  if (!copy_stream) HIPCHK(hipStreamSynchronize(cs));
   return BK_OK;
 }
 

@@ -350,30 +350,46 @@ class ManyBookEnv:
             check(self._L.bk_history(self._h, first_step, n_steps, first_book, nb, _lib.p32(out)))
         return out
 
-    def stream_history(self, n_steps: int, chunk: int, on_chunk=None) -> dict:
+    def stream_history(self, n_steps: int, chunk: int, on_chunk=None, trades: bool = False,
+                       trade_records_per_chunk: Optional[int] = None) -> dict:
         """Run ``n_steps`` in chunks while the previous chunk's L2 records stream to pinned host memory on a copy
-        stream (double-buffered; needs history_capacity >= 2 * chunk).  ``on_chunk(first_step, array[chunk, B, W])`` is
-        called once a chunk has landed (the array is reused two chunks later).  Returns timing figures."""
+        stream (double-buffered; needs history_capacity >= 2 * chunk).  ``on_chunk(first_step, l2[chunk, B, W])`` is
+        called once a chunk has landed (the arrays are reused two chunks later).  With ``trades=True`` the chunk's trade
+        records travel too, compacted on the device into one dense stream (``bk_trades_compact``):
+        ``on_chunk(first_step, l2, (offsets[B+1], records))``; needs trade_capacity >= the trades of one chunk per
+        book.  Returns timing figures."""
         import time
 
         if chunk < 1 or self.history_capacity < 2 * chunk:
             raise ValueError("stream_history needs history_capacity >= 2 * chunk")
         L, W, B = self._L, self.width, self.n_books
         out_t = C.POINTER(C.c_uint32)
-        streams, bufs = [], []
+        tcap = int(trade_records_per_chunk or 64 * chunk * B) if trades else 0
+        streams, bufs, tbufs = [], [], []
         for _ in range(2):  # chunk k uses stream/buffer k % 2: copy k overlaps run k+1, and is awaited before run k+2
             cs, p = C.c_void_p(), C.c_void_p()
             check(L.bk_stream_create(C.byref(cs)))
             check(L.bk_pinned_alloc(chunk * B * W * 4, C.byref(p)))
             streams.append(cs)
             bufs.append((p, np.ctypeslib.as_array(C.cast(p, out_t), shape=(chunk, B, W))))
-        inflight = [None, None]  # per buffer: (first_step, n_steps)
+            if trades:
+                pr, po = C.c_void_p(), C.c_void_p()
+                check(L.bk_pinned_alloc(tcap * 40, C.byref(pr)))
+                check(L.bk_pinned_alloc((B + 1) * 8, C.byref(po)))
+                rec = np.ctypeslib.as_array(C.cast(pr, C.POINTER(C.c_uint8)), shape=(tcap * 40,)).view(_lib.TRADE_DTYPE)
+                off = np.ctypeslib.as_array(C.cast(po, C.POINTER(C.c_uint64)), shape=(B + 1,))
+                tbufs.append((pr, po, rec, off))
+        inflight = [None, None]  # per buffer: (first_step, n_steps, n_trade_records)
 
         def land(i):
             if inflight[i] is not None:
                 check(L.bk_stream_sync(streams[i]))
                 if on_chunk is not None:
-                    on_chunk(inflight[i][0], bufs[i][1][: inflight[i][1]])
+                    first, c, nt = inflight[i]
+                    if trades:
+                        on_chunk(first, bufs[i][1][:c], (tbufs[i][3], tbufs[i][2][:nt]))
+                    else:
+                        on_chunk(first, bufs[i][1][:c])
                 inflight[i] = None
 
         done, k, nbytes = 0, 0, 0
@@ -386,7 +402,18 @@ class ManyBookEnv:
                 first = self.steps_done()
                 self.run(c, sync=False)
                 check(L.bk_history_copy_async(self._h, first, c, 0, B, C.cast(bufs[i][0], out_t), streams[i]))
-                inflight[i] = (first, c)
+                nt = 0
+                if trades:
+                    check(L.bk_stream_sync(streams[1 - i]))  # the device's dense buffer is still being copied out
+                    total = C.c_uint64(0)
+                    check(L.bk_trades_compact(self._h, C.byref(total)))
+                    nt = int(total.value)
+                    if nt > tcap:
+                        raise _lib.CapacityError(f"{nt} trade records in one chunk exceed trade_records_per_chunk={tcap}")
+                    check(L.bk_trades_compact_copy_async(self._h, tbufs[i][0], C.cast(tbufs[i][1], C.POINTER(C.c_uint64)),
+                                                         streams[i]))
+                    nbytes += nt * 40 + (B + 1) * 8
+                inflight[i] = (first, c, nt)
                 nbytes += c * B * W * 4
                 done += c
                 k += 1
@@ -399,6 +426,9 @@ class ManyBookEnv:
                 L.bk_stream_sync(cs)
                 L.bk_pinned_free(p)
                 L.bk_stream_destroy(cs)
+            for pr, po, _, _ in tbufs:
+                L.bk_pinned_free(pr)
+                L.bk_pinned_free(po)
         return {"seconds": dt, "book_steps_per_s": B * n_steps / dt, "d2h_gb_per_s": nbytes / dt / 1e9, "bytes": nbytes}
 
     def clear_history(self):
@@ -422,6 +452,16 @@ class ManyBookEnv:
         if n:
             check(self._L.bk_get_trades(self._h, book, first, n, a.ctypes.data_as(C.c_void_p)))
         return a
+
+    def drain_trades(self) -> Tuple[np.ndarray, np.ndarray]:
+        """All retained trade records of all books as ONE dense array + CSR offsets (book b: ``rec[off[b]:off[b+1]]``),
+        compacted on the device; the records are then consumed (like ``clear_trades``)."""
+        total = C.c_uint64(0)
+        check(self._L.bk_trades_compact(self._h, C.byref(total)))
+        rec = np.zeros(int(total.value), dtype=_lib.TRADE_DTYPE)
+        off = np.zeros(self.n_books + 1, dtype=np.uint64)
+        check(self._L.bk_trades_compact_copy_async(self._h, rec.ctypes.data_as(C.c_void_p), _lib.p64(off), None))
+        return off, rec
 
     def clear_trades(self):
         check(self._L.bk_clear_trades(self._h))

@@ -219,6 +219,14 @@ int bk_trade_count(bk_env* env, uint32_t book, uint64_t* total, uint64_t* first_
 int bk_trade_counts(bk_env* env, uint64_t* totals /* [n_books] */);
 int bk_get_trades(bk_env* env, uint32_t book, uint64_t first, uint64_t n, bk_trade* out);
 int bk_clear_trades(bk_env* env);
+/* Trade egress at scale (Env::get_trades, env.rs:277-280, for every book at once): bk_trades_compact gathers all
+ * retained records into one dense device stream in the bk_trade layout with CSR offsets (book b owns
+ * [offsets[b], offsets[b+1])) and marks them consumed (like bk_clear_trades); *out_total = number of records.
+ * bk_trades_compact_copy_async copies that stream (records: out_total x bk_trade, offsets: n_books + 1) to the host on
+ * `copy_stream`, ordered after the compaction (NULL: the env's stream, synchronous), so it overlaps the next bk_run.
+ * A book whose records overflowed trade_capacity keeps its BK_FLAG_TRADE_OVERFLOW flag: nothing is dropped silently. */
+int bk_trades_compact(bk_env* env, uint64_t* out_total);
+int bk_trades_compact_copy_async(bk_env* env, bk_trade* records, uint64_t* offsets, void* copy_stream);
 int bk_time(bk_env* env, uint32_t book, uint64_t* out);          /* OrderBook::get_time */
 int bk_set_time(bk_env* env, uint32_t book, uint64_t t);         /* OrderBook::set_time, orderbook.rs:183-185 */
 int bk_trade_vol(bk_env* env, uint32_t book, uint32_t* out);     /* OrderBook::get_trade_vol (live) */

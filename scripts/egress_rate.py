@@ -32,3 +32,14 @@ for chunk in (10, 25):
         st = env2.stream_history(100, chunk)
         print(f"streamed chunk={chunk}: {st['book_steps_per_s']/1e6:.1f} M book-steps/s, D2H {st['d2h_gb_per_s']:.1f} GB/s sustained")
     del env2
+
+# L2 records AND trade records (compacted on the device) streamed together
+for chunk in (10,):
+    env3 = bourse_amd.ManyBookEnv(B, 101, 0, 2, 100_000, levels=L, max_live_orders=128, trade_capacity=64 * chunk,
+                                  history_capacity=2 * chunk)
+    env3.set_random_agents(groups)
+    env3.run(chunk); env3.clear_trades()
+    for rep in range(2):
+        st = env3.stream_history(100, chunk, trades=True, trade_records_per_chunk=48 * chunk * B)
+        print(f"streamed L2 + trades chunk={chunk}: {st['book_steps_per_s']/1e6:.1f} M book-steps/s, D2H {st['d2h_gb_per_s']:.1f} GB/s sustained")
+    del env3

@@ -945,3 +945,59 @@ def test_json_golden_snapshot_loads_on_gpu(bk):
     bids = [x["price"] for x in act if x["side"] == "Bid"]
     asks = [x["price"] for x in act if x["side"] == "Ask"]
     assert ob.bid_ask() == (max(bids, default=0), min(asks, default=2**32 - 1))
+
+
+def test_trade_stream_compaction_matches_oracle(bk, oracle):
+    """bk_trades_compact: every book's records as one dense CSR stream, chunk after chunk, equals the oracle's trades."""
+    B, chunks = 300, [7, 1, 12, 5]
+    env = bk.ManyBookEnv(B, 21, 0, 2, 100_000, levels=16, max_live_orders=64, trade_capacity=64 * max(chunks))
+    env.set_random_agents(C2_GROUPS)
+    ref = oracle.ManyBooks(B, 21, 0, 2, 100_000, True, 16, C2_GROUPS)
+    done = np.zeros(B, dtype=np.int64)
+    for i, c in enumerate(chunks):
+        env.set_pipeline(("fused", "split")[i % 2])
+        env.run(c)
+        ref.run(c, 4)
+        off, rec = env.drain_trades()
+        assert off[0] == 0 and off[-1] == len(rec) and np.all(np.diff(off.astype(np.int64)) >= 0)
+        want_counts = ref.trade_counts().astype(np.int64) - done
+        assert np.array_equal(np.diff(off.astype(np.int64)), want_counts)
+        for b in (0, 1, B // 2, B - 1):
+            exp = ref.book(b).trades_array()[done[b]:]
+            got = rec[int(off[b]):int(off[b + 1])]
+            for f in ("t", "side", "price", "vol", "active_id", "passive_id"):
+                assert np.array_equal(got[f], exp[f]), (i, b, f)
+        done += want_counts
+        total, base = env.trade_count(0)
+        assert total == base == done[0]  # consumed
+    off, rec = env.drain_trades()
+    assert len(rec) == 0 and not off.any()
+    assert not env.flags().any()
+
+
+def test_streaming_l2_and_trades_together(bk, oracle):
+    B, T, chunk = 50, 24, 4
+    env = bk.ManyBookEnv(B, 5, 0, 2, 100_000, levels=16, max_live_orders=64, trade_capacity=64 * chunk,
+                         history_capacity=2 * chunk)
+    env.set_random_agents(C2_GROUPS)
+    ref = oracle.ManyBooks(B, 5, 0, 2, 100_000, True, 16, C2_GROUPS)
+    ref.run(T, 2)
+    want = ref.history()
+    got_l2, got_tr = {}, {b: [] for b in range(B)}
+
+    def on_chunk(first, l2, tr):
+        got_l2[first] = l2.copy()
+        off, rec = tr
+        for b in range(B):
+            got_tr[b].append(rec[int(off[b]):int(off[b + 1])].copy())
+
+    env.stream_history(T, chunk, on_chunk=on_chunk, trades=True)
+    for first, arr in got_l2.items():
+        assert np.array_equal(arr, want[first:first + chunk])
+    for b in range(B):
+        got = np.concatenate(got_tr[b])
+        exp = ref.book(b).trades_array()
+        assert len(got) == len(exp)
+        for f in ("t", "side", "price", "vol", "active_id", "passive_id"):
+            assert np.array_equal(got[f], exp[f]), (b, f)
+    assert not env.flags().any()
