@@ -158,7 +158,8 @@ def main():
     dt = time.perf_counter() - t0
     env.profile(False)
     kind0 = "k_run_mixed" if mixed else "k_run_random"
-    per_kind = {k: env.profile_read_kind(i) for i, k in enumerate((kind0, "k_agents_fsm", "k_step_batch", "k_step_events"))}
+    kind1 = "k_agents_mixed_lanes" if mixed else "k_agents_fsm"
+    per_kind = {k: env.profile_read_kind(i) for i, k in enumerate((kind0, kind1, "k_step_batch", "k_step_events"))}
     env.profile_read()
     if dist is not None:
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
@@ -186,10 +187,14 @@ def main():
     per_bs = {
         kind0: 2.0 * S / spl + W4 + 32.0 * tr_per_bs,
         "k_agents_fsm": 32.0 + 96.0 + 2.0 * ev_per_bs + 8.0 * new_per_bs,
+        # lane-per-book members' update: RNG + live-mask line + touches in; the members' lists in and out (2-byte slots,
+        # about one entry per resting order ~ events), 16 B per new order into the pool, the shuffled event list out
+        "k_agents_mixed_lanes": 192.0 + 4.0 * ev_per_bs + 16.0 * new_per_bs + 2.0 * ev_per_bs,
         "k_step_batch": 2.0 * S + 64.0 + 2.0 * ev_per_bs + 8.0 * new_per_bs + W4 + 32.0 * tr_per_bs,
         "k_step_events": 2.0 * S + 2.0 * W4 + 20.0 * ev_per_bs + 32.0 * tr_per_bs,
     }
-    bs_per_launch = {kind0: B * spl, "k_agents_fsm": B / parts, "k_step_batch": B / parts, "k_step_events": B}
+    bs_per_launch = {kind0: B * spl, "k_agents_fsm": B / parts, "k_agents_mixed_lanes": B / parts, "k_step_batch": B / parts,
+                     "k_step_events": B}
     pmc = {}
     try:
         pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(args.workload, {})
@@ -236,7 +241,7 @@ def main():
             "parallelism": f"independent book shards x{world}, 64 B stats all-gather per launch" if world > 1
             else "single GPU",
             "trades_per_book_step": tr_per_bs, "events_per_book_step": ev_per_bs,
-            "pipeline": f"split (k_agents_fsm + k_step_batch per step, {parts} book parts on separate streams)"
+            "pipeline": f"split ({kind1} + k_step_batch per step, {parts} book parts on separate streams)"
             if pipe == "split" else f"fused ({kind0})",
         },
         "roofline": {

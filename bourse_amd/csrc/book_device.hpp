@@ -31,7 +31,7 @@ enum Hdr : int {
   H_TRADE_BASE_LO, H_TRADE_BASE_HI, H_LAST_NTRADES, H_LAST_NEVENTS,
   H_LIVE0 = 32,  // live masks of the pool: dwords 32 + 2r (lo), 33 + 2r (hi), r < 8 (read by k_agents_fsm)
 };
-constexpr int POOL_FIELDS = 5;  // price, vol, id, seq, meta(bit0 live, bit1 bid)
+constexpr int POOL_FIELDS = 5;  // price, vol, id, seq, meta(bit0 live, bit1 bid, bit2 pending New, bits 8..15 owner tag)
 constexpr int MAX_GROUPS = 8;
 constexpr int MAX_ASSETS = 8;  // books per market (MarketEnv<ASSETS>)
 
@@ -550,7 +550,7 @@ __device__ __forceinline__ void load_book(Book<R>& B, Rng& rng, const uint32_t* 
   for (int r = 0; r < R; ++r) {
     B.live[r] = __ballot((meta[r] & 1u) != 0);
     B.bid[r] = __ballot((meta[r] & 2u) != 0);
-    B.pend[r] = 0;
+    B.pend[r] = __ballot((meta[r] & 4u) != 0);  // only the split mixed-agent pipeline stores books with pending orders
   }
   B.tr_k = B.tr_price = B.tr_vol = B.tr_act = B.tr_pas = 0;
   B.tr_n = 0;
@@ -592,7 +592,7 @@ __device__ __forceinline__ void store_book(const Book<R>& B, const Rng& rng, uin
     p[1 * 64 + lane] = B.vol[r];
     p[2 * 64 + lane] = B.id[r];
     p[3 * 64 + lane] = B.seq[r];
-    p[4 * 64 + lane] = (lane_bit(B.live[r]) ? 1u : 0u) | (lane_bit(B.bid[r]) ? 2u : 0u);
+    p[4 * 64 + lane] = (lane_bit(B.live[r]) ? 1u : 0u) | (lane_bit(B.bid[r]) ? 2u : 0u) | (lane_bit(B.pend[r]) ? 4u : 0u);
   }
 }
 
@@ -860,7 +860,9 @@ __global__ __launch_bounds__(64) void k_agents_fsm(DevArgs a) {
   }
 }
 
-template <int R, bool MKT>
+// POOLPEND (split pipeline of AgentSets with Noise/Momentum members, k_agents_mixed): the new orders already sit in the
+// pool with their pend bit and id (created by the members' update); the batch only carries the shuffled event list.
+template <int R, bool MKT, bool POOLPEND = false>
 __global__ __launch_bounds__(64) void k_step_batch(DevArgs a, uint64_t step_index, uint32_t write_last) {
   // one-wave workgroups: the dispatcher places every wave independently, so the wave slots left beside the
   // co-running k_agents_fsm waves are all usable (4-wave workgroups needed a free slot on every SIMD)
@@ -899,9 +901,15 @@ __global__ __launch_bounds__(64) void k_step_batch(DevArgs a, uint64_t step_inde
   const uint32_t bh = bt[lane];
   const uint32_t n_ev = rdl(bh, BT_NEV);
   uint32_t ev[R];
+  uint32_t owner[R];  // POOLPEND: the members' owner tags ride in meta bits 8..15 and must survive the store
   uint32_t base = B.next_id;
 #pragma unroll
   for (int r = 0; r < R; ++r) {
+    if (POOLPEND) {
+      ev[r] = reinterpret_cast<const uint16_t*>(bt + BT_EV)[r * 64 + lane];
+      owner[r] = st[HDR_DW + r * POOL_FIELDS * 64 + 4 * 64 + lane] & 0xFF00u;
+      continue;
+    }
     const uint64_t pend = mk64(rdl(bh, BT_PEND + 2 * r), rdl(bh, BT_PEND + 2 * r + 1)) & mine[r];
     const uint64_t side = mk64(rdl(bh, BT_SIDE + 2 * r), rdl(bh, BT_SIDE + 2 * r + 1));
     ev[r] = reinterpret_cast<const uint16_t*>(bt + BT_EV)[r * 64 + lane];
@@ -920,6 +928,13 @@ __global__ __launch_bounds__(64) void k_step_batch(DevArgs a, uint64_t step_inde
   const uint32_t ntr = step_from_list<R, MKT>(B, a, book, lane, ev, n_ev, lds[wv], a.hist_slot0, write_last != 0,
                                               MKT ? a.asset_tick[asset] : a.tick_size, mine, n_own);
   store_book<R>(B, rng, st, lane, step_index + 1, ntr, n_own);
+  if (POOLPEND) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      uint32_t* p = st + HDR_DW + r * POOL_FIELDS * 64 + 4 * 64;
+      p[lane] = (lane_bit(B.live[r]) ? 1u : 0u) | (lane_bit(B.bid[r]) ? 2u : 0u) | owner[r];
+    }
+  }
 }
 
 // ==================================================================================

@@ -130,6 +130,13 @@ struct bk_env {
   uint64_t tr_total = 0;
   DevBuf<MixedDesc> mixed_descs;  // AgentSets with Noise/Momentum members (k_run_mixed)
   uint32_t n_mixed = 0, n_fixed = 0;
+  // lane-per-book members' update (k_agents_mixed_lanes): the members' order lists, [member][entry][book]
+  DevBuf<uint16_t> ml_list;
+  DevBuf<uint32_t> ml_len, ml_inl;
+  bool ml_valid = false;  // the lists describe the pool as of steps_done (false after a wave-per-book launch / restore)
+  MixedLists lists() const {
+    return MixedLists{ml_list.p, ml_len.p, ml_inl.p, static_cast<uint32_t>(R) * 64u, cfg.n_books};
+  }
   std::vector<BookHost> books;
   std::vector<Group> groups;
   uint32_t n_agents_total = 0;
@@ -239,8 +246,29 @@ int launch_mixed(bk_env* env, const DevArgs& a, uint64_t first_step, uint32_t n_
 }
 
 // split pipeline: per step and per part one lane-per-book launch (RNG-serial phases) + one wave-per-book launch
-template <int R>
+// MIXED: 0 RandomAgents groups (k_agents_fsm), 1 AgentSet members one wave per book (k_agents_mixed), 2 members one lane
+// per book (k_agents_mixed_lanes)
+template <int R, int MIXED = 0>
 int launch_split(bk_env* env, const DevArgs& a0, uint64_t first_step, uint32_t n_steps) {
+  const MixedArgs ma{env->mixed_descs.p, env->n_mixed, env->n_fixed};
+  if (MIXED == 2) {
+    const size_t NB = env->cfg.n_books, cap = static_cast<size_t>(R) * 64;
+    if (!env->ml_list.p) {
+      HIPCHK(env->ml_list.alloc(MAX_MEMBERS * cap * NB));
+      HIPCHK(env->ml_len.alloc(MAX_MEMBERS * NB));
+      HIPCHK(env->ml_inl.alloc(2 * static_cast<size_t>(R) * NB));
+      env->ml_valid = false;
+    }
+    if (!env->ml_valid) {
+      hipLaunchKernelGGL(k_mixed_lists_rebuild<R>, dim3((env->cfg.n_books + 3) / 4), dim3(256), 0, env->stream, a0, ma,
+                         env->lists());
+      HIPCHK(hipGetLastError());
+      env->ml_valid = true;
+    }
+  } else if (MIXED == 1) {
+    env->ml_valid = false;
+  }
+  const MixedLists ml = env->lists();
   const uint32_t M = env->M;
   const uint32_t B = env->cfg.n_books / M;  // units the parts are cut in: books, or markets of M books
   int P = env->n_parts;
@@ -269,13 +297,21 @@ int launch_split(bk_env* env, const DevArgs& a0, uint64_t first_step, uint32_t n
       if (P > 1 && s == 0 && i > 0) HIPCHK(hipStreamWaitEvent(st, env->ev_first[i - 1], 0));  // stagger the parts
       {
         ProfScope ps(env, 1, st);
-        hipLaunchKernelGGL(k_agents_fsm<R>, dim3((nb + 63) / 64), dim3(64), 0, st, a);
+        if (MIXED == 2)
+          hipLaunchKernelGGL(k_agents_mixed_lanes<R>, dim3((nb + 63) / 64), dim3(64), 0, st, a, ma, ml);
+        else if (MIXED == 1)
+          hipLaunchKernelGGL(k_agents_mixed<R>, dim3((nb + 3) / 4), dim3(256), 0, st, a, ma);
+        else
+          hipLaunchKernelGGL(k_agents_fsm<R>, dim3((nb + 63) / 64), dim3(64), 0, st, a);
       }
       if (P > 1 && s == 0) HIPCHK(hipEventRecord(env->ev_first[i], st));
       {
         ProfScope ps(env, 2, st);
-        const uint32_t write_last = (s + 1 == n_steps || a.hist_cap == 0) ? 1u : 0u;
-        if (M > 1)
+        // the lane-per-book members' update reads the touches from the latest level-2 record: keep it current
+        const uint32_t write_last = (s + 1 == n_steps || a.hist_cap == 0 || MIXED == 2) ? 1u : 0u;
+        if (MIXED)
+          hipLaunchKernelGGL((k_step_batch<R, false, true>), dim3(nb), dim3(64), 0, st, a, first_step + s, write_last);
+        else if (M > 1)
           hipLaunchKernelGGL((k_step_batch<R, true>), dim3(nb * M), dim3(64), 0, st, a, first_step + s, write_last);
         else
           hipLaunchKernelGGL((k_step_batch<R, false>), dim3(nb), dim3(64), 0, st, a, first_step + s, write_last);
@@ -768,6 +804,7 @@ int bk_set_agents(bk_env* env, uint32_t n_members, const bk_agent_desc* members)
   HIPCHK(hipMemcpy(env->mixed_descs.p, ds.data(), ds.size() * sizeof(MixedDesc), hipMemcpyHostToDevice));
   env->n_mixed = n_members;
   env->n_fixed = fixed;
+  env->ml_valid = false;
   env->groups.clear();
   env->n_agents_total = 0;
   return BK_OK;
@@ -789,11 +826,34 @@ int bk_run(bk_env* env, uint64_t n_steps) {
   int rc = BK_OK;
   const uint32_t ns = static_cast<uint32_t>(n_steps);
   if (env->n_mixed) {
-    switch (env->R) {
-      case 1: rc = launch_mixed<1>(env, a, env->steps_done, ns); break;
-      case 2: rc = launch_mixed<2>(env, a, env->steps_done, ns); break;
-      case 4: rc = launch_mixed<4>(env, a, env->steps_done, ns); break;
-      default: rc = launch_mixed<8>(env, a, env->steps_done, ns); break;
+    // fused for small batches (the book stays in registers across steps); split above: the members' update and the
+    // event loop are two leaner kernels (no spills at R = 8) and the batch is cut in parts that overlap
+    // split (default from 3072 books, where it overtakes the fused kernel): members' update one LANE per book + the lean
+    // event kernel; mode 3 keeps the
+    // wave-per-book members' update (k_agents_mixed) selectable
+    const bool mlanes = env->pipeline == 2 || (env->pipeline == 0 && env->cfg.n_books >= 3072);
+    if (mlanes) {
+      switch (env->R) {
+        case 1: rc = launch_split<1, 2>(env, a, env->steps_done, ns); break;
+        case 2: rc = launch_split<2, 2>(env, a, env->steps_done, ns); break;
+        case 4: rc = launch_split<4, 2>(env, a, env->steps_done, ns); break;
+        default: rc = launch_split<8, 2>(env, a, env->steps_done, ns); break;
+      }
+    } else if (env->pipeline == 3) {
+      switch (env->R) {
+        case 1: rc = launch_split<1, 1>(env, a, env->steps_done, ns); break;
+        case 2: rc = launch_split<2, 1>(env, a, env->steps_done, ns); break;
+        case 4: rc = launch_split<4, 1>(env, a, env->steps_done, ns); break;
+        default: rc = launch_split<8, 1>(env, a, env->steps_done, ns); break;
+      }
+    } else {
+      env->ml_valid = false;
+      switch (env->R) {
+        case 1: rc = launch_mixed<1>(env, a, env->steps_done, ns); break;
+        case 2: rc = launch_mixed<2>(env, a, env->steps_done, ns); break;
+        case 4: rc = launch_mixed<4>(env, a, env->steps_done, ns); break;
+        default: rc = launch_mixed<8>(env, a, env->steps_done, ns); break;
+      }
     }
     if (rc != BK_OK) return rc;
     env->steps_done += n_steps;
@@ -803,7 +863,7 @@ int bk_run(bk_env* env, uint64_t n_steps) {
   // phases on the scalar unit of ONE wave per book; the split pipeline runs them one lane per book and needs
   // >= 64 books per wave to pay off.  auto: split once the batch fills the chip several times over.
   // Markets always take the split pipeline: the market's RNG-serial phase is one lane, its books are M waves.
-  const bool split = env->pipeline == 2 || env->M > 1 ||
+  const bool split = env->pipeline >= 2 || env->M > 1 ||
                      (env->pipeline == 0 && env->cfg.n_books >= 8192 && a.n_groups > 0);
   if (split) {
     switch (env->R) {
@@ -1178,6 +1238,7 @@ int bk_load_book(bk_env* env, uint32_t book, uint64_t t, uint32_t trade_vol, uin
   if (n_trades)
     HIPCHK(hipMemcpy(env->trades.p + static_cast<size_t>(book) * env->cfg.trade_capacity, tr.data(),
                      n_trades * sizeof(DevTrade), hipMemcpyHostToDevice));
+  env->ml_valid = false;
   bh.n_uploaded = n_orders;
   bh.log_fresh = false;
   bh.time_offset = t - (env->cfg.start_time + env->steps_done * env->cfg.step_size);
@@ -1329,7 +1390,9 @@ int bk_profile_read_kind(bk_env* env, int kind, double* total_ms, uint64_t* n_la
 
 int bk_get_pipeline(bk_env* env, int* split, int* n_parts) {
   if (!env) return fail(BK_INVALID_ARGUMENT, "null env");
-  const bool sp = env->pipeline == 2 || (env->pipeline == 0 && env->cfg.n_books >= 8192 && !env->groups.empty());
+  const bool sp = env->pipeline >= 2 || env->M > 1 ||
+                  (env->pipeline == 0 && (env->n_mixed ? env->cfg.n_books >= 3072
+                                                       : env->cfg.n_books >= 8192 && !env->groups.empty()));
   int P = env->n_parts;
   if (env->cfg.n_books < 4096u * P) P = 1;
   if (split) *split = sp ? 1 : 0;
@@ -1338,7 +1401,8 @@ int bk_get_pipeline(bk_env* env, int* split, int* n_parts) {
 }
 
 int bk_set_pipeline(bk_env* env, int mode) {
-  if (!env || mode < 0 || mode > 2) return fail(BK_INVALID_ARGUMENT, "pipeline mode must be 0 (auto), 1 (fused) or 2 (split)");
+  if (!env || mode < 0 || mode > 3)
+    return fail(BK_INVALID_ARGUMENT, "pipeline mode must be 0 (auto), 1 (fused), 2 (split) or 3 (split, wave-per-book agents)");
   env->pipeline = mode;
   return BK_OK;
 }
@@ -1348,7 +1412,9 @@ int bk_set_pipeline(bk_env* env, int mode) {
 // here the whole simulation state IS the per-book device block (pool, clock, counters, RNG), so a checkpoint
 // is one device-to-host copy.  Host-driven envs (order log + host order table) are not covered.
 uint64_t bk_checkpoint_bytes(const bk_env* env) {
-  return env ? 16 + static_cast<uint64_t>(env->cfg.n_books) * env->stride * 4 : 0;
+  // header (steps_done, shape) + per-book state blocks + the latest level-2 records (Env::level_2_data; the
+  // lane-per-book members' update reads the touches from there)
+  return env ? 16 + static_cast<uint64_t>(env->cfg.n_books) * (env->stride + env->W) * 4 : 0;
 }
 
 int bk_checkpoint_save(bk_env* env, void* out, uint64_t nbytes) {
@@ -1361,7 +1427,10 @@ int bk_checkpoint_save(bk_env* env, void* out, uint64_t nbytes) {
   uint64_t* h = static_cast<uint64_t*>(out);
   h[0] = env->steps_done;
   h[1] = (static_cast<uint64_t>(env->cfg.n_books) << 32) | env->stride;
-  HIPCHK(hipMemcpy(h + 2, env->state.p, static_cast<size_t>(env->cfg.n_books) * env->stride * 4, hipMemcpyDeviceToHost));
+  const size_t sb = static_cast<size_t>(env->cfg.n_books) * env->stride * 4;
+  HIPCHK(hipMemcpy(h + 2, env->state.p, sb, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(reinterpret_cast<char*>(h + 2) + sb, env->l2_last.p, static_cast<size_t>(env->cfg.n_books) * env->W * 4,
+                   hipMemcpyDeviceToHost));
   return BK_OK;
 }
 
@@ -1369,10 +1438,14 @@ int bk_checkpoint_load(bk_env* env, const void* in, uint64_t nbytes) {
   if (!env || !in) return fail(BK_INVALID_ARGUMENT, "null argument");
   const uint64_t* h = static_cast<const uint64_t*>(in);
   if (nbytes < bk_checkpoint_bytes(env) || h[1] != ((static_cast<uint64_t>(env->cfg.n_books) << 32) | env->stride))
-    return fail(BK_INVALID_ARGUMENT, "checkpoint does not match this env (n_books / pool size)");
+    return fail(BK_INVALID_ARGUMENT, "checkpoint does not match this env (n_books / pool size / levels)");
   if (int rc = use_device(env)) return rc;
   HIPCHK(hipStreamSynchronize(env->stream));
-  HIPCHK(hipMemcpy(env->state.p, h + 2, static_cast<size_t>(env->cfg.n_books) * env->stride * 4, hipMemcpyHostToDevice));
+  const size_t sb = static_cast<size_t>(env->cfg.n_books) * env->stride * 4;
+  HIPCHK(hipMemcpy(env->state.p, h + 2, sb, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(env->l2_last.p, reinterpret_cast<const char*>(h + 2) + sb,
+                   static_cast<size_t>(env->cfg.n_books) * env->W * 4, hipMemcpyHostToDevice));
+  env->ml_valid = false;
   env->steps_done = h[0];
   env->hist_base = h[0];  // retained history/trade records restart at the restored step
   const uint32_t B = env->cfg.n_books;

@@ -56,7 +56,14 @@ struct MixedArgs {
 #undef ZIG_TABLE_BEGIN
 #undef ZIG_TABLE_END
 
+// pin a wave-uniform 64-bit value to scalar registers (the f64 code around the generator otherwise drags the RNG
+// arithmetic onto the vector unit: v_mad_u64_u32 chains instead of s_mul / s_lshl)
+__device__ __forceinline__ uint64_t pin_scalar(uint64_t x) {
+  return mk64(rfl((uint32_t)x), rfl((uint32_t)(x >> 32)));
+}
 __device__ __forceinline__ uint64_t next_u64(Rng& rng) {
+  rng.s0 = pin_scalar(rng.s0);
+  rng.s1 = pin_scalar(rng.s1);
   uint64_t r = rng.s0 * 5ull;
   r = (r << 7) | (r >> 57);
   r *= 9ull;
@@ -123,7 +130,7 @@ template <int R>
 struct MixedCtx {
   uint32_t ev[R];     // event list (slot indices)
   uint32_t owner[R];  // member index + 1 of the limit order resting / pending in the slot, 0 = none
-  uint64_t dyn[R];    // slots available for dynamic allocation (index >= n_fixed)
+  uint32_t n_fixed;   // slots [0, n_fixed) belong to RandomAgents members; the rest is allocated dynamically
   uint32_t n_ev;
 };
 
@@ -136,7 +143,10 @@ __device__ __forceinline__ void mixed_create(Book<R>& B, MixedCtx<R>& C, int lan
   int slot = -1;
 #pragma unroll
   for (int r = R - 1; r >= 0; --r) {
-    const uint64_t fr = ~(B.live[r] | B.pend[r]) & C.dyn[r];
+    // dynamic slots of this register: index >= n_fixed (rebuilt here: 2R fewer live SGPRs than a mask array)
+    const uint32_t lo = C.n_fixed > 64u * r ? C.n_fixed - 64u * r : 0u;
+    const uint64_t dyn = lo >= 64u ? 0ull : (~0ull << lo);
+    const uint64_t fr = ~(B.live[r] | B.pend[r]) & dyn;
     if (fr) slot = r * 64 + (int)__builtin_ctzll(fr);
   }
   if (slot < 0) {
@@ -189,6 +199,169 @@ __device__ __forceinline__ void mixed_cancel_live(Book<R>& B, MixedCtx<R>& C, Rn
   (void)lane;
 }
 
+// member state that lives across steps: momentum / last mid price per member (momentum_agent.rs:108-117)
+struct MixedState {
+  uint32_t gflags;
+  double g_mom[MAX_MEMBERS], g_last[MAX_MEMBERS];
+};
+__device__ __forceinline__ void mixed_load_state(MixedState& S, const uint32_t* st, int lane) {
+  const uint32_t hdr = st[lane];
+  S.gflags = rdl(hdr, H_GFLAGS);
+#pragma unroll
+  for (int j = 0; j < MAX_MEMBERS; ++j) {
+    S.g_mom[j] = pm::from_bits(mk64(rdl(hdr, H_GST + 4 * j), rdl(hdr, H_GST + 4 * j + 1)));
+    S.g_last[j] = pm::from_bits(mk64(rdl(hdr, H_GST + 4 * j + 2), rdl(hdr, H_GST + 4 * j + 3)));
+  }
+}
+// after store_book: member state into the header, owner tags (+ live / bid / pend bits) into the pool's meta words
+template <int R>
+__device__ __forceinline__ void mixed_store_state(const MixedState& S, const Book<R>& B, const MixedCtx<R>& C,
+                                                  uint32_t* st, int lane) {
+  uint32_t h2 = st[lane];
+  auto put = [&](int idx, uint32_t v) { h2 = (lane == idx) ? v : h2; };
+  put(H_GFLAGS, S.gflags);
+#pragma unroll
+  for (int j = 0; j < MAX_MEMBERS; ++j) {
+    const uint64_t mb = pm::to_bits(S.g_mom[j]), lb = pm::to_bits(S.g_last[j]);
+    put(H_GST + 4 * j, (uint32_t)mb);
+    put(H_GST + 4 * j + 1, (uint32_t)(mb >> 32));
+    put(H_GST + 4 * j + 2, (uint32_t)lb);
+    put(H_GST + 4 * j + 3, (uint32_t)(lb >> 32));
+  }
+  st[lane] = h2;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    uint32_t* p = st + HDR_DW + r * POOL_FIELDS * 64 + 4 * 64;
+    p[lane] = (lane_bit(B.live[r]) ? 1u : 0u) | (lane_bit(B.bid[r]) ? 2u : 0u) | (lane_bit(B.pend[r]) ? 4u : 0u) |
+              (C.owner[r] << 8);
+  }
+}
+template <int R>
+__device__ __forceinline__ void mixed_load_ctx(MixedCtx<R>& C, const uint32_t* st, const MixedArgs& ma, int lane) {
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    C.ev[r] = 0;
+    C.owner[r] = (st[HDR_DW + r * POOL_FIELDS * 64 + 4 * 64 + lane] >> 8) & 0xFFu;
+  }
+  C.n_fixed = ma.n_fixed;
+  C.n_ev = 0;
+}
+
+// One step's agents.update(env, rng) for every member in declaration order (crates/macros/src/lib.rs:57-73) followed
+// by transactions.shuffle(rng) (env.rs:121): fills C.ev / C.n_ev and parks the new orders in the pool.
+template <int R>
+__device__ __forceinline__ void mixed_update_and_shuffle(Book<R>& B, MixedCtx<R>& C, Rng& rng, const MixedArgs& ma,
+                                                         MixedState& S, int lane) {
+  C.n_ev = 0;
+  // OrderBook::mid_price (orderbook.rs:272-276) of the book as the agents see it (updates only queue events)
+  double mid;
+  {
+    uint32_t mb = 0u, mk = 0xFFFFFFFFu;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      mb = max(mb, sel(B.live[r] & B.bid[r], B.price[r], 0u));
+      mk = min(mk, sel(B.live[r] & ~B.bid[r], B.price[r], 0xFFFFFFFFu));
+    }
+    const uint32_t bid = wave_umax(mb), ask = wave_umin(mk);
+    mid = static_cast<double>(bid) + 0.5 * static_cast<double>(ask - bid);
+  }
+  for (uint32_t j = 0; j < ma.n_desc; ++j) {
+    const MixedDesc D = ma.descs[j];
+    if (D.type == 0) {
+      // ---- RandomAgents::update (random_agent.rs:85-119), fixed slots [slot_base, slot_base + n)
+      for (uint32_t i = 0; i < D.n; ++i) {
+        const uint32_t n = D.slot_base + i;
+        const uint32_t x = rng.next_u32();
+        if ((x >> 8) < D.thr) {
+          slot_write<R>(C.ev, C.n_ev, n);
+          C.n_ev += 1;
+          if (!mask_test<R>(B.live, n)) {
+            const uint32_t side = rng.below(2u, 0x7FFFFFFFu);
+            const uint32_t tick = D.tick_lo + rng.below(D.tick_rng, D.tick_zone);
+            const uint32_t vol = D.vol_lo + rng.below(D.vol_rng, D.vol_zone);
+            slot_write<R>(B.price, n, tick * D.tick_size);
+            slot_write<R>(B.vol, n, vol);
+            slot_write<R>(B.id, n, B.next_id);
+            B.next_id += 1;
+            mask_set<R>(B.bid, n, side != 0);
+            mask_set<R>(B.pend, n, true);
+          }
+        }
+      }
+    } else {
+      const uint32_t tag = j + 1;
+      mixed_cancel_live<R>(B, C, rng, lane, tag, D.keep_thr);
+      if (D.type == 1) {
+        // ---- NoiseAgent::update (noise_agent.rs:127-176)
+        for (uint32_t t = 0; t < D.n; ++t) {
+          if ((rng.next_u32() >> 8) < D.thr_limit) {                // gen::<f32>() < p_limit
+            const bool buy = next_u64(rng) < 0x8000000000000000ull;  // gen_bool(0.5)
+            const double dist = pm::fabs_(uni(pm::exp(D.mu + D.sigma * sample_standard_normal(rng))));
+            const uint32_t price =
+                rfl(buy ? round_price_down(mid - dist, D.tick_f) : round_price_up(mid + dist, D.tick_f));
+            mixed_create<R>(B, C, lane, buy, price, D.trade_vol, tag);
+          }
+          if ((rng.next_u32() >> 8) < D.thr_market) {                // gen::<f32>() < p_market
+            const bool buy = next_u64(rng) < 0x8000000000000000ull;
+            mixed_create<R>(B, C, lane, buy, buy ? 0xFFFFFFFFu : 0u, D.trade_vol, 0u);
+          }
+        }
+      } else {
+        // ---- MomentumAgent::update (momentum_agent.rs:146-208)
+        double m = 0.0, p_market = 0.0;
+        if ((S.gflags >> j) & 1u) {
+          double gm = S.g_mom[0], gl = S.g_last[0];
+#pragma unroll
+          for (int q = 1; q < MAX_MEMBERS; ++q) {
+            gm = ((uint32_t)q == j) ? S.g_mom[q] : gm;
+            gl = ((uint32_t)q == j) ? S.g_last[q] : gl;
+          }
+          m = uni(gm * (1.0 - D.decay) + D.decay * (mid - gl));
+          p_market = uni(D.demand * pm::tanh(D.scale * m) / D.n_f);
+        }
+        uint64_t thr_l, thr_m;
+        {
+          const double p_limit = D.order_ratio * p_market;
+          thr_l = thr53(p_limit);
+          thr_m = thr53(p_market);
+          thr_l = mk64(rfl((uint32_t)thr_l), rfl((uint32_t)(thr_l >> 32)));
+          thr_m = mk64(rfl((uint32_t)thr_m), rfl((uint32_t)(thr_m >> 32)));
+        }
+        const int sgn = (m > 0.0) ? 1 : ((m < 0.0) ? -1 : 0);
+        for (uint32_t t = 0; t < D.n; ++t) {
+          if ((next_u64(rng) >> 11) < thr_l) {  // gen::<f64>() < p_limit
+            if (sgn != 0) {
+              const double dist = pm::fabs_(uni(pm::exp(D.mu + D.sigma * sample_standard_normal(rng))));
+              const uint32_t price =
+                  rfl(sgn > 0 ? round_price_down(mid - dist, D.tick_f) : round_price_up(mid + dist, D.tick_f));
+              mixed_create<R>(B, C, lane, sgn > 0, price, D.trade_vol, tag);
+            }
+          }
+          if ((next_u64(rng) >> 11) < thr_m) {  // gen::<f64>() < p_market
+            if (sgn != 0) mixed_create<R>(B, C, lane, sgn > 0, sgn > 0 ? 0xFFFFFFFFu : 0u, D.trade_vol, 0u);
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < MAX_MEMBERS; ++q) {
+          if ((uint32_t)q == j) {
+            S.g_mom[q] = m;
+            S.g_last[q] = mid;
+          }
+        }
+        S.gflags |= 1u << j;
+      }
+    }
+  }
+  // ---- Env::step's shuffle (env.rs:121)
+  for (uint32_t i = C.n_ev; i-- > 1;) {
+    const uint32_t jx = rng.below(i + 1);
+    const uint32_t ai = slot_read<R>(C.ev, i), aj = slot_read<R>(C.ev, jx);
+    slot_write<R>(C.ev, i, aj);
+    slot_write<R>(C.ev, jx, ai);
+  }
+}
+
+// fused: n_steps x { members' update + shuffle; event loop + snapshot } with the book in registers (small batches)
 template <int R>
 __global__ __launch_bounds__(256) void k_run_mixed(DevArgs a, MixedArgs ma, uint64_t first_step, uint32_t n_steps) {
   __shared__ uint32_t lds[4][LDS_DW_PER_WAVE];
@@ -202,152 +375,361 @@ __global__ __launch_bounds__(256) void k_run_mixed(DevArgs a, MixedArgs ma, uint
   Rng rng;
   load_book<R>(B, rng, st, lane);
   MixedCtx<R> C;
-  const uint32_t hdr = st[lane];
-  uint32_t gflags = rdl(hdr, H_GFLAGS);
-  double g_mom[MAX_MEMBERS], g_last[MAX_MEMBERS];
-#pragma unroll
-  for (int j = 0; j < MAX_MEMBERS; ++j) {
-    g_mom[j] = pm::from_bits(mk64(rdl(hdr, H_GST + 4 * j), rdl(hdr, H_GST + 4 * j + 1)));
-    g_last[j] = pm::from_bits(mk64(rdl(hdr, H_GST + 4 * j + 2), rdl(hdr, H_GST + 4 * j + 3)));
-  }
-#pragma unroll
-  for (int r = 0; r < R; ++r) {
-    C.ev[r] = 0;
-    C.owner[r] = (st[HDR_DW + r * POOL_FIELDS * 64 + 4 * 64 + lane] >> 8) & 0xFFu;
-    C.dyn[r] = __ballot((uint32_t)(r * 64 + lane) >= ma.n_fixed);
-  }
+  MixedState S;
+  mixed_load_state(S, st, lane);
+  mixed_load_ctx<R>(C, st, ma, lane);
   uint32_t last_ntr = 0, last_nev = 0;
-
   for (uint32_t s = 0; s < n_steps; ++s) {
-    C.n_ev = 0;
-    // OrderBook::mid_price (orderbook.rs:272-276) of the book as the agents see it (updates only queue events)
-    double mid;
-    {
-      uint32_t mb = 0u, mk = 0xFFFFFFFFu;
-#pragma unroll
-      for (int r = 0; r < R; ++r) {
-        mb = max(mb, sel(B.live[r] & B.bid[r], B.price[r], 0u));
-        mk = min(mk, sel(B.live[r] & ~B.bid[r], B.price[r], 0xFFFFFFFFu));
-      }
-      const uint32_t bid = wave_umax(mb), ask = wave_umin(mk);
-          mid = static_cast<double>(bid) + 0.5 * static_cast<double>(ask - bid);
-    }
-    for (uint32_t j = 0; j < ma.n_desc; ++j) {  // members in declaration order (crates/macros/src/lib.rs:57-73)
-      const MixedDesc D = ma.descs[j];
-      if (D.type == 0) {
-        // ---- RandomAgents::update (random_agent.rs:85-119), fixed slots [slot_base, slot_base + n)
-        for (uint32_t i = 0; i < D.n; ++i) {
-          const uint32_t n = D.slot_base + i;
-          const uint32_t x = rng.next_u32();
-          if ((x >> 8) < D.thr) {
-            slot_write<R>(C.ev, C.n_ev, n);
-            C.n_ev += 1;
-            if (!mask_test<R>(B.live, n)) {
-              const uint32_t side = rng.below(2u, 0x7FFFFFFFu);
-              const uint32_t tick = D.tick_lo + rng.below(D.tick_rng, D.tick_zone);
-              const uint32_t vol = D.vol_lo + rng.below(D.vol_rng, D.vol_zone);
-              slot_write<R>(B.price, n, tick * D.tick_size);
-              slot_write<R>(B.vol, n, vol);
-              slot_write<R>(B.id, n, B.next_id);
-              B.next_id += 1;
-              mask_set<R>(B.bid, n, side != 0);
-              mask_set<R>(B.pend, n, true);
-            }
-          }
-        }
-      } else {
-        const uint32_t tag = j + 1;
-        mixed_cancel_live<R>(B, C, rng, lane, tag, D.keep_thr);
-        if (D.type == 1) {
-          // ---- NoiseAgent::update (noise_agent.rs:127-176)
-          for (uint32_t t = 0; t < D.n; ++t) {
-            if ((rng.next_u32() >> 8) < D.thr_limit) {                // gen::<f32>() < p_limit
-              const bool buy = next_u64(rng) < 0x8000000000000000ull;  // gen_bool(0.5)
-                          const double dist = pm::fabs_(uni(pm::exp(D.mu + D.sigma * sample_standard_normal(rng))));
-              const uint32_t price = rfl(buy ? round_price_down(mid - dist, D.tick_f) : round_price_up(mid + dist, D.tick_f));
-              mixed_create<R>(B, C, lane, buy, price, D.trade_vol, tag);
-            }
-            if ((rng.next_u32() >> 8) < D.thr_market) {                // gen::<f32>() < p_market
-              const bool buy = next_u64(rng) < 0x8000000000000000ull;
-              mixed_create<R>(B, C, lane, buy, buy ? 0xFFFFFFFFu : 0u, D.trade_vol, 0u);
-            }
-          }
-        } else {
-          // ---- MomentumAgent::update (momentum_agent.rs:146-208)
-          double m = 0.0, p_market = 0.0;
-          {
-                      if ((gflags >> j) & 1u) {
-              double gm = g_mom[0], gl = g_last[0];
-#pragma unroll
-              for (int q = 1; q < MAX_MEMBERS; ++q) {
-                gm = ((uint32_t)q == j) ? g_mom[q] : gm;
-                gl = ((uint32_t)q == j) ? g_last[q] : gl;
-              }
-              m = uni(gm * (1.0 - D.decay) + D.decay * (mid - gl));
-              p_market = uni(D.demand * pm::tanh(D.scale * m) / D.n_f);
-            }
-          }
-          uint64_t thr_l, thr_m;
-          {
-                      const double p_limit = D.order_ratio * p_market;
-            thr_l = thr53(p_limit);
-            thr_m = thr53(p_market);
-            thr_l = mk64(rfl((uint32_t)thr_l), rfl((uint32_t)(thr_l >> 32)));
-            thr_m = mk64(rfl((uint32_t)thr_m), rfl((uint32_t)(thr_m >> 32)));
-          }
-          const int sgn = (m > 0.0) ? 1 : ((m < 0.0) ? -1 : 0);
-          for (uint32_t t = 0; t < D.n; ++t) {
-            if ((next_u64(rng) >> 11) < thr_l) {  // gen::<f64>() < p_limit
-              if (sgn != 0) {
-                              const double dist = pm::fabs_(uni(pm::exp(D.mu + D.sigma * sample_standard_normal(rng))));
-                const uint32_t price = rfl(sgn > 0 ? round_price_down(mid - dist, D.tick_f) : round_price_up(mid + dist, D.tick_f));
-                mixed_create<R>(B, C, lane, sgn > 0, price, D.trade_vol, tag);
-              }
-            }
-            if ((next_u64(rng) >> 11) < thr_m) {  // gen::<f64>() < p_market
-              if (sgn != 0) mixed_create<R>(B, C, lane, sgn > 0, sgn > 0 ? 0xFFFFFFFFu : 0u, D.trade_vol, 0u);
-            }
-          }
-#pragma unroll
-          for (int q = 0; q < MAX_MEMBERS; ++q) {
-            if ((uint32_t)q == j) {
-              g_mom[q] = m;
-              g_last[q] = mid;
-            }
-          }
-          gflags |= 1u << j;
-        }
-      }
-    }
-    // ---- Env::step: shuffle (env.rs:121) then the shared event loop / snapshot
-    for (uint32_t i = C.n_ev; i-- > 1;) {
-      const uint32_t jx = rng.below(i + 1);
-      const uint32_t ai = slot_read<R>(C.ev, i), aj = slot_read<R>(C.ev, jx);
-      slot_write<R>(C.ev, i, aj);
-      slot_write<R>(C.ev, jx, ai);
-    }
+    mixed_update_and_shuffle<R>(B, C, rng, ma, S, lane);
     last_ntr = step_from_list<R>(B, a, book, lane, C.ev, C.n_ev, lds[wv],
                                  a.hist_cap ? (a.hist_slot0 + s) % a.hist_cap : 0u, s + 1 == n_steps || a.hist_cap == 0,
                                  a.tick_size, B.pend, last_nev);
   }
   store_book<R>(B, rng, st, lane, first_step + n_steps, last_ntr, last_nev);
-  // member state and owner tags
-  uint32_t h2 = st[lane];
-  auto put = [&](int idx, uint32_t v) { h2 = (lane == idx) ? v : h2; };
-  put(H_GFLAGS, gflags);
+  mixed_store_state<R>(S, B, C, st, lane);
+}
+
+// split: one step's members' update + shuffle per book; the new orders stay parked in the pool (pend bit in the
+// stored meta word), the shuffled event list goes to the book's step batch for k_step_batch<R, false, true>.
+template <int R>
+__global__ __launch_bounds__(256) void k_agents_mixed(DevArgs a, MixedArgs ma) {
+  const int lane = threadIdx.x & 63;
+  const uint32_t book = rfl(a.book_begin + blockIdx.x * 4 + (threadIdx.x >> 6));
+  if (book >= a.book_end) return;
+  uint32_t* st = a.state + (size_t)book * a.state_stride;
+  uint32_t* bt = a.batch + (size_t)book * a.batch_stride;
+  Book<R> B;
+  Rng rng;
+  load_book<R>(B, rng, st, lane);
+  MixedCtx<R> C;
+  MixedState S;
+  mixed_load_state(S, st, lane);
+  mixed_load_ctx<R>(C, st, ma, lane);
+  mixed_update_and_shuffle<R>(B, C, rng, ma, S, lane);
+  // the step counter / last-step figures are k_step_batch's to write: keep the header's values
+  const uint32_t hdr = st[lane];
+  store_book<R>(B, rng, st, lane, mk64(rdl(hdr, H_STEPS_LO), rdl(hdr, H_STEPS_HI)), rdl(hdr, H_LAST_NTRADES),
+                rdl(hdr, H_LAST_NEVENTS));
+  mixed_store_state<R>(S, B, C, st, lane);
+  if (lane == 0) bt[BT_NEV] = C.n_ev;
 #pragma unroll
-  for (int j = 0; j < MAX_MEMBERS; ++j) {
-    const uint64_t mb = pm::to_bits(g_mom[j]), lb = pm::to_bits(g_last[j]);
-    put(H_GST + 4 * j, (uint32_t)mb);
-    put(H_GST + 4 * j + 1, (uint32_t)(mb >> 32));
-    put(H_GST + 4 * j + 2, (uint32_t)lb);
-    put(H_GST + 4 * j + 3, (uint32_t)(lb >> 32));
+  for (int r = 0; r < R; ++r) reinterpret_cast<uint16_t*>(bt + BT_EV)[r * 64 + lane] = (uint16_t)C.ev[r];
+}
+
+// ==================================================================================
+// Lane-per-book members' update (the split pipeline's default for these AgentSets): 64 books per wave, every lane runs
+// its book's agents.update + shuffle as ordinary per-lane code — the RNG stream, the ziggurat / exp / tanh arithmetic and
+// the order creation are all SIMT across books instead of scalar code on one wave per book.  What a lane needs of its
+// book: the touch prices (mid price) from the last level-2 record, the pool's live masks (one 64-byte line of the
+// header), and the member's `orders` list, kept in creation order in an aux buffer laid out [member][entry][book] so
+// that the lanes' accesses coalesce.  New orders are written straight into free pool slots with their pend bit; the
+// event kernel is k_step_batch<R, false, true>.
+//
+// A slot counts as free when it is neither live, nor pending, nor still referenced by some member's list (`inl` masks):
+// a dead order's entry is purged at its member's next update, so "live bit set" alone identifies a list entry's order.
+// ==================================================================================
+struct MixedLists {
+  uint16_t* list;  // [MAX_MEMBERS][cap][n_books]: pool slots of the member's orders, oldest first
+  uint32_t* len;   // [MAX_MEMBERS][n_books]
+  uint32_t* inl;   // [2R][n_books]: slots referenced by the lists, 32 per word
+  uint32_t cap;    // entries per member = pool size
+  uint32_t n_books;
+};
+
+struct LaneRng {  // xoroshiro128** per lane
+  uint64_t s0, s1;
+  __device__ __forceinline__ uint64_t next_u64() {
+    uint64_t r = s0 * 5ull;
+    r = (r << 7) | (r >> 57);
+    r *= 9ull;
+    const uint64_t t1 = s1 ^ s0;
+    s0 = ((s0 << 24) | (s0 >> 40)) ^ t1 ^ (t1 << 16);
+    s1 = (t1 << 37) | (t1 >> 27);
+    return r;
   }
-  st[lane] = h2;
+  __device__ __forceinline__ uint32_t next_u32() { return (uint32_t)next_u64(); }
+  __device__ __forceinline__ uint32_t below(uint32_t range, uint32_t zone) {
+    for (;;) {
+      const uint64_t m = (uint64_t)next_u32() * range;
+      if ((uint32_t)m <= zone) return (uint32_t)(m >> 32);
+    }
+  }
+  __device__ __forceinline__ double f64() { return static_cast<double>(next_u64() >> 11) * (1.0 / 9007199254740992.0); }
+  __device__ __forceinline__ double open01() {
+    const double v = pm::from_bits(0x3FF0000000000000ull | (next_u64() >> 12));
+    return v - (1.0 - 2.220446049250313e-16 / 2.0);
+  }
+  __device__ __forceinline__ double std_normal() {  // rand_distr StandardNormal (256-layer ziggurat), as above
+    for (;;) {
+      const uint64_t bits = next_u64();
+      const uint32_t i = (uint32_t)bits & 0xffu;
+      const double u = pm::from_bits(0x4000000000000000ull | (bits >> 12)) - 3.0;
+      const double x = u * ZIG_NORM_X[i];
+      if (pm::fabs_(x) < ZIG_NORM_X[i + 1]) return x;
+      if (i == 0) {
+        const double Rz = 3.654152885361008796;
+        double xx = 1.0, yy = 0.0;
+        while (-2.0 * yy < xx * xx) {
+          const double x_ = open01();
+          const double y_ = open01();
+          xx = pm::log(x_) / Rz;
+          yy = pm::log(y_);
+        }
+        return (u < 0.0) ? xx - Rz : Rz - xx;
+      }
+      const double lhs = ZIG_NORM_F[i + 1] + (ZIG_NORM_F[i] - ZIG_NORM_F[i + 1]) * f64();
+      if (lhs < pm::exp(-x * x / 2.0)) return x;
+    }
+  }
+};
+
+template <int R>
+__global__ __launch_bounds__(64) void k_agents_mixed_lanes(DevArgs a, MixedArgs ma, MixedLists ml) {
+  __shared__ uint16_t list[64 * R * 64];  // event list of lane l: list[k * 64 + l]
+  const int lane = threadIdx.x;
+  const uint32_t b = a.book_begin + blockIdx.x * 64 + lane;
+  if (b >= a.book_end) return;
+  uint32_t* st = a.state + (size_t)b * a.state_stride;
+  uint32_t* bt = a.batch + (size_t)b * a.batch_stride;
+  const size_t NB = ml.n_books;
+
+  LaneRng rng;
+  {
+    const uint2 x0 = *reinterpret_cast<const uint2*>(st + H_S0_LO);
+    const uint2 x1 = *reinterpret_cast<const uint2*>(st + H_S1_LO);
+    rng.s0 = mk64(x0.x, x0.y);
+    rng.s1 = mk64(x1.x, x1.y);
+  }
+  uint32_t next_id = st[H_NEXT_ID];
+  uint32_t new_flags = 0, n_ev = 0;
+  // OrderBook::mid_price (orderbook.rs:272-276): the touches of the last level-2 record are the book's (the updates
+  // only queue events)
+  double mid;
+  {
+    const uint32_t* l2 = a.l2_last + (size_t)b * a.l2_width;
+    const uint32_t bid = l2[1], ask = l2[2];
+    mid = static_cast<double>(bid) + 0.5 * static_cast<double>(ask - bid);
+  }
+  // slot allocation cursor: word `wcur` of the occupancy (live | listed | allocated this step), lowest free bit first
+  const uint32_t n_fixed = ma.n_fixed;
+  uint32_t wcur = n_fixed >> 5, cw = 0xFFFFFFFFu;
+  auto load_word = [&](uint32_t w) -> uint32_t {
+    uint32_t v = st[H_LIVE0 + w] | ml.inl[(size_t)w * NB + b];
+    if (n_fixed > 32u * w) v |= (n_fixed - 32u * w >= 32u) ? 0xFFFFFFFFu : ((1u << (n_fixed - 32u * w)) - 1u);
+    return v;
+  };
+  if (wcur < 2u * R) cw = load_word(wcur);
+  auto pool_ptr = [&](uint32_t slot, int field) -> uint32_t* {
+    return st + HDR_DW + (slot >> 6) * (POOL_FIELDS * 64) + field * 64 + (slot & 63u);
+  };
+  // Env::place_order from a member: id + New event; returns the slot (or 0xFFFF when the pool is full: flagged)
+  auto create = [&](bool is_bid, uint32_t price, uint32_t vol, uint32_t tag) -> uint32_t {
+    const uint32_t id = next_id;
+    next_id += 1;  // create_order consumes the id (orderbook.rs:363)
+    while (cw == 0xFFFFFFFFu && wcur < 2u * R) {
+      wcur += 1;
+      if (wcur < 2u * R) cw = load_word(wcur);
+    }
+    if (wcur >= 2u * R) {
+      new_flags |= FLAG_POOL_OVERFLOW;  // reported, never silent: the order (and its event) is dropped
+      return 0xFFFFu;
+    }
+    const uint32_t bit = __builtin_ctz(~cw);
+    cw |= 1u << bit;
+    const uint32_t slot = wcur * 32u + bit;
+    *pool_ptr(slot, 0) = price;
+    *pool_ptr(slot, 1) = vol;
+    *pool_ptr(slot, 2) = id;
+    *pool_ptr(slot, 4) = 4u | (is_bid ? 2u : 0u) | (tag << 8);  // pending New
+    list[n_ev * 64 + lane] = (uint16_t)slot;
+    n_ev += 1;
+    return slot;
+  };
+
+  for (uint32_t j = 0; j < ma.n_desc; ++j) {  // members in declaration order (crates/macros/src/lib.rs:57-73)
+    const MixedDesc D = ma.descs[j];
+    if (D.type == 0) {
+      // ---- RandomAgents::update (random_agent.rs:85-119), fixed slots [slot_base, slot_base + n)
+      uint32_t lw = 0;
+      for (uint32_t i = 0; i < D.n; ++i) {
+        const uint32_t n = D.slot_base + i;
+        if (i == 0 || (n & 31u) == 0) lw = st[H_LIVE0 + (n >> 5)];
+        const uint32_t x = rng.next_u32();
+        if ((x >> 8) < D.thr) {
+          list[n_ev * 64 + lane] = (uint16_t)n;
+          n_ev += 1;
+          if (!((lw >> (n & 31u)) & 1u)) {
+            const uint32_t side = rng.below(2u, 0x7FFFFFFFu);
+            const uint32_t tick = D.tick_lo + rng.below(D.tick_rng, D.tick_zone);
+            const uint32_t vol = D.vol_lo + rng.below(D.vol_rng, D.vol_zone);
+            *pool_ptr(n, 0) = tick * D.tick_size;
+            *pool_ptr(n, 1) = vol;
+            *pool_ptr(n, 2) = next_id;
+            *pool_ptr(n, 4) = 4u | (side ? 2u : 0u);
+            next_id += 1;
+          }
+        }
+      }
+      continue;
+    }
+    // ---- common::cancel_live_orders (common.rs:56-75): Active orders of the list in order, one f32 draw each
+    const uint32_t tag = j + 1;
+    uint16_t* my = ml.list + (size_t)j * ml.cap * NB + b;
+    uint32_t len = ml.len[(size_t)j * NB + b], keep = 0;
+    {
+      uint32_t lw = 0, lwi = 0xFFFFFFFFu;
+      for (uint32_t i = 0; i < len; ++i) {
+        const uint32_t slot = my[(size_t)i * NB];
+        if ((slot >> 5) != lwi) {
+          lwi = slot >> 5;
+          lw = st[H_LIVE0 + lwi];
+        }
+        if (!((lw >> (slot & 31u)) & 1u)) {  // filled or cancelled meanwhile: forget it, the slot becomes allocatable
+          atomicAnd(&ml.inl[(size_t)(slot >> 5) * NB + b], ~(1u << (slot & 31u)));
+          continue;
+        }
+        const uint32_t x = rng.next_u32();
+        if ((int32_t)(x >> 8) > D.keep_thr) {  // gen::<f32>() > p_cancel: kept
+          my[(size_t)keep * NB] = (uint16_t)slot;
+          keep += 1;
+        } else {  // env.cancel_order(id); stays live (and unallocatable) until the event is processed
+          list[n_ev * 64 + lane] = (uint16_t)slot;
+          n_ev += 1;
+          atomicAnd(&ml.inl[(size_t)(slot >> 5) * NB + b], ~(1u << (slot & 31u)));
+        }
+      }
+    }
+    auto remember = [&](uint32_t slot) {  // live_orders.push(order_id)
+      if (slot == 0xFFFFu) return;
+      my[(size_t)keep * NB] = (uint16_t)slot;
+      keep += 1;
+      atomicOr(&ml.inl[(size_t)(slot >> 5) * NB + b], 1u << (slot & 31u));
+    };
+    if (D.type == 1) {
+      // ---- NoiseAgent::update (noise_agent.rs:127-176)
+      for (uint32_t t = 0; t < D.n; ++t) {
+        if ((rng.next_u32() >> 8) < D.thr_limit) {                   // gen::<f32>() < p_limit
+          const bool buy = rng.next_u64() < 0x8000000000000000ull;   // gen_bool(0.5)
+          const double dist = pm::fabs_(pm::exp(D.mu + D.sigma * rng.std_normal()));
+          const uint32_t price = buy ? round_price_down(mid - dist, D.tick_f) : round_price_up(mid + dist, D.tick_f);
+          remember(create(buy, price, D.trade_vol, tag));
+        }
+        if ((rng.next_u32() >> 8) < D.thr_market) {                  // gen::<f32>() < p_market
+          const bool buy = rng.next_u64() < 0x8000000000000000ull;
+          create(buy, buy ? 0xFFFFFFFFu : 0u, D.trade_vol, 0u);
+        }
+      }
+    } else {
+      // ---- MomentumAgent::update (momentum_agent.rs:146-208)
+      double m = 0.0, p_market = 0.0;
+      const uint32_t gflags = st[H_GFLAGS];
+      if ((gflags >> j) & 1u) {
+        const double gm = pm::from_bits(mk64(st[H_GST + 4 * j], st[H_GST + 4 * j + 1]));
+        const double gl = pm::from_bits(mk64(st[H_GST + 4 * j + 2], st[H_GST + 4 * j + 3]));
+        m = gm * (1.0 - D.decay) + D.decay * (mid - gl);
+        p_market = D.demand * pm::tanh(D.scale * m) / D.n_f;
+      }
+      const uint64_t thr_l = thr53(D.order_ratio * p_market), thr_m = thr53(p_market);
+      const int sgn = (m > 0.0) ? 1 : ((m < 0.0) ? -1 : 0);
+      for (uint32_t t = 0; t < D.n; ++t) {
+        if ((rng.next_u64() >> 11) < thr_l) {  // gen::<f64>() < p_limit
+          if (sgn != 0) {
+            const double dist = pm::fabs_(pm::exp(D.mu + D.sigma * rng.std_normal()));
+            const uint32_t price =
+                sgn > 0 ? round_price_down(mid - dist, D.tick_f) : round_price_up(mid + dist, D.tick_f);
+            remember(create(sgn > 0, price, D.trade_vol, tag));
+          }
+        }
+        if ((rng.next_u64() >> 11) < thr_m) {  // gen::<f64>() < p_market
+          if (sgn != 0) create(sgn > 0, sgn > 0 ? 0xFFFFFFFFu : 0u, D.trade_vol, 0u);
+        }
+      }
+      const uint64_t mb = pm::to_bits(m), lb = pm::to_bits(mid);
+      st[H_GST + 4 * j] = (uint32_t)mb;
+      st[H_GST + 4 * j + 1] = (uint32_t)(mb >> 32);
+      st[H_GST + 4 * j + 2] = (uint32_t)lb;
+      st[H_GST + 4 * j + 3] = (uint32_t)(lb >> 32);
+      st[H_GFLAGS] = gflags | (1u << j);
+    }
+    ml.len[(size_t)j * NB + b] = keep;
+  }
+
+  // ---- transactions.shuffle(rng) (env.rs:121)
+  {
+    uint32_t i = n_ev > 1 ? n_ev - 1 : 0;
+    while (i != 0) {
+      const uint32_t rg = i + 1;
+      const uint32_t jx = rng.below(rg, (rg << __builtin_clz(rg)) - 1u);
+      const uint16_t ai = list[i * 64 + lane], aj = list[jx * 64 + lane];
+      list[i * 64 + lane] = aj;
+      list[jx * 64 + lane] = ai;
+      --i;
+    }
+  }
+  *reinterpret_cast<uint2*>(st + H_S0_LO) = make_uint2((uint32_t)rng.s0, (uint32_t)(rng.s0 >> 32));
+  *reinterpret_cast<uint2*>(st + H_S1_LO) = make_uint2((uint32_t)rng.s1, (uint32_t)(rng.s1 >> 32));
+  st[H_NEXT_ID] = next_id;
+  if (new_flags) st[H_FLAGS] |= new_flags;
+  bt[BT_NEV] = n_ev;
+  for (uint32_t k = 0; k < n_ev; k += 2) {
+    const uint32_t lo = list[k * 64 + lane];
+    const uint32_t hi = (k + 1 < n_ev) ? list[(k + 1) * 64 + lane] : 0u;
+    bt[BT_EV + (k >> 1)] = lo | (hi << 16);
+  }
+}
+
+// (Re)build the members' lists from the pool after the wave-per-book kernels (or a restore) have run: live slots
+// tagged with the member, oldest order first.  One wave per book.
+template <int R>
+__global__ __launch_bounds__(256) void k_mixed_lists_rebuild(DevArgs a, MixedArgs ma, MixedLists ml) {
+  const int lane = threadIdx.x & 63;
+  const uint32_t book = rfl(blockIdx.x * 4 + (threadIdx.x >> 6));
+  if (book >= a.n_books) return;
+  const uint32_t* st = a.state + (size_t)book * a.state_stride;
+  const size_t NB = ml.n_books;
+  uint32_t id[R], meta[R];
+  uint64_t listed[R];
 #pragma unroll
   for (int r = 0; r < R; ++r) {
-    uint32_t* p = st + HDR_DW + r * POOL_FIELDS * 64 + 4 * 64;
-    p[lane] = (lane_bit(B.live[r]) ? 1u : 0u) | (lane_bit(B.bid[r]) ? 2u : 0u) | (C.owner[r] << 8);
+    id[r] = st[HDR_DW + r * POOL_FIELDS * 64 + 2 * 64 + lane];
+    meta[r] = st[HDR_DW + r * POOL_FIELDS * 64 + 4 * 64 + lane];
+    listed[r] = 0;
+  }
+  for (uint32_t j = 0; j < ma.n_desc; ++j) {
+    uint64_t mask[R];
+    uint64_t any = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      mask[r] = __ballot((meta[r] & 1u) && ((meta[r] >> 8) & 0xFFu) == j + 1);
+      any |= mask[r];
+      listed[r] |= mask[r];
+    }
+    uint32_t n = 0;
+    while (any) {
+      uint32_t m = 0xFFFFFFFFu;
+#pragma unroll
+      for (int r = 0; r < R; ++r) m = min(m, sel(mask[r], id[r], 0xFFFFFFFFu));
+      const uint32_t idmin = wave_umin(m);
+      int slot = 0;
+      any = 0;
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const uint64_t hit = mask[r] & __ballot(id[r] == idmin);
+        if (hit) slot = r * 64 + (int)__builtin_ctzll(hit);
+        mask[r] &= ~hit;
+        any |= mask[r];
+      }
+      if (lane == 0) ml.list[((size_t)j * ml.cap + n) * NB + book] = (uint16_t)slot;
+      n += 1;
+    }
+    if (lane == 0) ml.len[(size_t)j * NB + book] = n;
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    if (lane == 0) {
+      ml.inl[(size_t)(2 * r) * NB + book] = (uint32_t)listed[r];
+      ml.inl[(size_t)(2 * r + 1) * NB + book] = (uint32_t)(listed[r] >> 32);
+    }
   }
 }
 

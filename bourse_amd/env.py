@@ -532,8 +532,9 @@ class ManyBookEnv:
         return float(ms.value), int(n.value)
 
     def set_pipeline(self, mode: str):
-        """'auto' | 'fused' | 'split' — kernel pipeline of run(); results are identical."""
-        check(self._L.bk_set_pipeline(self._h, {"auto": 0, "fused": 1, "split": 2}[mode]))
+        """'auto' | 'fused' | 'split' | 'split_wave' — kernel pipeline of run(); results are identical.  ('split_wave':
+        AgentSets with Noise/Momentum members keep their update one wave per book; for RandomAgents it equals 'split'.)"""
+        check(self._L.bk_set_pipeline(self._h, {"auto": 0, "fused": 1, "split": 2, "split_wave": 3}[mode]))
 
     def pipeline(self) -> Tuple[str, int]:
         """('fused' | 'split', number of book parts launched on separate streams) that run() will use."""

@@ -609,11 +609,14 @@ MOM_P = dict(tick_size=2, p_cancel=0.1, trade_vol=100, decay=1.0, demand=5.0, sc
 
 
 def _compare_members(bk, oracle, n_books, members, levels, n_steps, tick=1, step_size=1_000_000, seed=101, pool=256,
-                     chunks=None):
+                     chunks=None, pipeline="fused"):
     env = bk.ManyBookEnv(n_books, seed, 0, tick, step_size, True, levels=levels, max_live_orders=pool,
                          trade_capacity=64 * n_steps * 8, history_capacity=n_steps)
     env.set_agents(members)
-    for c in (chunks or [n_steps]):
+    for i, c in enumerate(chunks or [n_steps]):
+        # fused = k_run_mixed; split = k_agents_mixed_lanes + k_step_batch per step; split_wave = k_agents_mixed + k_step_batch;
+    # "mixed" cycles through the three between launches (they share the device state; the lane kernel's lists are rebuilt)
+        env.set_pipeline(("fused", "split", "split_wave")[i % 3] if pipeline == "mixed" else pipeline)
         env.run(c)
     ref = oracle.ManyBooks(n_books, seed, 0, tick, step_size, True, levels, members=members)
     ref.run(n_steps, 2)
@@ -640,10 +643,12 @@ def _compare_members(bk, oracle, n_books, members, levels, n_steps, tick=1, step
     return hist
 
 
-def test_noise_agents_on_device(bk, oracle):
-    _compare_members(bk, oracle, 24, [("noise", 0, 20, NOISE_P)], levels=10, n_steps=80)
+@pytest.mark.parametrize("pipeline", PIPELINES + ["split_wave"])
+def test_noise_agents_on_device(bk, oracle, pipeline):
+    _compare_members(bk, oracle, 24, [("noise", 0, 20, NOISE_P)], levels=10, n_steps=80, pipeline=pipeline)
     _compare_members(bk, oracle, 5, [("noise", 3, 50, dict(NOISE_P, p_limit=0.6, p_market=0.1, p_cancel=0.3, price_dist_sigma=2.5,
-                                                           price_dist_mu=1.0, tick_size=4))], levels=16, n_steps=60, tick=2)
+                                                           price_dist_mu=1.0, tick_size=4))], levels=16, n_steps=60, tick=2,
+                     pipeline=pipeline)
 
 
 def test_momentum_and_noise_doc_example_on_device(bk, oracle):
@@ -651,19 +656,32 @@ def test_momentum_and_noise_doc_example_on_device(bk, oracle):
     members = [("momentum", 0, 10, MOM_P), ("noise", 10, 20, NOISE_P)]
     a = _compare_members(bk, oracle, 16, members, levels=10, n_steps=50)
     b = _compare_members(bk, oracle, 16, members, levels=10, n_steps=50, chunks=[7, 1, 42])
-    assert np.array_equal(a, b)
+    c = _compare_members(bk, oracle, 16, members, levels=10, n_steps=50, pipeline="split")
+    d = _compare_members(bk, oracle, 16, members, levels=10, n_steps=50, chunks=[7, 1, 20, 3, 9, 10], pipeline="mixed")
+    e = _compare_members(bk, oracle, 16, members, levels=10, n_steps=50, pipeline="split_wave")
+    assert np.array_equal(a, b) and np.array_equal(a, c) and np.array_equal(a, d) and np.array_equal(a, e)
 
 
 def test_mixed_random_noise_momentum_set_on_device(bk, oracle):
     members = [("random", 40, (1073741800, 1073741840), (10, 20), 2, 0.5), ("noise", 0, 30, dict(NOISE_P, p_limit=0.4)),
                ("momentum", 100, 25, dict(MOM_P, demand=8.0, scale=0.01, decay=0.5)), ("noise", 200, 10, dict(NOISE_P, price_dist_sigma=3.0))]
     _compare_members(bk, oracle, 12, members, levels=32, n_steps=60, tick=2, pool=512)
+    _compare_members(bk, oracle, 12, members, levels=32, n_steps=60, tick=2, pool=512, chunks=[11, 20, 10, 4, 15], pipeline="mixed")
+    _compare_members(bk, oracle, 70, members, levels=32, n_steps=60, tick=2, pool=512, pipeline="split")
+
+
+def test_mixed_members_split_pipeline_in_parts(bk, oracle):
+    # enough books for the three-part staggered launch of k_agents_mixed + k_step_batch
+    members = [("momentum", 0, 10, MOM_P), ("noise", 10, 20, NOISE_P)]
+    _compare_members(bk, oracle, 12300, members, levels=10, n_steps=8, pool=128, pipeline="split")
 
 
 def test_c5_as_written_momentum_plus_noise_512_agents(bk, oracle):
     # BASELINE configs[4]: 512 momentum + "market-maker" (= NoiseAgent, the reference has no market maker) agents, 64 levels
     members = [("momentum", 0, 256, dict(MOM_P, demand=20.0)), ("noise", 256, 256, dict(NOISE_P, p_limit=0.3, p_cancel=0.2))]
     _compare_members(bk, oracle, 6, members, levels=64, n_steps=40, pool=512)
+    _compare_members(bk, oracle, 6, members, levels=64, n_steps=40, pool=512, pipeline="split")
+    _compare_members(bk, oracle, 6, members, levels=64, n_steps=40, pool=512, pipeline="split_wave")
 
 
 @pytest.mark.parametrize("seed", range(8))
@@ -1001,3 +1019,27 @@ def test_streaming_l2_and_trades_together(bk, oracle):
         for f in ("t", "side", "price", "vol", "active_id", "passive_id"):
             assert np.array_equal(got[f], exp[f]), (b, f)
     assert not env.flags().any()
+
+
+def test_checkpoint_restore_with_noise_and_momentum_members(bk):
+    """The checkpoint carries the books AND their latest level-2 records (the lane-per-book members' update takes the
+    mid price from there); the members' lists are rebuilt from the pool after a restore."""
+    members = [("momentum", 0, 10, MOM_P), ("noise", 10, 20, NOISE_P)]
+
+    def mk(pipeline):
+        e = bk.ManyBookEnv(40, 9, 0, 1, 1_000_000, levels=10, max_live_orders=128, trade_capacity=4096, history_capacity=64)
+        e.set_agents(members)
+        e.set_pipeline(pipeline)
+        return e
+
+    a = mk("split")
+    a.run(17)
+    ck = a.checkpoint()
+    a.run(23)
+    for pipeline in ("split", "fused", "split_wave"):
+        b = mk(pipeline)
+        b.restore(ck)
+        b.run(23)
+        assert np.array_equal(a.history()[17:], b.history()), pipeline
+        assert [a.rng_state(i) for i in range(40)] == [b.rng_state(i) for i in range(40)]
+        assert np.array_equal(a.trade_counts(), b.trade_counts())
