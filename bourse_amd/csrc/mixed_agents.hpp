@@ -577,25 +577,34 @@ __global__ __launch_bounds__(64) void k_agents_mixed_lanes(DevArgs a, MixedArgs 
     uint16_t* my = ml.list + (size_t)j * ml.cap * NB + b;
     uint32_t len = ml.len[(size_t)j * NB + b], keep = 0;
     {
+      // entries are fetched eight at a time BEFORE any of them is processed: the list is compacted in place (writes
+      // never pass the read position), and a load issued after a store to the same array would wait for it
       uint32_t lw = 0, lwi = 0xFFFFFFFFu;
-      for (uint32_t i = 0; i < len; ++i) {
-        const uint32_t slot = my[(size_t)i * NB];
-        if ((slot >> 5) != lwi) {
-          lwi = slot >> 5;
-          lw = st[H_LIVE0 + lwi];
-        }
-        if (!((lw >> (slot & 31u)) & 1u)) {  // filled or cancelled meanwhile: forget it, the slot becomes allocatable
-          atomicAnd(&ml.inl[(size_t)(slot >> 5) * NB + b], ~(1u << (slot & 31u)));
-          continue;
-        }
-        const uint32_t x = rng.next_u32();
-        if ((int32_t)(x >> 8) > D.keep_thr) {  // gen::<f32>() > p_cancel: kept
-          my[(size_t)keep * NB] = (uint16_t)slot;
-          keep += 1;
-        } else {  // env.cancel_order(id); stays live (and unallocatable) until the event is processed
-          list[n_ev * 64 + lane] = (uint16_t)slot;
-          n_ev += 1;
-          atomicAnd(&ml.inl[(size_t)(slot >> 5) * NB + b], ~(1u << (slot & 31u)));
+      for (uint32_t i0 = 0; i0 < len; i0 += 8) {
+        uint32_t ent[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) ent[q] = (i0 + q < len) ? my[(size_t)(i0 + q) * NB] : 0xFFFFu;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const uint32_t slot = ent[q];
+          if (slot == 0xFFFFu) continue;
+          if ((slot >> 5) != lwi) {
+            lwi = slot >> 5;
+            lw = st[H_LIVE0 + lwi];
+          }
+          if (!((lw >> (slot & 31u)) & 1u)) {  // filled or cancelled meanwhile: forget it, the slot becomes allocatable
+            atomicAnd(&ml.inl[(size_t)(slot >> 5) * NB + b], ~(1u << (slot & 31u)));
+            continue;
+          }
+          const uint32_t x = rng.next_u32();
+          if ((int32_t)(x >> 8) > D.keep_thr) {  // gen::<f32>() > p_cancel: kept
+            my[(size_t)keep * NB] = (uint16_t)slot;
+            keep += 1;
+          } else {  // env.cancel_order(id); stays live (and unallocatable) until the event is processed
+            list[n_ev * 64 + lane] = (uint16_t)slot;
+            n_ev += 1;
+            atomicAnd(&ml.inl[(size_t)(slot >> 5) * NB + b], ~(1u << (slot & 31u)));
+          }
         }
       }
     }
