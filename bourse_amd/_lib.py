@@ -101,6 +101,7 @@ SIGNATURES = {
     "bk_set_tick_sizes": (_i32, [_vp, _u32, _p32]),
     "bk_set_random_market_agents": (_i32, [_vp, _u32, C.POINTER(RandomAgentsCfg), _p32]),
     "bk_set_agents": (_i32, [_vp, _u32, C.POINTER(AgentDesc)]),
+    "bk_set_market_agents": (_i32, [_vp, _u32, C.POINTER(AgentDesc), _p32]),
     "bk_run": (_i32, [_vp, _u64]),
     "bk_l2_width": (_u32, [_vp]),
     "bk_level2": (_i32, [_vp, _u32, _u32, _p32]),

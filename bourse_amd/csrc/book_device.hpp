@@ -36,7 +36,7 @@ constexpr int MAX_GROUPS = 8;
 constexpr int MAX_ASSETS = 8;  // books per market (MarketEnv<ASSETS>)
 
 constexpr uint32_t FLAG_POOL_OVERFLOW = 1u, FLAG_TRADE_OVERFLOW = 2u, FLAG_STEP_SIZE = 4u,
-                   FLAG_ORDER_LOG_FULL = 8u, FLAG_UNKNOWN_ORDER = 16u, FLAG_HIST_OVERFLOW = 32u;
+                   FLAG_ORDER_LOG_FULL = 8u, FLAG_UNKNOWN_ORDER = 16u, FLAG_HIST_OVERFLOW = 32u, FLAG_PRICE_TICK = 64u;
 
 struct Group {  // RandomAgents::new, host-preprocessed
   uint32_t n;          // agents in the group
@@ -603,11 +603,12 @@ __device__ __forceinline__ void store_book(const Book<R>& B, const Rng& rng, uin
 // ----------------------------------------------------------------------------------
 // MKT: the list is the MARKET's queue (market_env.rs:110-121); this book processes the events of its own agents'
 // slots (`mine`) at their global positions t0 + k and skips the rest.  Returns trades; `n_own` = events processed.
-template <int R, bool MKT = false>
+// TAGGED (MKT lists written by k_agents_mixed_lanes): entry = slot | asset << 12, ownership by the tag.
+template <int R, bool MKT = false, bool TAGGED = false>
 __device__ __forceinline__ uint32_t step_from_list(Book<R>& B, const DevArgs& a, uint32_t book, int lane,
                                                    const uint32_t (&ev)[R], uint32_t n_ev, uint32_t* bins,
                                                    uint32_t hist_slot, bool write_last, uint32_t tick,
-                                                   const uint64_t (&mine)[R], uint32_t& n_own) {
+                                                   const uint64_t (&mine)[R], uint32_t& n_own, uint32_t asset = 0) {
   const uint64_t step_size = mk64(a.step_lo, a.step_hi);
   const uint64_t t0 = B.t;
   B.trade_vol = 0;  // reset_trade_vol (env.rs:118)
@@ -619,8 +620,12 @@ __device__ __forceinline__ uint32_t step_from_list(Book<R>& B, const DevArgs& a,
     if (n_ev > kb) {
       const uint32_t cnt = (n_ev - kb) < 64u ? (n_ev - kb) : 64u;
       for (uint32_t l = 0; l < cnt; ++l) {
-        const uint32_t slot = rdl(ev[re], l);
-        if (MKT) {
+        uint32_t slot = rdl(ev[re], l);
+        if (MKT && TAGGED) {
+          if ((slot >> 12) != asset) continue;
+          slot &= 0xFFFu;
+          ++n_own;
+        } else if (MKT) {
           if (!mask_test<R>(mine, slot)) continue;
           ++n_own;
         }
@@ -925,8 +930,9 @@ __global__ __launch_bounds__(64) void k_step_batch(DevArgs a, uint64_t step_inde
   }
   B.next_id = base;
   uint32_t n_own = 0;
-  const uint32_t ntr = step_from_list<R, MKT>(B, a, book, lane, ev, n_ev, lds[wv], a.hist_slot0, write_last != 0,
-                                              MKT ? a.asset_tick[asset] : a.tick_size, mine, n_own);
+  const uint32_t ntr = step_from_list<R, MKT, MKT && POOLPEND>(B, a, book, lane, ev, n_ev, lds[wv], a.hist_slot0,
+                                                               write_last != 0, MKT ? a.asset_tick[asset] : a.tick_size,
+                                                               mine, n_own, asset);
   store_book<R>(B, rng, st, lane, step_index + 1, ntr, n_own);
   if (POOLPEND) {
 #pragma unroll

@@ -134,8 +134,19 @@ struct bk_env {
   DevBuf<uint16_t> ml_list;
   DevBuf<uint32_t> ml_len, ml_inl;
   bool ml_valid = false;  // the lists describe the pool as of steps_done (false after a wave-per-book launch / restore)
+  uint32_t member_asset[MAX_MEMBERS] = {0, 0, 0, 0};
+  uint32_t n_fixed_a[MAX_ASSETS] = {0, 0, 0, 0, 0, 0, 0, 0};
   MixedLists lists() const {
-    return MixedLists{ml_list.p, ml_len.p, ml_inl.p, static_cast<uint32_t>(R) * 64u, cfg.n_books};
+    return MixedLists{ml_list.p, ml_len.p, ml_inl.p, static_cast<uint32_t>(R) * 64u, cfg.n_books, cfg.n_books / M};
+  }
+  MixedArgs margs() const {
+    MixedArgs ma{};
+    ma.descs = mixed_descs.p;
+    ma.n_desc = n_mixed;
+    ma.n_fixed = n_fixed;
+    for (int i = 0; i < MAX_MEMBERS; ++i) ma.asset[i] = member_asset[i];
+    for (int i = 0; i < MAX_ASSETS; ++i) ma.n_fixed_a[i] = n_fixed_a[i];
+    return ma;
   }
   std::vector<BookHost> books;
   std::vector<Group> groups;
@@ -239,7 +250,7 @@ int launch_mixed(bk_env* env, const DevArgs& a, uint64_t first_step, uint32_t n_
   const uint32_t blocks = (env->cfg.n_books + 3) / 4;
   env->prof_now = env->profile > 0;
   ProfScope ps(env, 0);
-  MixedArgs ma{env->mixed_descs.p, env->n_mixed, env->n_fixed};
+  const MixedArgs ma = env->margs();
   hipLaunchKernelGGL(k_run_mixed<R>, dim3(blocks), dim3(256), 0, env->stream, a, ma, first_step, n_steps);
   HIPCHK(hipGetLastError());
   return BK_OK;
@@ -250,12 +261,12 @@ int launch_mixed(bk_env* env, const DevArgs& a, uint64_t first_step, uint32_t n_
 // per book (k_agents_mixed_lanes)
 template <int R, int MIXED = 0>
 int launch_split(bk_env* env, const DevArgs& a0, uint64_t first_step, uint32_t n_steps) {
-  const MixedArgs ma{env->mixed_descs.p, env->n_mixed, env->n_fixed};
+  const MixedArgs ma = env->margs();
   if (MIXED == 2) {
-    const size_t NB = env->cfg.n_books, cap = static_cast<size_t>(R) * 64;
+    const size_t NB = env->cfg.n_books, cap = static_cast<size_t>(R) * 64, NU = NB / env->M;
     if (!env->ml_list.p) {
-      HIPCHK(env->ml_list.alloc(MAX_MEMBERS * cap * NB));
-      HIPCHK(env->ml_len.alloc(MAX_MEMBERS * NB));
+      HIPCHK(env->ml_list.alloc(MAX_MEMBERS * cap * NU));
+      HIPCHK(env->ml_len.alloc(MAX_MEMBERS * NU));
       HIPCHK(env->ml_inl.alloc(2 * static_cast<size_t>(R) * NB));
       env->ml_valid = false;
     }
@@ -297,8 +308,10 @@ int launch_split(bk_env* env, const DevArgs& a0, uint64_t first_step, uint32_t n
       if (P > 1 && s == 0 && i > 0) HIPCHK(hipStreamWaitEvent(st, env->ev_first[i - 1], 0));  // stagger the parts
       {
         ProfScope ps(env, 1, st);
-        if (MIXED == 2)
-          hipLaunchKernelGGL(k_agents_mixed_lanes<R>, dim3((nb + 63) / 64), dim3(64), 0, st, a, ma, ml);
+        if (MIXED == 2 && M > 1)
+          hipLaunchKernelGGL((k_agents_mixed_lanes<R, true>), dim3((nb + 63) / 64), dim3(64), 0, st, a, ma, ml);
+        else if (MIXED == 2)
+          hipLaunchKernelGGL((k_agents_mixed_lanes<R, false>), dim3((nb + 63) / 64), dim3(64), 0, st, a, ma, ml);
         else if (MIXED == 1)
           hipLaunchKernelGGL(k_agents_mixed<R>, dim3((nb + 3) / 4), dim3(256), 0, st, a, ma);
         else
@@ -309,7 +322,9 @@ int launch_split(bk_env* env, const DevArgs& a0, uint64_t first_step, uint32_t n
         ProfScope ps(env, 2, st);
         // the lane-per-book members' update reads the touches from the latest level-2 record: keep it current
         const uint32_t write_last = (s + 1 == n_steps || a.hist_cap == 0 || MIXED == 2) ? 1u : 0u;
-        if (MIXED)
+        if (MIXED && M > 1)
+          hipLaunchKernelGGL((k_step_batch<R, true, true>), dim3(nb * M), dim3(64), 0, st, a, first_step + s, write_last);
+        else if (MIXED)
           hipLaunchKernelGGL((k_step_batch<R, false, true>), dim3(nb), dim3(64), 0, st, a, first_step + s, write_last);
         else if (M > 1)
           hipLaunchKernelGGL((k_step_batch<R, true>), dim3(nb * M), dim3(64), 0, st, a, first_step + s, write_last);
@@ -734,8 +749,24 @@ int bk_set_tick_sizes(bk_env* env, uint32_t n, const uint32_t* tick_sizes) {
   return BK_OK;
 }
 
+static int set_agents_impl(bk_env* env, uint32_t n_members, const bk_agent_desc* members, const uint32_t* assets);
+
 int bk_set_agents(bk_env* env, uint32_t n_members, const bk_agent_desc* members) {
   if (!env || (!members && n_members)) return fail(BK_INVALID_ARGUMENT, "null argument");
+  if (env->M > 1) return fail(BK_INVALID_ARGUMENT, "markets (assets > 1) take bk_set_market_agents");
+  return set_agents_impl(env, n_members, members, nullptr);
+}
+
+// A MarketAgentSet of RandomMarketAgents / NoiseMarketAgent / MomentumMarketAgent members (random_agent.rs:164-247,
+// noise_agent.rs:226-340, momentum_agent.rs:282-397): member i trades asset assets[i] of every market.
+int bk_set_market_agents(bk_env* env, uint32_t n_members, const bk_agent_desc* members, const uint32_t* assets) {
+  if (!env || (!members && n_members) || (!assets && n_members)) return fail(BK_INVALID_ARGUMENT, "null argument");
+  for (uint32_t i = 0; i < n_members; ++i)
+    if (assets[i] >= env->M) return fail(BK_INVALID_ARGUMENT, "member asset index out of range");
+  return set_agents_impl(env, n_members, members, assets);
+}
+
+static int set_agents_impl(bk_env* env, uint32_t n_members, const bk_agent_desc* members, const uint32_t* assets) {
   bool all_random = true;
   for (uint32_t i = 0; i < n_members; ++i) all_random = all_random && members[i].type == BK_AGENT_RANDOM;
   if (all_random) {
@@ -743,20 +774,21 @@ int bk_set_agents(bk_env* env, uint32_t n_members, const bk_agent_desc* members)
     for (uint32_t i = 0; i < n_members; ++i)
       g[i] = bk_random_agents{members[i].n_agents, members[i].tick_lo, members[i].tick_hi, members[i].vol_lo,
                               members[i].vol_hi, members[i].tick_size, members[i].activity_rate};
-    return bk_set_random_agents(env, n_members, g.data());
+    return bk_set_random_market_agents(env, n_members, g.data(), assets);
   }
   if (n_members > MAX_MEMBERS) return fail(BK_INVALID_ARGUMENT, "at most 4 members in a set with Noise/Momentum agents");
-  if (env->M > 1) return fail(BK_INVALID_ARGUMENT, "markets (assets > 1) run RandomMarketAgents only");
   if (int rc = use_device(env)) return rc;
   std::vector<MixedDesc> ds(n_members);
-  uint32_t fixed = 0;
+  uint32_t fixed_a[MAX_ASSETS] = {0, 0, 0, 0, 0, 0, 0, 0};
   for (uint32_t i = 0; i < n_members; ++i) {
+    const uint32_t as = assets ? assets[i] : 0u;
+    uint32_t& fixed = fixed_a[as];  // fixed RandomAgents slots are counted per book
     const bk_agent_desc& m = members[i];
     MixedDesc& D = ds[i];
     std::memset(&D, 0, sizeof(D));
     D.type = m.type;
     D.n = m.n_agents;
-    if (m.tick_size == 0 || m.tick_size % env->cfg.tick_size != 0)
+    if (m.tick_size == 0 || m.tick_size % env->asset_tick[as] != 0)
       return fail(BK_PRICE_NOT_TICK_MULTIPLE, "member tick_size must be a non-zero multiple of the env tick_size");
     if (m.type == BK_AGENT_RANDOM) {
       if (m.tick_lo >= m.tick_hi || m.vol_lo >= m.vol_hi || m.tick_lo == 0 ||
@@ -798,12 +830,16 @@ int bk_set_agents(bk_env* env, uint32_t n_members, const bk_agent_desc* members)
       return fail(BK_INVALID_ARGUMENT, "unknown agent type");
     }
   }
-  if (fixed >= env->cfg.max_live_orders)
-    return fail(BK_CAPACITY, "RandomAgents members leave no pool slots for the other members' orders");
+  uint32_t fixed = fixed_a[0];
+  for (uint32_t as = 0; as < env->M; ++as)
+    if (fixed_a[as] >= env->cfg.max_live_orders)
+      return fail(BK_CAPACITY, "RandomAgents members leave no pool slots for the other members' orders");
   HIPCHK(env->mixed_descs.alloc(n_members));
   HIPCHK(hipMemcpy(env->mixed_descs.p, ds.data(), ds.size() * sizeof(MixedDesc), hipMemcpyHostToDevice));
   env->n_mixed = n_members;
   env->n_fixed = fixed;
+  for (uint32_t i = 0; i < MAX_MEMBERS; ++i) env->member_asset[i] = (assets && i < n_members) ? assets[i] : 0u;
+  for (uint32_t as = 0; as < MAX_ASSETS; ++as) env->n_fixed_a[as] = fixed_a[as];
   env->ml_valid = false;
   env->groups.clear();
   env->n_agents_total = 0;
@@ -831,7 +867,7 @@ int bk_run(bk_env* env, uint64_t n_steps) {
     // split (default from 3072 books, where it overtakes the fused kernel): members' update one LANE per book + the lean
     // event kernel; mode 3 keeps the
     // wave-per-book members' update (k_agents_mixed) selectable
-    const bool mlanes = env->pipeline == 2 || (env->pipeline == 0 && env->cfg.n_books >= 3072);
+    const bool mlanes = env->pipeline == 2 || env->M > 1 || (env->pipeline == 0 && env->cfg.n_books >= 3072);
     if (mlanes) {
       switch (env->R) {
         case 1: rc = launch_split<1, 2>(env, a, env->steps_done, ns); break;

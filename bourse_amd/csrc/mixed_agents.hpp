@@ -48,6 +48,10 @@ struct MixedArgs {
   const MixedDesc* descs;
   uint32_t n_desc;
   uint32_t n_fixed;  // pool slots reserved for RandomAgents members
+  // MarketEnv mode (NoiseMarketAgent / MomentumMarketAgent / RandomMarketAgents members): the asset each member trades
+  // and the fixed slots reserved in each asset's book
+  uint32_t asset[MAX_MEMBERS];
+  uint32_t n_fixed_a[MAX_ASSETS];
 };
 
 #define ZIG_TABLE_BEGIN(name) __constant__ const double name[257] = {
@@ -131,6 +135,7 @@ struct MixedCtx {
   uint32_t ev[R];     // event list (slot indices)
   uint32_t owner[R];  // member index + 1 of the limit order resting / pending in the slot, 0 = none
   uint32_t n_fixed;   // slots [0, n_fixed) belong to RandomAgents members; the rest is allocated dynamically
+  uint32_t tick;      // the book's tick size (create_order's check)
   uint32_t n_ev;
 };
 
@@ -138,6 +143,13 @@ struct MixedCtx {
 template <int R>
 __device__ __forceinline__ void mixed_create(Book<R>& B, MixedCtx<R>& C, int lane, bool is_bid, uint32_t price,
                                              uint32_t vol, uint32_t owner_tag) {
+  // create_order's tick check (orderbook.rs:367-382); the reference `.unwrap()`s the Err (common.rs:107,140), i.e.
+  // panics: flagged, and like an Err nothing is created (no id, no event).  Reachable when a log-normal offset drives
+  // the price to the u32::MAX clamp on a book whose tick does not divide it.  Market orders carry no price.
+  if (owner_tag != 0 && price % C.tick != 0) {
+    B.flags |= FLAG_PRICE_TICK;
+    return;
+  }
   const uint32_t id = B.next_id;
   B.next_id += 1;  // create_order consumes the id (orderbook.rs:363)
   int slot = -1;
@@ -378,6 +390,7 @@ __global__ __launch_bounds__(256) void k_run_mixed(DevArgs a, MixedArgs ma, uint
   MixedState S;
   mixed_load_state(S, st, lane);
   mixed_load_ctx<R>(C, st, ma, lane);
+  C.tick = a.tick_size;
   uint32_t last_ntr = 0, last_nev = 0;
   for (uint32_t s = 0; s < n_steps; ++s) {
     mixed_update_and_shuffle<R>(B, C, rng, ma, S, lane);
@@ -405,6 +418,7 @@ __global__ __launch_bounds__(256) void k_agents_mixed(DevArgs a, MixedArgs ma) {
   MixedState S;
   mixed_load_state(S, st, lane);
   mixed_load_ctx<R>(C, st, ma, lane);
+  C.tick = a.tick_size;
   mixed_update_and_shuffle<R>(B, C, rng, ma, S, lane);
   // the step counter / last-step figures are k_step_batch's to write: keep the header's values
   const uint32_t hdr = st[lane];
@@ -434,6 +448,7 @@ struct MixedLists {
   uint32_t* inl;   // [2R][n_books]: slots referenced by the lists, 32 per word
   uint32_t cap;    // entries per member = pool size
   uint32_t n_books;
+  uint32_t n_units;  // lists are per market (= book when assets == 1)
 };
 
 struct LaneRng {  // xoroshiro128** per lane
@@ -483,47 +498,82 @@ struct LaneRng {  // xoroshiro128** per lane
   }
 };
 
-template <int R>
+// MKT: the lane owns a MARKET (books [b*M, b*M + M)): one RNG stream, one event queue; member j trades asset
+// ma.asset[j] (NoiseMarketAgent / MomentumMarketAgent / RandomMarketAgents: noise_agent.rs:281-339,
+// momentum_agent.rs:328-396, random_agent.rs:204-247); event entries carry the asset in bits 12..14.
+template <int R, bool MKT>
 __global__ __launch_bounds__(64) void k_agents_mixed_lanes(DevArgs a, MixedArgs ma, MixedLists ml) {
   __shared__ uint16_t list[64 * R * 64];  // event list of lane l: list[k * 64 + l]
+  __shared__ uint32_t cur_w[MKT ? MAX_ASSETS * 64 : 64], cur_c[MKT ? MAX_ASSETS * 64 : 64];  // per-asset alloc cursors
   const int lane = threadIdx.x;
-  const uint32_t b = a.book_begin + blockIdx.x * 64 + lane;
+  const uint32_t b = a.book_begin + blockIdx.x * 64 + lane;  // book, or market when MKT
   if (b >= a.book_end) return;
-  uint32_t* st = a.state + (size_t)b * a.state_stride;
-  uint32_t* bt = a.batch + (size_t)b * a.batch_stride;
-  const size_t NB = ml.n_books;
+  const uint32_t M = MKT ? a.assets : 1u;
+  uint32_t* st0 = a.state + (size_t)b * M * a.state_stride;
+  uint32_t* bt = a.batch + (size_t)b * M * a.batch_stride;
+  const size_t NB = ml.n_books, NU = ml.n_units;
 
   LaneRng rng;
   {
-    const uint2 x0 = *reinterpret_cast<const uint2*>(st + H_S0_LO);
-    const uint2 x1 = *reinterpret_cast<const uint2*>(st + H_S1_LO);
+    const uint2 x0 = *reinterpret_cast<const uint2*>(st0 + H_S0_LO);
+    const uint2 x1 = *reinterpret_cast<const uint2*>(st0 + H_S1_LO);
     rng.s0 = mk64(x0.x, x0.y);
     rng.s1 = mk64(x1.x, x1.y);
   }
-  uint32_t next_id = st[H_NEXT_ID];
-  uint32_t new_flags = 0, n_ev = 0;
-  // OrderBook::mid_price (orderbook.rs:272-276): the touches of the last level-2 record are the book's (the updates
-  // only queue events)
-  double mid;
-  {
-    const uint32_t* l2 = a.l2_last + (size_t)b * a.l2_width;
-    const uint32_t bid = l2[1], ask = l2[2];
-    mid = static_cast<double>(bid) + 0.5 * static_cast<double>(ask - bid);
-  }
+  uint32_t n_ev = 0;
+  // the book the current member trades on
+  uint32_t* st = st0;
+  uint32_t bk = b * M, asset = 0, n_fixed = MKT ? ma.n_fixed_a[0] : ma.n_fixed;
+  uint32_t next_id = 0, new_flags = 0;
   // slot allocation cursor: word `wcur` of the occupancy (live | listed | allocated this step), lowest free bit first
-  const uint32_t n_fixed = ma.n_fixed;
-  uint32_t wcur = n_fixed >> 5, cw = 0xFFFFFFFFu;
+  uint32_t wcur = 0, cw = 0xFFFFFFFFu;
   auto load_word = [&](uint32_t w) -> uint32_t {
-    uint32_t v = st[H_LIVE0 + w] | ml.inl[(size_t)w * NB + b];
+    uint32_t v = st[H_LIVE0 + w] | ml.inl[(size_t)w * NB + bk];
     if (n_fixed > 32u * w) v |= (n_fixed - 32u * w >= 32u) ? 0xFFFFFFFFu : ((1u << (n_fixed - 32u * w)) - 1u);
     return v;
   };
-  if (wcur < 2u * R) cw = load_word(wcur);
+  if (MKT) {
+    for (uint32_t as = 0; as < M; ++as) cur_w[as * 64 + lane] = 0xFFFFFFFFu;  // not opened yet
+  } else {
+    wcur = n_fixed >> 5;
+    if (wcur < 2u * R) cw = load_word(wcur);
+    next_id = st[H_NEXT_ID];
+  }
+  auto open_book = [&](uint32_t as) {  // MKT: switch to the member's asset
+    asset = as;
+    st = st0 + (size_t)as * a.state_stride;
+    bk = b * M + as;
+    n_fixed = ma.n_fixed_a[as];
+    next_id = st[H_NEXT_ID];
+    new_flags = 0;
+    wcur = cur_w[as * 64 + lane];
+    cw = cur_c[as * 64 + lane];
+    if (wcur == 0xFFFFFFFFu) {
+      wcur = n_fixed >> 5;
+      cw = wcur < 2u * R ? load_word(wcur) : 0xFFFFFFFFu;
+    }
+  };
+  auto close_book = [&]() {
+    st[H_NEXT_ID] = next_id;
+    if (new_flags) st[H_FLAGS] |= new_flags;
+    cur_w[asset * 64 + lane] = wcur;
+    cur_c[asset * 64 + lane] = cw;
+  };
   auto pool_ptr = [&](uint32_t slot, int field) -> uint32_t* {
     return st + HDR_DW + (slot >> 6) * (POOL_FIELDS * 64) + field * 64 + (slot & 63u);
   };
+  auto push_event = [&](uint32_t slot) {
+    list[n_ev * 64 + lane] = (uint16_t)(slot | (asset << 12));
+    n_ev += 1;
+  };
   // Env::place_order from a member: id + New event; returns the slot (or 0xFFFF when the pool is full: flagged)
   auto create = [&](bool is_bid, uint32_t price, uint32_t vol, uint32_t tag) -> uint32_t {
+    // create_order's tick check (orderbook.rs:367-382): the reference `.unwrap()`s the Err, i.e. panics — flagged, and
+    // like an Err nothing is created (see mixed_create).  Market orders (tag 0 here) carry no price.
+    if (tag != 0 && price % (MKT ? a.asset_tick[asset] : a.tick_size) != 0) {
+      new_flags |= FLAG_PRICE_TICK;
+      return 0xFFFFu;
+    }
     const uint32_t id = next_id;
     next_id += 1;  // create_order consumes the id (orderbook.rs:363)
     while (cw == 0xFFFFFFFFu && wcur < 2u * R) {
@@ -541,13 +591,21 @@ __global__ __launch_bounds__(64) void k_agents_mixed_lanes(DevArgs a, MixedArgs 
     *pool_ptr(slot, 1) = vol;
     *pool_ptr(slot, 2) = id;
     *pool_ptr(slot, 4) = 4u | (is_bid ? 2u : 0u) | (tag << 8);  // pending New
-    list[n_ev * 64 + lane] = (uint16_t)slot;
-    n_ev += 1;
+    push_event(slot);
     return slot;
   };
 
   for (uint32_t j = 0; j < ma.n_desc; ++j) {  // members in declaration order (crates/macros/src/lib.rs:57-73)
     const MixedDesc D = ma.descs[j];
+    if (MKT) open_book(ma.asset[j]);
+    // OrderBook::mid_price (orderbook.rs:272-276): the touches of the book's last level-2 record (updates only queue
+    // events, so the book is still the one that record describes)
+    double mid;
+    {
+      const uint32_t* l2 = a.l2_last + (size_t)bk * a.l2_width;
+      const uint32_t bid = l2[1], ask = l2[2];
+      mid = static_cast<double>(bid) + 0.5 * static_cast<double>(ask - bid);
+    }
     if (D.type == 0) {
       // ---- RandomAgents::update (random_agent.rs:85-119), fixed slots [slot_base, slot_base + n)
       uint32_t lw = 0;
@@ -556,8 +614,7 @@ __global__ __launch_bounds__(64) void k_agents_mixed_lanes(DevArgs a, MixedArgs 
         if (i == 0 || (n & 31u) == 0) lw = st[H_LIVE0 + (n >> 5)];
         const uint32_t x = rng.next_u32();
         if ((x >> 8) < D.thr) {
-          list[n_ev * 64 + lane] = (uint16_t)n;
-          n_ev += 1;
+          push_event(n);
           if (!((lw >> (n & 31u)) & 1u)) {
             const uint32_t side = rng.below(2u, 0x7FFFFFFFu);
             const uint32_t tick = D.tick_lo + rng.below(D.tick_rng, D.tick_zone);
@@ -570,12 +627,13 @@ __global__ __launch_bounds__(64) void k_agents_mixed_lanes(DevArgs a, MixedArgs 
           }
         }
       }
+      if (MKT) close_book();
       continue;
     }
     // ---- common::cancel_live_orders (common.rs:56-75): Active orders of the list in order, one f32 draw each
     const uint32_t tag = j + 1;
-    uint16_t* my = ml.list + (size_t)j * ml.cap * NB + b;
-    uint32_t len = ml.len[(size_t)j * NB + b], keep = 0;
+    uint16_t* my = ml.list + (size_t)j * ml.cap * NU + b;
+    uint32_t len = ml.len[(size_t)j * NU + b], keep = 0;
     {
       // entries are fetched eight at a time BEFORE any of them is processed: the list is compacted in place (writes
       // never pass the read position), and a load issued after a store to the same array would wait for it
@@ -583,7 +641,7 @@ __global__ __launch_bounds__(64) void k_agents_mixed_lanes(DevArgs a, MixedArgs 
       for (uint32_t i0 = 0; i0 < len; i0 += 8) {
         uint32_t ent[8];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) ent[q] = (i0 + q < len) ? my[(size_t)(i0 + q) * NB] : 0xFFFFu;
+        for (int q = 0; q < 8; ++q) ent[q] = (i0 + q < len) ? my[(size_t)(i0 + q) * NU] : 0xFFFFu;
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
           const uint32_t slot = ent[q];
@@ -593,26 +651,25 @@ __global__ __launch_bounds__(64) void k_agents_mixed_lanes(DevArgs a, MixedArgs 
             lw = st[H_LIVE0 + lwi];
           }
           if (!((lw >> (slot & 31u)) & 1u)) {  // filled or cancelled meanwhile: forget it, the slot becomes allocatable
-            atomicAnd(&ml.inl[(size_t)(slot >> 5) * NB + b], ~(1u << (slot & 31u)));
+            ml.inl[(size_t)(slot >> 5) * NB + bk] &= ~(1u << (slot & 31u));  // the lane's own word: plain read-modify-write
             continue;
           }
           const uint32_t x = rng.next_u32();
           if ((int32_t)(x >> 8) > D.keep_thr) {  // gen::<f32>() > p_cancel: kept
-            my[(size_t)keep * NB] = (uint16_t)slot;
+            my[(size_t)keep * NU] = (uint16_t)slot;
             keep += 1;
           } else {  // env.cancel_order(id); stays live (and unallocatable) until the event is processed
-            list[n_ev * 64 + lane] = (uint16_t)slot;
-            n_ev += 1;
-            atomicAnd(&ml.inl[(size_t)(slot >> 5) * NB + b], ~(1u << (slot & 31u)));
+            push_event(slot);
+            ml.inl[(size_t)(slot >> 5) * NB + bk] &= ~(1u << (slot & 31u));  // the lane's own word: plain read-modify-write
           }
         }
       }
     }
     auto remember = [&](uint32_t slot) {  // live_orders.push(order_id)
       if (slot == 0xFFFFu) return;
-      my[(size_t)keep * NB] = (uint16_t)slot;
+      my[(size_t)keep * NU] = (uint16_t)slot;
       keep += 1;
-      atomicOr(&ml.inl[(size_t)(slot >> 5) * NB + b], 1u << (slot & 31u));
+      ml.inl[(size_t)(slot >> 5) * NB + bk] |= 1u << (slot & 31u);
     };
     if (D.type == 1) {
       // ---- NoiseAgent::update (noise_agent.rs:127-176)
@@ -660,7 +717,8 @@ __global__ __launch_bounds__(64) void k_agents_mixed_lanes(DevArgs a, MixedArgs 
       st[H_GST + 4 * j + 3] = (uint32_t)(lb >> 32);
       st[H_GFLAGS] = gflags | (1u << j);
     }
-    ml.len[(size_t)j * NB + b] = keep;
+    ml.len[(size_t)j * NU + b] = keep;
+    if (MKT) close_book();
   }
 
   // ---- transactions.shuffle(rng) (env.rs:121)
@@ -675,10 +733,15 @@ __global__ __launch_bounds__(64) void k_agents_mixed_lanes(DevArgs a, MixedArgs 
       --i;
     }
   }
-  *reinterpret_cast<uint2*>(st + H_S0_LO) = make_uint2((uint32_t)rng.s0, (uint32_t)(rng.s0 >> 32));
-  *reinterpret_cast<uint2*>(st + H_S1_LO) = make_uint2((uint32_t)rng.s1, (uint32_t)(rng.s1 >> 32));
-  st[H_NEXT_ID] = next_id;
-  if (new_flags) st[H_FLAGS] |= new_flags;
+  for (uint32_t as = 0; as < M; ++as) {  // every book of a market carries a copy of the market's RNG state
+    uint32_t* h = st0 + (size_t)as * a.state_stride;
+    *reinterpret_cast<uint2*>(h + H_S0_LO) = make_uint2((uint32_t)rng.s0, (uint32_t)(rng.s0 >> 32));
+    *reinterpret_cast<uint2*>(h + H_S1_LO) = make_uint2((uint32_t)rng.s1, (uint32_t)(rng.s1 >> 32));
+  }
+  if (!MKT) {
+    st[H_NEXT_ID] = next_id;
+    if (new_flags) st[H_FLAGS] |= new_flags;
+  }
   bt[BT_NEV] = n_ev;
   for (uint32_t k = 0; k < n_ev; k += 2) {
     const uint32_t lo = list[k * 64 + lane];
@@ -695,7 +758,8 @@ __global__ __launch_bounds__(256) void k_mixed_lists_rebuild(DevArgs a, MixedArg
   const uint32_t book = rfl(blockIdx.x * 4 + (threadIdx.x >> 6));
   if (book >= a.n_books) return;
   const uint32_t* st = a.state + (size_t)book * a.state_stride;
-  const size_t NB = ml.n_books;
+  const size_t NB = ml.n_books, NU = ml.n_units;
+  const uint32_t unit = book / a.assets, my_asset = book - unit * a.assets;  // assets == 1: unit == book
   uint32_t id[R], meta[R];
   uint64_t listed[R];
 #pragma unroll
@@ -705,6 +769,7 @@ __global__ __launch_bounds__(256) void k_mixed_lists_rebuild(DevArgs a, MixedArg
     listed[r] = 0;
   }
   for (uint32_t j = 0; j < ma.n_desc; ++j) {
+    if (a.assets > 1 && ma.asset[j] != my_asset) continue;  // the member trades another asset of the market
     uint64_t mask[R];
     uint64_t any = 0;
 #pragma unroll
@@ -728,10 +793,10 @@ __global__ __launch_bounds__(256) void k_mixed_lists_rebuild(DevArgs a, MixedArg
         mask[r] &= ~hit;
         any |= mask[r];
       }
-      if (lane == 0) ml.list[((size_t)j * ml.cap + n) * NB + book] = (uint16_t)slot;
+      if (lane == 0) ml.list[((size_t)j * ml.cap + n) * NU + unit] = (uint16_t)slot;
       n += 1;
     }
-    if (lane == 0) ml.len[(size_t)j * NB + book] = n;
+    if (lane == 0) ml.len[(size_t)j * NU + unit] = n;
   }
 #pragma unroll
   for (int r = 0; r < R; ++r) {

@@ -283,7 +283,7 @@ class ManyBookEnv:
         check(self._L.bk_set_random_market_agents(self._h, len(gs), arr, _lib.p32(assets)))
         self.groups = gs
 
-    def set_agents(self, members):
+    def set_agents(self, members, assets=None):
         """A ``#[derive(AgentSet)]`` struct: members updated in declaration order (ref crates/macros/src/lib.rs:57-73).
         Each member is a RandomAgents / NoiseAgent / MomentumAgent instance or the equivalent tuple
         ``("random", n, tick_range, vol_range, tick_size, rate)`` / ``("noise"|"momentum", id_start, n, params_dict)``."""
@@ -313,8 +313,18 @@ class ManyBookEnv:
                 else:
                     d.decay, d.demand = float(p["decay"]), float(p["demand"])
                     d.scale, d.order_ratio = float(p["scale"]), float(p["order_ratio"])
-        check(self._L.bk_set_agents(self._h, len(ms), arr))
+        if assets is not None:
+            as_arr = np.asarray(list(assets), dtype=np.uint32)
+            check(self._L.bk_set_market_agents(self._h, len(ms), arr, _lib.p32(as_arr)))
+        else:
+            check(self._L.bk_set_agents(self._h, len(ms), arr))
         self.members = ms
+
+    def set_market_agents(self, members):
+        """A ``#[derive(MarketAgentSet)]`` struct: ``[(asset, member), ...]`` with members as in ``set_agents`` — the
+        multi-asset twins RandomMarketAgents / NoiseMarketAgent / MomentumMarketAgent (needs ``assets > 1``)."""
+        members = list(members)
+        self.set_agents([m for _, m in members], assets=[int(a) for a, _ in members])
 
     def run(self, n_steps: int, sync: bool = True):
         """``sim_runner``'s loop body ``n_steps`` times in ONE kernel launch (runner.rs:53-68)."""

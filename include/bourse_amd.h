@@ -38,6 +38,8 @@ enum bk_status {
 #define BK_FLAG_ORDER_LOG_FULL 8u  /* order id beyond the order-log capacity */
 #define BK_FLAG_UNKNOWN_ORDER 16u  /* cancel/modify of an id that was never created */
 #define BK_FLAG_HIST_OVERFLOW 32u  /* (unused: the L2 history is a ring; reading a step that was overwritten is an error) */
+#define BK_FLAG_PRICE_TICK 64u     /* a Noise/Momentum agent's limit price (clamped to u32::MAX) was not a tick multiple:
+                                     * the reference panics here (`.unwrap()`, common.rs:107,140); the order is not created */
 
 typedef struct bk_env bk_env;
 
@@ -187,6 +189,10 @@ int bk_set_random_market_agents(bk_env* env, uint32_t n_groups, const bk_random_
  * Noise/Momentum members price orders with f64 log-normal offsets: their outputs match the CPU oracle bit for bit
  * but only statistically match a Rust build (third-party sampling + libm). */
 int bk_set_agents(bk_env* env, uint32_t n_members, const bk_agent_desc* members);
+/* Market mode: a MarketAgentSet of RandomMarketAgents / NoiseMarketAgent / MomentumMarketAgent members
+ * (random_agent.rs:164-247, noise_agent.rs:226-340, momentum_agent.rs:282-397); member i trades asset assets[i] of every
+ * market and draws from the market's RNG in declaration order. */
+int bk_set_market_agents(bk_env* env, uint32_t n_members, const bk_agent_desc* members, const uint32_t* assets);
 /* sim_runner's loop body n_steps times for every book: agents.update(env, rng); env.step(rng)
  * (crates/step_sim/src/runner.rs:53-68), sharing each book's RNG between agents and shuffle. */
 int bk_run(bk_env* env, uint64_t n_steps);

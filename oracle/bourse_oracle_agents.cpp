@@ -70,98 +70,126 @@ Price round_price_down(double p, double tick_size) {
   return static_cast<Price>(p);
 }
 
-// ref common.rs:54-76: filter Active, then partition by `gen::<f32>() > p_cancel` (kept) in list order
-std::vector<OrderId> cancel_live_orders(Env& env, Rng& rng, const std::vector<OrderId>& orders, float p_cancel) {
+// The single-asset agents and their multi-asset twins run the same update against "the book I trade on": a small
+// access adapter (Env, or one asset of a MarketEnv) keeps one restatement of the logic for both
+// (ref common.rs:54-141 vs :156-258 differ only in `env.place_order(asset, ..)` / MarketOrderId).
+namespace {
+struct EnvAccess {
+  Env& env;
+  const OrderBook& book() const { return env.order_book; }
+  void cancel(OrderId id) { env.cancel_order(id); }
+  OrderId place(Side side, Vol vol, TraderId trader, std::optional<Price> price) {
+    OrderId id = 0;
+    const int rc = env.place_order(side, vol, trader, price, &id);
+    (void)rc;  // .unwrap(): tick-multiple prices by construction
+    return id;
+  }
+};
+struct MarketAccess {
+  MarketEnv& env;
+  uint32_t asset;
+  const OrderBook& book() const { return env.market.order_books[asset]; }
+  void cancel(OrderId id) { env.cancel_order(asset, id); }
+  OrderId place(Side side, Vol vol, TraderId trader, std::optional<Price> price) {
+    OrderId id = 0;
+    const int rc = env.place_order(asset, side, vol, trader, price, &id);
+    (void)rc;
+    return id;
+  }
+};
+
+// ref common.rs:54-76 (/ :156-175): filter Active, then partition by `gen::<f32>() > p_cancel` (kept) in list order
+template <class A>
+std::vector<OrderId> cancel_live(A acc, Rng& rng, const std::vector<OrderId>& orders, float p_cancel) {
   std::vector<OrderId> live, to_cancel;
   for (OrderId id : orders) {
-    if (env.order_book.orders[id].order.status != Status::Active) continue;
+    if (acc.book().orders[id].order.status != Status::Active) continue;
     if (rng.gen_f32() > p_cancel)
       live.push_back(id);
     else
       to_cancel.push_back(id);
   }
-  for (OrderId id : to_cancel) env.cancel_order(id);
+  for (OrderId id : to_cancel) acc.cancel(id);
   return live;
 }
-
-// ref common.rs:92-108 / :124-141
-static OrderId place_buy_limit_order(Env& env, Rng& rng, const LogNormal& d, double mid, double tick, Vol vol,
-                                     TraderId trader) {
+// ref common.rs:92-108 / :124-141 (/ :197-258)
+template <class A>
+OrderId place_buy_limit(A acc, Rng& rng, const LogNormal& d, double mid, double tick, Vol vol, TraderId trader) {
   const double dist = pm::fabs_(d.sample(rng));
-  const Price price = round_price_down(mid - dist, tick);
-  OrderId id = 0;
-  const int rc = env.place_order(Side::Bid, vol, trader, price, &id);
-  (void)rc;  // .unwrap(): a tick-multiple price by construction
-  return id;
+  return acc.place(Side::Bid, vol, trader, round_price_down(mid - dist, tick));
 }
-static OrderId place_sell_limit_order(Env& env, Rng& rng, const LogNormal& d, double mid, double tick, Vol vol,
-                                      TraderId trader) {
+template <class A>
+OrderId place_sell_limit(A acc, Rng& rng, const LogNormal& d, double mid, double tick, Vol vol, TraderId trader) {
   const double dist = pm::fabs_(d.sample(rng));
-  const Price price = round_price_up(mid + dist, tick);
-  OrderId id = 0;
-  const int rc = env.place_order(Side::Ask, vol, trader, price, &id);
-  (void)rc;
-  return id;
+  return acc.place(Side::Ask, vol, trader, round_price_up(mid + dist, tick));
+}
+
+template <class A>
+void noise_update(NoiseAgent& g, A acc, Rng& rng) {  // noise_agent.rs:127-176 (/ :281-339)
+  std::vector<OrderId> live = cancel_live(acc, rng, g.orders, g.params.p_cancel);
+  const double mid = acc.book().mid_price();
+  for (TraderId trader : g.trader_ids) {
+    if (rng.gen_f32() < g.params.p_limit) {
+      const bool buy = gen_bool_half(rng);
+      live.push_back(buy ? place_buy_limit(acc, rng, g.price_dist, mid, g.tick_size, g.params.trade_vol, trader)
+                         : place_sell_limit(acc, rng, g.price_dist, mid, g.tick_size, g.params.trade_vol, trader));
+    }
+    if (rng.gen_f32() < g.params.p_market) {
+      const bool buy = gen_bool_half(rng);
+      acc.place(buy ? Side::Bid : Side::Ask, g.params.trade_vol, trader, std::nullopt);
+    }
+  }
+  g.orders = live;
+}
+
+template <class A>
+void momentum_update(MomentumAgent& g, A acc, Rng& rng) {  // momentum_agent.rs:146-208 (/ :328-396)
+  std::vector<OrderId> live = cancel_live(acc, rng, g.orders, g.params.p_cancel);
+  const double mid = acc.book().mid_price();
+  double m = 0.0, p_market = 0.0;
+  if (g.has_last_price) {
+    m = g.momentum * (1.0 - g.params.decay) + g.params.decay * (mid - g.last_price);
+    p_market = g.params.demand * pm::tanh(g.params.scale * m) / g.n;
+  }
+  const double p_limit = g.params.order_ratio * p_market;
+  for (TraderId trader : g.trader_ids) {
+    if (gen_f64(rng) < p_limit) {
+      if (m > 0.0)
+        live.push_back(place_buy_limit(acc, rng, g.price_dist, mid, g.tick_size, g.params.trade_vol, trader));
+      else if (m < 0.0)
+        live.push_back(place_sell_limit(acc, rng, g.price_dist, mid, g.tick_size, g.params.trade_vol, trader));
+    }
+    if (gen_f64(rng) < p_market) {
+      if (m > 0.0)
+        acc.place(Side::Bid, g.params.trade_vol, trader, std::nullopt);
+      else if (m < 0.0)
+        acc.place(Side::Ask, g.params.trade_vol, trader, std::nullopt);
+    }
+  }
+  g.momentum = m;
+  g.last_price = mid;
+  g.has_last_price = true;
+  g.orders = live;
+}
+}  // namespace
+
+std::vector<OrderId> cancel_live_orders(Env& env, Rng& rng, const std::vector<OrderId>& orders, float p_cancel) {
+  return cancel_live(EnvAccess{env}, rng, orders, p_cancel);
 }
 
 NoiseAgent::NoiseAgent(TraderId agent_id_start, uint16_t n_agents, NoiseAgentParams p)  // noise_agent.rs:110-123
     : tick_size(static_cast<double>(p.tick_size)), price_dist{p.price_dist_mu, p.price_dist_sigma}, params(p) {
   for (TraderId t = agent_id_start; t < agent_id_start + n_agents; ++t) trader_ids.push_back(t);
 }
-
-void NoiseAgent::update(Env& env, Rng& rng) {  // noise_agent.rs:127-176
-  std::vector<OrderId> live = cancel_live_orders(env, rng, orders, params.p_cancel);
-  const double mid = env.order_book.mid_price();
-  for (TraderId trader : trader_ids) {
-    if (rng.gen_f32() < params.p_limit) {
-      const bool buy = gen_bool_half(rng);
-      const OrderId id = buy ? place_buy_limit_order(env, rng, price_dist, mid, tick_size, params.trade_vol, trader)
-                             : place_sell_limit_order(env, rng, price_dist, mid, tick_size, params.trade_vol, trader);
-      live.push_back(id);
-    }
-    if (rng.gen_f32() < params.p_market) {
-      const bool buy = gen_bool_half(rng);
-      OrderId id = 0;
-      env.place_order(buy ? Side::Bid : Side::Ask, params.trade_vol, trader, std::nullopt, &id);
-    }
-  }
-  orders = live;
-}
+void NoiseAgent::update(Env& env, Rng& rng) { noise_update(*this, EnvAccess{env}, rng); }
+void NoiseMarketAgent::update(MarketEnv& env, Rng& rng) { noise_update(core, MarketAccess{env, asset}, rng); }
 
 MomentumAgent::MomentumAgent(TraderId agent_id_start, uint16_t n_agents, MomentumParams p)  // momentum_agent.rs:128-142
     : price_dist{p.price_dist_mu, p.price_dist_sigma}, n(static_cast<double>(n_agents)),
       tick_size(static_cast<double>(p.tick_size)), params(p) {
   for (TraderId t = agent_id_start; t < agent_id_start + n_agents; ++t) trader_ids.push_back(t);
 }
-
-void MomentumAgent::update(Env& env, Rng& rng) {  // momentum_agent.rs:146-208
-  std::vector<OrderId> live = cancel_live_orders(env, rng, orders, params.p_cancel);
-  const double mid = env.order_book.mid_price();
-  double m = 0.0, p_market = 0.0;
-  if (has_last_price) {
-    m = momentum * (1.0 - params.decay) + params.decay * (mid - last_price);
-    p_market = params.demand * pm::tanh(params.scale * m) / n;
-  }
-  const double p_limit = params.order_ratio * p_market;
-  for (TraderId trader : trader_ids) {
-    if (gen_f64(rng) < p_limit) {
-      if (m > 0.0)
-        live.push_back(place_buy_limit_order(env, rng, price_dist, mid, tick_size, params.trade_vol, trader));
-      else if (m < 0.0)
-        live.push_back(place_sell_limit_order(env, rng, price_dist, mid, tick_size, params.trade_vol, trader));
-    }
-    if (gen_f64(rng) < p_market) {
-      OrderId id = 0;
-      if (m > 0.0)
-        env.place_order(Side::Bid, params.trade_vol, trader, std::nullopt, &id);
-      else if (m < 0.0)
-        env.place_order(Side::Ask, params.trade_vol, trader, std::nullopt, &id);
-    }
-  }
-  momentum = m;
-  last_price = mid;
-  has_last_price = true;
-  orders = live;
-}
+void MomentumAgent::update(Env& env, Rng& rng) { momentum_update(*this, EnvAccess{env}, rng); }
+void MomentumMarketAgent::update(MarketEnv& env, Rng& rng) { momentum_update(core, MarketAccess{env, asset}, rng); }
 
 }  // namespace orc

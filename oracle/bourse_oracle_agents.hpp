@@ -78,4 +78,31 @@ struct MomentumAgent : AgentBase {
   void update(Env& env, Rng& rng) override;
 };
 
+// ---- multi-asset twins (ref noise_agent.rs:226-340 NoiseMarketAgent, momentum_agent.rs:282-397 MomentumMarketAgent,
+// common.rs:156-258 *_market helpers): the same update addressed to one asset of a MarketEnv, drawing from the MARKET's
+// RNG; orders are MarketOrderId = (asset, id) on that asset's book.
+struct MarketAgentBase {
+  virtual ~MarketAgentBase() = default;
+  virtual void update(MarketEnv& env, Rng& rng) = 0;  // MarketAgent::update, agents/mod.rs:162-170
+};
+struct RandomMarketAgentsBox : MarketAgentBase {
+  RandomMarketAgents inner;
+  explicit RandomMarketAgentsBox(RandomMarketAgents r) : inner(std::move(r)) {}
+  void update(MarketEnv& env, Rng& rng) override { inner.update(env, rng); }
+};
+struct NoiseMarketAgent : MarketAgentBase {
+  uint32_t asset;
+  NoiseAgent core;  // parameters, trader ids and the `orders` list (ids on the asset's book)
+  NoiseMarketAgent(uint32_t asset_, TraderId agent_id_start, uint16_t n_agents, NoiseAgentParams p)
+      : asset(asset_), core(agent_id_start, n_agents, p) {}
+  void update(MarketEnv& env, Rng& rng) override;
+};
+struct MomentumMarketAgent : MarketAgentBase {
+  uint32_t asset;
+  MomentumAgent core;
+  MomentumMarketAgent(uint32_t asset_, TraderId agent_id_start, uint16_t n_agents, MomentumParams p)
+      : asset(asset_), core(agent_id_start, n_agents, p) {}
+  void update(MarketEnv& env, Rng& rng) override;
+};
+
 }  // namespace orc

@@ -580,7 +580,7 @@ void orc_many_order_counts(void* mp, uint64_t* out) {
 // market m seeded seed_base + m.  groups: rows of {asset, n, tick_lo, tick_hi, vol_lo, vol_hi, tick_size, rate_bits}
 struct OneMarket {
   MarketEnv env;
-  std::vector<RandomMarketAgents> agents;
+  std::vector<std::unique_ptr<MarketAgentBase>> agents;  // a MarketAgentSet: members updated in declaration order
   Rng rng;
   OneMarket(Nanos start, const std::vector<Price>& ticks, Nanos step, bool trading, int levels, uint64_t seed)
       : env(start, ticks, step, trading, levels), rng(Rng::seed_from_u64(seed)) {}
@@ -602,7 +602,38 @@ void* orc_mkts_new(uint32_t n_markets, uint64_t seed_base, uint64_t start, uint3
       const uint32_t* r = groups + 8 * g;
       float rate;
       std::memcpy(&rate, &r[7], 4);
-      k->agents.emplace_back(r[0], r[1], r[2], r[3], r[4], r[5], r[6], rate);
+      k->agents.push_back(std::make_unique<RandomMarketAgentsBox>(
+          RandomMarketAgents(r[0], r[1], r[2], r[3], r[4], r[5], r[6], rate)));
+    }
+    m->mk.push_back(std::move(k));
+  }
+  return m;
+}
+// the same with any mix of market members: n_desc OrcAgentDesc records + the asset each member trades
+void* orc_mkts_new_mixed(uint32_t n_markets, uint64_t seed_base, uint64_t start, uint32_t assets,
+                         const uint32_t* tick_sizes, uint64_t step, int trading, int levels, int n_desc,
+                         const void* descs, const uint32_t* member_asset) {
+  auto* m = new OrcMarkets();
+  m->levels = levels;
+  m->assets = static_cast<int>(assets);
+  const std::vector<Price> ticks(tick_sizes, tick_sizes + assets);
+  const OrcAgentDesc* d = static_cast<const OrcAgentDesc*>(descs);
+  for (uint32_t i = 0; i < n_markets; ++i) {
+    auto k = std::make_unique<OneMarket>(start, ticks, step, trading != 0, levels, seed_base + i);
+    for (int g = 0; g < n_desc; ++g) {
+      const OrcAgentDesc& x = d[g];
+      const uint32_t as = member_asset[g];
+      if (x.type == 0)
+        k->agents.push_back(std::make_unique<RandomMarketAgentsBox>(
+            RandomMarketAgents(as, x.n, x.tick_lo, x.tick_hi, x.vol_lo, x.vol_hi, x.tick_size, x.rate)));
+      else if (x.type == 1)
+        k->agents.push_back(std::make_unique<NoiseMarketAgent>(
+            as, x.trader_start, static_cast<uint16_t>(x.n),
+            NoiseAgentParams{x.tick_size, x.p_limit, x.p_market, x.p_cancel, x.trade_vol, x.mu, x.sigma}));
+      else
+        k->agents.push_back(std::make_unique<MomentumMarketAgent>(
+            as, x.trader_start, static_cast<uint16_t>(x.n),
+            MomentumParams{x.tick_size, x.p_cancel, x.trade_vol, x.decay, x.demand, x.scale, x.order_ratio, x.mu, x.sigma}));
     }
     m->mk.push_back(std::move(k));
   }
@@ -618,7 +649,7 @@ int orc_mkts_run(void* mp, uint64_t n_steps, int n_threads) {
     for (size_t b = lo; b < hi; ++b) {
       OneMarket& k = *m->mk[b];
       for (uint64_t s = 0; s < n_steps; ++s) {
-        for (RandomMarketAgents& a : k.agents) a.update(k.env, k.rng);  // MarketAgentSet: fields in order
+        for (auto& a : k.agents) a->update(k.env, k.rng);  // MarketAgentSet: fields in order
         int r = k.env.step(k.rng);
         if (r != ORC_OK) rc = r;
       }

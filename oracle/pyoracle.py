@@ -165,6 +165,7 @@ def lib() -> C.CDLL:
     sig("orc_round_price_down", u32, dbl, dbl)
     sig("orc_version", i32)
     sig("orc_mkts_new", vp, u32, u64, u64, u32, p32, u64, i32, i32, i32, p32)
+    sig("orc_mkts_new_mixed", vp, u32, u64, u64, u32, p32, u64, i32, i32, i32, vp, p32)
     sig("orc_mkts_free", None, vp)
     sig("orc_mkts_run", i32, vp, u64, i32)
     sig("orc_mkts_place", i32, vp, u32, u32, i32, u32, u32, i32, u32, p64)
@@ -861,10 +862,18 @@ class ManyMarkets:
     crates/step_sim/src/market_env.rs, runner.rs:108-131); market m seeded seed + m.  Books are addressed flat as
     market * assets + asset.  groups: (asset, n, (tick_lo, tick_hi), (vol_lo, vol_hi), tick_size, rate)."""
 
-    def __init__(self, n_markets, seed, start_time, tick_sizes, step_size, trading, levels, groups=()):
+    def __init__(self, n_markets, seed, start_time, tick_sizes, step_size, trading, levels, groups=(), members=None):
         self.n_markets, self.assets, self.levels = int(n_markets), len(tick_sizes), int(levels)
         self.n_books = self.n_markets * self.assets
         self.ticks = [int(t) for t in tick_sizes]
+        if members is not None:  # [(asset, member)], member as in agent_descs(): Random / Noise / Momentum market twins
+            d = agent_descs([m for _, m in members])
+            asset = np.asarray([a for a, _ in members], dtype=np.uint32)
+            tk = np.asarray(self.ticks, dtype=np.uint32)
+            self._m = lib().orc_mkts_new_mixed(self.n_markets, int(seed), int(start_time), self.assets, _p32(tk),
+                                               int(step_size), int(bool(trading)), self.levels, len(d),
+                                               d.ctypes.data_as(C.c_void_p), _p32(asset))
+            return
         g = np.zeros((max(len(groups), 1), 8), dtype=np.uint32)
         for i, (asset, n, tr, vr, ts, rate) in enumerate(groups):
             g[i, :7] = (asset, n, tr[0], tr[1], vr[0], vr[1], ts)

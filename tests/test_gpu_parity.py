@@ -1043,3 +1043,72 @@ def test_checkpoint_restore_with_noise_and_momentum_members(bk):
         assert np.array_equal(a.history()[17:], b.history()), pipeline
         assert [a.rng_state(i) for i in range(40)] == [b.rng_state(i) for i in range(40)]
         assert np.array_equal(a.trade_counts(), b.trade_counts())
+
+
+def _compare_market_members(bk, oracle, n_markets, ticks, members, levels, n_steps, seed=101, step_size=1_000_000, pool=256,
+                            chunks=None, allow_flags=0):
+    A = len(ticks)
+    env = bk.ManyMarketEnv(n_markets, seed, 0, ticks, step_size, True, levels=levels, max_live_orders=pool,
+                           trade_capacity=64 * n_steps * 8, history_capacity=n_steps)
+    env.set_market_agents(members)
+    for c in (chunks or [n_steps]):
+        env.run(c)
+    ref = oracle.ManyMarkets(n_markets, seed, 0, ticks, step_size, True, levels, members=members)
+    ref.run(n_steps, 4)
+    assert not (env.flags() & ~np.uint32(allow_flags)).any(), np.unique(env.flags())
+    hist, want = env.history(), ref.history()
+    if not np.array_equal(hist, want):
+        bad = np.argwhere(hist != want)[0]
+        raise AssertionError(f"L2 history differs first at (step, book, word) = {bad}: {hist[tuple(bad)]} vs {want[tuple(bad)]}")
+    want_rng = ref.rng_states()
+    n_tr = 0
+    for m in sorted(set([0, 1, n_markets // 2, n_markets - 1])):
+        for a in range(A):
+            b = env.book(m, a)
+            assert env.rng_state(b) == (int(want_rng[m, 0]), int(want_rng[m, 1])), (m, a)
+            got, exp = env.trades(b, first=0), ref.book(m, a).trades_array()
+            assert len(got) == len(exp), (m, a)
+            n_tr += len(exp)
+            for f in ("t", "side", "price", "vol", "active_id", "passive_id"):
+                assert np.array_equal(got[f], exp[f]), (m, a, f)
+            live, o = env.live_orders(b), ref.book(m, a).orders_array()
+            act = o[o["status"] == 1]
+            assert set(zip(live["order_id"].tolist(), live["price"].tolist(), live["vol"].tolist(), live["side"].tolist())) == \
+                set(zip(act["order_id"].tolist(), act["price"].tolist(), act["vol"].tolist(), act["side"].tolist()))
+    assert n_tr > 0
+    env.close()
+    return hist
+
+
+def test_noise_and_momentum_market_agents_doc_examples(bk, oracle):
+    # ref noise_agent.rs:196-222 (NoiseMarketAgent::new(0, 5, 0, params) on MarketEnv<1>) and momentum_agent.rs:251-279
+    a = _compare_market_members(bk, oracle, 40, [1, 1], [(0, ("noise", 0, 5, NOISE_P)), (1, ("noise", 5, 5, NOISE_P))],
+                                levels=10, n_steps=60)
+    b = _compare_market_members(bk, oracle, 40, [1, 1], [(0, ("noise", 0, 5, NOISE_P)), (1, ("noise", 5, 5, NOISE_P))],
+                                levels=10, n_steps=60, chunks=[9, 1, 50])
+    assert np.array_equal(a, b)
+    m3 = [(1, ("momentum", 0, 10, MOM_P)), (1, ("noise", 10, 20, NOISE_P)), (0, ("noise", 30, 20, dict(NOISE_P, tick_size=1)))]
+    _compare_market_members(bk, oracle, 33, [1, 1], m3, levels=10, n_steps=50)
+
+
+def test_agent_price_clamped_off_tick_is_flagged(bk, oracle):
+    """A log-normal offset (sigma 10) can push a limit price to the u32::MAX clamp, which a tick-2 book rejects: the
+    reference `.unwrap()`s that Err (common.rs:107,140) and panics.  Here the order is not created (as the Err implies,
+    and as the oracle does) and the book is flagged BK_FLAG_PRICE_TICK — never silent."""
+    m3 = [(1, ("momentum", 0, 10, MOM_P)), (1, ("noise", 10, 20, NOISE_P)), (0, ("noise", 30, 20, dict(NOISE_P, tick_size=1)))]
+    env = bk.ManyMarketEnv(33, 101, 0, [1, 2], 1_000_000, True, levels=10, max_live_orders=256, trade_capacity=64 * 50 * 8,
+                           history_capacity=50)
+    env.set_market_agents(m3)
+    env.run(50)
+    ref = oracle.ManyMarkets(33, 101, 0, [1, 2], 1_000_000, True, 10, members=m3)
+    ref.run(50, 2)
+    f = env.flags()
+    assert (f & 64).any() and not (f & ~np.uint32(64)).any() and not (f[0::2] != 0).any()  # only tick-2 books (asset 1)
+    assert np.array_equal(env.history(), ref.history())
+
+
+def test_market_agent_set_all_member_kinds_three_assets(bk, oracle):
+    members = [(2, ("random", 30, (1073741800, 1073741840), (10, 20), 2, 0.5)), (0, ("noise", 0, 30, dict(NOISE_P, p_limit=0.4))),
+               (2, ("momentum", 100, 25, dict(MOM_P, demand=8.0, scale=0.01, decay=0.5))),
+               (2, ("noise", 200, 10, dict(NOISE_P, price_dist_sigma=3.0)))]
+    _compare_market_members(bk, oracle, 70, [2, 1, 1], members, levels=16, n_steps=40, pool=256, chunks=[13, 27])

@@ -105,3 +105,26 @@ def test_momentum_agents_never_sell_quirk_and_doc_example_runs(oracle):
     mom = o[o["trader_id"] < 10]
     assert len(mom) > 0 and mom["side"].all()  # p_market < 0 when momentum < 0: momentum agents only ever buy
     assert np.all(o["price"][(o["price"] != 0) & (o["price"] != 2**32 - 1)] % 2 == 0)
+
+
+def test_market_twins_on_a_one_asset_market_equal_the_single_asset_agents(oracle):
+    """NoiseMarketAgent / MomentumMarketAgent (noise_agent.rs:281-339, momentum_agent.rs:328-396) run the same update as
+    NoiseAgent / MomentumAgent against `env.get_market().get_order_book(asset)`: on MarketEnv<1> they are identical."""
+    noise = dict(tick_size=2, p_limit=0.2, p_market=0.2, p_cancel=0.1, trade_vol=100, price_dist_mu=0.0, price_dist_sigma=1.0)
+    mom = dict(tick_size=2, p_cancel=0.1, trade_vol=100, decay=1.0, demand=5.0, scale=0.5, order_ratio=1.0,
+               price_dist_mu=0.0, price_dist_sigma=10.0)
+    members = [("momentum", 0, 10, mom), ("noise", 10, 20, noise), ("random", 8, (1000, 1010), (5, 9), 1, 0.5)]
+    a = oracle.ManyBooks(3, 11, 0, 1, 1_000_000, True, 10, members=members)
+    b = oracle.ManyMarkets(3, 11, 0, [1], 1_000_000, True, 10, members=[(0, m) for m in members])
+    a.run(40)
+    b.run(40)
+    assert np.array_equal(a.history(), b.history()) and np.array_equal(a.rng_states(), b.rng_states())
+    assert a.trade_counts().sum() > 0
+
+
+def test_market_twins_trade_their_own_asset_only(oracle):
+    noise = dict(tick_size=1, p_limit=0.5, p_market=0.2, p_cancel=0.1, trade_vol=10, price_dist_mu=0.0, price_dist_sigma=1.0)
+    m = oracle.ManyMarkets(2, 5, 0, [1, 1, 1], 1_000_000, True, 10, members=[(2, ("noise", 0, 10, noise))])
+    m.run(20)
+    for mk in range(2):
+        assert m.book(mk, 0).n_orders() == 0 and m.book(mk, 1).n_orders() == 0 and m.book(mk, 2).n_orders() > 0
