@@ -1112,3 +1112,62 @@ def test_market_agent_set_all_member_kinds_three_assets(bk, oracle):
                (2, ("momentum", 100, 25, dict(MOM_P, demand=8.0, scale=0.01, decay=0.5))),
                (2, ("noise", 200, 10, dict(NOISE_P, price_dist_sigma=3.0)))]
     _compare_market_members(bk, oracle, 70, [2, 1, 1], members, levels=16, n_steps=40, pool=256, chunks=[13, 27])
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_fuzz_agent_sets_and_markets_vs_oracle(bk, oracle, seed):
+    """Randomly drawn AgentSets / MarketAgentSets (1-4 members of every kind, 1-3 assets, random parameters and tick
+    sizes, random launch chunking) against the oracle.  Off-tick clamped prices may be flagged (both sides drop them)."""
+    rng = np.random.default_rng(7000 + seed)
+    A = int(rng.integers(1, 4))
+    ticks = [int(rng.choice([1, 1, 2, 5])) for _ in range(A)]
+    members, fixed = [], [0] * A
+    for j in range(int(rng.integers(1, 5))):
+        a = int(rng.integers(0, A))
+        kind = rng.choice(["random", "noise", "momentum"])
+        tsz = ticks[a] * int(rng.integers(1, 3))
+        if kind == "random":
+            n = int(rng.integers(1, 40))
+            lo = int(rng.integers(10_000, 20_000))
+            m = ("random", n, (lo, lo + int(rng.integers(1, 30))), (1, int(rng.integers(2, 50))), tsz, float(rng.random()))
+            fixed[a] += n
+        elif kind == "noise":
+            m = ("noise", 100 * j, int(rng.integers(1, 60)), dict(
+                tick_size=tsz, p_limit=float(rng.random() * 0.6), p_market=float(rng.random() * 0.3),
+                p_cancel=float(rng.random() * 0.5), trade_vol=int(rng.integers(1, 200)),
+                price_dist_mu=float(rng.normal()), price_dist_sigma=float(rng.random() * 3)))
+        else:
+            m = ("momentum", 100 * j, int(rng.integers(1, 60)), dict(
+                tick_size=tsz, p_cancel=float(rng.random() * 0.5), trade_vol=int(rng.integers(1, 200)),
+                decay=float(rng.random()), demand=float(rng.random() * 20), scale=float(rng.random()),
+                order_ratio=float(rng.random() * 2), price_dist_mu=float(rng.normal()), price_dist_sigma=float(rng.random() * 4)))
+        members.append((a, m))
+    NM, T, levels = int(rng.integers(1, 90)), int(rng.integers(5, 50)), int(rng.integers(1, 33))
+    chunks, left = [], T
+    while left:
+        c = int(rng.integers(1, left + 1))
+        chunks.append(c)
+        left -= c
+    if A == 1:
+        env = bk.ManyBookEnv(NM, seed, 0, ticks[0], 1_000_000, True, levels=levels, max_live_orders=512,
+                             trade_capacity=64 * T * 8, history_capacity=T)
+        env.set_agents([m for _, m in members])
+        ref = oracle.ManyBooks(NM, seed, 0, ticks[0], 1_000_000, True, levels, members=[m for _, m in members])
+    else:
+        env = bk.ManyMarketEnv(NM, seed, 0, ticks, 1_000_000, True, levels=levels, max_live_orders=512,
+                               trade_capacity=64 * T * 8, history_capacity=T)
+        env.set_market_agents(members)
+        ref = oracle.ManyMarkets(NM, seed, 0, ticks, 1_000_000, True, levels, members=members)
+    for i, c in enumerate(chunks):
+        if A == 1:
+            env.set_pipeline(("split", "fused", "split_wave")[(i + seed) % 3])
+        env.run(c)
+    ref.run(T, 4)
+    assert not (env.flags() & ~np.uint32(64)).any(), np.unique(env.flags())
+    hist, want = env.history(), ref.history()
+    if not np.array_equal(hist, want):
+        bad = np.argwhere(hist != want)[0]
+        raise AssertionError(f"A={A} ticks={ticks} members={members} chunks={chunks}: first at {bad}")
+    want_rng = ref.rng_states()
+    for u in range(NM):
+        assert env.rng_state(u * A) == (int(want_rng[u, 0]), int(want_rng[u, 1])), u
