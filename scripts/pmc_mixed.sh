@@ -1,7 +1,7 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 i=0
-for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU" "SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_WAIT_INST_ANY" "SQ_INSTS_LDS SQ_INSTS_VMEM SQ_ACTIVE_INST_ANY SQ_IFETCH" "SQ_WAIT_ANY SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VALU SQ_INST_LEVEL_SMEM"; do
+for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU" "SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_VMEM SQ_INSTS_LDS" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_BRANCH SQ_ACTIVE_INST_ANY"; do
   i=$((i+1))
-  rocprofv3 --pmc $set --kernel-trace -d $R/gpurun_out/pmcM2/p$i -o out -f csv -- python3 $R/bench.py --workload C5M --steps 10 --warmup 10 --steps-per-launch 10 --no-cpu-baseline --profile-every 0 > /dev/null 2>&1
+  rocprofv3 --pmc $set --kernel-trace -d $R/gpurun_out/pmcM3/p$i -o out -f csv -- python3 $R/bench.py --workload C5M --steps 10 --warmup 10 --steps-per-launch 10 --no-cpu-baseline --profile-every 0 > /dev/null 2>&1
 done
