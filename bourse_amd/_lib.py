@@ -90,6 +90,7 @@ SIGNATURES = {
     "bk_cancel_order": (_i32, [_vp, _u32, _u64]),
     "bk_modify_order": (_i32, [_vp, _u32, _u64, _i32, _u32, _i32, _u32]),
     "bk_submit_instructions": (_i32, [_vp, _u32, _sz, _p32, _p8, _p32, _p32, _p32, _p64, _p64, C.POINTER(_sz)]),
+    "bk_submit_instructions_csr": (_i32, [_vp, _p64, _p32, _p8, _p32, _p32, _p32, _p64, _p64, C.POINTER(_sz)]),
     "bk_enable_trading": (_i32, [_vp, _i32]),
     "bk_step": (_i32, [_vp]),
     "bk_order_status": (_i32, [_vp, _u32, _u64, _p8]),

@@ -74,10 +74,7 @@ struct DevArgs {
   DevOrderLog* order_log;
   // host-driven event batch (k_step_events only); CSR per book
   const uint32_t* ev_off;    // [n_books + 1]
-  const uint32_t* ev_word;   // kind | bid<<8 | has_price<<9 | has_vol<<10
-  const uint32_t* ev_id;
-  const uint32_t* ev_price;
-  const uint32_t* ev_vol;
+  const uint4* ev;           // {word = kind | bid<<8 | has_price<<9 | has_vol<<10 | asset<<16, id, price, vol}
   // split pipeline: per-book step batch written by k_agents_fsm, consumed by k_step_batch
   uint32_t* batch;
   uint32_t batch_stride;  // dwords per book: 64 + 160 * R
@@ -1008,12 +1005,13 @@ __global__ __launch_bounds__(64) void k_step_events(DevArgs a, uint64_t step_ind
   }
   for (uint32_t k = 0; k < n_ev; ++k) {
     const uint32_t e = e0 + rfl(perm[k]);
-    const uint32_t w = rfl(a.ev_word[e]);
+    const uint4 evr = a.ev[e];  // one 16-byte record per event, the same for every lane
+    const uint32_t w = rfl(evr.x);
     if (((w >> 16) & 0xFFu) != asset) continue;  // another asset's event
     ++n_own;
-    const uint32_t id = rfl(a.ev_id[e]);
-    const uint32_t ep = rfl(a.ev_price[e]);
-    const uint32_t evv = rfl(a.ev_vol[e]);
+    const uint32_t id = rfl(evr.y);
+    const uint32_t ep = rfl(evr.z);
+    const uint32_t evv = rfl(evr.w);
     const uint32_t kind = w & 0xFFu;
     const uint64_t tk = t0 + k;
     if (kind == 0) {

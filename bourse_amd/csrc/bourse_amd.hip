@@ -27,7 +27,7 @@ static_assert(sizeof(bk_config) == 72 && sizeof(bk_random_agents) == 28 && sizeo
                   sizeof(bk_order) == 48,
               "C ABI struct layout (mirrored by bourse_amd/_lib.py)");
 static_assert(sizeof(bk_agent_desc) == 104, "bk_agent_desc layout (mirrored by bourse_amd/_lib.py)");
-static_assert(sizeof(DevTrade) == 32 && sizeof(DevOrderLog) == 48, "device record layout");
+static_assert(sizeof(DevTrade) == 32 && sizeof(DevOrderLog) == 48 && sizeof(uint4) == 16, "device record layout");
 
 namespace {
 
@@ -78,6 +78,7 @@ struct HostOrder {  // immutable half of an order, fixed at create_order (orderb
 struct HostEvent {
   uint32_t word, id, price, vol;
 };
+static_assert(sizeof(HostEvent) == 16, "HostEvent is uploaded as one uint4 per event");
 struct BookHost {
   std::vector<HostOrder> orders;
   std::vector<HostEvent> queue;
@@ -112,7 +113,10 @@ struct bk_env {
   uint32_t asset_tick[MAX_ASSETS] = {0, 0, 0, 0, 0, 0, 0, 0};
   uint32_t W = 0, stride = 0;
   hipStream_t stream = nullptr;
-  DevBuf<uint32_t> state, l2_last, hist, ev_off, ev_word, ev_id, ev_price, ev_vol, batch;
+  DevBuf<uint32_t> state, l2_last, hist, ev_off, batch;
+  DevBuf<uint4> ev;               // this step's events, 16 B each (HostEvent layout), CSR by book / market
+  HostEvent* ev_stage = nullptr;  // pinned staging of the same (uploaded at link speed)
+  uint32_t* off_stage = nullptr;
   uint32_t batch_stride = 0;
   int pipeline = 0;  // 0 auto, 1 fused (k_run_random), 2 split (k_agents_fsm + k_step_batch)
   // split pipeline: the batch is cut into n_parts contiguous parts, each on its own stream and started one
@@ -188,10 +192,7 @@ struct bk_env {
     a.trades = trades.p;
     a.order_log = order_log.p;
     a.ev_off = ev_off.p;
-    a.ev_word = ev_word.p;
-    a.ev_id = ev_id.p;
-    a.ev_price = ev_price.p;
-    a.ev_vol = ev_vol.p;
+    a.ev = ev.p;
     a.batch = batch.p;
     a.batch_stride = batch_stride;
     a.book_begin = 0;
@@ -498,6 +499,8 @@ void bk_env_destroy(bk_env* env) {
     (void)hipEventDestroy(pr.a);
     (void)hipEventDestroy(pr.b);
   }
+  if (env->ev_stage) (void)hipHostFree(env->ev_stage);
+  if (env->off_stage) (void)hipHostFree(env->off_stage);
   if (env->ev_fork) {
     (void)hipEventDestroy(env->ev_fork);
     for (int i = 0; i < 4; ++i) {
@@ -582,6 +585,28 @@ int bk_submit_instructions(bk_env* env, uint32_t book, size_t n, const uint32_t*
   return BK_OK;
 }
 
+// The same for EVERY book in one call (SURVEY §8b "batched SoA ops"): the instructions of book b are elements
+// [book_offsets[b], book_offsets[b + 1]) of the arrays.  Semantics per book as bk_submit_instructions; stops at the first
+// bad price of any book (*n_done = index of the offending element, earlier elements stay queued).
+int bk_submit_instructions_csr(bk_env* env, const uint64_t* book_offsets, const uint32_t* action, const uint8_t* side,
+                               const uint32_t* vol, const uint32_t* trader_id, const uint32_t* price,
+                               const uint64_t* order_id, uint64_t* out_ids, size_t* n_done) {
+  if (!env || !book_offsets) return fail(BK_INVALID_ARGUMENT, "null argument");
+  const uint32_t B = env->cfg.n_books;
+  if (n_done) *n_done = 0;
+  for (uint32_t b = 0; b < B; ++b) {
+    const uint64_t lo = book_offsets[b], hi = book_offsets[b + 1];
+    if (hi < lo) return fail(BK_INVALID_ARGUMENT, "book_offsets must be non-decreasing");
+    if (hi == lo) continue;
+    size_t done = 0;
+    const int rc = bk_submit_instructions(env, b, hi - lo, action + lo, side + lo, vol + lo, trader_id + lo, price + lo,
+                                          order_id + lo, out_ids ? out_ids + lo : nullptr, &done);
+    if (n_done) *n_done = lo + done;
+    if (rc != BK_OK) return rc;
+  }
+  return BK_OK;
+}
+
 int bk_enable_trading(bk_env* env, int enabled) {
   if (!env) return fail(BK_INVALID_ARGUMENT, "null env");
   if (int rc = use_device(env)) return rc;
@@ -611,33 +636,28 @@ int bk_step(bk_env* env) {
     total += qh.queue.size();
   }
   off[NM] = static_cast<uint32_t>(total);
-  std::vector<uint32_t> w(total), id(total), pr(total), vo(total);
-  size_t k = 0;
-  for (size_t m = 0; m < NM; ++m)
-    for (const HostEvent& e : env->books[m * M].queue) {
-      w[k] = e.word;
-      id[k] = e.id;
-      pr[k] = e.price;
-      vo[k] = e.vol;
-      ++k;
-    }
   HIPCHK(hipStreamSynchronize(env->stream));  // previous step may still read the event buffers
-  if (total > env->ev_capacity) {
+  if (total > env->ev_capacity || !env->off_stage) {
     const size_t cap = std::max<size_t>(total * 2, 1024);
-    HIPCHK(env->ev_word.alloc(cap));
-    HIPCHK(env->ev_id.alloc(cap));
-    HIPCHK(env->ev_price.alloc(cap));
-    HIPCHK(env->ev_vol.alloc(cap));
+    HIPCHK(env->ev.alloc(cap));
+    if (env->ev_stage) HIPCHK(hipHostFree(env->ev_stage));
+    env->ev_stage = nullptr;
+    HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&env->ev_stage), cap * sizeof(HostEvent), hipHostMallocDefault));
+    if (!env->off_stage)
+      HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&env->off_stage), (B + 1) * sizeof(uint32_t), hipHostMallocDefault));
     env->ev_capacity = cap;
   }
-  HIPCHK(hipMemcpyAsync(env->ev_off.p, off.data(), (NM + 1) * 4, hipMemcpyHostToDevice, env->stream));
-  if (total) {
-    HIPCHK(hipMemcpyAsync(env->ev_word.p, w.data(), total * 4, hipMemcpyHostToDevice, env->stream));
-    HIPCHK(hipMemcpyAsync(env->ev_id.p, id.data(), total * 4, hipMemcpyHostToDevice, env->stream));
-    HIPCHK(hipMemcpyAsync(env->ev_price.p, pr.data(), total * 4, hipMemcpyHostToDevice, env->stream));
-    HIPCHK(hipMemcpyAsync(env->ev_vol.p, vo.data(), total * 4, hipMemcpyHostToDevice, env->stream));
+  // flatten straight into pinned memory: one 16-byte record per event, one copy, uploaded at link speed
+  size_t k = 0;
+  for (size_t m = 0; m < NM; ++m) {
+    const std::vector<HostEvent>& q = env->books[m * M].queue;
+    if (!q.empty()) std::memcpy(env->ev_stage + k, q.data(), q.size() * sizeof(HostEvent));
+    k += q.size();
   }
-  HIPCHK(hipStreamSynchronize(env->stream));  // pageable sources must stay alive until copied
+  std::memcpy(env->off_stage, off.data(), (NM + 1) * sizeof(uint32_t));
+  HIPCHK(hipMemcpyAsync(env->ev_off.p, env->off_stage, (NM + 1) * 4, hipMemcpyHostToDevice, env->stream));
+  if (total)
+    HIPCHK(hipMemcpyAsync(env->ev.p, env->ev_stage, total * sizeof(HostEvent), hipMemcpyHostToDevice, env->stream));
   const DevArgs a = env->args();
   int rc = BK_OK;
   switch (env->R) {

@@ -175,6 +175,28 @@ class ManyBookEnv:
                                              _lib.p64(out), C.byref(done)))
         return out
 
+    def submit_instructions_all(self, book_offsets, instructions) -> np.ndarray:
+        """``submit_instructions`` for every book in one call: book b's instructions are elements
+        ``[book_offsets[b], book_offsets[b + 1])`` of the six arrays (C ABI ``bk_submit_instructions_csr``)."""
+        action, sides, vols, traders, prices, order_ids = instructions
+        off = np.ascontiguousarray(book_offsets, dtype=np.uint64)
+        if len(off) != self.n_books + 1:
+            raise ValueError("book_offsets needs n_books + 1 entries")
+        action = np.ascontiguousarray(action, dtype=np.uint32)
+        sides = np.ascontiguousarray(np.asarray(sides).astype(np.uint8))
+        vols = np.ascontiguousarray(vols, dtype=np.uint32)
+        traders = np.ascontiguousarray(traders, dtype=np.uint32)
+        prices = np.ascontiguousarray(prices, dtype=np.uint32)
+        order_ids = np.ascontiguousarray(order_ids, dtype=np.uint64)
+        if not (len(action) == len(sides) == len(vols) == len(traders) == len(prices) == len(order_ids) == int(off[-1])):
+            raise ValueError("instruction arrays must all have book_offsets[-1] elements")
+        out = np.full(len(action), 2**64 - 1, dtype=np.uint64)
+        done = C.c_size_t(0)
+        check(self._L.bk_submit_instructions_csr(self._h, _lib.p64(off), _lib.p32(action), _lib.p8(sides), _lib.p32(vols),
+                                                 _lib.p32(traders), _lib.p32(prices), _lib.p64(order_ids), _lib.p64(out),
+                                                 C.byref(done)))
+        return out
+
     def enable_trading(self):
         check(self._L.bk_enable_trading(self._h, 1))
 

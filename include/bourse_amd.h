@@ -155,6 +155,11 @@ int bk_modify_order(bk_env* env, uint32_t book, uint64_t order_id, int has_price
 int bk_submit_instructions(bk_env* env, uint32_t book, size_t n, const uint32_t* action, const uint8_t* side,
                            const uint32_t* vol, const uint32_t* trader_id, const uint32_t* price,
                            const uint64_t* order_id, uint64_t* out_ids, size_t* n_done);
+/* The same for every book in one call: book b's instructions are elements [book_offsets[b], book_offsets[b+1]) of the
+ * arrays (CSR over n_books + 1 offsets).  *n_done = global index reached. */
+int bk_submit_instructions_csr(bk_env* env, const uint64_t* book_offsets, const uint32_t* action, const uint8_t* side,
+                               const uint32_t* vol, const uint32_t* trader_id, const uint32_t* price,
+                               const uint64_t* order_id, uint64_t* out_ids, size_t* n_done);
 int bk_enable_trading(bk_env* env, int enabled);         /* Env::{enable,disable}_trading, env.rs:138-145 */
 /* Env::step, env.rs:116-135, for every book: shuffle + process the queued events, snapshot L2 */
 int bk_step(bk_env* env);

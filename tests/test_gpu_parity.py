@@ -1171,3 +1171,41 @@ def test_fuzz_agent_sets_and_markets_vs_oracle(bk, oracle, seed):
     want_rng = ref.rng_states()
     for u in range(NM):
         assert env.rng_state(u * A) == (int(want_rng[u, 0]), int(want_rng[u, 1])), u
+
+
+def test_batched_submit_for_all_books_matches_per_book_calls(bk, oracle):
+    """bk_submit_instructions_csr: one call queues every book's instructions (SURVEY §8b batched SoA ops)."""
+    B, T = 64, 6
+    a = bk.ManyBookEnv(B, 3, 0, 1, 1000, levels=10, max_live_orders=128, max_orders=4096, trade_capacity=4096, history_capacity=T)
+    refs = [oracle.StepEnvNumpy(3 + b, 0, 1, 1000) for b in range(B)]
+    rng = np.random.default_rng(4)
+    for _ in range(T):
+        counts = rng.integers(0, 20, size=B)
+        off = np.concatenate([[0], np.cumsum(counts)]).astype(np.uint64)
+        n = int(off[-1])
+        action = rng.choice([0, 1, 1, 1, 2], size=n).astype(np.uint32)
+        sides = rng.integers(0, 2, size=n).astype(bool)
+        vols = rng.integers(1, 30, size=n).astype(np.uint32)
+        traders = rng.integers(0, 9, size=n).astype(np.uint32)
+        prices = rng.integers(95, 106, size=n).astype(np.uint32)
+        ids = np.zeros(n, dtype=np.uint64)
+        for b in range(B):  # cancels refer to ids that exist in that book
+            lo, hi = int(off[b]), int(off[b + 1])
+            n_orders = refs[b].book.n_orders()
+            for i in range(lo, hi):
+                if action[i] == 2:
+                    if n_orders:
+                        ids[i] = rng.integers(0, n_orders)
+                    else:
+                        action[i] = 0
+        got = a.submit_instructions_all(off, (action, sides, vols, traders, prices, ids))
+        for b in range(B):
+            lo, hi = int(off[b]), int(off[b + 1])
+            want = refs[b].submit_instructions((action[lo:hi], sides[lo:hi], vols[lo:hi], traders[lo:hi], prices[lo:hi], ids[lo:hi]))
+            assert np.array_equal(got[lo:hi], np.asarray(want, dtype=np.uint64)), b
+        a.step()
+        for r in refs:
+            r.step()
+    h = a.history()
+    for b in range(B):
+        assert np.array_equal(h[:, b], refs[b].history()), b
