@@ -21,3 +21,20 @@ for s in range(40):
         else: env.modify_order(int(rng.choice(ids)), None if rng.random()<0.4 else int(rng.integers(40,60))*2, None if rng.random()<0.3 else int(rng.integers(0,50)))
     env.step()
 print('host ok', len(env.get_trades()))
+mk = pyoracle.ManyMarkets(6, 3, 0, [1, 2, 1], 1000000, True, 10, members=[(2, ("momentum", 0, 10, MOM)), (0, ("noise", 10, 20, dict(NOI, tick_size=1))),
+                                                                           (1, ("random", 12, (40, 60), (1, 9), 2, 0.7)), (2, ("noise", 50, 10, NOI))])
+mk.run(50, 2); print('market agents ok', sum(mk.book(m, a).n_orders() for m in range(6) for a in range(3)))
+mk2 = pyoracle.ManyMarkets(2, 3, 0, [1, 2], 1000, True, 10)
+for s in range(20):
+    for k in range(8):
+        a = int(rng.integers(0, 2)); n = mk2.book(0, a).n_orders()
+        if n and rng.random() < 0.3: mk2.cancel_order(0, a, int(rng.integers(0, n)))
+        elif n and rng.random() < 0.2: mk2.modify_order(0, a, int(rng.integers(0, n)), None, int(rng.integers(1, 9)))
+        else: mk2.place_order(0, a, bool(rng.integers(0, 2)), int(rng.integers(1, 20)), 1, int(rng.integers(45, 55)) * 2)
+    mk2.step()
+print('market host ok', mk2.n_steps())
+ob = pyoracle.OrderBook(0, 1)
+for i in range(30):
+    ob.set_time(i + 1); ob.place_order(bool(i % 2), 5 + i % 7, 1, 100 + (i * 7) % 11)
+ob.save_json_snapshot('/tmp/_asan_ob.json'); lb = pyoracle.order_book_from_json('/tmp/_asan_ob.json')
+assert lb.state() == ob.state(); print('json ok', ob.n_orders())
