@@ -271,6 +271,14 @@ int launch_split(bk_env* env, const DevArgs& a0, uint64_t first_step, uint32_t n
       HIPCHK(env->ml_inl.alloc(2 * static_cast<size_t>(R) * NB));
       env->ml_valid = false;
     }
+    static bool lds_attr_set = false;  // per instantiation: allow > 64 KB of dynamic LDS (160 KB per workgroup on MI355X)
+    if (!lds_attr_set) {
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_agents_mixed_lanes<R, true>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(mixed_lanes_lds_bytes(R, true))));
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_agents_mixed_lanes<R, false>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(mixed_lanes_lds_bytes(R, false))));
+      lds_attr_set = true;
+    }
     if (!env->ml_valid) {
       hipLaunchKernelGGL(k_mixed_lists_rebuild<R>, dim3((env->cfg.n_books + 3) / 4), dim3(256), 0, env->stream, a0, ma,
                          env->lists());
@@ -310,9 +318,11 @@ int launch_split(bk_env* env, const DevArgs& a0, uint64_t first_step, uint32_t n
       {
         ProfScope ps(env, 1, st);
         if (MIXED == 2 && M > 1)
-          hipLaunchKernelGGL((k_agents_mixed_lanes<R, true>), dim3((nb + 63) / 64), dim3(64), 0, st, a, ma, ml);
+          hipLaunchKernelGGL((k_agents_mixed_lanes<R, true>), dim3((nb + 63) / 64), dim3(64),
+                             mixed_lanes_lds_bytes(R, true), st, a, ma, ml);
         else if (MIXED == 2)
-          hipLaunchKernelGGL((k_agents_mixed_lanes<R, false>), dim3((nb + 63) / 64), dim3(64), 0, st, a, ma, ml);
+          hipLaunchKernelGGL((k_agents_mixed_lanes<R, false>), dim3((nb + 63) / 64), dim3(64),
+                             mixed_lanes_lds_bytes(R, false), st, a, ma, ml);
         else if (MIXED == 1)
           hipLaunchKernelGGL(k_agents_mixed<R>, dim3((nb + 3) / 4), dim3(256), 0, st, a, ma);
         else

@@ -474,13 +474,15 @@ struct LaneRng {  // xoroshiro128** per lane
     const double v = pm::from_bits(0x3FF0000000000000ull | (next_u64() >> 12));
     return v - (1.0 - 2.220446049250313e-16 / 2.0);
   }
-  __device__ __forceinline__ double std_normal() {  // rand_distr StandardNormal (256-layer ziggurat), as above
+  // rand_distr StandardNormal (256-layer ziggurat), as above; zx / zf = the tables (staged in LDS by the caller: a
+  // lane's index is its own, and a table miss would be a full memory round trip in a latency-bound kernel)
+  __device__ __forceinline__ double std_normal(const double* zx, const double* zf) {
     for (;;) {
       const uint64_t bits = next_u64();
       const uint32_t i = (uint32_t)bits & 0xffu;
       const double u = pm::from_bits(0x4000000000000000ull | (bits >> 12)) - 3.0;
-      const double x = u * ZIG_NORM_X[i];
-      if (pm::fabs_(x) < ZIG_NORM_X[i + 1]) return x;
+      const double x = u * zx[i];
+      if (pm::fabs_(x) < zx[i + 1]) return x;
       if (i == 0) {
         const double Rz = 3.654152885361008796;
         double xx = 1.0, yy = 0.0;
@@ -492,7 +494,7 @@ struct LaneRng {  // xoroshiro128** per lane
         }
         return (u < 0.0) ? xx - Rz : Rz - xx;
       }
-      const double lhs = ZIG_NORM_F[i + 1] + (ZIG_NORM_F[i] - ZIG_NORM_F[i + 1]) * f64();
+      const double lhs = zf[i + 1] + (zf[i] - zf[i + 1]) * f64();
       if (lhs < pm::exp(-x * x / 2.0)) return x;
     }
   }
@@ -501,11 +503,30 @@ struct LaneRng {  // xoroshiro128** per lane
 // MKT: the lane owns a MARKET (books [b*M, b*M + M)): one RNG stream, one event queue; member j trades asset
 // ma.asset[j] (NoiseMarketAgent / MomentumMarketAgent / RandomMarketAgents: noise_agent.rs:281-339,
 // momentum_agent.rs:328-396, random_agent.rs:204-247); event entries carry the asset in bits 12..14.
+constexpr size_t mixed_lanes_lds_bytes(int R, bool mkt) {
+  return (size_t)(32 * R * 64 + 2 * (2 * R * 64) + 2 * (mkt ? MAX_ASSETS * 64 : 64)) * 4 + 2 * 257 * sizeof(double);
+}
+
 template <int R, bool MKT>
 __global__ __launch_bounds__(64) void k_agents_mixed_lanes(DevArgs a, MixedArgs ma, MixedLists ml) {
-  __shared__ uint16_t list[64 * R * 64];  // event list of lane l: list[k * 64 + l]
-  __shared__ uint32_t cur_w[MKT ? MAX_ASSETS * 64 : 64], cur_c[MKT ? MAX_ASSETS * 64 : 64];  // per-asset alloc cursors
+  // dynamic LDS (up to ~82 KB at R = 8; MI355X allows 160 KB per workgroup), see mixed_lanes_lds_bytes():
+  //   event list of lane l: list[k * 64 + l] (u16) | live / listed masks of the open book, word w of lane l at
+  //   [w * 64 + l] | per-asset allocation cursors (MKT) | ziggurat tables.  Everything a lane looks up per order lives
+  //   here: with one wave per SIMD every global round trip is exposed latency.
+  extern __shared__ uint32_t smem[];
+  uint16_t* list = reinterpret_cast<uint16_t*>(smem);
+  uint32_t* lds_live = smem + 32 * R * 64;
+  uint32_t* lds_inl = lds_live + 2 * R * 64;
+  uint32_t* cur_w = lds_inl + 2 * R * 64;
+  uint32_t* cur_c = cur_w + (MKT ? MAX_ASSETS * 64 : 64);
+  double* zx = reinterpret_cast<double*>(cur_c + (MKT ? MAX_ASSETS * 64 : 64));
+  double* zf = zx + 257;
   const int lane = threadIdx.x;
+  for (int i = lane; i < 257; i += 64) {
+    zx[i] = ZIG_NORM_X[i];
+    zf[i] = ZIG_NORM_F[i];
+  }
+  __syncthreads();
   const uint32_t b = a.book_begin + blockIdx.x * 64 + lane;  // book, or market when MKT
   if (b >= a.book_end) return;
   const uint32_t M = MKT ? a.assets : 1u;
@@ -527,14 +548,36 @@ __global__ __launch_bounds__(64) void k_agents_mixed_lanes(DevArgs a, MixedArgs 
   uint32_t next_id = 0, new_flags = 0;
   // slot allocation cursor: word `wcur` of the occupancy (live | listed | allocated this step), lowest free bit first
   uint32_t wcur = 0, cw = 0xFFFFFFFFu;
+  // stage the open book's live masks (one 64-byte line of its header) and listed masks in LDS / write the latter back
+  auto stage_masks = [&]() {
+#pragma unroll
+    for (int q = 0; q < (2 * R) / 4; ++q) {
+      const uint4 v = *reinterpret_cast<const uint4*>(st + H_LIVE0 + 4 * q);
+      lds_live[(4 * q + 0) * 64 + lane] = v.x;
+      lds_live[(4 * q + 1) * 64 + lane] = v.y;
+      lds_live[(4 * q + 2) * 64 + lane] = v.z;
+      lds_live[(4 * q + 3) * 64 + lane] = v.w;
+    }
+    if (R == 1) {
+      lds_live[lane] = st[H_LIVE0];
+      lds_live[64 + lane] = st[H_LIVE0 + 1];
+    }
+#pragma unroll
+    for (int w = 0; w < 2 * R; ++w) lds_inl[w * 64 + lane] = ml.inl[(size_t)w * NB + bk];
+  };
+  auto unstage_masks = [&]() {
+#pragma unroll
+    for (int w = 0; w < 2 * R; ++w) ml.inl[(size_t)w * NB + bk] = lds_inl[w * 64 + lane];
+  };
   auto load_word = [&](uint32_t w) -> uint32_t {
-    uint32_t v = st[H_LIVE0 + w] | ml.inl[(size_t)w * NB + bk];
+    uint32_t v = lds_live[w * 64 + lane] | lds_inl[w * 64 + lane];
     if (n_fixed > 32u * w) v |= (n_fixed - 32u * w >= 32u) ? 0xFFFFFFFFu : ((1u << (n_fixed - 32u * w)) - 1u);
     return v;
   };
   if (MKT) {
     for (uint32_t as = 0; as < M; ++as) cur_w[as * 64 + lane] = 0xFFFFFFFFu;  // not opened yet
   } else {
+    stage_masks();
     wcur = n_fixed >> 5;
     if (wcur < 2u * R) cw = load_word(wcur);
     next_id = st[H_NEXT_ID];
@@ -546,6 +589,7 @@ __global__ __launch_bounds__(64) void k_agents_mixed_lanes(DevArgs a, MixedArgs 
     n_fixed = ma.n_fixed_a[as];
     next_id = st[H_NEXT_ID];
     new_flags = 0;
+    stage_masks();
     wcur = cur_w[as * 64 + lane];
     cw = cur_c[as * 64 + lane];
     if (wcur == 0xFFFFFFFFu) {
@@ -554,6 +598,7 @@ __global__ __launch_bounds__(64) void k_agents_mixed_lanes(DevArgs a, MixedArgs 
     }
   };
   auto close_book = [&]() {
+    unstage_masks();
     st[H_NEXT_ID] = next_id;
     if (new_flags) st[H_FLAGS] |= new_flags;
     cur_w[asset * 64 + lane] = wcur;
@@ -611,7 +656,7 @@ __global__ __launch_bounds__(64) void k_agents_mixed_lanes(DevArgs a, MixedArgs 
       uint32_t lw = 0;
       for (uint32_t i = 0; i < D.n; ++i) {
         const uint32_t n = D.slot_base + i;
-        if (i == 0 || (n & 31u) == 0) lw = st[H_LIVE0 + (n >> 5)];
+        if (i == 0 || (n & 31u) == 0) lw = lds_live[(n >> 5) * 64 + lane];
         const uint32_t x = rng.next_u32();
         if ((x >> 8) < D.thr) {
           push_event(n);
@@ -648,10 +693,10 @@ __global__ __launch_bounds__(64) void k_agents_mixed_lanes(DevArgs a, MixedArgs 
           if (slot == 0xFFFFu) continue;
           if ((slot >> 5) != lwi) {
             lwi = slot >> 5;
-            lw = st[H_LIVE0 + lwi];
+            lw = lds_live[lwi * 64 + lane];
           }
           if (!((lw >> (slot & 31u)) & 1u)) {  // filled or cancelled meanwhile: forget it, the slot becomes allocatable
-            ml.inl[(size_t)(slot >> 5) * NB + bk] &= ~(1u << (slot & 31u));  // the lane's own word: plain read-modify-write
+            atomicAnd(&lds_inl[(slot >> 5) * 64 + lane], ~(1u << (slot & 31u)));  // ds_and, nothing to wait for
             continue;
           }
           const uint32_t x = rng.next_u32();
@@ -660,7 +705,7 @@ __global__ __launch_bounds__(64) void k_agents_mixed_lanes(DevArgs a, MixedArgs 
             keep += 1;
           } else {  // env.cancel_order(id); stays live (and unallocatable) until the event is processed
             push_event(slot);
-            ml.inl[(size_t)(slot >> 5) * NB + bk] &= ~(1u << (slot & 31u));  // the lane's own word: plain read-modify-write
+            atomicAnd(&lds_inl[(slot >> 5) * 64 + lane], ~(1u << (slot & 31u)));  // ds_and, nothing to wait for
           }
         }
       }
@@ -669,14 +714,14 @@ __global__ __launch_bounds__(64) void k_agents_mixed_lanes(DevArgs a, MixedArgs 
       if (slot == 0xFFFFu) return;
       my[(size_t)keep * NU] = (uint16_t)slot;
       keep += 1;
-      ml.inl[(size_t)(slot >> 5) * NB + bk] |= 1u << (slot & 31u);
+      atomicOr(&lds_inl[(slot >> 5) * 64 + lane], 1u << (slot & 31u));
     };
     if (D.type == 1) {
       // ---- NoiseAgent::update (noise_agent.rs:127-176)
       for (uint32_t t = 0; t < D.n; ++t) {
         if ((rng.next_u32() >> 8) < D.thr_limit) {                   // gen::<f32>() < p_limit
           const bool buy = rng.next_u64() < 0x8000000000000000ull;   // gen_bool(0.5)
-          const double dist = pm::fabs_(pm::exp(D.mu + D.sigma * rng.std_normal()));
+          const double dist = pm::fabs_(pm::exp(D.mu + D.sigma * rng.std_normal(zx, zf)));
           const uint32_t price = buy ? round_price_down(mid - dist, D.tick_f) : round_price_up(mid + dist, D.tick_f);
           remember(create(buy, price, D.trade_vol, tag));
         }
@@ -700,7 +745,7 @@ __global__ __launch_bounds__(64) void k_agents_mixed_lanes(DevArgs a, MixedArgs 
       for (uint32_t t = 0; t < D.n; ++t) {
         if ((rng.next_u64() >> 11) < thr_l) {  // gen::<f64>() < p_limit
           if (sgn != 0) {
-            const double dist = pm::fabs_(pm::exp(D.mu + D.sigma * rng.std_normal()));
+            const double dist = pm::fabs_(pm::exp(D.mu + D.sigma * rng.std_normal(zx, zf)));
             const uint32_t price =
                 sgn > 0 ? round_price_down(mid - dist, D.tick_f) : round_price_up(mid + dist, D.tick_f);
             remember(create(sgn > 0, price, D.trade_vol, tag));
@@ -739,6 +784,7 @@ __global__ __launch_bounds__(64) void k_agents_mixed_lanes(DevArgs a, MixedArgs 
     *reinterpret_cast<uint2*>(h + H_S1_LO) = make_uint2((uint32_t)rng.s1, (uint32_t)(rng.s1 >> 32));
   }
   if (!MKT) {
+    unstage_masks();
     st[H_NEXT_ID] = next_id;
     if (new_flags) st[H_FLAGS] |= new_flags;
   }
