@@ -13,6 +13,7 @@
 #include <cstring>
 #include <memory>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/bourse_amd.h"
@@ -602,18 +603,55 @@ int bk_submit_instructions_csr(bk_env* env, const uint64_t* book_offsets, const 
                                const uint32_t* vol, const uint32_t* trader_id, const uint32_t* price,
                                const uint64_t* order_id, uint64_t* out_ids, size_t* n_done) {
   if (!env || !book_offsets) return fail(BK_INVALID_ARGUMENT, "null argument");
-  const uint32_t B = env->cfg.n_books;
+  const uint32_t B = env->cfg.n_books, M = env->M, NM = B / M;
   if (n_done) *n_done = 0;
-  for (uint32_t b = 0; b < B; ++b) {
-    const uint64_t lo = book_offsets[b], hi = book_offsets[b + 1];
-    if (hi < lo) return fail(BK_INVALID_ARGUMENT, "book_offsets must be non-decreasing");
-    if (hi == lo) continue;
-    size_t done = 0;
-    const int rc = bk_submit_instructions(env, b, hi - lo, action + lo, side + lo, vol + lo, trader_id + lo, price + lo,
-                                          order_id + lo, out_ids ? out_ids + lo : nullptr, &done);
-    if (n_done) *n_done = lo + done;
-    if (rc != BK_OK) return rc;
+  for (uint32_t b = 0; b < B; ++b)
+    if (book_offsets[b + 1] < book_offsets[b]) return fail(BK_INVALID_ARGUMENT, "book_offsets must be non-decreasing");
+  // The host half of Env (tick check, id assignment, queueing) is independent per book (per market: the queue is the
+  // market's): large batches are spread over host threads, each owning a contiguous range of markets.
+  auto work = [&](uint32_t m_lo, uint32_t m_hi, int* rc_out, size_t* done_out, std::string* err) {
+    *rc_out = BK_OK;
+    for (uint32_t b = m_lo * M; b < m_hi * M; ++b) {
+      const uint64_t lo = book_offsets[b], hi = book_offsets[b + 1];
+      if (hi == lo) continue;
+      size_t done = 0;
+      const int rc = bk_submit_instructions(env, b, hi - lo, action + lo, side + lo, vol + lo, trader_id + lo, price + lo,
+                                            order_id + lo, out_ids ? out_ids + lo : nullptr, &done);
+      if (rc != BK_OK) {
+        *rc_out = rc;
+        *done_out = lo + done;
+        *err = bk_last_error();  // thread-local in the worker
+        return;
+      }
+    }
+    *done_out = book_offsets[static_cast<size_t>(m_hi) * M];
+  };
+  const uint64_t total = book_offsets[B];
+  unsigned nt = 1;
+  if (total >= 65536 && NM >= 64) {
+    nt = std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u);
+    if (const char* e = std::getenv("BOURSE_AMD_HOST_THREADS")) nt = std::max(1, std::atoi(e));
+    nt = std::min<unsigned>(nt, NM);
   }
+  std::vector<int> rcs(nt, BK_OK);
+  std::vector<size_t> dones(nt, 0);
+  std::vector<std::string> errs(nt);
+  if (nt == 1) {
+    work(0, NM, &rcs[0], &dones[0], &errs[0]);
+  } else {
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < nt; ++t)
+      th.emplace_back(work, static_cast<uint32_t>(static_cast<uint64_t>(NM) * t / nt),
+                      static_cast<uint32_t>(static_cast<uint64_t>(NM) * (t + 1) / nt), &rcs[t], &dones[t], &errs[t]);
+    for (auto& x : th) x.join();
+  }
+  for (unsigned t = 0; t < nt; ++t) {  // the first failing range in book order decides (books after it may be queued too)
+    if (rcs[t] != BK_OK) {
+      if (n_done) *n_done = dones[t];
+      return fail(rcs[t], errs[t]);
+    }
+  }
+  if (n_done) *n_done = total;
   return BK_OK;
 }
 

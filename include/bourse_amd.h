@@ -156,7 +156,9 @@ int bk_submit_instructions(bk_env* env, uint32_t book, size_t n, const uint32_t*
                            const uint32_t* vol, const uint32_t* trader_id, const uint32_t* price,
                            const uint64_t* order_id, uint64_t* out_ids, size_t* n_done);
 /* The same for every book in one call: book b's instructions are elements [book_offsets[b], book_offsets[b+1]) of the
- * arrays (CSR over n_books + 1 offsets).  *n_done = global index reached. */
+ * arrays (CSR over n_books + 1 offsets).  *n_done = global index reached.  Large batches are spread over host threads
+ * (one contiguous range of books each; BOURSE_AMD_HOST_THREADS overrides the count); on an error, books after the failing
+ * one may already be queued. */
 int bk_submit_instructions_csr(bk_env* env, const uint64_t* book_offsets, const uint32_t* action, const uint8_t* side,
                                const uint32_t* vol, const uint32_t* trader_id, const uint32_t* price,
                                const uint64_t* order_id, uint64_t* out_ids, size_t* n_done);
