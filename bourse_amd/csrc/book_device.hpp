@@ -88,6 +88,8 @@ struct DevArgs {
 // step batch layout (dwords): [0] n_ev; [8+2r, 9+2r] placing-agents mask r; [24+2r, 25+2r] bid mask of the
 // placements; [64, 64+32R) shuffled event list (u16 agent indices); then uint2 {price, vol} per agent slot.
 constexpr int BT_NEV = 0, BT_PEND = 8, BT_SIDE = 24, BT_EV = 64;
+// event words of k_agents_fsm: slot in bits 0..8, EV_BID / EV_NEW classify the event
+constexpr uint32_t EV_NEW = 0x8000u, EV_BID = 0x4000u, EV_SLOT = 0x1FFu;
 
 // ----------------------------------------------------------------------------------
 // wave primitives
@@ -411,21 +413,23 @@ __device__ __forceinline__ bool match(Book<R>& B, const DevArgs& a, uint32_t boo
 // no-op if the order was filled meanwhile).  The whole handler is instantiated per pool register RS and selected by
 // ONE uniform branch on the slot index, so every pool access inside uses a compile-time register and no flag has to
 // survive between stages (scalar instructions are the scarce resource of this kernel).
-template <int R, int RS>
+// CLS: the event word itself says New / Cancellation and the side (`ew`, k_agents_fsm's lists); otherwise the slot's
+// pend and side masks do.
+template <int R, int RS, bool CLS = false>
 __device__ __forceinline__ void slot_event_at(Book<R>& B, const DevArgs& a, uint32_t book, uint64_t t0, int lane,
-                                              uint32_t k, uint32_t sl) {
+                                              uint32_t k, uint32_t sl, uint32_t ew = 0) {
   const LogCtx nolog{nullptr, 0};
   const uint64_t bit = 1ull << sl;
-  if (!(B.pend[RS] & bit)) {
+  if (CLS ? !(ew & EV_NEW) : !(B.pend[RS] & bit)) {
     B.live[RS] &= ~bit;  // Cancellation
     return;
   }
-  B.pend[RS] &= ~bit;
+  if (!CLS) B.pend[RS] &= ~bit;
   const uint32_t p = rdl(B.price[RS], sl);
   uint32_t v = rdl(B.vol[RS], sl);
   const uint32_t id = rdl(B.id[RS], sl);
   bool filled = false, market;
-  if (B.bid[RS] & bit) {
+  if (CLS ? (ew & EV_BID) != 0 : (B.bid[RS] & bit) != 0) {
     market = p == 0xFFFFFFFFu;
     if (B.trading) filled = match_side<R, true>(B, a, book, t0, lane, k, p, v, id, nolog);
   } else {
@@ -440,16 +444,16 @@ __device__ __forceinline__ void slot_event_at(Book<R>& B, const DevArgs& a, uint
   }
 }
 
-template <int R, int RS = 0>
+template <int R, int RS = 0, bool CLS = false>
 __device__ __forceinline__ void process_slot_event(Book<R>& B, const DevArgs& a, uint32_t book, uint64_t t0, int lane,
-                                                   uint32_t k, uint32_t n) {
+                                                   uint32_t k, uint32_t n, uint32_t ew = 0) {
   if constexpr (RS + 1 < R) {
     if ((n >> 6) == (uint32_t)RS)
-      slot_event_at<R, RS>(B, a, book, t0, lane, k, n & 63);
+      slot_event_at<R, RS, CLS>(B, a, book, t0, lane, k, n & 63, ew);
     else
-      process_slot_event<R, RS + 1>(B, a, book, t0, lane, k, n);
+      process_slot_event<R, RS + 1, CLS>(B, a, book, t0, lane, k, n, ew);
   } else {
-    slot_event_at<R, RS>(B, a, book, t0, lane, k, n & 63);
+    slot_event_at<R, RS, CLS>(B, a, book, t0, lane, k, n & 63, ew);
   }
 }
 
@@ -601,7 +605,7 @@ __device__ __forceinline__ void store_book(const Book<R>& B, const Rng& rng, uin
 // MKT: the list is the MARKET's queue (market_env.rs:110-121); this book processes the events of its own agents'
 // slots (`mine`) at their global positions t0 + k and skips the rest.  Returns trades; `n_own` = events processed.
 // TAGGED (MKT lists written by k_agents_mixed_lanes): entry = slot | asset << 12, ownership by the tag.
-template <int R, bool MKT = false, bool TAGGED = false>
+template <int R, bool MKT = false, bool TAGGED = false, bool CLS = false>
 __device__ __forceinline__ uint32_t step_from_list(Book<R>& B, const DevArgs& a, uint32_t book, int lane,
                                                    const uint32_t (&ev)[R], uint32_t n_ev, uint32_t* bins,
                                                    uint32_t hist_slot, bool write_last, uint32_t tick,
@@ -618,6 +622,8 @@ __device__ __forceinline__ uint32_t step_from_list(Book<R>& B, const DevArgs& a,
       const uint32_t cnt = (n_ev - kb) < 64u ? (n_ev - kb) : 64u;
       for (uint32_t l = 0; l < cnt; ++l) {
         uint32_t slot = rdl(ev[re], l);
+        const uint32_t ew = slot;
+        if (CLS) slot &= EV_SLOT;
         if (MKT && TAGGED) {
           if ((slot >> 12) != asset) continue;
           slot &= 0xFFFu;
@@ -626,7 +632,7 @@ __device__ __forceinline__ uint32_t step_from_list(Book<R>& B, const DevArgs& a,
           if (!mask_test<R>(mine, slot)) continue;
           ++n_own;
         }
-        process_slot_event<R>(B, a, book, t0, lane, kb + l, slot);
+        process_slot_event<R, 0, CLS>(B, a, book, t0, lane, kb + l, slot, ew);
       }
     }
   }
@@ -796,8 +802,6 @@ __global__ __launch_bounds__(64) void k_agents_fsm(DevArgs a) {
       const uint64_t m = (uint64_t)x * range;
       const bool acc = (!is_act) & ((uint32_t)m <= zone);
       const uint32_t val = (uint32_t)(m >> 32);
-      if (hit) list[n_ev * 64 + lane] = (uint16_t)n;  // queue an event for agent n
-      n_ev += hit ? 1u : 0u;
       uint64_t w = live[0];
 #pragma unroll
       for (int r = 1; r < R; ++r) w = ((n >> 6) == (uint32_t)r) ? live[r] : w;
@@ -806,6 +810,12 @@ __global__ __launch_bounds__(64) void k_agents_fsm(DevArgs a) {
       const bool acc_vol = acc & (phase == PH_VOL);
       cur_side = acc_side ? val : cur_side;                             // 0 = Ask, 1 = Bid ([Ask, Bid].choose, :99)
       cur_price = acc_tick ? (G.tick_lo + val) * G.tick_size : cur_price;  // tick * tick_size (:100,:107)
+      // The agent's event is queued once its kind is known (still in agent order: a lane finishes agent n before it
+      // starts n + 1), and carries it: bit 15 = New, bit 14 = bid, so the event kernel does not consult the pend / side
+      // masks (EV_NEW / EV_BID).  A hit on a held Active order is its cancellation (:95-97).
+      const bool queue = (hit & holds_live) | acc_vol;
+      if (queue) list[n_ev * 64 + lane] = (uint16_t)(acc_vol ? (n | EV_NEW | (cur_side << 14)) : n);
+      n_ev += queue ? 1u : 0u;
       if (acc_vol) {                                                    // vol drawn last (:101): the order is complete
         pv[n] = make_uint2(cur_price, G.vol_lo + val);
         const uint32_t wi = (n >> 5) * 64 + lane;
@@ -923,11 +933,11 @@ __global__ __launch_bounds__(64) void k_step_batch(DevArgs a, uint64_t step_inde
     B.id[r] = sel(pend, base + rank, B.id[r]);
     base += __builtin_popcountll(pend);
     B.bid[r] = (B.bid[r] & ~pend) | (side & pend);
-    B.pend[r] = pend;
+    B.pend[r] = 0;  // the event words classify themselves (EV_NEW): no pend mask is carried through the event loop
   }
   B.next_id = base;
   uint32_t n_own = 0;
-  const uint32_t ntr = step_from_list<R, MKT, MKT && POOLPEND>(B, a, book, lane, ev, n_ev, lds[wv], a.hist_slot0,
+  const uint32_t ntr = step_from_list<R, MKT, MKT && POOLPEND, !POOLPEND>(B, a, book, lane, ev, n_ev, lds[wv], a.hist_slot0,
                                                                write_last != 0, MKT ? a.asset_tick[asset] : a.tick_size,
                                                                mine, n_own, asset);
   store_book<R>(B, rng, st, lane, step_index + 1, ntr, n_own);
