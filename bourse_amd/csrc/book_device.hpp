@@ -619,7 +619,7 @@ __device__ __forceinline__ uint32_t step_from_list(Book<R>& B, const DevArgs& a,
   for (int re = 0; re < R; ++re) {  // events at t0 + k (env.rs:123-127); entry k lives in lane k & 63 of ev[k >> 6]
     const uint32_t kb = re * 64;
     if (n_ev > kb) {
-      const uint32_t cnt = (n_ev - kb) < 64u ? (n_ev - kb) : 64u;
+      const uint32_t cnt = rfl((n_ev - kb) < 64u ? (n_ev - kb) : 64u);
       for (uint32_t l = 0; l < cnt; ++l) {
         uint32_t slot = rdl(ev[re], l);
         const uint32_t ew = slot;
