@@ -134,6 +134,23 @@ __device__ __forceinline__ uint32_t wave_add(uint32_t x) {  // wrapping u32 sum
   return rdl(x, 63);
 }
 
+// The four reductions of the level-2 snapshot (max, min, add, add) interleaved: every DPP op is separated from the
+// previous op on the same register by three others, so the 2 wait states a VGPR-write -> DPP-read needs are filled with
+// useful work instead of s_nop (28 fewer instructions per step, and the four chains overlap).
+#define BK_DPP4(CTRL)                                                     \
+  "v_max_u32_dpp %0, %0, %0 " CTRL "\n\tv_min_u32_dpp %1, %1, %1 " CTRL "\n\t" \
+  "v_add_u32_dpp %2, %2, %2 " CTRL "\n\tv_add_u32_dpp %3, %3, %3 " CTRL "\n\t"
+__device__ __forceinline__ void wave_reduce4(uint32_t& mx, uint32_t& mn, uint32_t& s1, uint32_t& s2) {
+  asm("s_nop 1\n\t" BK_DPP4("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf") BK_DPP4("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")
+          BK_DPP4("row_half_mirror row_mask:0xf bank_mask:0xf") BK_DPP4("row_mirror row_mask:0xf bank_mask:0xf")
+              BK_DPP4("row_bcast:15 row_mask:0xa bank_mask:0xf") BK_DPP4("row_bcast:31 row_mask:0xc bank_mask:0xf") "s_nop 1"
+      : "+v"(mx), "+v"(mn), "+v"(s1), "+v"(s2));
+  mx = rdl(mx, 63);
+  mn = rdl(mn, 63);
+  s1 = rdl(s1, 63);
+  s2 = rdl(s2, 63);
+}
+
 __device__ __forceinline__ uint64_t mk64(uint32_t lo, uint32_t hi) { return ((uint64_t)hi << 32) | lo; }
 
 // ----------------------------------------------------------------------------------
@@ -474,9 +491,10 @@ __device__ __forceinline__ void snapshot(const Book<R>& B, const DevArgs& a, uin
     sb += sel(lb, B.vol[r], 0u);
     sa += sel(la, B.vol[r], 0u);
   }
-  const uint32_t bid_best = wave_umax(mb);  // empty side -> 0        (side.rs:194-196)
-  const uint32_t ask_best = wave_umin(ma);  // empty side -> u32::MAX (side.rs:99-104)
-  const uint32_t bid_vol = wave_add(sb), ask_vol = wave_add(sa);
+  wave_reduce4(mb, ma, sb, sa);
+  const uint32_t bid_best = mb;  // empty side -> 0        (side.rs:194-196)
+  const uint32_t ask_best = ma;  // empty side -> u32::MAX (side.rs:99-104)
+  const uint32_t bid_vol = sb, ask_vol = sa;
 
   for (uint32_t j = lane; j < 4 * L; j += 64) bins[j] = 0;
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
