@@ -1209,3 +1209,25 @@ def test_batched_submit_for_all_books_matches_per_book_calls(bk, oracle):
     h = a.history()
     for b in range(B):
         assert np.array_equal(h[:, b], refs[b].history()), b
+
+
+def test_full_size_c3_exact_parity_vs_oracle(bk, oracle):
+    """The headline configuration itself (65 536 books x 128 agents x 32 levels, the shipped split pipeline in three
+    parts): every book's level-2 history, trade count and RNG state against the oracle run on all host threads."""
+    B, T = 65536, 12
+    env = bk.ManyBookEnv(B, 101, 0, 2, 100_000, levels=32, max_live_orders=128, trade_capacity=64 * T, history_capacity=T)
+    env.set_random_agents(C3_GROUPS)
+    assert env.pipeline() == ("split", 3)
+    env.run(T)
+    ref = oracle.ManyBooks(B, 101, 0, 2, 100_000, True, 32, C3_GROUPS)
+    ref.run(T, os.cpu_count() or 8)
+    assert not env.flags().any()
+    assert np.array_equal(env.history(), ref.history())
+    assert np.array_equal(env.trade_counts(), ref.trade_counts())
+    want = ref.rng_states()
+    got = np.array([env.rng_state(b) for b in range(0, B, 97)], dtype=np.uint64)
+    assert np.array_equal(got, want[::97])
+    for b in (0, 21845, 43690, B - 1):  # first / last book of every part
+        g, e = env.trades(b, first=0), ref.book(b).trades_array()
+        for f in g.dtype.names:
+            assert np.array_equal(g[f], e[f]), (b, f)
