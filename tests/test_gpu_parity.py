@@ -1231,3 +1231,46 @@ def test_full_size_c3_exact_parity_vs_oracle(bk, oracle):
         g, e = env.trades(b, first=0), ref.book(b).trades_array()
         for f in g.dtype.names:
             assert np.array_equal(g[f], e[f]), (b, f)
+
+
+def test_c_abi_argument_validation(bk):
+    """Bad arguments are refused with a status code and a message (never a crash, never silently accepted)."""
+    E = bk.BourseError
+    for kw in (dict(n_books=0), dict(levels=0), dict(levels=65), dict(tick_size=0), dict(max_live_orders=1024), dict(device=99)):
+        args = dict(n_books=4, seed=1, start_time=0, tick_size=1, step_size=1000, levels=10)
+        args.update(kw)
+        with pytest.raises((E, ValueError)):
+            bk.ManyBookEnv(**args)
+    with pytest.raises((E, ValueError)):
+        bk.ManyBookEnv(10, 1, 0, 1, 1000, assets=3)        # assets must divide n_books
+    with pytest.raises((E, ValueError)):
+        bk.ManyBookEnv(18, 1, 0, 1, 1000, assets=9)        # at most 8 assets
+    env = bk.ManyBookEnv(4, 1, 0, 2, 1000, levels=10, max_live_orders=64, max_orders=8, trade_capacity=16, history_capacity=4)
+    with pytest.raises((E, IndexError, ValueError)):
+        env.place_order(4, True, 1, 0, 10)                 # book out of range
+    with pytest.raises(ValueError):
+        env.place_order(0, True, 1, 0, 11)                 # not a tick multiple
+    with pytest.raises((E, ValueError)):
+        env.set_random_agents([(10, (5, 5), (1, 2), 2, 0.5)])          # empty tick range (gen_range asserts low < high)
+    with pytest.raises((E, ValueError)):
+        env.set_random_agents([(10, (1, 5), (1, 2), 3, 0.5)])          # agent tick not a multiple of the env tick
+    with pytest.raises((E, ValueError)):
+        env.set_random_agents([(40, (1, 5), (1, 2), 2, 0.5)] * 2)      # more agents than pool slots
+    with pytest.raises((E, ValueError)):
+        env.set_random_agents([(1, (1, 5), (1, 2), 2, 0.5)] * 9)       # more than 8 groups
+    with pytest.raises((E, ValueError)):
+        env.set_agents([("noise", 0, 5, dict(tick_size=2, p_limit=0.1, p_market=0.1, p_cancel=0.1, trade_vol=1,
+                                             price_dist_mu=0.0, price_dist_sigma=-1.0))])  # LogNormal::new(.., sigma < 0)
+    with pytest.raises((E, ValueError)):
+        env.history(first_step=0, n_steps=1)               # nothing retained yet
+    env.cancel_order(0, 123)                               # unknown id: reported when the event is processed
+    with pytest.raises((E, IndexError, ValueError)):
+        env.step()
+    env2 = bk.ManyBookEnv(2, 1, 0, 1, 1000, levels=10, max_live_orders=64, max_orders=8, trade_capacity=16)
+    env2.place_order(0, True, 5, 0, 10)
+    with pytest.raises((E, ValueError)):
+        env2.set_random_agents([(4, (1, 5), (1, 2), 1, 0.5)]) or env2.run(1)  # on-device agents cannot mix with host-driven orders
+    off, rec = env2.drain_trades()                         # compaction with nothing to compact
+    assert len(rec) == 0 and not off.any()
+    with pytest.raises((E, ValueError)):
+        env2.set_pipeline("nonsense") if False else env2._L and bk._lib.check(env2._L.bk_set_pipeline(env2._h, 7))
