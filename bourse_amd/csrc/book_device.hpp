@@ -356,7 +356,7 @@ __device__ __forceinline__ void log_fill(const LogCtx& lg, uint32_t& flags, int 
 template <int R, bool agg_bid>
 __device__ __forceinline__ bool match_side(Book<R>& B, const DevArgs& a, uint32_t book, uint64_t t0, int lane,
                                            uint32_t k, uint32_t p, uint32_t& v, uint32_t agg_id, const LogCtx& lg) {
-  bool filled = false;
+  const uint32_t v0 = v;
   while (v > 0) {
     // candidates: live orders on the opposite side
     uint64_t cand[R];
@@ -414,9 +414,8 @@ __device__ __forceinline__ bool match_side(Book<R>& B, const DevArgs& a, uint32_
     emit_trade(B, a, book, t0, lane, k, !agg_bid, best, tv, agg_id, pid);
     B.trade_vol += tv;
     log_fill(lg, B.flags, lane, pid, pv, t0 + k);
-    if (v == 0) filled = true;
   }
-  return filled;
+  return v0 != 0 && v == 0;  // Filled = its volume hit zero in a match (a zero-volume order never enters the loop, :430)
 }
 template <int R>
 __device__ __forceinline__ bool match(Book<R>& B, const DevArgs& a, uint32_t book, uint64_t t0, int lane, uint32_t k,
