@@ -87,6 +87,7 @@ def main():
     ap.add_argument("--books", type=int, default=0, help="books per GPU (default: the workload's)")
     ap.add_argument("--steps-per-launch", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--l1-gather", action="store_true", help="also all-gather every book's L1 record per launch (SURVEY 8e ii)")
     ap.add_argument("--no-history", action="store_true", help="keep only the latest L2 record (diagnostic)")
     ap.add_argument("--pipeline", default="auto", choices=["auto", "fused", "split"])
     ap.add_argument("--profile-every", type=int, default=8, help="HIP-event-time every Nth step's kernels (0 = none)")
@@ -131,6 +132,7 @@ def main():
         env.set_random_agents(groups)
     env.set_pipeline(args.pipeline)
     gather = parallel.StatsGather(env, dist) if dist is not None else None
+    l1 = parallel.L1Gather(env, dist) if (dist is not None and args.l1_gather) else None
 
     def run_steps(n):
         done = 0
@@ -141,6 +143,8 @@ def main():
             env.run(c, sync=False)
             if gather is not None:
                 gather.all_gather()   # 64 B per GPU over RCCL; never on the stepping critical path
+            if l1 is not None:
+                l1.all_gather()       # optional tier: 36 B per book, queued behind the launch on the same stream
             done += c
 
     run_steps(args.warmup)
@@ -258,6 +262,12 @@ def main():
         out["config"]["stats_allgather"] = {"zero_copy": gather.zero_copy, "n_books": g["n_books"], "sum_trades": g["sum_trades"]}
         if g["n_books"] != world * B:
             raise SystemExit(f"stats all-gather inconsistent: {g}")
+    if l1 is not None:
+        rec = l1.result()
+        mine = env.level2()[:, :9]
+        if rec.shape != (world * B, 9) or not np.array_equal(rec[rank * B:(rank + 1) * B], mine):
+            raise SystemExit("L1 all-gather inconsistent with this rank's level-2 records")
+        out["config"]["l1_allgather"] = {"bytes_per_gpu": int(B * 36), "books": int(rec.shape[0])}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(groups, levels)
     env.close()

@@ -130,6 +130,7 @@ SIGNATURES = {
     "bk_live_orders": (_i32, [_vp, _u32, _u32, _vp, _p32]),
     "bk_stats_compute": (_i32, [_vp, C.POINTER(Stats)]),
     "bk_stats_device_ptr": (_i32, [_vp, C.POINTER(_vp)]),
+    "bk_level2_device_ptr": (_i32, [_vp, C.POINTER(_vp)]),
     "bk_profile_enable": (_i32, [_vp, _i32]),
     "bk_profile_read": (_i32, [_vp, C.POINTER(C.c_double), _p64, _i32]),
     "bk_profile_read_kind": (_i32, [_vp, _i32, C.POINTER(C.c_double), _p64]),

@@ -1455,6 +1455,14 @@ int bk_stats_device_ptr(bk_env* env, void** out) {
   return BK_OK;
 }
 
+// the latest level-2 records on the device: u32[n_books][bk_l2_width()], for on-device consumers (e.g. the optional
+// per-book L1 all-gather across GPUs); valid until the env is destroyed, contents as of the work queued so far
+int bk_level2_device_ptr(bk_env* env, void** out) {
+  if (!env || !out) return fail(BK_INVALID_ARGUMENT, "null argument");
+  *out = env->l2_last.p;
+  return BK_OK;
+}
+
 // ------------------------------------------------------------------ measurement
 int bk_profile_enable(bk_env* env, int on) {
   if (!env) return fail(BK_INVALID_ARGUMENT, "null env");

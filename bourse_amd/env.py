@@ -544,6 +544,12 @@ class ManyBookEnv:
         check(self._L.bk_stats_device_ptr(self._h, C.byref(out)))
         return int(out.value)
 
+    def level2_device_ptr(self) -> int:
+        """Device address of the latest level-2 records, u32[n_books][width] (for on-device consumers)."""
+        out = C.c_void_p()
+        check(self._L.bk_level2_device_ptr(self._h, C.byref(out)))
+        return int(out.value)
+
     def stats_compute_async(self):
         check(self._L.bk_stats_compute(self._h, None))
 

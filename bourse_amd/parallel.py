@@ -101,3 +101,34 @@ class StatsGather:
 
     def result(self) -> Dict[str, int]:
         return combine_stats(self.out.cpu().numpy())
+
+
+L1_WORDS = 9  # [trade_vol, bid, ask, ask_vol, bid_vol, bid_touch_vol, bid_touch_n, ask_touch_vol, ask_touch_n]
+
+
+class _DevicePtr32:
+    def __init__(self, ptr: int, shape):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": "<i4", "data": (ptr, False), "version": 2}
+
+
+class L1Gather:
+    """Optional second tier of the stats exchange: every book's level-1 record — the 9 leading words of
+    its level-2 record, ``StepEnvNumpy.level_1_data`` layout — all-gathered over RCCL: 36 B per book, 2.4 MB per GPU at
+    65 536 books, on the env's stream and overlappable with the next launch.  ``all_gather()`` returns an
+    int32[world, n_books, 9] device tensor (a view of the words; reinterpret as uint32 on the host)."""
+
+    def __init__(self, env, dist):
+        import torch
+
+        self.env, self.dist, self.torch = env, dist, torch
+        self.l2 = torch.as_tensor(_DevicePtr32(env.level2_device_ptr(), (env.n_books, env.width)), device="cuda")
+        self.out = torch.empty((dist.get_world_size(), env.n_books, L1_WORDS), dtype=torch.int32, device="cuda")
+
+    def all_gather(self):
+        mine = self.l2[:, :L1_WORDS].contiguous()  # zero-copy view of the library's records, packed on the device
+        self.dist.all_gather_into_tensor(self.out.view(-1), mine.view(-1))
+        return self.out
+
+    def result(self) -> np.ndarray:
+        """uint32[world * n_books, 9] on the host, books in global order (rank-major = contiguous shards)."""
+        return self.out.cpu().numpy().view(np.uint32).reshape(-1, L1_WORDS)

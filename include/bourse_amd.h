@@ -254,6 +254,9 @@ int bk_live_orders(bk_env* env, uint32_t book, uint32_t cap, bk_order* out, uint
 int bk_stats_compute(bk_env* env, bk_stats* out_host);
 /* device address of the 64-byte record (for an RCCL all-gather issued by the caller) */
 int bk_stats_device_ptr(bk_env* env, void** out);
+/* Device pointer of the latest level-2 records, u32[n_books][bk_l2_width()] (Env::level_2_data of every book), for
+ * on-device consumers: the optional per-book L1 all-gather of SURVEY §8e (ii) reads its 9 leading words per book. */
+int bk_level2_device_ptr(bk_env* env, void** out);
 
 /* ------------------------------------------------------------- measurement */
 /* accumulate HIP-event timings of the step kernels: on = 0 off, N >= 1 time the kernels of every Nth step */
