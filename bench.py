@@ -245,6 +245,7 @@ def main():
             "parallelism": f"independent book shards x{world}, 64 B stats all-gather per launch" if world > 1
             else "single GPU",
             "trades_per_book_step": tr_per_bs, "events_per_book_step": ev_per_bs,
+            "events_per_s": ev_per_bs * value, "trades_per_s": tr_per_bs * value,
             "pipeline": f"split ({kind1} + k_step_batch per step, {parts} book parts on separate streams)"
             if pipe == "split" else f"fused ({kind0})",
         },
