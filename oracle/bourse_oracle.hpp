@@ -23,6 +23,8 @@
 //     known-answer vector (tests/test_oracle_rng.py); seed_from_u64 /
 //     gen_range / shuffle / choose / f32 follow the crates' algorithms as
 //     restated below and are the specification for the HIP path.
+//     To pin them: integration/rust/pin_rng (real crates) must print exactly
+//     tests/golden/rng_pin_expected.txt (this oracle, tools/gen_rng_pin.py).
 //
 // All `ref:` citations are paths relative to /root/reference.
 #pragma once

@@ -437,3 +437,19 @@ def test_json_snapshot_serde_layout(oracle, tmp_path):
     ob.set_time(7)
     assert lb.place_order(False, 6, 9, 50) == ob.place_order(False, 6, 9, 50) == 2
     assert lb.state() == ob.state()
+
+
+def test_rng_pin_file_is_what_the_oracle_produces(oracle):
+    # tests/golden/rng_pin_expected.txt is the file integration/rust/pin_rng (the real rand / rand_xoshiro / rand_distr
+    # crates) is diffed against; it must stay in sync with the oracle's restated sampling.
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("gen_rng_pin", os.path.join(root, "tools", "gen_rng_pin.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    want = open(os.path.join(root, "tests", "golden", "rng_pin_expected.txt")).read().splitlines()
+    assert mod.lines() == want
+    # published known answers the file must carry: SplitMix64 seeding of xoroshiro128** (rand_core seed_from_u64)
+    assert want[0].startswith("next_u64: ")
+    assert len(want) == 12
