@@ -124,9 +124,10 @@ struct bk_env {
   // k_agents_fsm apart, so the latency-bound lane-per-book kernel of one part runs under the issue-bound
   // wave-per-book kernel of another.
   int n_parts = 3;
-  hipStream_t part_stream[4] = {nullptr, nullptr, nullptr, nullptr};
-  hipEvent_t ev_fork = nullptr, ev_first[4] = {nullptr, nullptr, nullptr, nullptr},
-             ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
+  uint32_t min_part = 4096;  // books (markets) per part below which the batch is cut in fewer parts
+  static constexpr int MAX_PARTS = 8;
+  hipStream_t part_stream[MAX_PARTS] = {};
+  hipEvent_t ev_fork = nullptr, ev_first[MAX_PARTS] = {}, ev_join[MAX_PARTS] = {};
   DevBuf<DevTrade> trades;
   DevBuf<DevOrderLog> order_log;
   DevBuf<DevStats> stats;
@@ -138,9 +139,14 @@ struct bk_env {
   // lane-per-book members' update (k_agents_mixed_lanes): the members' order lists, [member][entry][book]
   DevBuf<uint16_t> ml_list;
   DevBuf<uint32_t> ml_len, ml_inl;
+  bool lds_attr_set = false;  // hipFuncAttributeMaxDynamicSharedMemorySize applied on this env's device
   bool ml_valid = false;  // the lists describe the pool as of steps_done (false after a wave-per-book launch / restore)
   uint32_t member_asset[MAX_MEMBERS] = {0, 0, 0, 0};
   uint32_t n_fixed_a[MAX_ASSETS] = {0, 0, 0, 0, 0, 0, 0, 0};
+  int parts() const {
+    const uint32_t units = cfg.n_books / M;
+    return static_cast<int>(std::max(1u, std::min(static_cast<uint32_t>(n_parts), units / min_part)));
+  }
   MixedLists lists() const {
     return MixedLists{ml_list.p, ml_len.p, ml_inl.p, static_cast<uint32_t>(R) * 64u, cfg.n_books, cfg.n_books / M};
   }
@@ -272,13 +278,12 @@ int launch_split(bk_env* env, const DevArgs& a0, uint64_t first_step, uint32_t n
       HIPCHK(env->ml_inl.alloc(2 * static_cast<size_t>(R) * NB));
       env->ml_valid = false;
     }
-    static bool lds_attr_set = false;  // per instantiation: allow > 64 KB of dynamic LDS (160 KB per workgroup on MI355X)
-    if (!lds_attr_set) {
+    if (!env->lds_attr_set) {  // allow > 64 KB of dynamic LDS (160 KB per workgroup on MI355X); the attribute is per device
       HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_agents_mixed_lanes<R, true>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(mixed_lanes_lds_bytes(R, true))));
       HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_agents_mixed_lanes<R, false>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(mixed_lanes_lds_bytes(R, false))));
-      lds_attr_set = true;
+      env->lds_attr_set = true;
     }
     if (!env->ml_valid) {
       hipLaunchKernelGGL(k_mixed_lists_rebuild<R>, dim3((env->cfg.n_books + 3) / 4), dim3(256), 0, env->stream, a0, ma,
@@ -292,11 +297,10 @@ int launch_split(bk_env* env, const DevArgs& a0, uint64_t first_step, uint32_t n
   const MixedLists ml = env->lists();
   const uint32_t M = env->M;
   const uint32_t B = env->cfg.n_books / M;  // units the parts are cut in: books, or markets of M books
-  int P = env->n_parts;
-  if (env->cfg.n_books < 4096u * P) P = 1;  // small batches: one part on the caller's stream
+  const int P = env->parts();  // small batches: one part on the caller's stream
   if (P > 1 && !env->ev_fork) {
     HIPCHK(hipEventCreateWithFlags(&env->ev_fork, hipEventDisableTiming));
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < bk_env::MAX_PARTS; ++i) {
       HIPCHK(hipStreamCreateWithFlags(&env->part_stream[i], hipStreamNonBlocking));
       HIPCHK(hipEventCreateWithFlags(&env->ev_first[i], hipEventDisableTiming));
       HIPCHK(hipEventCreateWithFlags(&env->ev_join[i], hipEventDisableTiming));
@@ -352,6 +356,17 @@ int launch_split(bk_env* env, const DevArgs& a0, uint64_t first_step, uint32_t n
       HIPCHK(hipStreamWaitEvent(env->stream, env->ev_join[i], 0));
     }
   }
+  return BK_OK;
+}
+
+// make `later` wait for the work queued on `earlier` so far
+int order_after(hipStream_t later, hipStream_t earlier) {
+  hipEvent_t ev = nullptr;
+  HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  hipError_t e = hipEventRecord(ev, earlier);
+  if (e == hipSuccess) e = hipStreamWaitEvent(later, ev, 0);
+  (void)hipEventDestroy(ev);  // released once the wait has been satisfied
+  if (e != hipSuccess) return fail(BK_HIP_ERROR, std::string("stream ordering: ") + hipGetErrorString(e));
   return BK_OK;
 }
 
@@ -473,7 +488,11 @@ int bk_env_create(const bk_config* cfg, bk_env** out) {
   }
   if (const char* np = std::getenv("BOURSE_AMD_SPLIT_PARTS")) {
     const int v = std::atoi(np);
-    if (v >= 1 && v <= 4) env->n_parts = v;
+    if (v >= 1 && v <= bk_env::MAX_PARTS) env->n_parts = v;
+  }
+  if (const char* mp = std::getenv("BOURSE_AMD_MIN_PART")) {
+    const int v = std::atoi(mp);
+    if (v >= 64) env->min_part = static_cast<uint32_t>(v);
   }
   HIPCHK(env->ev_off.alloc(B + 1));
   HIPCHK(hipMemset(env->ev_off.p, 0, (B + 1) * sizeof(uint32_t)));
@@ -514,7 +533,7 @@ void bk_env_destroy(bk_env* env) {
   if (env->off_stage) (void)hipHostFree(env->off_stage);
   if (env->ev_fork) {
     (void)hipEventDestroy(env->ev_fork);
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < bk_env::MAX_PARTS; ++i) {
       (void)hipStreamSynchronize(env->part_stream[i]);
       (void)hipStreamDestroy(env->part_stream[i]);
       (void)hipEventDestroy(env->ev_first[i]);
@@ -581,6 +600,8 @@ int bk_submit_instructions(bk_env* env, uint32_t book, size_t n, const uint32_t*
                            const uint64_t* order_id, uint64_t* out_ids, size_t* n_done) {
   if (int rc = check_book(env, book)) return rc;
   if (n_done) *n_done = 0;
+  if (n && (!action || !side || !vol || !trader_id || !price || !order_id))
+    return fail(BK_INVALID_ARGUMENT, "null instruction array");
   for (size_t i = 0; i < n; ++i) {
     uint64_t id = ~0ull;  // usize::MAX for non-new instructions (step_sim_numpy.rs:255-268)
     if (action[i] == 1) {
@@ -605,6 +626,8 @@ int bk_submit_instructions_csr(bk_env* env, const uint64_t* book_offsets, const 
   if (!env || !book_offsets) return fail(BK_INVALID_ARGUMENT, "null argument");
   const uint32_t B = env->cfg.n_books, M = env->M, NM = B / M;
   if (n_done) *n_done = 0;
+  if (book_offsets[B] > book_offsets[0] && (!action || !side || !vol || !trader_id || !price || !order_id))
+    return fail(BK_INVALID_ARGUMENT, "null instruction array");
   for (uint32_t b = 0; b < B; ++b)
     if (book_offsets[b + 1] < book_offsets[b]) return fail(BK_INVALID_ARGUMENT, "book_offsets must be non-decreasing");
   // The host half of Env (tick check, id assignment, queueing) is independent per book (per market: the queue is the
@@ -750,7 +773,8 @@ int bk_order_count(bk_env* env, uint32_t book, uint64_t* out) {
 int bk_get_orders(bk_env* env, uint32_t book, uint64_t first, uint64_t n, bk_order* out) {
   if (int rc = check_book(env, book)) return rc;
   BookHost& bh = env->books[book];
-  if (first + n > bh.orders.size()) return fail(BK_INVALID_ARGUMENT, "order range out of bounds");
+  if (first > bh.orders.size() || n > bh.orders.size() - first) return fail(BK_INVALID_ARGUMENT, "order range out of bounds");
+  if (n && !out) return fail(BK_INVALID_ARGUMENT, "null argument");
   if (bh.orders.size() > env->cfg.max_orders && env->cfg.max_orders > 0 && bh.n_uploaded > env->cfg.max_orders)
     return fail(BK_CAPACITY, "order log capacity exceeded");
   if (int rc = use_device(env)) return rc;
@@ -1022,7 +1046,8 @@ int bk_history_len(bk_env* env, uint64_t* first_step, uint64_t* n_steps) {
 static int hist_copy(bk_env* env, uint64_t first_step, uint64_t n_steps, uint32_t first_book, uint32_t n_books,
                      uint32_t* out, hipStream_t cs, bool async) {
   if (!env || !out) return fail(BK_INVALID_ARGUMENT, "null argument");
-  if (!env->cfg.history_capacity || first_step < hist_first(env) || first_step + n_steps > env->steps_done)
+  if (!env->cfg.history_capacity || first_step < hist_first(env) || first_step > env->steps_done ||
+      n_steps > env->steps_done - first_step)
     return fail(BK_INVALID_ARGUMENT, "step range not retained (history is a ring of history_capacity steps)");
   if (static_cast<uint64_t>(first_book) + n_books > env->cfg.n_books)
     return fail(BK_INVALID_ARGUMENT, "book range out of bounds");
@@ -1063,11 +1088,7 @@ int bk_history_copy_async(bk_env* env, uint64_t first_step, uint64_t n_steps, ui
   if (!env || !copy_stream) return fail(BK_INVALID_ARGUMENT, "null argument");
   if (int rc = use_device(env)) return rc;
   hipStream_t cs = static_cast<hipStream_t>(copy_stream);
-  hipEvent_t ev;
-  HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-  HIPCHK(hipEventRecord(ev, env->stream));
-  HIPCHK(hipStreamWaitEvent(cs, ev, 0));
-  HIPCHK(hipEventDestroy(ev));
+  if (int rc = order_after(cs, env->stream)) return rc;
   return hist_copy(env, first_step, n_steps, first_book, n_books, out, cs, true);
 }
 
@@ -1132,7 +1153,8 @@ int bk_get_trades(bk_env* env, uint32_t book, uint64_t first, uint64_t n, bk_tra
   if (int rc = check_book(env, book)) return rc;
   uint64_t total = 0, base = 0;
   if (int rc = bk_trade_count(env, book, &total, &base)) return rc;
-  if (first < base || first + n > total) return fail(BK_INVALID_ARGUMENT, "trade range not retained");
+  if (first < base || first > total || n > total - first) return fail(BK_INVALID_ARGUMENT, "trade range not retained");
+  if (n && !out) return fail(BK_INVALID_ARGUMENT, "null argument");
   if (first + n - base > env->cfg.trade_capacity)
     return fail(BK_CAPACITY, "trade records beyond trade_capacity were dropped");
   if (n == 0) return BK_OK;
@@ -1184,13 +1206,8 @@ int bk_trades_compact_copy_async(bk_env* env, bk_trade* records, uint64_t* offse
   if (!env->tr_off.p) return fail(BK_INVALID_ARGUMENT, "call bk_trades_compact first");
   if (int rc = use_device(env)) return rc;
   hipStream_t cs = copy_stream ? static_cast<hipStream_t>(copy_stream) : env->stream;
-  if (copy_stream) {
-    hipEvent_t ev;
-    HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-    HIPCHK(hipEventRecord(ev, env->stream));
-    HIPCHK(hipStreamWaitEvent(cs, ev, 0));
-    HIPCHK(hipEventDestroy(ev));
-  }
+  if (copy_stream)
+    if (int rc = order_after(cs, env->stream)) return rc;
   HIPCHK(hipMemcpyAsync(offsets, env->tr_off.p, (static_cast<size_t>(env->cfg.n_books) + 1) * 8, hipMemcpyDeviceToHost, cs));
   if (env->tr_total)
     HIPCHK(hipMemcpyAsync(records, env->tr_dense.p, env->tr_total * sizeof(bk_trade), hipMemcpyDeviceToHost, cs));
@@ -1214,7 +1231,7 @@ int bk_get_order_keys(bk_env* env, uint32_t book, uint64_t first, uint64_t n, ui
                       uint64_t* key_time) {
   if (int rc = check_book(env, book)) return rc;
   BookHost& bh = env->books[book];
-  if (first + n > bh.orders.size()) return fail(BK_INVALID_ARGUMENT, "order range out of bounds");
+  if (first > bh.orders.size() || n > bh.orders.size() - first) return fail(BK_INVALID_ARGUMENT, "order range out of bounds");
   if (env->cfg.max_orders == 0) return fail(BK_INVALID_ARGUMENT, "order log disabled (max_orders == 0)");
   if (bh.n_uploaded > env->cfg.max_orders) return fail(BK_CAPACITY, "order log capacity exceeded");
   if (int rc = use_device(env)) return rc;
@@ -1370,6 +1387,7 @@ int bk_time(bk_env* env, uint32_t book, uint64_t* out) {
 
 int bk_trade_vol(bk_env* env, uint32_t book, uint32_t* out) {
   if (int rc = check_book(env, book)) return rc;
+  if (!out) return fail(BK_INVALID_ARGUMENT, "null argument");
   return read_hdr(env, book, H_TRADE_VOL, 1, out);
 }
 
@@ -1390,6 +1408,7 @@ int bk_book_flags(bk_env* env, uint32_t* out) {
 
 int bk_rng_state(bk_env* env, uint32_t book, uint64_t out_state[2]) {
   if (int rc = check_book(env, book)) return rc;
+  if (!out_state) return fail(BK_INVALID_ARGUMENT, "null argument");
   uint32_t h[4];
   if (int rc = read_hdr(env, book, H_S0_LO, 4, h)) return rc;
   out_state[0] = (static_cast<uint64_t>(h[1]) << 32) | h[0];
@@ -1399,6 +1418,7 @@ int bk_rng_state(bk_env* env, uint32_t book, uint64_t out_state[2]) {
 
 int bk_live_orders(bk_env* env, uint32_t book, uint32_t cap, bk_order* out, uint32_t* n_out) {
   if (int rc = check_book(env, book)) return rc;
+  if (cap && !out) return fail(BK_INVALID_ARGUMENT, "null argument");
   std::vector<uint32_t> st(env->stride);
   if (int rc = read_hdr(env, book, 0, static_cast<int>(env->stride), st.data())) return rc;
   struct Live {
@@ -1505,8 +1525,7 @@ int bk_get_pipeline(bk_env* env, int* split, int* n_parts) {
   const bool sp = env->pipeline >= 2 || env->M > 1 ||
                   (env->pipeline == 0 && (env->n_mixed ? env->cfg.n_books >= 3072
                                                        : env->cfg.n_books >= 8192 && !env->groups.empty()));
-  int P = env->n_parts;
-  if (env->cfg.n_books < 4096u * P) P = 1;
+  const int P = env->parts();
   if (split) *split = sp ? 1 : 0;
   if (n_parts) *n_parts = sp ? P : 1;
   return BK_OK;
@@ -1572,6 +1591,7 @@ uint64_t bk_state_bytes_per_book(const bk_env* env) { return env ? static_cast<u
 
 // DPP reduction self-test (tests only): in[n_waves*64] -> out[n_waves*4] = {min, max, sum, sel-sum}
 int bk_selftest_reduce(const uint32_t* in_host, uint32_t n_waves, uint32_t* out_host) {
+  if (!in_host || !out_host) return fail(BK_INVALID_ARGUMENT, "null argument");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(BK_NO_DEVICE, "no HIP device available");
   DevBuf<uint32_t> in, out;

@@ -1274,3 +1274,17 @@ def test_c_abi_argument_validation(bk):
     assert len(rec) == 0 and not off.any()
     with pytest.raises((E, ValueError)):
         env2.set_pipeline("nonsense") if False else env2._L and bk._lib.check(env2._L.bk_set_pipeline(env2._h, 7))
+    # raw ABI: null arrays and ranges that wrap are refused, not dereferenced
+    import ctypes as C
+    L, h = env2._L, env2._h
+    nd = C.c_size_t(0)
+    assert L.bk_submit_instructions(h, 0, 3, None, None, None, None, None, None, None, C.byref(nd)) == bk._lib.BK_INVALID
+    assert L.bk_get_orders(h, 0, 0, 1, None) == bk._lib.BK_INVALID
+    assert L.bk_get_orders(h, 0, 2**64 - 1, 2, None) == bk._lib.BK_INVALID      # first + n wraps
+    assert L.bk_get_trades(h, 0, 2**64 - 1, 2, None) == bk._lib.BK_INVALID
+    assert L.bk_get_order_keys(h, 0, 2**64 - 1, 2, None, None) == bk._lib.BK_INVALID
+    assert L.bk_rng_state(h, 0, None) == bk._lib.BK_INVALID
+    assert L.bk_trade_vol(h, 0, None) == bk._lib.BK_INVALID
+    assert L.bk_live_orders(h, 0, 4, None, None) == bk._lib.BK_INVALID
+    assert L.bk_history(h, 2**64 - 1, 2, 0, 1, (C.c_uint32 * 64)()) == bk._lib.BK_INVALID
+    assert b"null" in L.bk_last_error() or b"range" in L.bk_last_error() or b"retained" in L.bk_last_error()
