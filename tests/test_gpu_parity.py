@@ -1288,3 +1288,22 @@ def test_c_abi_argument_validation(bk):
     assert L.bk_live_orders(h, 0, 4, None, None) == bk._lib.BK_INVALID
     assert L.bk_history(h, 2**64 - 1, 2, 0, 1, (C.c_uint32 * 64)()) == bk._lib.BK_INVALID
     assert b"null" in L.bk_last_error() or b"range" in L.bk_last_error() or b"retained" in L.bk_last_error()
+
+
+@pytest.mark.parametrize("parts", [2, 3, 5, 8])
+def test_split_pipeline_any_number_of_parts(bk, oracle, parts, monkeypatch):
+    """The split pipeline cuts the batch into min(parts, units / min_part) contiguous parts on separate streams: the
+    partition must not show in the results (RandomAgents, AgentSet members one lane per book, markets)."""
+    monkeypatch.setenv("BOURSE_AMD_SPLIT_PARTS", str(parts))
+    monkeypatch.setenv("BOURSE_AMD_MIN_PART", "64")
+    groups = [(40, (40, 56), (10, 20), 2, 0.8), (24, (40, 56), (50, 70), 2, 0.3)]
+    env = bk.ManyBookEnv(64 * parts + 37, 1, 0, 2, 100_000, levels=8, max_live_orders=64)
+    env.set_random_agents(groups)
+    env.set_pipeline("split")
+    assert env.pipeline() == ("split", parts)
+    env.close()
+    _compare_random(bk, oracle, 64 * parts + 37, groups, 16, 12, pipeline="split", chunks=[5, 7])
+    members = [("momentum", 0, 10, MOM_P), ("noise", 10, 20, NOISE_P)]
+    _compare_members(bk, oracle, 64 * parts + 5, members, levels=10, n_steps=14, pipeline="split", chunks=[6, 8])
+    mgroups = [(0, 24, (40, 56), (10, 20), 2, 0.8), (1, 24, (40, 56), (10, 20), 2, 0.8), (1, 16, (40, 56), (50, 70), 2, 0.2)]
+    _compare_markets(bk, oracle, 64 * parts + 9, [2, 2], mgroups, 16, 8)
