@@ -234,19 +234,24 @@ __device__ __forceinline__ void slot_write(uint32_t (&v)[R], uint32_t n, uint32_
   for (int r = 0; r < R; ++r)
     if ((n >> 6) == (uint32_t)r) v[r] = wrl(val, n & 63, v[r]);
 }
+// Both written so that every element is touched unconditionally with a per-element select: an `if (index == r) m[r] = ..`
+// chain is turned back into ONE dynamically indexed access by LLVM at R >= 4, which defeats scalar replacement and
+// moves the whole Book into scratch memory.
 template <int R>
 __device__ __forceinline__ bool mask_test(const uint64_t (&m)[R], uint32_t n) {
-  uint64_t w = m[0];
+  uint64_t w = 0;
 #pragma unroll
-  for (int r = 1; r < R; ++r) w = ((n >> 6) == (uint32_t)r) ? m[r] : w;
+  for (int r = 0; r < R; ++r) w |= m[r] & (((n >> 6) == (uint32_t)r) ? ~0ull : 0ull);
   return (w >> (n & 63)) & 1ull;
 }
 template <int R>
 __device__ __forceinline__ void mask_set(uint64_t (&m)[R], uint32_t n, bool on) {
   const uint64_t bit = 1ull << (n & 63);
 #pragma unroll
-  for (int r = 0; r < R; ++r)
-    if ((n >> 6) == (uint32_t)r) m[r] = on ? (m[r] | bit) : (m[r] & ~bit);
+  for (int r = 0; r < R; ++r) {
+    const uint64_t b = ((n >> 6) == (uint32_t)r) ? bit : 0ull;
+    m[r] = on ? (m[r] | b) : (m[r] & ~b);
+  }
 }
 
 // ----------------------------------------------------------------------------------
@@ -996,7 +1001,9 @@ __device__ __forceinline__ int find_free_slot(const Book<R>& B) {
 template <int R>
 __global__ __launch_bounds__(64) void k_step_events(DevArgs a, uint64_t step_index) {
   __shared__ uint32_t bins[LDS_DW_PER_WAVE];
-  __shared__ uint16_t perm[EV_LDS_CAP];
+  // the shuffle permutation: dynamic LDS sized by the host to this step's longest queue (<= EV_LDS_CAP entries), so
+  // that quiet steps do not pay 16 KB of LDS per one-wave workgroup in occupancy
+  extern __shared__ uint16_t perm[];
   const int lane = threadIdx.x;
   const uint32_t book = blockIdx.x;
   // MarketEnv mode: the event queue belongs to the MARKET (book / assets); every book of the market shuffles it with
@@ -1030,15 +1037,17 @@ __global__ __launch_bounds__(64) void k_step_events(DevArgs a, uint64_t step_ind
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
   }
+  uint4 evr = make_uint4(0u, 0u, 0u, 0u);
   for (uint32_t k = 0; k < n_ev; ++k) {
-    const uint32_t e = e0 + rfl(perm[k]);
-    const uint4 evr = a.ev[e];  // one 16-byte record per event, the same for every lane
-    const uint32_t w = rfl(evr.x);
+    // the 16-byte records of 64 shuffled positions are fetched at once, one per lane (one memory round trip per 64
+    // events instead of one per event), then broadcast one by one
+    if ((k & 63u) == 0u && k + lane < n_ev) evr = a.ev[e0 + perm[k + lane]];
+    const uint32_t w = rdl(evr.x, k & 63u);
     if (((w >> 16) & 0xFFu) != asset) continue;  // another asset's event
     ++n_own;
-    const uint32_t id = rfl(evr.y);
-    const uint32_t ep = rfl(evr.z);
-    const uint32_t evv = rfl(evr.w);
+    const uint32_t id = rdl(evr.y, k & 63u);
+    const uint32_t ep = rdl(evr.z, k & 63u);
+    const uint32_t evv = rdl(evr.w, k & 63u);
     const uint32_t kind = w & 0xFFu;
     const uint64_t tk = t0 + k;
     if (kind == 0) {

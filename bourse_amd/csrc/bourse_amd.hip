@@ -10,8 +10,12 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <atomic>
+#include <condition_variable>
 #include <cstring>
+#include <functional>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -105,6 +109,73 @@ struct DevBuf {
   }
 };
 
+// Host threads for the per-book half of Env that stays on the host (tick check, id assignment, queueing, flattening
+// the queues for upload): books are independent, each task owns a contiguous range of markets.  Workers persist for the
+// life of the env (a std::thread per call costs more than the work of a small step).
+class HostPool {
+ public:
+  explicit HostPool(unsigned n_workers) {
+    for (unsigned i = 0; i < n_workers; ++i) workers_.emplace_back([this] { loop(); });
+  }
+  ~HostPool() {
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      stop_ = true;
+    }
+    cv_.notify_all();
+    for (auto& t : workers_) t.join();
+  }
+  unsigned threads() const { return static_cast<unsigned>(workers_.size()) + 1; }  // + the calling thread
+  // fn(task) for task in [0, n_tasks); returns when every task has finished.  One run() at a time.
+  void run(unsigned n_tasks, const std::function<void(unsigned)>& fn) {
+    if (n_tasks == 0) return;
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      fn_ = &fn;
+      n_tasks_ = n_tasks;
+      next_.store(0);
+      pending_ = n_tasks;
+      ++generation_;
+    }
+    cv_.notify_all();
+    work();
+    std::unique_lock<std::mutex> lk(mu_);
+    done_cv_.wait(lk, [this] { return pending_ == 0; });
+    fn_ = nullptr;
+  }
+
+ private:
+  void work() {
+    for (;;) {
+      const unsigned t = next_.fetch_add(1);
+      if (t >= n_tasks_) return;
+      (*fn_.load())(t);
+      std::lock_guard<std::mutex> lk(mu_);
+      if (--pending_ == 0) done_cv_.notify_all();
+    }
+  }
+  void loop() {
+    uint64_t seen = 0;
+    for (;;) {
+      {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_.wait(lk, [&] { return stop_ || generation_ != seen; });
+        if (stop_) return;
+        seen = generation_;
+      }
+      work();
+    }
+  }
+  std::vector<std::thread> workers_;
+  std::mutex mu_;
+  std::condition_variable cv_, done_cv_;
+  std::atomic<const std::function<void(unsigned)>*> fn_{nullptr};
+  std::atomic<unsigned> next_{0}, n_tasks_{0};
+  unsigned pending_ = 0;
+  uint64_t generation_ = 0;
+  bool stop_ = false;
+};
+
 }  // namespace
 
 struct bk_env {
@@ -160,6 +231,15 @@ struct bk_env {
     return ma;
   }
   std::vector<BookHost> books;
+  std::unique_ptr<HostPool> pool;  // host threads for large host-driven batches (created on first use)
+  HostPool& host_pool() {
+    if (!pool) {
+      unsigned nt = std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u);
+      if (const char* e = std::getenv("BOURSE_AMD_HOST_THREADS")) nt = static_cast<unsigned>(std::max(1, std::atoi(e)));
+      pool.reset(new HostPool(nt - 1));
+    }
+    return *pool;
+  }
   std::vector<Group> groups;
   uint32_t n_agents_total = 0;
   uint64_t steps_done = 0, hist_base = 0;
@@ -245,10 +325,11 @@ int launch_run(bk_env* env, const DevArgs& a, uint64_t first_step, uint32_t n_st
   return BK_OK;
 }
 template <int R>
-int launch_events(bk_env* env, const DevArgs& a, uint64_t step_index) {
+int launch_events(bk_env* env, const DevArgs& a, uint64_t step_index, uint32_t max_queue) {
   env->prof_now = env->profile > 0;
   ProfScope ps(env, 3);
-  hipLaunchKernelGGL(k_step_events<R>, dim3(env->cfg.n_books), dim3(64), 0, env->stream, a, step_index);
+  const uint32_t perm_bytes = ((max_queue + 63u) & ~63u) * 2u + 128u;  // u16 permutation of the longest queue
+  hipLaunchKernelGGL(k_step_events<R>, dim3(env->cfg.n_books), dim3(64), perm_bytes, env->stream, a, step_index);
   HIPCHK(hipGetLastError());
   return BK_OK;
 }
@@ -651,23 +732,18 @@ int bk_submit_instructions_csr(bk_env* env, const uint64_t* book_offsets, const 
   };
   const uint64_t total = book_offsets[B];
   unsigned nt = 1;
-  if (total >= 65536 && NM >= 64) {
-    nt = std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u);
-    if (const char* e = std::getenv("BOURSE_AMD_HOST_THREADS")) nt = std::max(1, std::atoi(e));
-    nt = std::min<unsigned>(nt, NM);
-  }
+  if (total >= 65536 && NM >= 64) nt = std::min<unsigned>(env->host_pool().threads(), NM);
   std::vector<int> rcs(nt, BK_OK);
   std::vector<size_t> dones(nt, 0);
   std::vector<std::string> errs(nt);
-  if (nt == 1) {
-    work(0, NM, &rcs[0], &dones[0], &errs[0]);
-  } else {
-    std::vector<std::thread> th;
-    for (unsigned t = 0; t < nt; ++t)
-      th.emplace_back(work, static_cast<uint32_t>(static_cast<uint64_t>(NM) * t / nt),
-                      static_cast<uint32_t>(static_cast<uint64_t>(NM) * (t + 1) / nt), &rcs[t], &dones[t], &errs[t]);
-    for (auto& x : th) x.join();
-  }
+  auto task = [&](unsigned t) {
+    work(static_cast<uint32_t>(static_cast<uint64_t>(NM) * t / nt),
+         static_cast<uint32_t>(static_cast<uint64_t>(NM) * (t + 1) / nt), &rcs[t], &dones[t], &errs[t]);
+  };
+  if (nt == 1)
+    task(0);
+  else
+    env->host_pool().run(nt, task);
   for (unsigned t = 0; t < nt; ++t) {  // the first failing range in book order decides (books after it may be queued too)
     if (rcs[t] != BK_OK) {
       if (n_done) *n_done = dones[t];
@@ -693,18 +769,16 @@ int bk_step(bk_env* env) {
   if (!env) return fail(BK_INVALID_ARGUMENT, "null env");
   if (int rc = use_device(env)) return rc;
   const size_t B = env->cfg.n_books, M = env->M, NM = B / M;
-  // validate + flatten the queues (CSR, one row per market; a market of one book when assets == 1)
+  // CSR offsets of the queues (one row per market; a market of one book when assets == 1)
   std::vector<uint32_t> off(NM + 1, 0u);
   size_t total = 0;
+  uint32_t max_queue = 0;
   for (size_t m = 0; m < NM; ++m) {
-    const BookHost& qh = env->books[m * M];
-    if (qh.queue.size() > EV_LDS_CAP)
-      return fail(BK_CAPACITY, "more than 8192 events queued for one book (market) in one step");
-    for (const HostEvent& e : qh.queue)
-      if ((e.word & 0xFFu) != 0 && e.id >= env->books[m * M + ((e.word >> 16) & 0xFFu)].orders.size())
-        return fail(BK_UNKNOWN_ORDER_ID, "No order with id " + std::to_string(e.id) + " exists");
+    const size_t q = env->books[m * M].queue.size();
+    if (q > EV_LDS_CAP) return fail(BK_CAPACITY, "more than 8192 events queued for one book (market) in one step");
     off[m] = static_cast<uint32_t>(total);
-    total += qh.queue.size();
+    total += q;
+    max_queue = std::max(max_queue, static_cast<uint32_t>(q));
   }
   off[NM] = static_cast<uint32_t>(total);
   HIPCHK(hipStreamSynchronize(env->stream));  // previous step may still read the event buffers
@@ -718,13 +792,31 @@ int bk_step(bk_env* env) {
       HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&env->off_stage), (B + 1) * sizeof(uint32_t), hipHostMallocDefault));
     env->ev_capacity = cap;
   }
-  // flatten straight into pinned memory: one 16-byte record per event, one copy, uploaded at link speed
-  size_t k = 0;
-  for (size_t m = 0; m < NM; ++m) {
-    const std::vector<HostEvent>& q = env->books[m * M].queue;
-    if (!q.empty()) std::memcpy(env->ev_stage + k, q.data(), q.size() * sizeof(HostEvent));
-    k += q.size();
-  }
+  // validate (an id that was never created: orderbook.rs:642) and flatten straight into pinned memory: one 16-byte
+  // record per event, uploaded at link speed.  Markets are independent: large batches are spread over the host threads.
+  unsigned nt = 1;
+  if (total >= 32768 && NM >= 64) nt = std::min<unsigned>(env->host_pool().threads(), static_cast<unsigned>(NM));
+  std::vector<size_t> bad_market(nt, NM);
+  std::vector<uint32_t> bad_id(nt, 0u);
+  auto task = [&](unsigned t) {
+    const size_t m_lo = NM * t / nt, m_hi = NM * (t + 1) / nt;
+    for (size_t m = m_lo; m < m_hi; ++m) {
+      const std::vector<HostEvent>& q = env->books[m * M].queue;
+      for (const HostEvent& e : q)
+        if ((e.word & 0xFFu) != 0 && e.id >= env->books[m * M + ((e.word >> 16) & 0xFFu)].orders.size()) {
+          bad_market[t] = m;
+          bad_id[t] = e.id;
+          return;
+        }
+      if (!q.empty()) std::memcpy(env->ev_stage + off[m], q.data(), q.size() * sizeof(HostEvent));
+    }
+  };
+  if (nt == 1)
+    task(0);
+  else
+    env->host_pool().run(nt, task);
+  for (unsigned t = 0; t < nt; ++t)  // the first offender in market order; nothing has been uploaded or cleared
+    if (bad_market[t] != NM) return fail(BK_UNKNOWN_ORDER_ID, "No order with id " + std::to_string(bad_id[t]) + " exists");
   std::memcpy(env->off_stage, off.data(), (NM + 1) * sizeof(uint32_t));
   HIPCHK(hipMemcpyAsync(env->ev_off.p, env->off_stage, (NM + 1) * 4, hipMemcpyHostToDevice, env->stream));
   if (total)
@@ -732,10 +824,10 @@ int bk_step(bk_env* env) {
   const DevArgs a = env->args();
   int rc = BK_OK;
   switch (env->R) {
-    case 1: rc = launch_events<1>(env, a, env->steps_done); break;
-    case 2: rc = launch_events<2>(env, a, env->steps_done); break;
-    case 4: rc = launch_events<4>(env, a, env->steps_done); break;
-    default: rc = launch_events<8>(env, a, env->steps_done); break;
+    case 1: rc = launch_events<1>(env, a, env->steps_done, max_queue); break;
+    case 2: rc = launch_events<2>(env, a, env->steps_done, max_queue); break;
+    case 4: rc = launch_events<4>(env, a, env->steps_done, max_queue); break;
+    default: rc = launch_events<8>(env, a, env->steps_done, max_queue); break;
   }
   if (rc != BK_OK) return rc;
   env->steps_done += 1;
