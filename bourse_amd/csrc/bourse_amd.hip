@@ -73,6 +73,10 @@ uint32_t activity_threshold(float rate) {
   return static_cast<uint32_t>(std::ceil(x));
 }
 
+// batch sizes from which bk_run's auto mode takes the split pipeline (measured crossovers: scripts/size_sweep.py,
+// scripts/parts_size_sweep.py, scripts/c5m_sweep.sh)
+constexpr uint32_t RANDOM_SPLIT_MIN_BOOKS = 8192, MIXED_SPLIT_MIN_BOOKS = 4096;
+
 uint32_t sample_zone(uint32_t range) { return (range << __builtin_clz(range)) - 1u; }  // App. B.3
 
 struct HostOrder {  // immutable half of an order, fixed at create_order (orderbook.rs:356-396)
@@ -1046,12 +1050,10 @@ int bk_run(bk_env* env, uint64_t n_steps) {
   int rc = BK_OK;
   const uint32_t ns = static_cast<uint32_t>(n_steps);
   if (env->n_mixed) {
-    // fused for small batches (the book stays in registers across steps); split above: the members' update and the
-    // event loop are two leaner kernels (no spills at R = 8) and the batch is cut in parts that overlap
-    // split (default from 3072 books, where it overtakes the fused kernel): members' update one LANE per book + the lean
-    // event kernel; mode 3 keeps the
-    // wave-per-book members' update (k_agents_mixed) selectable
-    const bool mlanes = env->pipeline == 2 || env->M > 1 || (env->pipeline == 0 && env->cfg.n_books >= 3072);
+    // fused for small batches (the book stays in registers across steps); from MIXED_SPLIT_MIN_BOOKS books (where it
+    // overtakes the fused kernel, scripts/c5m_sweep.sh) the members' update runs one LANE per book in front of the lean
+    // event kernel, the batch cut in parts that overlap.  Mode 3 keeps the wave-per-book members' update selectable.
+    const bool mlanes = env->pipeline == 2 || env->M > 1 || (env->pipeline == 0 && env->cfg.n_books >= MIXED_SPLIT_MIN_BOOKS);
     if (mlanes) {
       switch (env->R) {
         case 1: rc = launch_split<1, 2>(env, a, env->steps_done, ns); break;
@@ -1084,7 +1086,7 @@ int bk_run(bk_env* env, uint64_t n_steps) {
   // >= 64 books per wave to pay off.  auto: split once the batch fills the chip several times over.
   // Markets always take the split pipeline: the market's RNG-serial phase is one lane, its books are M waves.
   const bool split = env->pipeline >= 2 || env->M > 1 ||
-                     (env->pipeline == 0 && env->cfg.n_books >= 8192 && a.n_groups > 0);
+                     (env->pipeline == 0 && env->cfg.n_books >= RANDOM_SPLIT_MIN_BOOKS && a.n_groups > 0);
   if (split) {
     switch (env->R) {
       case 1: rc = launch_split<1>(env, a, env->steps_done, ns); break;
@@ -1615,8 +1617,8 @@ int bk_profile_read_kind(bk_env* env, int kind, double* total_ms, uint64_t* n_la
 int bk_get_pipeline(bk_env* env, int* split, int* n_parts) {
   if (!env) return fail(BK_INVALID_ARGUMENT, "null env");
   const bool sp = env->pipeline >= 2 || env->M > 1 ||
-                  (env->pipeline == 0 && (env->n_mixed ? env->cfg.n_books >= 3072
-                                                       : env->cfg.n_books >= 8192 && !env->groups.empty()));
+                  (env->pipeline == 0 && (env->n_mixed ? env->cfg.n_books >= MIXED_SPLIT_MIN_BOOKS
+                                                       : env->cfg.n_books >= RANDOM_SPLIT_MIN_BOOKS && !env->groups.empty()));
   const int P = env->parts();
   if (split) *split = sp ? 1 : 0;
   if (n_parts) *n_parts = sp ? P : 1;
