@@ -1307,3 +1307,76 @@ def test_split_pipeline_any_number_of_parts(bk, oracle, parts, monkeypatch):
     _compare_members(bk, oracle, 64 * parts + 5, members, levels=10, n_steps=14, pipeline="split", chunks=[6, 8])
     mgroups = [(0, 24, (40, 56), (10, 20), 2, 0.8), (1, 24, (40, 56), (10, 20), 2, 0.8), (1, 16, (40, 56), (50, 70), 2, 0.2)]
     _compare_markets(bk, oracle, 64 * parts + 9, [2, 2], mgroups, 16, 8)
+
+
+def _bulk_instructions(rng, B, N, step, n_prev):
+    n = B * N
+    action = np.ones(n, dtype=np.uint32)
+    ids = np.zeros(n, dtype=np.uint64)
+    if step:
+        canc = rng.random(n) < 0.3
+        action[canc] = 2
+        ids[canc] = rng.integers(0, max(n_prev, 1), size=int(canc.sum()))  # ids every book has created by now
+    return (action, rng.integers(0, 2, size=n).astype(bool), rng.integers(1, 30, size=n).astype(np.uint32),
+            np.zeros(n, dtype=np.uint32), rng.integers(90, 111, size=n).astype(np.uint32), ids)
+
+
+def test_host_threads_do_not_change_the_host_driven_path(bk, oracle, monkeypatch):
+    """Large host-driven batches are spread over the env's host threads (bk_submit_instructions_csr: tick check, id
+    assignment, queueing; bk_step: validation + flattening into the upload buffer).  Same ids, same books as one thread,
+    and as the oracle; errors name the first offender in book order."""
+    B, N, T = 2048, 40, 3
+    off = np.arange(B + 1, dtype=np.uint64) * N
+    envs = {}
+    for nt in (1, 7):
+        monkeypatch.setenv("BOURSE_AMD_HOST_THREADS", str(nt))
+        env = bk.ManyBookEnv(B, 9, 0, 1, 100_000, levels=10, max_live_orders=256, max_orders=N * (T + 1),
+                             trade_capacity=N * (T + 1), history_capacity=T)
+        rng = np.random.default_rng(11)
+        got_ids = []
+        for s in range(T):
+            ins = _bulk_instructions(rng, B, N, s, int(0.6 * N * s))
+            got_ids.append(env.submit_instructions_all(off, ins))
+            env.step()
+            if nt == 1 and s == T - 1:
+                last = ins
+        envs[nt] = (env, got_ids)
+    (e1, ids1), (e7, ids7) = envs[1], envs[7]
+    for a, b in zip(ids1, ids7):
+        assert np.array_equal(a, b)
+    assert np.array_equal(e1.history(), e7.history())
+    assert np.array_equal(e1.trade_counts(), e7.trade_counts()) and int(e1.trade_counts().sum()) > 0
+    for b in (0, 1, B // 2, B - 1):
+        for f in e1.trades(b, first=0).dtype.names:
+            assert np.array_equal(e1.trades(b, first=0)[f], e7.trades(b, first=0)[f])
+    # against the oracle: replay book b's slice of the same instruction stream
+    rng = np.random.default_rng(11)
+    streams = [_bulk_instructions(rng, B, N, s, int(0.6 * N * s)) for s in range(T)]
+    for b in (0, 777, B - 1):
+        ref = oracle.StepEnvNumpy(9 + b, 0, 1, 100_000)  # 10 levels, as bourse.core.StepEnvNumpy
+        for s in range(T):
+            lo, hi = b * N, (b + 1) * N
+            want = ref.submit_instructions(tuple(x[lo:hi] for x in streams[s]))
+            assert np.array_equal(ids7[s][lo:hi], np.asarray(want, dtype=np.uint64))
+            ref.step()
+        assert np.array_equal(e7.history()[:, b], ref.history()), b
+    # errors: a price off the tick grid in the middle of a threaded batch stops that book's range at the offender
+    e7.close()
+    e1.close()
+    env = bk.ManyBookEnv(B, 9, 0, 2, 100_000, levels=12, max_live_orders=256, max_orders=4 * N, trade_capacity=4 * N)
+    ins = list(_bulk_instructions(np.random.default_rng(1), B, N, 0, 0))
+    ins[4] = (ins[4] // 2 * 2).astype(np.uint32)
+    bad = 1234 * N + 7
+    ins[4][bad] = 101
+    with pytest.raises(ValueError, match="101"):
+        env.submit_instructions_all(off, tuple(ins))
+    assert env.order_count(1234) == 7 and env.order_count(0) == N
+    # ... and an unknown id in a threaded bk_step is refused before anything is uploaded or cleared
+    env2 = bk.ManyBookEnv(B, 9, 0, 1, 100_000, levels=12, max_live_orders=256, max_orders=4 * N, trade_capacity=4 * N)
+    ins = list(_bulk_instructions(np.random.default_rng(2), B, N, 0, 0))
+    ins[0][5 * N + 3] = 2
+    ins[5][5 * N + 3] = 10_000
+    env2.submit_instructions_all(off, tuple(ins))
+    with pytest.raises((bk.BourseError, IndexError, ValueError), match="10000"):
+        env2.step()
+    assert env2.steps_done() == 0
