@@ -563,7 +563,14 @@ int bk_env_create(const bk_config* cfg, bk_env** out) {
   HIPCHK(env->hist.alloc(static_cast<size_t>(cfg->history_capacity) * B * env->W));
   HIPCHK(env->trades.alloc(B * cfg->trade_capacity));
   HIPCHK(env->order_log.alloc(B * cfg->max_orders));
-  HIPCHK(env->stats.alloc(1));
+  HIPCHK(env->stats.alloc(2));  // [0] the record, [1] its reset template
+  {
+    DevStats init{};
+    init.min_bid = 0xFFFFFFFFu;
+    init.min_ask = 0xFFFFFFFFu;
+    HIPCHK(hipMemcpy(env->stats.p + 1, &init, sizeof(init), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(env->stats.p, &init, sizeof(init), hipMemcpyHostToDevice));
+  }
   env->batch_stride = 64 + 160 * R;
   HIPCHK(env->batch.alloc(B * env->batch_stride));
   HIPCHK(hipMemset(env->batch.p, 0, B * env->batch_stride * sizeof(uint32_t)));
@@ -1546,11 +1553,9 @@ int bk_live_orders(bk_env* env, uint32_t book, uint32_t cap, bk_order* out, uint
 int bk_stats_compute(bk_env* env, bk_stats* out_host) {
   if (!env) return fail(BK_INVALID_ARGUMENT, "null env");
   if (int rc = use_device(env)) return rc;
-  DevStats init{};
-  init.min_bid = 0xFFFFFFFFu;
-  init.min_ask = 0xFFFFFFFFu;
-  HIPCHK(hipMemcpyAsync(env->stats.p, &init, sizeof(init), hipMemcpyHostToDevice, env->stream));
-  HIPCHK(hipStreamSynchronize(env->stream));
+  // reset the record from the template kept next to it: a device-to-device copy in stream order, so that queueing the
+  // reduction never waits for the stepping kernels in front of it (the per-launch all-gather of a sharded run)
+  HIPCHK(hipMemcpyAsync(env->stats.p, env->stats.p + 1, sizeof(DevStats), hipMemcpyDeviceToDevice, env->stream));
   const uint32_t B = env->cfg.n_books;
   const uint32_t blocks = std::min<uint32_t>((B + 255) / 256, 1024);
   hipLaunchKernelGGL(k_stats, dim3(blocks), dim3(256), 0, env->stream, env->state.p, env->stride, env->l2_last.p,
