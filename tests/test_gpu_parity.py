@@ -1380,3 +1380,36 @@ def test_host_threads_do_not_change_the_host_driven_path(bk, oracle, monkeypatch
     with pytest.raises((bk.BourseError, IndexError, ValueError), match="10000"):
         env2.step()
     assert env2.steps_done() == 0
+
+
+def test_host_driven_step_at_the_event_capacity_boundary(bk, oracle):
+    """One step may carry up to 8192 events per book (the device-side shuffle permutation lives in LDS, sized by the
+    step's longest queue): exactly 8192 is processed and matches the oracle, 8193 is refused without side effects."""
+    N = 8192
+    env = bk.ManyBookEnv(3, 21, 0, 1, 100_000, levels=10, max_live_orders=512, max_orders=N + 8, trade_capacity=N,
+                         history_capacity=2)
+    ref = oracle.StepEnvNumpy(21 + 1, 0, 1, 100_000)  # book 1 carries the big step
+    rng = np.random.default_rng(5)
+    # crossing flow so that the 512-slot pool never fills: alternating sides around one price, small volumes
+    sides = (np.arange(N) % 2).astype(bool)
+    vols = rng.integers(1, 4, size=N).astype(np.uint32)
+    prices = np.where(sides, 101, 100).astype(np.uint32)   # bids at 101, asks at 100: every order finds a counterparty
+    ins = (np.ones(N, dtype=np.uint32), sides, vols, np.zeros(N, dtype=np.uint32), prices, np.zeros(N, dtype=np.uint64))
+    off = np.array([0, 0, N, N], dtype=np.uint64)
+    got = env.submit_instructions_all(off, ins)
+    want = ref.submit_instructions(ins)
+    assert np.array_equal(got, np.asarray(want, dtype=np.uint64))
+    env.place_order(0, True, 5, 0, 99)       # a quiet neighbour: 1 event
+    env.step()
+    ref.step()
+    assert not env.flags().any(), env.flags()
+    assert np.array_equal(env.history()[:, 1], ref.history())
+    g, e = env.trades(1, first=0), ref.get_trades()
+    assert len(g) == len(e) > 1000
+    assert env.rng_state(1) == tuple(int(x) for x in ref.rng_state())
+    # one more than the capacity: refused, queues intact, nothing stepped
+    more = tuple(np.concatenate([x, x[:1]]) for x in ins)
+    env.submit_instructions_all(np.array([0, 0, N + 1, N + 1], dtype=np.uint64), more)
+    with pytest.raises(bk.CapacityError):
+        env.step()
+    assert env.steps_done() == 1
