@@ -233,6 +233,9 @@ def main():
                  "valu_per_book_step": valu, "peak_insts_per_s": peak, "salu_frac": salu * per_gpu / peak,
                  "valu_frac": valu * per_gpu / peak, "events_per_s_per_cu": ev_per_bs * per_gpu / N_CU,
                  "assumed_clock_ghz": CLOCK_GHZ, "n_cu": N_CU}
+        occ = pmc.get(dominant, {}).get("occupancy")
+        if occ:  # achieved occupancy of the dominant kernel (PMC, committed under profiles/)
+            issue["occupancy"] = occ
     out = {
         "metric": "book-steps/sec", "value": value, "unit": "book-steps/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": dt * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
