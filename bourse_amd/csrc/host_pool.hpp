@@ -1,0 +1,82 @@
+// host_pool.hpp - persistent host worker threads of a bk_env (plain C++17, no HIP): used by bourse_amd.hip, unit- and
+// thread-sanitizer-tested on the CPU by tests/test_host_pool.py.
+#pragma once
+#include <atomic>
+#include <condition_variable>
+#include <cstdint>
+#include <functional>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+namespace bkd {
+
+// Host threads for the per-book half of Env that stays on the host (tick check, id assignment, queueing, flattening
+// the queues for upload): books are independent, each task owns a contiguous range of markets.  Workers persist for the
+// life of the env (a std::thread per call costs more than the work of a small step).
+class HostPool {
+ public:
+  explicit HostPool(unsigned n_workers) {
+    for (unsigned i = 0; i < n_workers; ++i) workers_.emplace_back([this] { loop(); });
+  }
+  ~HostPool() {
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      stop_ = true;
+    }
+    cv_.notify_all();
+    for (auto& t : workers_) t.join();
+  }
+  unsigned threads() const { return static_cast<unsigned>(workers_.size()) + 1; }  // + the calling thread
+  // fn(task) for task in [0, n_tasks); returns when every task has finished.  One run() at a time.
+  void run(unsigned n_tasks, const std::function<void(unsigned)>& fn) {
+    if (n_tasks == 0) return;
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      fn_ = &fn;
+      n_tasks_ = n_tasks;
+      next_.store(0);
+      pending_ = n_tasks;
+      ++generation_;
+    }
+    cv_.notify_all();
+    work();
+    std::unique_lock<std::mutex> lk(mu_);
+    done_cv_.wait(lk, [this] { return pending_ == 0; });
+    fn_ = nullptr;
+  }
+
+ private:
+  void work() {
+    for (;;) {
+      const unsigned t = next_.fetch_add(1);
+      if (t >= n_tasks_) return;
+      (*fn_.load())(t);
+      std::lock_guard<std::mutex> lk(mu_);
+      if (--pending_ == 0) done_cv_.notify_all();
+    }
+  }
+  void loop() {
+    uint64_t seen = 0;
+    for (;;) {
+      {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_.wait(lk, [&] { return stop_ || generation_ != seen; });
+        if (stop_) return;
+        seen = generation_;
+      }
+      work();
+    }
+  }
+  std::vector<std::thread> workers_;
+  std::mutex mu_;
+  std::condition_variable cv_, done_cv_;
+  std::atomic<const std::function<void(unsigned)>*> fn_{nullptr};
+  std::atomic<unsigned> next_{0}, n_tasks_{0};
+  unsigned pending_ = 0;
+  uint64_t generation_ = 0;
+  bool stop_ = false;
+};
+
+
+}  // namespace bkd

@@ -1,0 +1,33 @@
+// CPU unit test of bkd::HostPool (bourse_amd/csrc/host_pool.hpp): every task runs exactly once, run() returns only when
+// all are done, the pool is reusable back to back, and the caller takes part.  Built with -fsanitize=thread by
+// tests/test_host_pool.py.
+#include <atomic>
+#include <cstdio>
+#include <numeric>
+#include <vector>
+
+#include "../../bourse_amd/csrc/host_pool.hpp"
+
+int main() {
+  for (unsigned workers : {0u, 1u, 3u, 7u}) {
+    bkd::HostPool pool(workers);
+    if (pool.threads() != workers + 1) return 1;
+    for (int round = 0; round < 200; ++round) {
+      const unsigned n = 1 + (round * 7) % 23;
+      std::vector<int> hits(n, 0);       // each element written by exactly one task
+      std::atomic<long> sum{0};
+      pool.run(n, [&](unsigned t) {
+        hits[t] += 1;
+        long s = 0;
+        for (int i = 0; i < 1000 * ((int)t % 3 + 1); ++i) s += i;  // uneven task lengths
+        sum += s > 0 ? 1 : 1;
+      });
+      for (int h : hits)
+        if (h != 1) { std::printf("task ran %d times (workers %u round %d)\n", h, workers, round); return 2; }
+      if (sum.load() != (long)n) return 3;
+    }
+    pool.run(0, [&](unsigned) {});  // no tasks: returns at once
+  }
+  std::puts("host_pool ok");
+  return 0;
+}
