@@ -22,6 +22,7 @@
 
 #include "../../include/bourse_amd.h"
 #include "book_device.hpp"
+#include "host_math.hpp"
 #include "host_pool.hpp"
 #include "mixed_agents.hpp"
 
@@ -51,34 +52,9 @@ int fail(int code, const std::string& msg) {
       return fail(BK_HIP_ERROR, std::string(#expr) + ": " + hipGetErrorString(_e));               \
   } while (0)
 
-// rand_xoshiro 0.6.0 `seed_from_u64` for Xoroshiro128StarStar: two SplitMix64 outputs
-void seed_from_u64(uint64_t seed, uint64_t& s0, uint64_t& s1) {
-  uint64_t x = seed;
-  auto next = [&x]() {
-    x += 0x9e3779b97f4a7c15ull;
-    uint64_t z = x;
-    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
-    z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
-    return z ^ (z >> 31);
-  };
-  s0 = next();
-  s1 = next();
-}
-
-// `gen::<f32>() < rate` with gen = (u32 >> 8) * 2^-24 (App. B.5) as an integer threshold on (u32 >> 8):
-// k * 2^-24 < rate  <=>  k < rate * 2^24 (exact in double)  <=>  k < ceil(rate * 2^24).
-uint32_t activity_threshold(float rate) {
-  if (!(rate > 0.0f)) return 0;  // also NaN
-  const double x = static_cast<double>(rate) * 16777216.0;
-  if (x >= 16777216.0) return 16777216u;
-  return static_cast<uint32_t>(std::ceil(x));
-}
-
 // batch sizes from which bk_run's auto mode takes the split pipeline (measured crossovers: scripts/size_sweep.py,
 // scripts/parts_size_sweep.py, scripts/c5m_sweep.sh)
 constexpr uint32_t RANDOM_SPLIT_MIN_BOOKS = 8192, MIXED_SPLIT_MIN_BOOKS = 4096;
-
-uint32_t sample_zone(uint32_t range) { return (range << __builtin_clz(range)) - 1u; }  // App. B.3
 
 struct HostOrder {  // immutable half of an order, fixed at create_order (orderbook.rs:356-396)
   uint8_t bid;
@@ -939,13 +915,7 @@ static int set_agents_impl(bk_env* env, uint32_t n_members, const bk_agent_desc*
         return fail(BK_INVALID_ARGUMENT, "LogNormal::new(mu, sigma) needs finite mu and sigma >= 0");  // .unwrap()
       D.thr_limit = activity_threshold(m.p_limit);
       D.thr_market = activity_threshold(m.p_market);
-      // keep iff gen::<f32>() > p_cancel: k * 2^-24 > p  <=>  k > floor(p * 2^24)
-      if (m.p_cancel != m.p_cancel) {
-        D.keep_thr = 1 << 24;  // NaN: never kept
-      } else {
-        const double y = std::floor(static_cast<double>(m.p_cancel) * 16777216.0);
-        D.keep_thr = y < 0.0 ? -1 : (y > 16777216.0 ? (1 << 24) : static_cast<int32_t>(y));
-      }
+      D.keep_thr = keep_threshold(m.p_cancel);
       D.trade_vol = m.trade_vol;
       D.mu = m.price_dist_mu;
       D.sigma = m.price_dist_sigma;

@@ -1,0 +1,62 @@
+// CPU test of bourse_amd/csrc/host_math.hpp: the integer thresholds must decide exactly like the reference's f32
+// comparisons for EVERY k near the boundary (and a random sample elsewhere); SplitMix64 seeding against the oracle.
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <random>
+
+#include "../../bourse_amd/csrc/host_math.hpp"
+
+static float gen_f32(uint32_t k) { return static_cast<float>(k) * (1.0f / 16777216.0f); }  // rand 0.8.5 Standard f32, k = u32 >> 8
+
+int main(int argc, char** argv) {
+  std::mt19937_64 rng(7);
+  const float special[] = {0.0f, -0.0f, 1.0f, 0.5f, 0.8f, 0.2f, 1e-9f, 0.99999994f, 1.0000001f, 2.0f, -1.0f, 5.9604645e-08f,
+                           std::nanf(""), INFINITY, -INFINITY, 0.1f, 0.3f, 0.7f};
+  long checked = 0;
+  auto check_rate = [&](float rate) -> int {
+    const uint32_t thr = bkd::activity_threshold(rate);
+    const int32_t keep = bkd::keep_threshold(rate);
+    auto one = [&](uint32_t k) -> int {
+      const bool want_hit = gen_f32(k) < rate;            // random_agent.rs:91-93
+      const bool want_keep = gen_f32(k) > rate;           // common.rs:68
+      if ((k < thr) != want_hit) { std::printf("activity: rate %.9g k %u\n", rate, k); return 1; }
+      if ((static_cast<int32_t>(k) > keep) != want_keep) { std::printf("keep: p %.9g k %u\n", rate, k); return 1; }
+      ++checked;
+      return 0;
+    };
+    for (uint32_t k : {0u, 1u, 2u, 16777214u, 16777215u})
+      if (one(k)) return 1;
+    for (int d = -3; d <= 3; ++d) {
+      const int64_t a = static_cast<int64_t>(thr) + d, b = static_cast<int64_t>(keep) + d;
+      if (a >= 0 && a < 16777216 && one(static_cast<uint32_t>(a))) return 1;
+      if (b >= 0 && b < 16777216 && one(static_cast<uint32_t>(b))) return 1;
+    }
+    for (int i = 0; i < 8; ++i)
+      if (one(static_cast<uint32_t>(rng() >> 40))) return 1;
+    return 0;
+  };
+  for (float r : special)
+    if (check_rate(r)) return 1;
+  for (int i = 0; i < 200000; ++i) {
+    uint32_t bits = static_cast<uint32_t>(rng());
+    if (i % 2) bits = (bits & 0x007FFFFFu) | ((100u + (bits >> 23) % 28u) << 23);  // concentrate on (2^-27, 2)
+    float r;
+    std::memcpy(&r, &bits, 4);
+    if (check_rate(r)) return 1;
+  }
+  // sample_zone: accept iff lo32(x * range) <= zone must leave exactly floor(2^32 / range) * range accepted values...
+  // checked through its defining property: zone + 1 is the largest multiple pattern (range << lz) - 1
+  for (uint32_t range : {1u, 2u, 3u, 10u, 16u, 20u, 32u, 64u, 90u, 1000u, 0x80000000u, 0xFFFFFFFFu}) {
+    const uint32_t z = bkd::sample_zone(range);
+    const int lz = __builtin_clz(range);
+    if (z != ((range << lz) - 1u)) return 2;
+    if (z < range - 1u) return 2;  // at least one full period of residues is accepted
+  }
+  uint64_t s0, s1;
+  bkd::seed_from_u64(101, s0, s1);
+  if (argc > 1) std::printf("%llu %llu\n", (unsigned long long)s0, (unsigned long long)s1);
+  std::printf("host_math ok (%ld comparisons)\n", checked);
+  return 0;
+}
