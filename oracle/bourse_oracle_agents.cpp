@@ -78,10 +78,12 @@ struct EnvAccess {
   Env& env;
   const OrderBook& book() const { return env.order_book; }
   void cancel(OrderId id) { env.cancel_order(id); }
-  OrderId place(Side side, Vol vol, TraderId trader, std::optional<Price> price) {
+  // The reference `.unwrap()`s create_order's Result (common.rs:107,140): an Err (a limit price that the u32::MAX clamp
+  // left off the tick grid) is a panic there.  Here, as on the device, such an order simply does not exist: no id, no
+  // event, nothing remembered by the agent (nullopt).
+  std::optional<OrderId> place(Side side, Vol vol, TraderId trader, std::optional<Price> price) {
     OrderId id = 0;
-    const int rc = env.place_order(side, vol, trader, price, &id);
-    (void)rc;  // .unwrap(): tick-multiple prices by construction
+    if (env.place_order(side, vol, trader, price, &id) != 0) return std::nullopt;
     return id;
   }
 };
@@ -90,10 +92,9 @@ struct MarketAccess {
   uint32_t asset;
   const OrderBook& book() const { return env.market.order_books[asset]; }
   void cancel(OrderId id) { env.cancel_order(asset, id); }
-  OrderId place(Side side, Vol vol, TraderId trader, std::optional<Price> price) {
+  std::optional<OrderId> place(Side side, Vol vol, TraderId trader, std::optional<Price> price) {
     OrderId id = 0;
-    const int rc = env.place_order(asset, side, vol, trader, price, &id);
-    (void)rc;
+    if (env.place_order(asset, side, vol, trader, price, &id) != 0) return std::nullopt;
     return id;
   }
 };
@@ -114,12 +115,12 @@ std::vector<OrderId> cancel_live(A acc, Rng& rng, const std::vector<OrderId>& or
 }
 // ref common.rs:92-108 / :124-141 (/ :197-258)
 template <class A>
-OrderId place_buy_limit(A acc, Rng& rng, const LogNormal& d, double mid, double tick, Vol vol, TraderId trader) {
+std::optional<OrderId> place_buy_limit(A acc, Rng& rng, const LogNormal& d, double mid, double tick, Vol vol, TraderId trader) {
   const double dist = pm::fabs_(d.sample(rng));
   return acc.place(Side::Bid, vol, trader, round_price_down(mid - dist, tick));
 }
 template <class A>
-OrderId place_sell_limit(A acc, Rng& rng, const LogNormal& d, double mid, double tick, Vol vol, TraderId trader) {
+std::optional<OrderId> place_sell_limit(A acc, Rng& rng, const LogNormal& d, double mid, double tick, Vol vol, TraderId trader) {
   const double dist = pm::fabs_(d.sample(rng));
   return acc.place(Side::Ask, vol, trader, round_price_up(mid + dist, tick));
 }
@@ -131,8 +132,10 @@ void noise_update(NoiseAgent& g, A acc, Rng& rng) {  // noise_agent.rs:127-176 (
   for (TraderId trader : g.trader_ids) {
     if (rng.gen_f32() < g.params.p_limit) {
       const bool buy = gen_bool_half(rng);
-      live.push_back(buy ? place_buy_limit(acc, rng, g.price_dist, mid, g.tick_size, g.params.trade_vol, trader)
-                         : place_sell_limit(acc, rng, g.price_dist, mid, g.tick_size, g.params.trade_vol, trader));
+      const std::optional<OrderId> id =
+          buy ? place_buy_limit(acc, rng, g.price_dist, mid, g.tick_size, g.params.trade_vol, trader)
+              : place_sell_limit(acc, rng, g.price_dist, mid, g.tick_size, g.params.trade_vol, trader);
+      if (id) live.push_back(*id);
     }
     if (rng.gen_f32() < g.params.p_market) {
       const bool buy = gen_bool_half(rng);
@@ -154,10 +157,12 @@ void momentum_update(MomentumAgent& g, A acc, Rng& rng) {  // momentum_agent.rs:
   const double p_limit = g.params.order_ratio * p_market;
   for (TraderId trader : g.trader_ids) {
     if (gen_f64(rng) < p_limit) {
+      std::optional<OrderId> id;
       if (m > 0.0)
-        live.push_back(place_buy_limit(acc, rng, g.price_dist, mid, g.tick_size, g.params.trade_vol, trader));
+        id = place_buy_limit(acc, rng, g.price_dist, mid, g.tick_size, g.params.trade_vol, trader);
       else if (m < 0.0)
-        live.push_back(place_sell_limit(acc, rng, g.price_dist, mid, g.tick_size, g.params.trade_vol, trader));
+        id = place_sell_limit(acc, rng, g.price_dist, mid, g.tick_size, g.params.trade_vol, trader);
+      if (id) live.push_back(*id);
     }
     if (gen_f64(rng) < p_market) {
       if (m > 0.0)

