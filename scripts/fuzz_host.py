@@ -1,0 +1,18 @@
+"""Fuzz the host-driven path over fresh seeds: single-book place/cancel/modify streams (StepEnv) and multi-asset market
+streams, against the oracle (GPU box).  FUZZ_LO / FUZZ_HI select the seed range."""
+import os, sys
+ROOT = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import bourse_amd as bk, pyoracle as oracle
+import test_gpu_parity as T
+bad = 0
+lo, hi = int(os.environ.get("FUZZ_LO", 100)), int(os.environ.get("FUZZ_HI", 400))
+for seed in range(lo, hi):
+    for fn in (T.test_host_driven_random_stream_matches_oracle, T.test_market_host_driven_random_stream):
+        try:
+            fn(bk, oracle, seed)
+        except AssertionError as e:
+            bad += 1; print(fn.__name__, "seed", seed, "FAIL", str(e)[:300])
+        except Exception as e:
+            bad += 1; print(fn.__name__, "seed", seed, "ERR", type(e).__name__, str(e)[:300])
+print("done, failures:", bad, "of", 2 * (hi - lo))
