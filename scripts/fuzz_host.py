@@ -5,6 +5,7 @@ ROOT = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import bourse_amd as bk, pyoracle as oracle
 import test_gpu_parity as T
+import pathlib, tempfile
 bad = 0
 lo, hi = int(os.environ.get("FUZZ_LO", 100)), int(os.environ.get("FUZZ_HI", 400))
 for seed in range(lo, hi):
@@ -15,4 +16,11 @@ for seed in range(lo, hi):
             bad += 1; print(fn.__name__, "seed", seed, "FAIL", str(e)[:300])
         except Exception as e:
             bad += 1; print(fn.__name__, "seed", seed, "ERR", type(e).__name__, str(e)[:300])
-print("done, failures:", bad, "of", 2 * (hi - lo))
+    try:  # immediate-mode OrderBook: JSON snapshot vs the oracle's, cross-loaded, continued on all four books
+        with tempfile.TemporaryDirectory() as d:
+            T.test_json_snapshot_matches_oracle_and_round_trips(bk, oracle, pathlib.Path(d), seed)
+    except AssertionError as e:
+        bad += 1; print("json seed", seed, "FAIL", str(e)[:300])
+    except Exception as e:
+        bad += 1; print("json seed", seed, "ERR", type(e).__name__, str(e)[:300])
+print("done, failures:", bad, "of", 3 * (hi - lo))

@@ -907,9 +907,10 @@ def _random_book_ops(rng, books, t0, n_ops):
     return t
 
 
-def test_json_snapshot_matches_oracle_and_round_trips(bk, oracle, tmp_path):
+@pytest.mark.parametrize("seed", [12, 13])
+def test_json_snapshot_matches_oracle_and_round_trips(bk, oracle, tmp_path, seed):
     import json
-    rng = np.random.default_rng(12)
+    rng = np.random.default_rng(seed)
     g, o = bk.core.OrderBook(0, 2), oracle.OrderBook(0, 2)
     t = _random_book_ops(rng, [g, o], 0, 150)
     # the device's serde state (orders WITH their priority keys, trades, clock, trade_vol) equals the oracle's
