@@ -1151,15 +1151,23 @@ def test_fuzz_agent_sets_and_markets_vs_oracle(bk, oracle, seed):
         c = int(rng.integers(1, left + 1))
         chunks.append(c)
         left -= c
+    # pool size (registers per pool field R = pool / 64) from its own stream: seeds keep their configuration
+    pool = int(np.random.default_rng(99 + seed).choice([128, 256, 512, 512]))
     if A == 1:
-        env = bk.ManyBookEnv(NM, seed, 0, ticks[0], 1_000_000, True, levels=levels, max_live_orders=512,
+        env = bk.ManyBookEnv(NM, seed, 0, ticks[0], 1_000_000, True, levels=levels, max_live_orders=pool,
                              trade_capacity=64 * T * 8, history_capacity=T)
-        env.set_agents([m for _, m in members])
+        try:
+            env.set_agents([m for _, m in members])
+        except bk.CapacityError:
+            pytest.skip("the drawn RandomAgents members do not fit the drawn pool")
         ref = oracle.ManyBooks(NM, seed, 0, ticks[0], 1_000_000, True, levels, members=[m for _, m in members])
     else:
-        env = bk.ManyMarketEnv(NM, seed, 0, ticks, 1_000_000, True, levels=levels, max_live_orders=512,
+        env = bk.ManyMarketEnv(NM, seed, 0, ticks, 1_000_000, True, levels=levels, max_live_orders=pool,
                                trade_capacity=64 * T * 8, history_capacity=T)
-        env.set_market_agents(members)
+        try:
+            env.set_market_agents(members)
+        except bk.CapacityError:
+            pytest.skip("the drawn RandomAgents members do not fit the drawn pool")
         ref = oracle.ManyMarkets(NM, seed, 0, ticks, 1_000_000, True, levels, members=members)
     for i, c in enumerate(chunks):
         if A == 1:
