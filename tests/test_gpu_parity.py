@@ -1118,7 +1118,7 @@ def test_market_agent_set_all_member_kinds_three_assets(bk, oracle):
 # 5072: a sell limit clamped to u32::MAX off the tick grid is dropped while the book's order 0 is still Active (the oracle
 # once left a bogus id 0 in the member's list for such a drop and then drew a cancel decision for order 0)
 @pytest.mark.parametrize("seed", list(range(6)) + [5072])
-def test_fuzz_agent_sets_and_markets_vs_oracle(bk, oracle, seed):
+def test_fuzz_agent_sets_and_markets_vs_oracle(bk, oracle, seed, checkpoint_at=3):
     """Randomly drawn AgentSets / MarketAgentSets (1-4 members of every kind, 1-3 assets, random parameters and tick
     sizes, random launch chunking) against the oracle.  Off-tick clamped prices may be flagged (both sides drop them)."""
     rng = np.random.default_rng(7000 + seed)
@@ -1153,21 +1153,24 @@ def test_fuzz_agent_sets_and_markets_vs_oracle(bk, oracle, seed):
         left -= c
     # pool size (registers per pool field R = pool / 64) from its own stream: seeds keep their configuration
     pool = int(np.random.default_rng(99 + seed).choice([128, 256, 512, 512]))
-    if A == 1:
-        env = bk.ManyBookEnv(NM, seed, 0, ticks[0], 1_000_000, True, levels=levels, max_live_orders=pool,
-                             trade_capacity=64 * T * 8, history_capacity=T)
+    def mk():
         try:
-            env.set_agents([m for _, m in members])
+            if A == 1:
+                e = bk.ManyBookEnv(NM, seed, 0, ticks[0], 1_000_000, True, levels=levels, max_live_orders=pool,
+                                   trade_capacity=64 * T * 8, history_capacity=T)
+                e.set_agents([m for _, m in members])
+            else:
+                e = bk.ManyMarketEnv(NM, seed, 0, ticks, 1_000_000, True, levels=levels, max_live_orders=pool,
+                                     trade_capacity=64 * T * 8, history_capacity=T)
+                e.set_market_agents(members)
         except bk.CapacityError:
             pytest.skip("the drawn RandomAgents members do not fit the drawn pool")
+        return e
+
+    env = mk()
+    if A == 1:
         ref = oracle.ManyBooks(NM, seed, 0, ticks[0], 1_000_000, True, levels, members=[m for _, m in members])
     else:
-        env = bk.ManyMarketEnv(NM, seed, 0, ticks, 1_000_000, True, levels=levels, max_live_orders=pool,
-                               trade_capacity=64 * T * 8, history_capacity=T)
-        try:
-            env.set_market_agents(members)
-        except bk.CapacityError:
-            pytest.skip("the drawn RandomAgents members do not fit the drawn pool")
         ref = oracle.ManyMarkets(NM, seed, 0, ticks, 1_000_000, True, levels, members=members)
     for i, c in enumerate(chunks):
         if A == 1:
@@ -1184,6 +1187,25 @@ def test_fuzz_agent_sets_and_markets_vs_oracle(bk, oracle, seed):
     want_rng = ref.rng_states()
     for u in range(NM):
         assert env.rng_state(u * A) == (int(want_rng[u, 0]), int(want_rng[u, 1])), u
+    if checkpoint_at is not None and len(chunks) > 1:
+        # the same run interrupted by a checkpoint at a chunk boundary and continued in a FRESH env on another pipeline
+        j = 1 + checkpoint_at % (len(chunks) - 1)
+        a = mk()
+        for i, c in enumerate(chunks[:j]):
+            if A == 1:
+                a.set_pipeline(("split", "fused", "split_wave")[(i + seed) % 3])
+            a.run(c)
+        ck = a.checkpoint()
+        b = mk()
+        b.restore(ck)
+        for i, c in enumerate(chunks[j:]):
+            if A == 1:
+                b.set_pipeline(("fused", "split_wave", "split")[(i + seed) % 3])
+            b.run(c)
+        done = sum(chunks[:j])
+        assert np.array_equal(b.history(), want[done:]), f"after restore at step {done}"
+        for u in range(NM):
+            assert b.rng_state(u * A) == (int(want_rng[u, 0]), int(want_rng[u, 1])), u
 
 
 def test_batched_submit_for_all_books_matches_per_book_calls(bk, oracle):
