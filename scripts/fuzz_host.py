@@ -24,3 +24,18 @@ for seed in range(lo, hi):
     except Exception as e:
         bad += 1; print("json seed", seed, "ERR", type(e).__name__, str(e)[:300])
 print("done, failures:", bad, "of", 3 * (hi - lo))
+
+# streaming egress (L2 ring + compacted trade stream) over random shapes: T not a multiple of the chunk, tiny and
+# multi-part batches, every pipeline
+import numpy as np
+srng = np.random.default_rng(lo)
+sbad = 0
+for i in range(max(20, (hi - lo) // 10)):
+    shape = (int(srng.integers(1, 200)), int(srng.integers(1, 40)), int(srng.integers(1, 9)), str(srng.choice(["auto", "fused", "split"])))
+    try:
+        T.test_streaming_l2_and_trades_together(bk, oracle, shape)
+    except AssertionError as e:
+        sbad += 1; print("stream", shape, "FAIL", str(e)[:300])
+    except Exception as e:
+        sbad += 1; print("stream", shape, "ERR", type(e).__name__, str(e)[:300])
+print("streaming shapes failed:", sbad)

@@ -994,11 +994,13 @@ def test_trade_stream_compaction_matches_oracle(bk, oracle):
     assert not env.flags().any()
 
 
-def test_streaming_l2_and_trades_together(bk, oracle):
-    B, T, chunk = 50, 24, 4
+@pytest.mark.parametrize("shape", [(50, 24, 4, "auto"), (130, 21, 7, "split"), (3, 9, 1, "fused")])
+def test_streaming_l2_and_trades_together(bk, oracle, shape):
+    B, T, chunk, pipeline = shape  # T need not be a multiple of chunk: the last chunk is short
     env = bk.ManyBookEnv(B, 5, 0, 2, 100_000, levels=16, max_live_orders=64, trade_capacity=64 * chunk,
                          history_capacity=2 * chunk)
     env.set_random_agents(C2_GROUPS)
+    env.set_pipeline(pipeline)
     ref = oracle.ManyBooks(B, 5, 0, 2, 100_000, True, 16, C2_GROUPS)
     ref.run(T, 2)
     want = ref.history()
