@@ -160,7 +160,7 @@ def test_book_offset_sharding_is_seed_transparent(bk):
     assert s_part["sum_trades"] == int(part.trade_counts().sum())
 
 
-def test_trade_capacity_overflow_is_flagged_not_silent(bk):
+def test_trade_capacity_overflow_is_flagged_not_silent(bk, oracle):
     env = bk.ManyBookEnv(4, 101, 0, 2, 100_000, levels=16, max_live_orders=64, trade_capacity=8, history_capacity=30)
     env.set_random_agents(C2_GROUPS)
     env.run(30)
@@ -170,6 +170,15 @@ def test_trade_capacity_overflow_is_flagged_not_silent(bk):
     with pytest.raises(bk.CapacityError):
         env.trades(0, first=0)
     assert len(env.trades(0, first=0, n=8)) == 8
+    # only RECORDS are lost: the books, the counts and the retained records are still the oracle's
+    ref = oracle.ManyBooks(4, 101, 0, 2, 100_000, True, 16, C2_GROUPS)
+    ref.run(30, 2)
+    assert np.array_equal(env.history(), ref.history())
+    assert np.array_equal(env.trade_counts(), ref.trade_counts())
+    for b in range(4):
+        got, exp = env.trades(b, first=0, n=8), ref.book(b).trades_array()[:8]
+        for f in got.dtype.names:
+            assert np.array_equal(got[f], exp[f]), (b, f)
     env.run(5)  # the L2 history is a ring of the last 30 steps: stepping on is fine ...
     first, n = env.history_len()
     assert (first, n) == (5, 30)
