@@ -3,7 +3,7 @@ Usage: make -C oracle asan && LD_PRELOAD=$(gcc -print-file-name=libasan.so) ASAN
 import sys, os, ctypes
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'oracle'))
 import pyoracle
-pyoracle._LIB_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'oracle', 'libbourse_oracle_asan.so')
+pyoracle._LIB_PATH = os.environ.get('BOURSE_ORACLE_ASAN_LIB') or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'oracle', 'libbourse_oracle_asan.so')
 pyoracle.build = lambda force=False: pyoracle._LIB_PATH
 import numpy as np
 C3=[(64,(32,64),(10,20),2,0.8),(64,(32,64),(50,70),2,0.2)]
