@@ -45,36 +45,40 @@ WORKLOADS["C5M"] = (8192, 64, [("momentum", 0, 256, MOM_P), ("noise", 256, 256, 
 TICK, STEP_SIZE, SEED = 2, 100_000, 101
 
 
-def cpu_baseline(groups, levels, budget_s=15.0):
+def cpu_baseline(groups, levels, n_books, budget_s=12.0):
     if any(isinstance(g[0], str) for g in groups):
-        return _cpu_baseline(dict(members=groups), levels, budget_s)
-    return _cpu_baseline(dict(groups=groups), levels, budget_s)
+        return _cpu_baseline(dict(members=groups), levels, n_books, budget_s)
+    return _cpu_baseline(dict(groups=groups), levels, n_books, budget_s)
 
 
-def _cpu_baseline(agents_kw, levels, budget_s=15.0):
+def _cpu_baseline(agents_kw, levels, n_books, budget_s=12.0):
     """Time the CPU oracle (kind "port": C++ restatement of the reference algorithm, ordered maps per
-    side, one Env per book) on all host cores, on a bounded sample of the same workload."""
+    side, one Env per book) on all host cores, on a bounded sample of the same workload: the workload's own number of
+    books (so that the working set is the real one, not a cache-resident toy), a few steps, three timed repetitions."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import pyoracle
 
     cores = os.cpu_count() or 1
-    warm, steps = 20, 100
-    # size the sample from a quick single-thread probe so the leg takes ~budget_s
     probe = pyoracle.ManyBooks(64, SEED, 0, TICK, STEP_SIZE, True, levels, **agents_kw)
     t = time.perf_counter()
-    probe.run(warm + 10, 1)
-    rate1 = 64 * (warm + 10) / (time.perf_counter() - t)
-    books = int(max(cores * 8, min(8192, rate1 * cores * 0.5 * budget_s / (warm + steps))))
+    probe.run(30, 1)
+    rate1 = 64 * 30 / (time.perf_counter() - t)
+    books = int(min(n_books, 65536))
+    est = rate1 * min(cores, books) * 0.04  # measured: 256 hardware threads deliver ~9x one thread on this workload
+    warm = 10
+    steps = int(max(5, min(100, est * budget_s / 3.0 / books - warm / 3.0)))
     many = pyoracle.ManyBooks(books, SEED, 0, TICK, STEP_SIZE, True, levels, **agents_kw)
     many.run(warm, cores)
-    t = time.perf_counter()
-    many.run(steps, cores)
-    dt = time.perf_counter() - t
+    vals = []
+    for _ in range(3):
+        t = time.perf_counter()
+        many.run(steps, cores)
+        vals.append(books * steps / (time.perf_counter() - t))
     return {
-        "value": books * steps / dt, "unit": "book-steps/s", "cores": cores, "kind": "port",
-        "sample": f"{books} books x {steps} steps after {warm} warm-up steps, same agents/levels/seeds, "
-                  f"{cores} host threads (books statically partitioned), oracle/libbourse_oracle.so -O3",
-        "single_thread_probe": rate1,
+        "value": float(np.median(vals)), "unit": "book-steps/s", "cores": cores, "kind": "port",
+        "sample": f"{books} books x {steps} steps, median of 3 repetitions after {warm} warm-up steps, same agents/levels/"
+                  f"seeds, {cores} host threads (books statically partitioned), oracle/libbourse_oracle.so -O3",
+        "values": vals, "single_thread_probe": rate1,
     }
 
 
@@ -296,7 +300,7 @@ def main():
             raise SystemExit("L1 all-gather inconsistent with this rank's level-2 records")
         out["config"]["l1_allgather"] = {"bytes_per_gpu": int(B * 36), "books": int(rec.shape[0])}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(groups, levels)
+        out["cpu_baseline"] = cpu_baseline(groups, levels, B)
     env.close()
     if dist is not None:
         dist.barrier()
