@@ -1459,3 +1459,30 @@ def test_host_driven_step_at_the_event_capacity_boundary(bk, oracle):
     with pytest.raises(bk.CapacityError):
         env.step()
     assert env.steps_done() == 1
+
+
+def test_readers_on_book_and_step_windows(bk):
+    """bk_history / bk_level2 on sub-ranges of books and of retained steps (strided device-to-host copies, across the
+    ring's wrap point) return exactly the corresponding slices of the full reads."""
+    B, cap = 37, 10
+    env = bk.ManyBookEnv(B, 3, 0, 2, 100_000, levels=7, max_live_orders=64, trade_capacity=4096, history_capacity=cap)
+    env.set_random_agents(C2_GROUPS)
+    env.run(6)
+    env.run(7)   # 13 steps done: the ring holds steps 3..12 and its wrap point lies inside the window
+    first, n = env.history_len()
+    assert (first, n) == (3, 10)
+    full = env.history()
+    assert full.shape == (10, B, env.width)
+    l2 = env.level2()
+    assert np.array_equal(full[-1], l2)
+    rng = np.random.default_rng(0)
+    for _ in range(25):
+        fb = int(rng.integers(0, B)); nb = int(rng.integers(1, B - fb + 1))
+        fs = int(rng.integers(first, first + n)); ns = int(rng.integers(1, first + n - fs + 1))
+        got = env.history(first_step=fs, n_steps=ns, first_book=fb, n_books=nb)
+        assert np.array_equal(got, full[fs - first:fs - first + ns, fb:fb + nb]), (fs, ns, fb, nb)
+        assert np.array_equal(env.level2(fb, nb), l2[fb:fb + nb])
+    with pytest.raises((bk.BourseError, ValueError)):
+        env.history(first_step=first, n_steps=1, first_book=B - 1, n_books=2)   # book window past the end
+    with pytest.raises((bk.BourseError, ValueError)):
+        env.level2(B, 1)
