@@ -1486,3 +1486,41 @@ def test_readers_on_book_and_step_windows(bk):
         env.history(first_step=first, n_steps=1, first_book=B - 1, n_books=2)   # book window past the end
     with pytest.raises((bk.BourseError, ValueError)):
         env.level2(B, 1)
+
+
+@pytest.mark.parametrize("pipeline", ["fused", "split"])
+def test_trading_disabled_with_on_device_agents(bk, oracle, pipeline):
+    """With trading off nothing matches: limit orders rest (crossed books are legal), market orders are Rejected
+    (orderbook.rs:526-529); toggling between launches takes effect from the next step."""
+    B, T = 40, 20
+    env = bk.ManyBookEnv(B, 7, 0, 2, 100_000, False, levels=16, max_live_orders=64, trade_capacity=4096, history_capacity=T)
+    env.set_random_agents(C2_GROUPS)
+    env.set_pipeline(pipeline)
+    env.run(T)
+    ref = oracle.ManyBooks(B, 7, 0, 2, 100_000, False, 16, C2_GROUPS)
+    ref.run(T, 2)
+    assert np.array_equal(env.history(), ref.history())
+    assert int(env.trade_counts().sum()) == 0 == int(ref.trade_counts().sum())
+    assert [env.rng_state(b) for b in range(B)] == [tuple(int(x) for x in r) for r in ref.rng_states()]
+    # AgentSet with market orders (Rejected while trading is off), then markets toggled between launches
+    members = [("momentum", 0, 10, MOM_P), ("noise", 10, 20, NOISE_P)]
+    env2 = bk.ManyBookEnv(12, 7, 0, 1, 1_000_000, False, levels=10, max_live_orders=256, trade_capacity=4096, history_capacity=30)
+    env2.set_agents(members)
+    env2.set_pipeline(pipeline)
+    env2.run(30)
+    ref2 = oracle.ManyBooks(12, 7, 0, 1, 1_000_000, False, 10, members=members)
+    ref2.run(30, 2)
+    assert np.array_equal(env2.history(), ref2.history())
+    assert [env2.rng_state(b) for b in range(12)] == [tuple(int(x) for x in r) for r in ref2.rng_states()]
+    groups = [(0, 24, (40, 56), (10, 20), 2, 0.8), (1, 24, (40, 56), (10, 20), 2, 0.8)]
+    m = bk.ManyMarketEnv(9, 5, 0, [2, 2], 100_000, True, levels=8, max_live_orders=64, trade_capacity=4096, history_capacity=24)
+    m.set_random_market_agents(groups)
+    r = oracle.ManyMarkets(9, 5, 0, [2, 2], 100_000, True, 8, groups)
+    for on, steps in ((True, 6), (False, 7), (True, 5), (False, 2), (True, 4)):
+        (m.enable_trading if on else m.disable_trading)()
+        r.set_trading(on)
+        m.run(steps)
+        r.run(steps, 2)
+    assert np.array_equal(m.history(), r.history())
+    want_counts = np.array([len(r.book(k, a).get_trades()) for k in range(9) for a in range(2)], dtype=np.uint64)
+    assert np.array_equal(m.trade_counts(), want_counts) and int(want_counts.sum()) > 0
