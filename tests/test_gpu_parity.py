@@ -1524,3 +1524,4 @@ def test_trading_disabled_with_on_device_agents(bk, oracle, pipeline):
     assert np.array_equal(m.history(), r.history())
     want_counts = np.array([len(r.book(k, a).get_trades()) for k in range(9) for a in range(2)], dtype=np.uint64)
     assert np.array_equal(m.trade_counts(), want_counts) and int(want_counts.sum()) > 0
+
