@@ -36,7 +36,8 @@ constexpr int MAX_GROUPS = 8;
 constexpr int MAX_ASSETS = 8;  // books per market (MarketEnv<ASSETS>)
 
 constexpr uint32_t FLAG_POOL_OVERFLOW = 1u, FLAG_TRADE_OVERFLOW = 2u, FLAG_STEP_SIZE = 4u,
-                   FLAG_ORDER_LOG_FULL = 8u, FLAG_UNKNOWN_ORDER = 16u, FLAG_HIST_OVERFLOW = 32u, FLAG_PRICE_TICK = 64u;
+                   FLAG_ORDER_LOG_FULL = 8u, FLAG_UNKNOWN_ORDER = 16u, FLAG_HIST_OVERFLOW = 32u, FLAG_PRICE_TICK = 64u,
+                   FLAG_EVENT_OVERFLOW = 128u;
 
 struct Group {  // RandomAgents::new, host-preprocessed
   uint32_t n;          // agents in the group

@@ -607,6 +607,14 @@ __global__ __launch_bounds__(64) void k_agents_mixed_lanes(DevArgs a, MixedArgs 
   auto pool_ptr = [&](uint32_t slot, int field) -> uint32_t* {
     return st + HDR_DW + (slot >> 6) * (POOL_FIELDS * 64) + field * 64 + (slot & 63u);
   };
+  // The step's event list holds 64 * R entries per unit.  One book can never queue more (every event refers to its own
+  // pool slot); a MARKET's joint queue can, when its books together keep more than one pool's worth of orders in play:
+  // the event is then dropped and the book flagged (BK_FLAG_EVENT_OVERFLOW) - never written past the list.
+  auto event_room = [&]() -> bool {
+    if (n_ev < 64u * R) return true;
+    new_flags |= FLAG_EVENT_OVERFLOW;
+    return false;
+  };
   auto push_event = [&](uint32_t slot) {
     list[n_ev * 64 + lane] = (uint16_t)(slot | (asset << 12));
     n_ev += 1;
@@ -619,6 +627,7 @@ __global__ __launch_bounds__(64) void k_agents_mixed_lanes(DevArgs a, MixedArgs 
       new_flags |= FLAG_PRICE_TICK;
       return 0xFFFFu;
     }
+    if (!event_room()) return 0xFFFFu;
     const uint32_t id = next_id;
     next_id += 1;  // create_order consumes the id (orderbook.rs:363)
     while (cw == 0xFFFFFFFFu && wcur < 2u * R) {
@@ -658,7 +667,7 @@ __global__ __launch_bounds__(64) void k_agents_mixed_lanes(DevArgs a, MixedArgs 
         const uint32_t n = D.slot_base + i;
         if (i == 0 || (n & 31u) == 0) lw = lds_live[(n >> 5) * 64 + lane];
         const uint32_t x = rng.next_u32();
-        if ((x >> 8) < D.thr) {
+        if ((x >> 8) < D.thr && event_room()) {
           push_event(n);
           if (!((lw >> (n & 31u)) & 1u)) {
             const uint32_t side = rng.below(2u, 0x7FFFFFFFu);
@@ -703,9 +712,12 @@ __global__ __launch_bounds__(64) void k_agents_mixed_lanes(DevArgs a, MixedArgs 
           if ((int32_t)(x >> 8) > D.keep_thr) {  // gen::<f32>() > p_cancel: kept
             my[(size_t)keep * NU] = (uint16_t)slot;
             keep += 1;
-          } else {  // env.cancel_order(id); stays live (and unallocatable) until the event is processed
+          } else if (event_room()) {  // env.cancel_order(id); stays live (and unallocatable) until the event is processed
             push_event(slot);
             atomicAnd(&lds_inl[(slot >> 5) * 64 + lane], ~(1u << (slot & 31u)));  // ds_and, nothing to wait for
+          } else {  // no room for the cancellation (flagged): the order stays the member's
+            my[(size_t)keep * NU] = (uint16_t)slot;
+            keep += 1;
           }
         }
       }
