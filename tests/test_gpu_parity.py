@@ -716,7 +716,8 @@ def test_fuzz_random_agent_configs_vs_oracle(bk, oracle, seed):
     n_books = int(rng.integers(1, 150))
     levels = int(rng.integers(1, 65))
     _compare_random(bk, oracle, n_books=n_books, groups=groups, levels=levels, n_steps=int(rng.integers(5, 40)),
-                    tick=tick, step_size=int(rng.choice([300, 100_000])), seed=int(rng.integers(0, 2**40)),
+                    tick=tick, step_size=max(int(rng.choice([300, 100_000])), total + 1),  # events per step < step_size (App. A.9)
+                    seed=int(rng.integers(0, 2**40)),
                     pipeline=str(rng.choice(["fused", "split", "mixed"])), chunks=None if rng.random() < 0.5 else [3, 1, 1],
                     max_live=max(64, total))
 
