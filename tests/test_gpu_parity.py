@@ -713,7 +713,7 @@ def test_fuzz_random_agent_configs_vs_oracle(bk, oracle, seed):
     if total == 0:
         groups[0] = (7,) + groups[0][1:]
         total = 7
-    n_books = int(rng.integers(1, 150))
+    n_books = int(rng.integers(1, 150)) * int(os.environ.get("BOURSE_FUZZ_BOOKS_SCALE", "1"))
     levels = int(rng.integers(1, 65))
     _compare_random(bk, oracle, n_books=n_books, groups=groups, levels=levels, n_steps=int(rng.integers(5, 40)),
                     tick=tick, step_size=max(int(rng.choice([300, 100_000])), total + 1),  # events per step < step_size (App. A.9)
@@ -1158,6 +1158,7 @@ def test_fuzz_agent_sets_and_markets_vs_oracle(bk, oracle, seed, checkpoint_at=3
                 order_ratio=float(rng.random() * 2), price_dist_mu=float(rng.normal()), price_dist_sigma=float(rng.random() * 4)))
         members.append((a, m))
     NM, T, levels = int(rng.integers(1, 90)), int(rng.integers(5, 50)), int(rng.integers(1, 33))
+    NM *= int(os.environ.get("BOURSE_FUZZ_BOOKS_SCALE", "1"))  # scripts/fuzz_parts.py: batches large enough for several parts
     chunks, left = [], T
     while left:
         c = int(rng.integers(1, left + 1))
