@@ -708,7 +708,10 @@ def test_fuzz_random_agent_configs_vs_oracle(bk, oracle, seed):
         vlo = int(rng.integers(1, 100))
         vw = int(rng.integers(1, 60))
         rate = float(rng.choice([0.0, 1.0, rng.random()]))
-        groups.append((n, (lo, lo + w), (vlo, vlo + vw), tick * int(rng.integers(1, 4)), rate))
+        tsz = tick * int(rng.integers(1, 4))
+        if os.environ.get("BOURSE_FUZZ_PRICE_TOP"):  # scripts/fuzz_parts.py: price windows ending at the top of u32
+            lo = (2**32 - 2) // tsz - w - (lo % 3)
+        groups.append((n, (lo, lo + w), (vlo, vlo + vw), tsz, rate))
         total += n
     if total == 0:
         groups[0] = (7,) + groups[0][1:]
