@@ -252,7 +252,10 @@ int bk_rng_state(bk_env* env, uint32_t book, uint64_t out_state[2]);
 int bk_live_orders(bk_env* env, uint32_t book, uint32_t cap, bk_order* out, uint32_t* n_out);
 
 /* ------------------------------------------------------ stats / multi-GPU */
-/* reduce this shard's books into one 64-byte record on the device; host copy returned */
+/* reduce this shard's books into one 64-byte record on the device.  out_host != NULL: waits and copies the record to the
+ * host.  out_host == NULL: fully asynchronous - the reduction is queued on the env's stream behind the stepping kernels
+ * and never synchronises the host (the record is then read on the device through bk_stats_device_ptr, e.g. by an RCCL
+ * all-gather on the same stream). */
 int bk_stats_compute(bk_env* env, bk_stats* out_host);
 /* device address of the 64-byte record (for an RCCL all-gather issued by the caller) */
 int bk_stats_device_ptr(bk_env* env, void** out);
