@@ -6,11 +6,14 @@ on-device RandomAgents (64 x rate 0.8 vol [10,20) + 64 x rate 0.2 vol [50,70), t
 32 levels/side, tick 2, step_size 100 000, seed 101 + global book index.  One "step" = one
 agents.update + Env::step for EVERY book (ref crates/step_sim/src/runner.rs:58-59).
 
-  python bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W [--scaling strong|weak]
 
-N > 1 is launched by torch.distributed.run (one rank per GPU, RCCL): books are independent, so
-each rank steps its own shard with NO data-path collective; the only exchange is a 64-byte
-market-stats all-gather per launch (weak scaling: 65 536 books per GPU).
+N > 1: one rank per GPU over RCCL.  Started plainly (`python bench.py --gpus N`), the parent process - before it
+imports torch or touches a GPU - starts `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a CHILD
+and exits with its code; started by torch.distributed.run itself (RANK / WORLD_SIZE in the environment) it is a rank.
+Books are independent, so each rank steps its own contiguous shard with NO data-path collective; the only exchange is a
+64-byte market-stats all-gather per launch.  Default = BASELINE configs[3]: STRONG scaling, 65 536 books in
+total, 65 536 / N per GPU, seeds by global book index; `--scaling weak` keeps 65 536 books per GPU.
 
 Prints ONE JSON line (rank 0) incl. `roofline` (HIP-event kernel time vs. HBM peak) and, at
 N = 1, `cpu_baseline` (the CPU oracle = literal restatement of the reference algorithm, timed on
@@ -82,13 +85,59 @@ def _cpu_baseline(agents_kw, levels, n_books, budget_s=12.0):
     }
 
 
+def spawn_ranks(n_gpus: int, argv) -> int:
+    """`python bench.py --gpus N` started by hand: run the N ranks as a child torch.distributed.run job.  Called before
+    torch is imported - a process that has initialised the GPU must never exec or fork into another program."""
+    import socket
+    import subprocess
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this pool (RCCL needs it)
+    env["MASTER_ADDR"] = "127.0.0.1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    return subprocess.call(cmd, env=env)
+
+
+def selftest_gloo(args, books_total_default):
+    """CPU-only check of the multi-rank plumbing (tests/test_bench_spawn.py): rendezvous, shard arithmetic and the
+    64-byte stats all-gather over gloo, with NO stepping (there is no CPU execution path to step with)."""
+    import torch
+    import torch.distributed as dist
+
+    from bourse_amd import parallel
+
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group(backend="gloo")
+    total = args.books or books_total_default
+    first, B = parallel.shard_books(total, rank, world) if args.scaling == "strong" else (rank * total, total)
+    rec = parallel.pack_stats({"n_books": B, "sum_trade_vol": 0, "sum_trades": first, "sum_events": 0, "sum_bid_vol": 0,
+                               "sum_ask_vol": 0, "min_bid": 0xFFFFFFFF, "max_bid": 0, "min_ask": 0xFFFFFFFF, "max_ask": 0})
+    out = parallel.all_gather_records(torch.from_numpy(rec.copy()), dist)
+    g = parallel.combine_stats(out.numpy())
+    dist.barrier()
+    if rank == 0:
+        print(json.dumps({"selftest": "gloo", "n_gpus": world, "scaling": args.scaling, "books_total": g["n_books"],
+                          "ranks_seen": int(out.shape[0]), "first_books_sum": g["sum_trades"]}))
+    dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--workload", default="C3", choices=sorted(WORKLOADS))
-    ap.add_argument("--books", type=int, default=0, help="books per GPU (default: the workload's)")
+    ap.add_argument("--books", type=int, default=0,
+                    help="books: in TOTAL with --scaling strong, per GPU with --scaling weak (default: the workload's)")
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
+                    help="N > 1: strong = the workload's books sharded over the GPUs (BASELINE configs[3]); weak = that many per GPU")
+    ap.add_argument("--selftest-gloo", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--steps-per-launch", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--l1-gather", action="store_true", help="also all-gather every book's L1 record per launch (SURVEY 8e ii)")
@@ -98,14 +147,18 @@ def main():
     ap.add_argument("--repeats", type=int, default=4, help="extra timed regions of --steps after the reported one (median in `runs`)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))  # nothing has touched torch or the GPU yet
+    if args.selftest_gloo:
+        return selftest_gloo(args, WORKLOADS[args.workload][0])
+
     import torch
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no GPU visible (bourse_amd has no CPU path)")
     torch.cuda.set_device(local_rank)
@@ -120,7 +173,14 @@ def main():
     from bourse_amd import parallel
 
     books_default, levels, groups = WORKLOADS[args.workload]
-    B = args.books or books_default
+    if args.scaling == "strong":  # the workload's books in total, contiguous shards (8 x 8 192)
+        books_total = args.books or books_default
+        first_book, B = parallel.shard_books(books_total, rank, world)
+        if B == 0:
+            raise SystemExit("fewer books than GPUs")
+    else:
+        B = args.books or books_default
+        first_book, books_total = rank * B, world * B
     mixed = any(isinstance(g[0], str) for g in groups)
     n_agents = sum(g[2] if isinstance(g[0], str) and g[0] != "random" else (g[1] if isinstance(g[0], str) else g[0])
                    for g in groups)
@@ -130,13 +190,15 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     env = bourse_amd.ManyBookEnv(B, SEED, 0, TICK, STEP_SIZE, True, levels=levels, max_live_orders=min(n_agents, 512),
                                  trade_capacity=trade_cap, history_capacity=hist_cap,
-                                 book_offset=rank * B, device=local_rank, stream=stream)
+                                 book_offset=first_book, device=local_rank, stream=stream, strict=False)
     if mixed:
         env.set_agents(groups)
     else:
         env.set_random_agents(groups)
     env.set_pipeline(args.pipeline)
     gather = parallel.StatsGather(env, dist) if dist is not None else None
+    if args.l1_gather and books_total != world * B:
+        raise SystemExit("--l1-gather needs equal shards (all_gather_into_tensor)")
     l1 = parallel.L1Gather(env, dist) if (dist is not None and args.l1_gather) else None
 
     def run_steps(n):
@@ -155,6 +217,7 @@ def main():
     run_steps(args.warmup)
     torch.cuda.synchronize()
     tc0 = int(env.trade_counts().sum())
+    oc0 = int(env.order_counts().sum())
     env.profile(args.profile_every)
     if dist is not None:
         dist.barrier()
@@ -179,9 +242,10 @@ def main():
     if flags.any():
         raise SystemExit(f"device flags set during the timed region: {np.unique(flags)} (trade/history capacity?)")
     n_trades = int(env.trade_counts().sum()) - tc0
+    n_new = int(env.order_counts().sum()) - oc0  # orders created = New events of the timed region (device counters)
     st = env.stats()
 
-    value = world * B * args.steps / dt
+    value = books_total * args.steps / dt  # whole job: every rank's books (shards differ by at most one book)
     # Roofline accounting: algorithmic HBM bytes per book-step of every step kernel, in the
     # device layout actually shipped (S = per-book state block, 32 B trade records, measured event/trade rates):
     #   k_run_random / k_run_mixed (fused, spl steps per launch): 2 S / spl + L2 record + 32 N_tr
@@ -191,7 +255,7 @@ def main():
     W4 = env.width * 4
     tr_per_bs = n_trades / (B * args.steps)
     ev_per_bs = st["sum_events"] / (B * (args.steps + args.warmup))
-    new_per_bs = 0.77 * ev_per_bs  # measured share of New events at C3 (49 of 64); exact value does not matter at 8 B each
+    new_per_bs = n_new / (B * args.steps)
     pipe, parts = env.pipeline()
     per_bs = {
         kind0: 2.0 * S / spl + W4 + 32.0 * tr_per_bs,
@@ -204,9 +268,17 @@ def main():
     }
     bs_per_launch = {kind0: B * spl, "k_agents_fsm": B / parts, "k_agents_mixed_lanes": B / parts, "k_step_batch": B / parts,
                      "k_step_events": B}
-    pmc = {}
+    # PMC figures (HBM traffic, instruction counts) cannot be collected inside this process: they are rocprofv3 --pmc
+    # passes of this same command (scripts/profile_round.sh), committed under profiles/ and REPLAYED here, keyed by
+    # workload, and only when this run has the profiled run's shape (books per launch): `traffic_source` says so.
+    pmc, pmc_src = {}, None
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(args.workload, {})
+        allp = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        pmc = allp.get(args.workload, {})
+        pmc_src = "profiles/pmc_traffic.json[%s] (rocprofv3 --pmc passes of `bench.py --workload %s`; replayed, not measured in this run)" % (
+            args.workload, args.workload)
+        if B != books_default:
+            pmc, pmc_src = {}, None  # another batch size: the per-book-step PMC figures of the profiled shape do not carry over
     except Exception:
         pass
     kernels = {}
@@ -243,15 +315,16 @@ def main():
             issue["occupancy"] = occ
     out = {
         "metric": "book-steps/sec", "value": value, "unit": "book-steps/s", "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": dt * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
+        "warmup": args.warmup, "ms_per_step": dt * 1e3 / args.steps, "higher_is_better": True, "scaling": args.scaling,
         "vs_baseline": None, "dtype": "u32", "data": "synthetic",
         "config": {
-            "workload": f"{args.workload}: {B} books/GPU x {n_agents} on-device agents "
+            "workload": f"{args.workload}: {books_total} books ({B}/GPU) x {n_agents} on-device agents "
                         f"({len(groups)} {'members: ' + '+'.join(g[0] for g in groups) if mixed else 'groups'}), {levels} levels/side, tick {TICK}, step_size {STEP_SIZE}, "
                         f"seed {SEED}+book",
-            "books_per_gpu": B, "agents_per_book": n_agents, "levels": levels, "steps_per_launch": spl,
-            "parallelism": f"independent book shards x{world}, 64 B stats all-gather per launch" if world > 1
-            else "single GPU",
+            "books_total": books_total, "books_per_gpu": B, "ranks": world, "agents_per_book": n_agents, "levels": levels,
+            "steps_per_launch": spl,
+            "parallelism": f"{books_total} books in {world} contiguous shards ({args.scaling} scaling), no data-path "
+                           f"collective, 64 B stats all-gather per launch" if world > 1 else "single GPU",
             "trades_per_book_step": tr_per_bs, "events_per_book_step": ev_per_bs,
             "events_per_s": ev_per_bs * value, "trades_per_s": tr_per_bs * value,
             "pipeline": f"split ({kind1} + k_step_batch per step, {parts} book parts on separate streams)"
@@ -283,20 +356,44 @@ def main():
             tm = torch.tensor([d], dtype=torch.float64, device="cuda")
             dist.all_reduce(tm, op=dist.ReduceOp.MAX)
             d = float(tm.item())
-        vals.append(world * B * args.steps / d)
+        vals.append(books_total * args.steps / d)
     out["runs"] = {"n": len(vals), "values": vals, "median": float(np.median(vals))}
+    # The per-launch roofline above is measured while the parts' kernels overlap each other on separate streams, which
+    # stretches every launch.  Two unambiguous figures beside it: (1) aggregate = the algorithmic bytes of ALL step
+    # kernels per step / the step's wall time; (2) the dominant kernel launched ALONE over the whole batch (one part).
+    R = out["roofline"]
+    step_bytes = sum(kernels[k]["bytes_per_book_step"] for k in kernels) * B  # every kernel visits every book once per step
+    R["achieved_node"] = step_bytes * world / (out["ms_per_step"] * 1e-3) / 1e9
+    R["peak_node"] = HBM_PEAK_GBPS * world
+    R["frac_node"] = R["achieved_node"] / R["peak_node"]
+    R["traffic_source"] = pmc_src if traffic is not None else None
+    if pipe == "split" and parts > 1:
+        env.set_split_parts(1, 64)
+        env.profile(1)
+        run_steps(min(16, args.steps))
+        env.sync()
+        env.profile(False)
+        ms1, n1 = env.profile_read_kind(2)
+        env.profile_read()
+        env.set_split_parts(3, 4096)
+        if n1:
+            a1 = per_bs["k_step_batch"] * B / (ms1 / n1 * 1e-3) / 1e9
+            R["standalone"] = {"kernel": "k_step_batch", "book_steps_per_launch": B, "avg_launch_ms": ms1 / n1, "launches": n1,
+                               "achieved": a1, "frac": a1 / HBM_PEAK_GBPS,
+                               "note": "one launch over the whole batch, nothing overlapping it (k_agents_fsm runs before it)"}
     flags = env.flags()
     if flags.any():
         raise SystemExit(f"device flags set during the repeated regions: {np.unique(flags)}")
     if gather is not None:
         g = gather.result()
-        out["config"]["stats_allgather"] = {"zero_copy": gather.zero_copy, "n_books": g["n_books"], "sum_trades": g["sum_trades"]}
-        if g["n_books"] != world * B:
+        out["config"]["stats_allgather"] = {"zero_copy": gather.zero_copy, "ranks_seen": int(gather.out.shape[0]),
+                                            "n_books": g["n_books"], "sum_trades": g["sum_trades"]}
+        if g["n_books"] != books_total or gather.out.shape[0] != world:
             raise SystemExit(f"stats all-gather inconsistent: {g}")
     if l1 is not None:
         rec = l1.result()
         mine = env.level2()[:, :9]
-        if rec.shape != (world * B, 9) or not np.array_equal(rec[rank * B:(rank + 1) * B], mine):
+        if rec.shape != (world * B, 9) or not np.array_equal(rec[rank * B:(rank + 1) * B], mine):  # equal shards only
             raise SystemExit("L1 all-gather inconsistent with this rank's level-2 records")
         out["config"]["l1_allgather"] = {"bytes_per_gpu": int(B * 36), "books": int(rec.shape[0])}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -14,7 +14,15 @@ from . import _build
 BK_OK, BK_PRICE, BK_UNKNOWN_ORDER, BK_CAPACITY, BK_STEP_SIZE, BK_INVALID, BK_HIP, BK_NO_DEVICE = range(8)
 
 FLAG_POOL_OVERFLOW, FLAG_TRADE_OVERFLOW, FLAG_STEP_SIZE, FLAG_ORDER_LOG_FULL = 1, 2, 4, 8
-FLAG_UNKNOWN_ORDER, FLAG_HIST_OVERFLOW = 16, 32
+FLAG_UNKNOWN_ORDER, FLAG_HIST_OVERFLOW, FLAG_PRICE_TICK, FLAG_EVENT_OVERFLOW = 16, 32, 64, 128
+FLAG_NAMES = {1: "POOL_OVERFLOW (live-order pool full: a resting order was dropped)",
+              2: "TRADE_OVERFLOW (trade_capacity exceeded: records dropped, counts exact)",
+              4: "STEP_SIZE (a step queued >= step_size events)",
+              8: "ORDER_LOG_FULL (order id beyond max_orders)",
+              16: "UNKNOWN_ORDER", 32: "HIST_OVERFLOW",
+              64: "PRICE_TICK (a Noise/Momentum limit price clamped to u32::MAX was not a tick multiple)",
+              128: "EVENT_OVERFLOW (a market queued more events in one step than its shared list holds)"}
+CAPACITY_FLAGS = FLAG_POOL_OVERFLOW | FLAG_TRADE_OVERFLOW | FLAG_ORDER_LOG_FULL | FLAG_EVENT_OVERFLOW
 
 
 class BourseError(RuntimeError):
@@ -137,6 +145,8 @@ SIGNATURES = {
     "bk_set_pipeline": (_i32, [_vp, _i32]),
     "bk_get_pipeline": (_i32, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "bk_state_bytes_per_book": (_u64, [_vp]),
+    "bk_set_split_parts": (_i32, [_vp, _i32, _u32]),
+    "bk_order_counts": (_i32, [_vp, _p64]),
     "bk_checkpoint_bytes": (_u64, [_vp]),
     "bk_checkpoint_save": (_i32, [_vp, _vp, _u64]),
     "bk_checkpoint_load": (_i32, [_vp, _vp, _u64]),

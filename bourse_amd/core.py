@@ -25,6 +25,11 @@ class _EnvBase:
                                 max_live_orders=max_live_orders, max_orders=max_orders,
                                 trade_capacity=trade_capacity, history_capacity=history_capacity, device=device)
         self._l2_cache = None
+        # The reference keeps every step's record forever (Level2DataRecords, data.rs:26-56); the device keeps a ring
+        # of history_capacity steps, drained into this host archive before it wraps.
+        self._hist_cap = int(history_capacity)
+        self._hist_archive = []
+        self._hist_pending = 0
 
     # -- shared
     def enable_trading(self):
@@ -36,6 +41,15 @@ class _EnvBase:
     def step(self):
         self._env.step()
         self._l2_cache = None
+        self._hist_pending += 1
+        if self._hist_cap and self._hist_pending >= self._hist_cap:
+            self._drain_history()
+
+    def _drain_history(self):
+        if self._hist_pending:
+            self._hist_archive.append(self._env.history()[:, 0, :].copy())
+            self._env.clear_history()
+            self._hist_pending = 0
 
     def _l2(self) -> np.ndarray:
         """[trade_vol(live), bid, ask, ask_vol, bid_vol, levels...] (step_sim_numpy.rs:353-365)."""
@@ -59,7 +73,9 @@ class _EnvBase:
         ]
 
     def _history(self) -> np.ndarray:
-        return self._env.history()[:, 0, :]
+        if not self._hist_archive:
+            return self._env.history()[:, 0, :]
+        return np.concatenate(self._hist_archive + [self._env.history()[:, 0, :]], axis=0)
 
     def get_market_data(self):
         # key set and layout: rust/src/step_sim.rs:562-607

@@ -637,7 +637,8 @@ __device__ __forceinline__ uint32_t step_from_list(Book<R>& B, const DevArgs& a,
   const uint64_t t0 = B.t;
   B.trade_vol = 0;  // reset_trade_vol (env.rs:118)
   const uint64_t trades_before = B.n_trades;
-  if ((uint64_t)n_ev >= step_size) B.flags |= FLAG_STEP_SIZE;
+  // step_size 0 = immediate mode (the clock is the caller's, OrderBook::set_time): no step window to overflow
+  if (step_size != 0 && (uint64_t)n_ev >= step_size) B.flags |= FLAG_STEP_SIZE;
 #pragma unroll
   for (int re = 0; re < R; ++re) {  // events at t0 + k (env.rs:123-127); entry k lives in lane k & 63 of ev[k >> 6]
     const uint32_t kb = re * 64;
@@ -1024,7 +1025,7 @@ __global__ __launch_bounds__(64) void k_step_events(DevArgs a, uint64_t step_ind
   const uint64_t t0 = B.t;
   B.trade_vol = 0;
   const uint64_t trades_before = B.n_trades;
-  if ((uint64_t)n_ev >= step_size && n_ev > 0) B.flags |= FLAG_STEP_SIZE;
+  if (step_size != 0 && (uint64_t)n_ev >= step_size) B.flags |= FLAG_STEP_SIZE;
   for (uint32_t j = lane; j < n_ev; j += 64) perm[j] = (uint16_t)j;
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();

@@ -45,6 +45,12 @@ int fail(int code, const std::string& msg) {
   return code;
 }
 
+uint64_t fnv1a(const void* p, size_t n, uint64_t h = 1469598103934665603ull) {
+  const unsigned char* c = static_cast<const unsigned char*>(p);
+  for (size_t i = 0; i < n; ++i) h = (h ^ c[i]) * 1099511628211ull;
+  return h;
+}
+
 #define HIPCHK(expr)                                                                              \
   do {                                                                                            \
     hipError_t _e = (expr);                                                                       \
@@ -156,6 +162,8 @@ struct bk_env {
   }
   std::vector<Group> groups;
   uint32_t n_agents_total = 0;
+  uint64_t agents_hash = 0;   // FNV-1a of the installed agent set (checkpoint compatibility)
+  bool device_flow = false;   // bk_run has stepped this env with on-device agents: host-driven orders are refused
   uint64_t steps_done = 0, hist_base = 0;
   uint32_t trading = 1;
   size_t ev_capacity = 0;
@@ -365,6 +373,14 @@ int order_after(hipStream_t later, hipStream_t earlier) {
   return BK_OK;
 }
 
+// Host-driven orders on an env whose books are populated by on-device agents would restart the order ids at 0 (colliding
+// with the agents' ids) and could take an agent's pool slot: one env runs ONE of the two flows.
+int host_flow_ok(bk_env* env) {
+  if (env->device_flow)
+    return fail(BK_INVALID_ARGUMENT, "host-driven orders cannot be mixed with bk_run's on-device agents on the same env");
+  return BK_OK;
+}
+
 int check_book(bk_env* env, uint32_t book) {
   if (!env) return fail(BK_INVALID_ARGUMENT, "null env");
   if (book >= env->cfg.n_books) return fail(BK_INVALID_ARGUMENT, "book index out of range");
@@ -562,6 +578,7 @@ int bk_env_sync(bk_env* env) {
 int bk_place_order(bk_env* env, uint32_t book, int bid, uint32_t vol, uint32_t trader_id, int has_price,
                    uint32_t price, uint64_t* out_order_id) {
   if (int rc = check_book(env, book)) return rc;
+  if (int rc = host_flow_ok(env)) return rc;
   const uint32_t asset = book % env->M, tick = env->asset_tick[asset];
   if (has_price && price % tick != 0)  // create_order's tick check, orderbook.rs:367-382
     return fail(BK_PRICE_NOT_TICK_MULTIPLE,
@@ -580,6 +597,7 @@ int bk_place_order(bk_env* env, uint32_t book, int bid, uint32_t vol, uint32_t t
 
 int bk_cancel_order(bk_env* env, uint32_t book, uint64_t order_id) {
   if (int rc = check_book(env, book)) return rc;
+  if (int rc = host_flow_ok(env)) return rc;
   // an id that was never created panics only when the event is PROCESSED (orderbook.rs:642): checked in bk_step
   const uint32_t asset = book % env->M;
   env->books[book - asset].queue.push_back(
@@ -590,6 +608,7 @@ int bk_cancel_order(bk_env* env, uint32_t book, uint64_t order_id) {
 int bk_modify_order(bk_env* env, uint32_t book, uint64_t order_id, int has_price, uint32_t new_price, int has_vol,
                     uint32_t new_vol) {
   if (int rc = check_book(env, book)) return rc;
+  if (int rc = host_flow_ok(env)) return rc;
   const uint32_t asset = book % env->M;
   const uint32_t w = 2u | (has_price ? 1u << 9 : 0u) | (has_vol ? 1u << 10 : 0u) | (asset << 16);
   env->books[book - asset].queue.push_back(
@@ -688,6 +707,7 @@ int bk_enable_trading(bk_env* env, int enabled) {
 
 int bk_step(bk_env* env) {
   if (!env) return fail(BK_INVALID_ARGUMENT, "null env");
+  if (int rc = host_flow_ok(env)) return rc;
   if (int rc = use_device(env)) return rc;
   const size_t B = env->cfg.n_books, M = env->M, NM = B / M;
   // CSR offsets of the queues (one row per market; a market of one book when assets == 1)
@@ -835,6 +855,7 @@ int bk_set_random_market_agents(bk_env* env, uint32_t n_groups, const bk_random_
   env->groups = gs;
   env->n_agents_total = static_cast<uint32_t>(total);
   env->n_mixed = 0;
+  env->agents_hash = gs.empty() ? 0 : fnv1a(gs.data(), gs.size() * sizeof(Group));
   return BK_OK;
 }
 
@@ -942,6 +963,7 @@ static int set_agents_impl(bk_env* env, uint32_t n_members, const bk_agent_desc*
   env->ml_valid = false;
   env->groups.clear();
   env->n_agents_total = 0;
+  env->agents_hash = fnv1a(env->member_asset, sizeof(env->member_asset), fnv1a(ds.data(), ds.size() * sizeof(MixedDesc)));
   return BK_OK;
 }
 
@@ -960,6 +982,7 @@ int bk_run(bk_env* env, uint64_t n_steps) {
   }
   int rc = BK_OK;
   const uint32_t ns = static_cast<uint32_t>(n_steps);
+  if (env->n_mixed || a.n_groups) env->device_flow = true;
   if (env->n_mixed) {
     // fused for small batches (the book stays in registers across steps); from MIXED_SPLIT_MIN_BOOKS books (where it
     // overtakes the fused kernel, scripts/c5m_sweep.sh) the members' update runs one LANE per book in front of the lean
@@ -1541,14 +1564,49 @@ int bk_set_pipeline(bk_env* env, int mode) {
   return BK_OK;
 }
 
+// split pipeline geometry: the batch is cut in min(n_parts, units / min_part) contiguous parts on separate streams
+int bk_set_split_parts(bk_env* env, int n_parts, uint32_t min_part) {
+  if (!env || n_parts < 1 || n_parts > bk_env::MAX_PARTS || min_part < 64)
+    return fail(BK_INVALID_ARGUMENT, "n_parts must be in 1..8 and min_part >= 64");
+  env->n_parts = n_parts;
+  env->min_part = min_part;
+  return BK_OK;
+}
+
+// orders created so far per book by the on-device agents (OrderBook::current_order_id, orderbook.rs:327-329)
+int bk_order_counts(bk_env* env, uint64_t* totals) {
+  if (!env || !totals) return fail(BK_INVALID_ARGUMENT, "null argument");
+  if (int rc = use_device(env)) return rc;
+  HIPCHK(hipStreamSynchronize(env->stream));
+  std::vector<uint32_t> v(env->cfg.n_books);
+  HIPCHK(hipMemcpy2D(v.data(), 4, env->state.p + H_NEXT_ID, static_cast<size_t>(env->stride) * 4, 4, env->cfg.n_books,
+                     hipMemcpyDeviceToHost));
+  for (size_t b = 0; b < v.size(); ++b) totals[b] = v[b];
+  return BK_OK;
+}
+
 // ---------------------------------------------------------------- checkpoint / resume (on-device order flow)
 // The reference cannot resume a running simulation (Env, agents and RNG are not serialisable);
 // here the whole simulation state IS the per-book device block (pool, clock, counters, RNG), so a checkpoint
 // is one device-to-host copy.  Host-driven envs (order log + host order table) are not covered.
+// header: 8 x u64 = {magic "BKCKPT02", steps_done, n_books << 32 | stride (pool size), levels width W << 32 | assets,
+// number of Noise/Momentum members << 32 | RandomAgents groups, hash of the installed agent set, trading flag, 0}
+constexpr uint64_t CKPT_MAGIC = 0x3230545043434B42ull;  // "BKCKPT02" little-endian
+constexpr size_t CKPT_HDR = 8;                            // u64 words
+static void ckpt_header(const bk_env* env, uint64_t* h) {
+  h[0] = CKPT_MAGIC;
+  h[1] = env->steps_done;
+  h[2] = (static_cast<uint64_t>(env->cfg.n_books) << 32) | env->stride;
+  h[3] = (static_cast<uint64_t>(env->W) << 32) | env->M;
+  h[4] = (static_cast<uint64_t>(env->n_mixed) << 32) | static_cast<uint32_t>(env->groups.size());
+  h[5] = env->agents_hash;
+  h[6] = env->trading;
+  h[7] = 0;
+}
 uint64_t bk_checkpoint_bytes(const bk_env* env) {
-  // header (steps_done, shape) + per-book state blocks + the latest level-2 records (Env::level_2_data; the
-  // lane-per-book members' update reads the touches from there)
-  return env ? 16 + static_cast<uint64_t>(env->cfg.n_books) * (env->stride + env->W) * 4 : 0;
+  // header + per-book state blocks + the latest level-2 records (Env::level_2_data; the lane-per-book members' update
+  // reads the touches from there)
+  return env ? CKPT_HDR * 8 + static_cast<uint64_t>(env->cfg.n_books) * (env->stride + env->W) * 4 : 0;
 }
 
 int bk_checkpoint_save(bk_env* env, void* out, uint64_t nbytes) {
@@ -1559,29 +1617,35 @@ int bk_checkpoint_save(bk_env* env, void* out, uint64_t nbytes) {
   if (int rc = use_device(env)) return rc;
   HIPCHK(hipStreamSynchronize(env->stream));
   uint64_t* h = static_cast<uint64_t*>(out);
-  h[0] = env->steps_done;
-  h[1] = (static_cast<uint64_t>(env->cfg.n_books) << 32) | env->stride;
+  ckpt_header(env, h);
   const size_t sb = static_cast<size_t>(env->cfg.n_books) * env->stride * 4;
-  HIPCHK(hipMemcpy(h + 2, env->state.p, sb, hipMemcpyDeviceToHost));
-  HIPCHK(hipMemcpy(reinterpret_cast<char*>(h + 2) + sb, env->l2_last.p, static_cast<size_t>(env->cfg.n_books) * env->W * 4,
-                   hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(h + CKPT_HDR, env->state.p, sb, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(reinterpret_cast<char*>(h + CKPT_HDR) + sb, env->l2_last.p,
+                   static_cast<size_t>(env->cfg.n_books) * env->W * 4, hipMemcpyDeviceToHost));
   return BK_OK;
 }
 
 int bk_checkpoint_load(bk_env* env, const void* in, uint64_t nbytes) {
   if (!env || !in) return fail(BK_INVALID_ARGUMENT, "null argument");
   const uint64_t* h = static_cast<const uint64_t*>(in);
-  if (nbytes < bk_checkpoint_bytes(env) || h[1] != ((static_cast<uint64_t>(env->cfg.n_books) << 32) | env->stride))
-    return fail(BK_INVALID_ARGUMENT, "checkpoint does not match this env (n_books / pool size / levels)");
+  if (nbytes < CKPT_HDR * 8 || h[0] != CKPT_MAGIC)
+    return fail(BK_INVALID_ARGUMENT, "not a bourse_amd checkpoint of this version (bad magic)");
+  uint64_t want[CKPT_HDR];
+  ckpt_header(env, want);
+  if (nbytes < bk_checkpoint_bytes(env) || h[2] != want[2] || h[3] != want[3])
+    return fail(BK_INVALID_ARGUMENT, "checkpoint does not match this env (n_books / pool size / levels / assets)");
+  if (h[4] != want[4] || h[5] != want[5])
+    return fail(BK_INVALID_ARGUMENT, "checkpoint was taken with a different agent set: install the same agents first");
   if (int rc = use_device(env)) return rc;
   HIPCHK(hipStreamSynchronize(env->stream));
   const size_t sb = static_cast<size_t>(env->cfg.n_books) * env->stride * 4;
-  HIPCHK(hipMemcpy(env->state.p, h + 2, sb, hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(env->l2_last.p, reinterpret_cast<const char*>(h + 2) + sb,
+  HIPCHK(hipMemcpy(env->state.p, h + CKPT_HDR, sb, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(env->l2_last.p, reinterpret_cast<const char*>(h + CKPT_HDR) + sb,
                    static_cast<size_t>(env->cfg.n_books) * env->W * 4, hipMemcpyHostToDevice));
   env->ml_valid = false;
-  env->steps_done = h[0];
-  env->hist_base = h[0];  // retained history/trade records restart at the restored step
+  env->steps_done = h[1];
+  env->hist_base = h[1];  // retained history/trade records restart at the restored step
+  env->trading = h[6] ? 1u : 0u;  // the host mirror of the books' trading flag (H_TRADING travels in the state blocks)
   const uint32_t B = env->cfg.n_books;
   hipLaunchKernelGGL(k_book_service, dim3((B + 255) / 256), dim3(256), 0, env->stream, env->state.p, env->stride, B, 0,
                      0u);

@@ -28,16 +28,19 @@ class HostPool {
     for (auto& t : workers_) t.join();
   }
   unsigned threads() const { return static_cast<unsigned>(workers_.size()) + 1; }  // + the calling thread
-  // fn(task) for task in [0, n_tasks); returns when every task has finished.  One run() at a time.
+  // fn(task) for task in [0, n_tasks), n_tasks <= 65535; returns when every task has finished.  One run() at a time.
   void run(unsigned n_tasks, const std::function<void(unsigned)>& fn) {
     if (n_tasks == 0) return;
+    if (n_tasks > 0xFFFFu) n_tasks = 0xFFFFu;
     {
       std::lock_guard<std::mutex> lk(mu_);
-      fn_ = &fn;
-      n_tasks_ = n_tasks;
-      next_.store(0);
+      fn_.store(&fn, std::memory_order_release);
       pending_ = n_tasks;
       ++generation_;
+      // generation, bound and next index are ONE word: a worker that is still leaving the previous run() can only claim
+      // a task by a compare-exchange on the value it read, so it can neither run a task of this generation twice nor
+      // apply the old bound to the new counter (the hazard of separate n_tasks / next words)
+      ctl_.store((generation_ << 32) | (static_cast<uint64_t>(n_tasks) << 16), std::memory_order_release);
     }
     cv_.notify_all();
     work();
@@ -49,9 +52,12 @@ class HostPool {
  private:
   void work() {
     for (;;) {
-      const unsigned t = next_.fetch_add(1);
-      if (t >= n_tasks_) return;
-      (*fn_.load())(t);
+      uint64_t cur = ctl_.load(std::memory_order_acquire);
+      const unsigned n = static_cast<unsigned>((cur >> 16) & 0xFFFFu), t = static_cast<unsigned>(cur & 0xFFFFu);
+      if (t >= n) return;
+      if (!ctl_.compare_exchange_weak(cur, cur + 1, std::memory_order_acq_rel)) continue;
+      // run() of the generation just claimed cannot return before this task is counted: fn_ is that generation's
+      (*fn_.load(std::memory_order_acquire))(t);
       std::lock_guard<std::mutex> lk(mu_);
       if (--pending_ == 0) done_cv_.notify_all();
     }
@@ -72,7 +78,7 @@ class HostPool {
   std::mutex mu_;
   std::condition_variable cv_, done_cv_;
   std::atomic<const std::function<void(unsigned)>*> fn_{nullptr};
-  std::atomic<unsigned> next_{0}, n_tasks_{0};
+  std::atomic<uint64_t> ctl_{0};  // [63:32] generation, [31:16] n_tasks, [15:0] next task index
   unsigned pending_ = 0;
   uint64_t generation_ = 0;
   bool stop_ = false;

@@ -110,8 +110,12 @@ class ManyBookEnv:
     def __init__(self, n_books: int, seed: int, start_time: int, tick_size: int, step_size: int, trading: bool = True,
                  levels: int = 10, max_live_orders: int = 128, max_orders: int = 0, trade_capacity: int = 4096,
                  history_capacity: int = 0, book_offset: int = 0, device: int = 0, stream: Optional[int] = None,
-                 assets: int = 1, tick_sizes: Optional[Sequence[int]] = None):
+                 assets: int = 1, tick_sizes: Optional[Sequence[int]] = None, strict: bool = True):
         self._L = _lib.load()
+        # strict: step() and synchronous run() raise when a book reports a capacity flag.  The reference's book is
+        # unbounded (crates/order_book/src/orderbook.rs:113-115); here pool / trade-record / order-log capacities are
+        # fixed, and an overflow must never pass silently.  strict=False leaves the sticky flags to flags().
+        self.strict = bool(strict)
         cfg = Config()
         cfg.assets = int(assets)
         self.assets = max(1, int(assets))
@@ -206,6 +210,24 @@ class ManyBookEnv:
     def step(self):
         """``Env::step`` (env.rs:116-135) for every book over the queued events."""
         check(self._L.bk_step(self._h))
+        if self.strict:
+            self.raise_on_flags()
+
+    def raise_on_flags(self, mask: Optional[int] = None):
+        """Raise ``CapacityError`` (capacity bits) / ``BourseError`` (step-size, price-tick) if any book carries a
+        sticky flag in ``mask`` (default: every flag except UNKNOWN_ORDER, which ``step`` reports itself)."""
+        f = self.flags()
+        m = np.uint32(~_lib.FLAG_UNKNOWN_ORDER & 0xFFFFFFFF if mask is None else mask)
+        bad = f & m
+        if not bad.any():
+            return
+        bits = int(np.bitwise_or.reduce(bad))
+        books = np.nonzero(bad)[0]
+        names = "; ".join(n for b, n in _lib.FLAG_NAMES.items() if bits & b)
+        msg = f"{len(books)} book(s) flagged (first: book {int(books[0])}): {names}"
+        if bits & _lib.CAPACITY_FLAGS:
+            raise _lib.CapacityError(_lib.BK_CAPACITY, msg)
+        raise _lib.BourseError(_lib.BK_STEP_SIZE if bits & _lib.FLAG_STEP_SIZE else _lib.BK_INVALID, msg)
 
     def order_status(self, book: int, order_id: int) -> int:
         out = C.c_uint8(0)
@@ -353,6 +375,8 @@ class ManyBookEnv:
         check(self._L.bk_run(self._h, int(n_steps)))
         if sync:
             self.sync()
+            if self.strict:
+                self.raise_on_flags()
 
     def sync(self):
         check(self._L.bk_env_sync(self._h))
@@ -498,6 +522,12 @@ class ManyBookEnv:
     def clear_trades(self):
         check(self._L.bk_clear_trades(self._h))
 
+    def order_counts(self) -> np.ndarray:
+        """Orders created so far per book by the on-device agents (``orders.len()``, orderbook.rs:327-329)."""
+        out = np.zeros(self.n_books, dtype=np.uint64)
+        check(self._L.bk_order_counts(self._h, _lib.p64(out)))
+        return out
+
     def time(self, book: int = 0) -> int:
         out = C.c_uint64(0)
         check(self._L.bk_time(self._h, book, C.byref(out)))
@@ -573,6 +603,10 @@ class ManyBookEnv:
         """'auto' | 'fused' | 'split' | 'split_wave' — kernel pipeline of run(); results are identical.  ('split_wave':
         AgentSets with Noise/Momentum members keep their update one wave per book; for RandomAgents it equals 'split'.)"""
         check(self._L.bk_set_pipeline(self._h, {"auto": 0, "fused": 1, "split": 2, "split_wave": 3}[mode]))
+
+    def set_split_parts(self, n_parts: int, min_part: int = 4096):
+        """Split pipeline: cut the batch in ``min(n_parts, books / min_part)`` parts on separate streams."""
+        check(self._L.bk_set_split_parts(self._h, int(n_parts), int(min_part)))
 
     def pipeline(self) -> Tuple[str, int]:
         """('fused' | 'split', number of book parts launched on separate streams) that run() will use."""

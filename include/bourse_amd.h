@@ -205,6 +205,9 @@ int bk_set_market_agents(bk_env* env, uint32_t n_members, const bk_agent_desc* m
 /* sim_runner's loop body n_steps times for every book: agents.update(env, rng); env.step(rng)
  * (crates/step_sim/src/runner.rs:53-68), sharing each book's RNG between agents and shuffle. */
 int bk_run(bk_env* env, uint64_t n_steps);
+/* One env runs ONE of the two order flows: once bk_run has stepped it with on-device agents, bk_place_order /
+ * bk_cancel_order / bk_modify_order / bk_submit_instructions* / bk_step return BK_INVALID_ARGUMENT (host order ids would
+ * restart at 0 and collide with the agents'); and bk_run refuses an env that holds host-placed orders. */
 
 /* ------------------------------------------------------------------ readers */
 /* Level-2 record width in u32: 5 + 4*levels, laid out as StepEnvNumpy.level_2_data
@@ -275,10 +278,17 @@ int bk_set_pipeline(bk_env* env, int mode);
 /* the pipeline bk_run will use: *split = 0/1; *n_parts = contiguous book parts launched on separate streams */
 int bk_get_pipeline(bk_env* env, int* split, int* n_parts);
 uint64_t bk_state_bytes_per_book(const bk_env* env);
+/* split-pipeline geometry: the batch is cut in min(n_parts, books / min_part) contiguous parts, each on its own HIP
+ * stream (defaults 3 and 4096; n_parts in 1..8, min_part >= 64).  Results never depend on it. */
+int bk_set_split_parts(bk_env* env, int n_parts, uint32_t min_part);
+/* orders created so far in every book by the on-device agents: OrderBook::current_order_id / orders.len()
+ * (crates/order_book/src/orderbook.rs:327-329), totals[n_books] */
+int bk_order_counts(bk_env* env, uint64_t* totals /* [n_books] */);
 
 /* ------------------------------------------------------ checkpoint / resume */
 /* Dump / restore the complete simulation state of an on-device-order-flow env (pool, clock, counters, per-book
- * RNG).  The reference has no counterpart: its Env/agents/RNG are not serialisable (only OrderBook JSON snapshots,
+ * RNG).  The image starts with a versioned header (magic, shape, levels, assets, a hash of the installed agent set):
+ * bk_checkpoint_load refuses an image taken from a differently shaped env or with different agents.  The reference has no counterpart: its Env/agents/RNG are not serialisable (only OrderBook JSON snapshots,
  * crates/order_book/src/orderbook.rs:811-832).  A restored env continues bit-identically. */
 uint64_t bk_checkpoint_bytes(const bk_env* env);
 int bk_checkpoint_save(bk_env* env, void* out, uint64_t nbytes);

@@ -17,7 +17,7 @@ def check(env, ref, T, chunk, n_units, stride):
 # 1. AgentSet (momentum + noise + random), 1024 books x 1500 steps, pipelines cycling every chunk
 members = [("momentum", 0, 64, MOM), ("noise", 64, 64, NOI), ("random", 32, (1_000_000_000, 1_000_000_032), (10, 20), 1, 0.5)]
 B, T, chunk = 1024, 1500, 100
-env = bk.ManyBookEnv(B, 7, 0, 1, 1_000_000, levels=16, max_live_orders=512, trade_capacity=256 * chunk, history_capacity=chunk)
+env = bk.ManyBookEnv(B, 7, 0, 1, 1_000_000, levels=16, max_live_orders=512, trade_capacity=256 * chunk, history_capacity=chunk, strict=False)
 env.set_agents(members)
 ref = oracle.ManyBooks(B, 7, 0, 1, 1_000_000, True, 16, members=members)
 t0 = time.time()
@@ -31,7 +31,7 @@ del env, ref
 # 2. markets of 3 assets with every member kind, 512 markets x 1200 steps
 mm = [(0, ("noise", 0, 40, NOI)), (2, ("momentum", 100, 40, MOM)), (1, ("random", 48, (1000, 1032), (10, 20), 1, 0.7)), (2, ("noise", 200, 24, NOI))]
 NM, T, chunk = 512, 1200, 100
-env = bk.ManyMarketEnv(NM, 9, 0, [1, 1, 1], 1_000_000, True, levels=16, max_live_orders=512, trade_capacity=256 * chunk, history_capacity=chunk)
+env = bk.ManyMarketEnv(NM, 9, 0, [1, 1, 1], 1_000_000, True, levels=16, max_live_orders=512, trade_capacity=256 * chunk, history_capacity=chunk, strict=False)
 env.set_market_agents(mm)
 ref = oracle.ManyMarkets(NM, 9, 0, [1, 1, 1], 1_000_000, True, 16, members=mm)
 t0 = time.time()

@@ -27,6 +27,16 @@ int main() {
       if (sum.load() != (long)n) return 3;
     }
     pool.run(0, [&](unsigned) {});  // no tasks: returns at once
+    // task counts that GROW from one run() to the next with empty tasks: a worker still leaving run k must not claim
+    // (or double-run) a task of run k + 1 under the old bound
+    for (int round = 0; round < 20000; ++round) {
+      const unsigned n = (round & 1) ? 64u : 1u;
+      std::vector<std::atomic<int>> hits(n);
+      for (auto& h : hits) h = 0;
+      pool.run(n, [&](unsigned t) { hits[t].fetch_add(1); });
+      for (unsigned t = 0; t < n; ++t)
+        if (hits[t].load() != 1) { std::printf("stress: task %u ran %d times\n", t, hits[t].load()); return 4; }
+    }
   }
   std::puts("host_pool ok");
   return 0;

@@ -163,7 +163,8 @@ def test_book_offset_sharding_is_seed_transparent(bk):
 def test_trade_capacity_overflow_is_flagged_not_silent(bk, oracle):
     env = bk.ManyBookEnv(4, 101, 0, 2, 100_000, levels=16, max_live_orders=64, trade_capacity=8, history_capacity=30)
     env.set_random_agents(C2_GROUPS)
-    env.run(30)
+    with pytest.raises(bk.CapacityError, match="TRADE_OVERFLOW"):  # strict (default): a synchronous run() raises
+        env.run(30)
     assert (env.flags() & 2).all()
     total, base = env.trade_count(0)
     assert total > 8 and base == 0
@@ -1065,7 +1066,7 @@ def _compare_market_members(bk, oracle, n_markets, ticks, members, levels, n_ste
                             chunks=None, allow_flags=0):
     A = len(ticks)
     env = bk.ManyMarketEnv(n_markets, seed, 0, ticks, step_size, True, levels=levels, max_live_orders=pool,
-                           trade_capacity=64 * n_steps * 8, history_capacity=n_steps)
+                           trade_capacity=64 * n_steps * 8, history_capacity=n_steps, strict=not allow_flags)
     env.set_market_agents(members)
     for c in (chunks or [n_steps]):
         env.run(c)
@@ -1115,7 +1116,8 @@ def test_agent_price_clamped_off_tick_is_flagged(bk, oracle):
     env = bk.ManyMarketEnv(33, 101, 0, [1, 2], 1_000_000, True, levels=10, max_live_orders=256, trade_capacity=64 * 50 * 8,
                            history_capacity=50)
     env.set_market_agents(m3)
-    env.run(50)
+    with pytest.raises(bk.BourseError, match="PRICE_TICK"):  # the reference panics here; strict envs raise after the run
+        env.run(50)
     ref = oracle.ManyMarkets(33, 101, 0, [1, 2], 1_000_000, True, 10, members=m3)
     ref.run(50, 2)
     f = env.flags()
@@ -1173,11 +1175,11 @@ def test_fuzz_agent_sets_and_markets_vs_oracle(bk, oracle, seed, checkpoint_at=3
         try:
             if A == 1:
                 e = bk.ManyBookEnv(NM, seed, 0, ticks[0], 1_000_000, True, levels=levels, max_live_orders=pool,
-                                   trade_capacity=64 * T * 8, history_capacity=T)
+                                   trade_capacity=64 * T * 8, history_capacity=T, strict=False)
                 e.set_agents([m for _, m in members])
             else:
                 e = bk.ManyMarketEnv(NM, seed, 0, ticks, 1_000_000, True, levels=levels, max_live_orders=pool,
-                                     trade_capacity=64 * T * 8, history_capacity=T)
+                                     trade_capacity=64 * T * 8, history_capacity=T, strict=False)
                 e.set_market_agents(members)
         except bk.CapacityError:
             pytest.skip("the drawn RandomAgents members do not fit the drawn pool")
@@ -1544,8 +1546,157 @@ def test_market_event_queue_overflow_is_flagged_not_silent(bk):
     members = [(0, ("noise", 0, 60, noisy)), (1, ("noise", 100, 60, noisy))]
     env = bk.ManyMarketEnv(70, 3, 0, [1, 1], 1_000_000, True, levels=8, max_live_orders=64, trade_capacity=4096, history_capacity=4)
     env.set_market_agents(members)
-    env.run(6)
+    with pytest.raises(bk.CapacityError, match="EVENT_OVERFLOW"):
+        env.run(6)
     f = env.flags()
     assert (f & 128).any() and not (f & ~np.uint32(1 | 64 | 128)).any(), np.unique(f)
     first, n = env.history_len()
     assert n == 4 and env.history().shape[0] == 4
+
+
+# ------------------------------------------------------------------- every BASELINE config at its stated size
+def _full_size_vs_oracle(bk, oracle, B, levels, T, groups=None, members=None, pool=None, trade_cap=None, pipelines=("auto",),
+                         allow_flags=0, rng_stride=61, sample_books=None):
+    """One BASELINE configuration at its FULL size: every book's level-2 record of every step, every book's trade count,
+    sampled RNG states and sampled trade streams against the oracle (all host threads).  The steps are cut into one
+    launch per entry of `pipelines` (the pipelines share the device state)."""
+    n_agents = sum(g[0] for g in groups) if groups else sum(m[2] for m in members)
+    env = bk.ManyBookEnv(B, 101, 0, 2, 100_000, levels=levels, max_live_orders=pool or min(n_agents, 512),
+                         trade_capacity=trade_cap or n_agents * T, history_capacity=T, strict=False)
+    if groups:
+        env.set_random_agents(groups)
+        ref = oracle.ManyBooks(B, 101, 0, 2, 100_000, True, levels, groups)
+    else:
+        env.set_agents(members)
+        ref = oracle.ManyBooks(B, 101, 0, 2, 100_000, True, levels, members=members)
+    cuts = [T // len(pipelines)] * len(pipelines)
+    cuts[-1] += T - sum(cuts)
+    used = []
+    for c, p in zip(cuts, pipelines):
+        env.set_pipeline(p)
+        used.append(env.pipeline())
+        env.run(c)
+    ref.run(T, os.cpu_count() or 8)
+    f = env.flags()
+    assert not (f & ~np.uint32(allow_flags)).any(), np.unique(f)
+    hist, want = env.history(), ref.history()
+    if not np.array_equal(hist, want):
+        bad = np.argwhere(hist != want)[0]
+        raise AssertionError(f"L2 history differs first at (step, book, word) = {bad}: {hist[tuple(bad)]} vs {want[tuple(bad)]}")
+    assert np.array_equal(env.trade_counts(), ref.trade_counts())
+    wr = ref.rng_states()
+    got = np.array([env.rng_state(b) for b in range(0, B, rng_stride)], dtype=np.uint64)
+    assert np.array_equal(got, wr[::rng_stride])
+    for b in sample_books or (0, B // 3, B // 2, B - 1):
+        g, e = env.trades(b, first=0), ref.book(b).trades_array()
+        for fld in g.dtype.names:
+            assert np.array_equal(g[fld], e[fld]), (b, fld)
+    env.close()
+    return used
+
+
+def test_full_size_c2_exact_parity_vs_oracle(bk, oracle):
+    """BASELINE configs[1]: 4 096 books x 64 RandomAgents x 16 levels, at its size, on the pipeline bk_run
+    picks by itself and on the other ones."""
+    _full_size_vs_oracle(bk, oracle, 4096, 16, 18, groups=C2_GROUPS, pipelines=("auto", "split", "fused"))
+
+
+def test_full_size_c5_standin_exact_parity_vs_oracle(bk, oracle):
+    """BASELINE configs[4] as the RandomAgents deep-book stress: 8 192 books x 512 agents x 64 levels."""
+    _full_size_vs_oracle(bk, oracle, 8192, 64, 8, groups=C5_GROUPS, pipelines=("auto", "fused"), trade_cap=512 * 8)
+
+
+def test_full_size_c5_as_written_exact_parity_vs_oracle(bk, oracle):
+    """BASELINE configs[4] as written: 8 192 books x (256 MomentumAgent + 256 NoiseAgent) x 64 levels, the bench's
+    parameters (bench.py C5M).  BK_FLAG_PRICE_TICK (a log-normal offset clamped to u32::MAX off the tick grid: the
+    reference panics, the order is not created - here and in the oracle) is the one flag allowed."""
+    mom = dict(tick_size=2, p_cancel=0.1, trade_vol=100, decay=1.0, demand=20.0, scale=0.5, order_ratio=1.0,
+               price_dist_mu=0.0, price_dist_sigma=10.0)
+    noise = dict(tick_size=2, p_limit=0.3, p_market=0.2, p_cancel=0.2, trade_vol=100, price_dist_mu=0.0, price_dist_sigma=1.0)
+    _full_size_vs_oracle(bk, oracle, 8192, 64, 12, members=[("momentum", 0, 256, mom), ("noise", 256, 256, noise)],
+                         pool=512, trade_cap=96 * 12, pipelines=("auto", "split_wave"), allow_flags=64, rng_stride=7)
+
+
+# ------------------------------------------------------------------- capacity / mode errors are raised, never silent
+def test_strict_env_raises_on_pool_overflow_in_step(bk):
+    """The reference's book is unbounded; a 65th resting order in a 64-slot pool must not vanish silently: step() raises."""
+    env = bk.ManyBookEnv(2, 1, 0, 1, 1000, levels=10, max_live_orders=64, max_orders=256, trade_capacity=64, history_capacity=4)
+    for i in range(64):
+        env.place_order(0, True, 1, 0, 10 + i)
+    env.step()                                   # exactly full: fine
+    env.place_order(0, True, 1, 0, 5)
+    with pytest.raises(bk.CapacityError, match="POOL_OVERFLOW"):
+        env.step()
+    lax = bk.ManyBookEnv(1, 1, 0, 1, 1000, levels=10, max_live_orders=64, max_orders=256, trade_capacity=64, strict=False)
+    for i in range(65):
+        lax.place_order(0, True, 1, 0, 10 + i)
+    lax.step()                                   # strict=False: the sticky flag is the report
+    assert lax.flags()[0] & 1
+
+
+def test_immediate_mode_order_book_flags_stay_clear(bk):
+    """step_size 0 (immediate mode) used to raise BK_FLAG_STEP_SIZE on every call; the flags must be pollable."""
+    from bourse_amd.core import OrderBook
+
+    ob = OrderBook(0, 1)
+    a = ob.place_order(True, 10, 0, price=50)
+    ob.place_order(False, 10, 1, price=60)
+    ob.cancel_order(a)
+    assert not ob._env.flags().any()
+
+
+def test_host_orders_refused_after_on_device_agents_ran(bk):
+    env = bk.ManyBookEnv(4, 1, 0, 2, 1000, levels=8, max_live_orders=64, max_orders=64, trade_capacity=1024, history_capacity=4)
+    env.set_random_agents(C2_GROUPS)
+    env.run(3)
+    for call in (lambda: env.place_order(0, True, 1, 0, 10), lambda: env.cancel_order(0, 0),
+                 lambda: env.modify_order(0, 0, new_vol=1), env.step):
+        with pytest.raises(bk.BourseError, match="on-device agents"):
+            call()
+
+
+def test_checkpoint_refuses_a_differently_configured_env(bk):
+    def mk(levels=16, groups=C2_GROUPS, books=8):
+        e = bk.ManyBookEnv(books, 101, 0, 2, 100_000, levels=levels, max_live_orders=64, trade_capacity=4096, history_capacity=8)
+        e.set_random_agents(groups)
+        return e
+    a = mk()
+    a.disable_trading()
+    a.run(5)
+    ck = a.checkpoint()
+    for other in (mk(levels=8), mk(books=4), mk(groups=[(32, (40, 56), (10, 20), 2, 0.7), C2_GROUPS[1]])):
+        with pytest.raises(bk.BourseError):
+            other.restore(ck)
+    bad = ck.copy()
+    bad[0] ^= 0xFF                                # magic
+    with pytest.raises(bk.BourseError, match="magic"):
+        mk().restore(bad)
+    b = mk()
+    b.restore(ck)                                 # same shape and agents: accepted, trading flag restored with the books
+    a.run(4)
+    b.run(4)
+    assert np.array_equal(a.level2(), b.level2()) and np.array_equal(a.trade_counts(), b.trade_counts())
+    b.enable_trading()
+    a.enable_trading()
+    a.run(3)
+    b.run(3)
+    assert np.array_equal(a.level2(), b.level2()) and int(a.trade_counts().sum()) > 0
+
+
+def test_step_env_history_outlives_the_device_ring(bk, oracle):
+    """StepEnv keeps every step's record like the reference (data.rs:26-56): the device ring is drained before it wraps."""
+    from bourse_amd.core import StepEnv
+
+    env = StepEnv(7, 0, 1, 1000, history_capacity=4)
+    ref = oracle.StepEnv(7, 0, 1, 1000)
+    for k in range(11):
+        for e in (env, ref):
+            e.place_order(True, 5 + k, 0, price=10 + k)
+            e.place_order(False, 3, 1, price=90 - k)
+            e.step()
+    for name in ("get_prices", "get_volumes", "get_touch_volumes", "get_trade_volumes"):
+        g, w = getattr(env, name)(), getattr(ref, name)()
+        g, w = (g if isinstance(g, tuple) else (g,)), (w if isinstance(w, tuple) else (w,))
+        for x, y in zip(g, w):
+            assert len(x) == 11 and np.array_equal(x, y), name
+    assert all(np.array_equal(v, ref.get_market_data()[k]) for k, v in env.get_market_data().items())
