@@ -25,6 +25,7 @@
 #include "host_math.hpp"
 #include "host_pool.hpp"
 #include "mixed_agents.hpp"
+#include "wave_agents.hpp"
 
 using namespace bkd;
 
@@ -61,6 +62,10 @@ uint64_t fnv1a(const void* p, size_t n, uint64_t h = 1469598103934665603ull) {
 // batch sizes from which bk_run's auto mode takes the split pipeline (measured crossovers: scripts/size_sweep.py,
 // scripts/parts_size_sweep.py, scripts/c5m_sweep.sh)
 constexpr uint32_t RANDOM_SPLIT_MIN_BOOKS = 8192, MIXED_SPLIT_MIN_BOOKS = 4096;
+// RandomAgents batches in [WAVE_MIN_BOOKS, WAVE_MAX_BOOKS] take the wave-parallel RNG decode (k_agents_wave) in front of
+// k_step_batch: below, the fused kernel's single launch per run wins; above, the lane-per-book k_agents_fsm costs fewer
+// issue slots per book-step and its latency is hidden by the other parts (scripts/size_sweep.py)
+constexpr uint32_t WAVE_MIN_BOOKS = 1024, WAVE_MAX_BOOKS = 24576;
 
 struct HostOrder {  // immutable half of an order, fixed at create_order (orderbook.rs:356-396)
   uint8_t bid;
@@ -110,7 +115,15 @@ struct bk_env {
   HostEvent* ev_stage = nullptr;  // pinned staging of the same (uploaded at link speed)
   uint32_t* off_stage = nullptr;
   uint32_t batch_stride = 0;
-  int pipeline = 0;  // 0 auto, 1 fused (k_run_random), 2 split (k_agents_fsm + k_step_batch)
+  int pipeline = 0;  // 0 auto, 1 fused (k_run_random), 2 split (k_agents_fsm + k_step_batch), 4 wave (k_agents_wave + k_step_batch)
+  DevBuf<uint4> jump_tabs;      // k_agents_wave: T^256 (block jump) then T^(4 << b), b = 0..5 (lane offsets): 7 x 8 KB
+  DevBuf<uint32_t> wcache;      // k_agents_wave: per-book lane states of the RNG block in progress
+  uint32_t wave_lookahead = 64;
+  int wave_parts = 0;           // 0 = as the lane split (n_parts / min_part)
+  bool use_wave() const {       // the pipeline bk_run takes for RandomAgents books
+    if (n_mixed || M > 1 || groups.empty()) return false;
+    return pipeline == 4 || (pipeline == 0 && cfg.n_books >= WAVE_MIN_BOOKS && cfg.n_books <= WAVE_MAX_BOOKS);
+  }
   // split pipeline: the batch is cut into n_parts contiguous parts, each on its own stream and started one
   // k_agents_fsm apart, so the latency-bound lane-per-book kernel of one part runs under the issue-bound
   // wave-per-book kernel of another.
@@ -298,9 +311,31 @@ int launch_split(bk_env* env, const DevArgs& a0, uint64_t first_step, uint32_t n
     env->ml_valid = false;
   }
   const MixedLists ml = env->lists();
+  const bool wave = MIXED == 0 && env->use_wave();
+  WaveArgs wva{};
+  if (wave) {
+    if (!env->jump_tabs.p) {
+      std::vector<uint32_t> all;
+      for (int t = 0; t < 7; ++t) {
+        const std::vector<uint32_t> tab = xoroshiro_jump_table(t == 0 ? WV_BLOCK : static_cast<uint64_t>(WV_K) << (t - 1));
+        all.insert(all.end(), tab.begin(), tab.end());
+      }
+      HIPCHK(env->jump_tabs.alloc(all.size() / 4));
+      HIPCHK(hipMemcpy(env->jump_tabs.p, all.data(), all.size() * 4, hipMemcpyHostToDevice));
+      HIPCHK(env->wcache.alloc(static_cast<size_t>(env->cfg.n_books) * WC_STRIDE));
+      HIPCHK(hipMemset(env->wcache.p, 0, static_cast<size_t>(env->cfg.n_books) * WC_STRIDE * 4));
+    }
+    wva.jt_block = env->jump_tabs.p;
+    wva.jt_lane = env->jump_tabs.p + 512;
+    wva.wcache = env->wcache.p;
+    wva.lookahead = env->wave_lookahead;
+  }
   const uint32_t M = env->M;
   const uint32_t B = env->cfg.n_books / M;  // units the parts are cut in: books, or markets of M books
-  const int P = env->parts();  // small batches: one part on the caller's stream
+  // small batches: one part on the caller's stream
+  const int P = (wave && env->wave_parts > 0)
+                    ? static_cast<int>(std::max(1u, std::min<uint32_t>(env->wave_parts, env->cfg.n_books / 64u)))
+                    : env->parts();
   if (P > 1 && !env->ev_fork) {
     HIPCHK(hipEventCreateWithFlags(&env->ev_fork, hipEventDisableTiming));
     for (int i = 0; i < bk_env::MAX_PARTS; ++i) {
@@ -333,6 +368,8 @@ int launch_split(bk_env* env, const DevArgs& a0, uint64_t first_step, uint32_t n
                              mixed_lanes_lds_bytes(R, false), st, a, ma, ml);
         else if (MIXED == 1)
           hipLaunchKernelGGL(k_agents_mixed<R>, dim3((nb + 3) / 4), dim3(256), 0, st, a, ma);
+        else if (wave)
+          hipLaunchKernelGGL(k_agents_wave<R>, dim3((nb + 3) / 4), dim3(256), 0, st, a, wva);
         else
           hipLaunchKernelGGL(k_agents_fsm<R>, dim3((nb + 63) / 64), dim3(64), 0, st, a);
       }
@@ -503,6 +540,7 @@ int bk_env_create(const bk_config* cfg, bk_env** out) {
   if (const char* pm = std::getenv("BOURSE_AMD_PIPELINE")) {
     if (std::strcmp(pm, "fused") == 0) env->pipeline = 1;
     if (std::strcmp(pm, "split") == 0) env->pipeline = 2;
+    if (std::strcmp(pm, "wave") == 0) env->pipeline = 4;
   }
   if (const char* np = std::getenv("BOURSE_AMD_SPLIT_PARTS")) {
     const int v = std::atoi(np);
@@ -1019,7 +1057,7 @@ int bk_run(bk_env* env, uint64_t n_steps) {
   // phases on the scalar unit of ONE wave per book; the split pipeline runs them one lane per book and needs
   // >= 64 books per wave to pay off.  auto: split once the batch fills the chip several times over.
   // Markets always take the split pipeline: the market's RNG-serial phase is one lane, its books are M waves.
-  const bool split = env->pipeline >= 2 || env->M > 1 ||
+  const bool split = env->pipeline >= 2 || env->M > 1 || env->use_wave() ||
                      (env->pipeline == 0 && env->cfg.n_books >= RANDOM_SPLIT_MIN_BOOKS && a.n_groups > 0);
   if (split) {
     switch (env->R) {
@@ -1548,19 +1586,34 @@ int bk_profile_read_kind(bk_env* env, int kind, double* total_ms, uint64_t* n_la
 
 int bk_get_pipeline(bk_env* env, int* split, int* n_parts) {
   if (!env) return fail(BK_INVALID_ARGUMENT, "null env");
-  const bool sp = env->pipeline >= 2 || env->M > 1 ||
+  const bool wv = env->use_wave();
+  const bool sp = wv || env->pipeline >= 2 || env->M > 1 ||
                   (env->pipeline == 0 && (env->n_mixed ? env->cfg.n_books >= MIXED_SPLIT_MIN_BOOKS
                                                        : env->cfg.n_books >= RANDOM_SPLIT_MIN_BOOKS && !env->groups.empty()));
-  const int P = env->parts();
-  if (split) *split = sp ? 1 : 0;
+  const int P = (wv && env->wave_parts > 0)
+                    ? static_cast<int>(std::max(1u, std::min<uint32_t>(env->wave_parts, env->cfg.n_books / 64u)))
+                    : env->parts();
+  if (split) *split = wv ? 2 : (sp ? 1 : 0);
   if (n_parts) *n_parts = sp ? P : 1;
   return BK_OK;
 }
 
 int bk_set_pipeline(bk_env* env, int mode) {
-  if (!env || mode < 0 || mode > 3)
-    return fail(BK_INVALID_ARGUMENT, "pipeline mode must be 0 (auto), 1 (fused), 2 (split) or 3 (split, wave-per-book agents)");
+  if (!env || mode < 0 || mode > 4)
+    return fail(BK_INVALID_ARGUMENT,
+                "pipeline mode must be 0 (auto), 1 (fused), 2 (split), 3 (split, wave-per-book AgentSet members) or 4 (wave: "
+                "wave-parallel RNG decode + event kernel, RandomAgents books)");
   env->pipeline = mode;
+  return BK_OK;
+}
+
+// k_agents_wave knobs: look-ahead of the vector path (1..64 draws; small values force the scalar slow path - tests),
+// parts the wave pipeline cuts the batch in (0 = as the lane split)
+int bk_set_wave_options(bk_env* env, uint32_t lookahead, int parts) {
+  if (!env || lookahead < 1 || lookahead > 64 || parts < 0 || parts > bk_env::MAX_PARTS)
+    return fail(BK_INVALID_ARGUMENT, "lookahead must be in 1..64 and parts in 0..8");
+  env->wave_lookahead = lookahead;
+  env->wave_parts = parts;
   return BK_OK;
 }
 

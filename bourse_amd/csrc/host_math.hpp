@@ -4,6 +4,7 @@
 #pragma once
 #include <cmath>
 #include <cstdint>
+#include <vector>
 
 namespace bkd {
 
@@ -40,5 +41,55 @@ inline int32_t keep_threshold(float p_cancel) {
 
 // UniformInt<u32>::sample_single's acceptance zone for `range` (App. B.3): accept iff lo32(x * range) <= zone
 inline uint32_t sample_zone(uint32_t range) { return (range << __builtin_clz(range)) - 1u; }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Jump-ahead of Xoroshiro128StarStar (rand_xoshiro 0.6.0).  The state transition T is linear over
+// GF(2) on the 128 state bits, so T^n is a 128 x 128 bit matrix; k_agents_wave applies it to a lane's state as the XOR
+// of 32 table entries, one per state nibble: entry (k, v) = T^n applied to the state whose only non-zero nibble is
+// nibble k = v.  Layout: 32 tables x 16 entries x 128 bit (little-endian words s0_lo, s0_hi, s1_lo, s1_hi) = 8 KB.
+inline void xoroshiro_step(uint64_t& s0, uint64_t& s1) {
+  const uint64_t t = s1 ^ s0;
+  s0 = ((s0 << 24) | (s0 >> 40)) ^ t ^ (t << 16);
+  s1 = (t << 37) | (t >> 27);
+}
+constexpr int JUMP_TABLE_WORDS = 32 * 16 * 4;  // u32 words of one table set
+inline std::vector<uint32_t> xoroshiro_jump_table(uint64_t n_steps) {
+  uint64_t col0[128], col1[128];  // T^n of every basis bit
+  for (int b = 0; b < 128; ++b) {
+    uint64_t s0 = b < 64 ? (1ull << b) : 0ull, s1 = b < 64 ? 0ull : (1ull << (b - 64));
+    for (uint64_t i = 0; i < n_steps; ++i) xoroshiro_step(s0, s1);
+    col0[b] = s0;
+    col1[b] = s1;
+  }
+  std::vector<uint32_t> tab(JUMP_TABLE_WORDS);
+  for (int k = 0; k < 32; ++k)
+    for (int v = 0; v < 16; ++v) {
+      uint64_t a0 = 0, a1 = 0;
+      for (int bit = 0; bit < 4; ++bit)
+        if ((v >> bit) & 1) {
+          a0 ^= col0[4 * k + bit];
+          a1 ^= col1[4 * k + bit];
+        }
+      uint32_t* e = tab.data() + (k * 16 + v) * 4;
+      e[0] = static_cast<uint32_t>(a0);
+      e[1] = static_cast<uint32_t>(a0 >> 32);
+      e[2] = static_cast<uint32_t>(a1);
+      e[3] = static_cast<uint32_t>(a1 >> 32);
+    }
+  return tab;
+}
+// the same lookup the device performs (host mirror, used by the CPU test)
+inline void xoroshiro_jump_apply(const uint32_t* tab, uint64_t& s0, uint64_t& s1) {
+  const uint32_t w[4] = {static_cast<uint32_t>(s0), static_cast<uint32_t>(s0 >> 32), static_cast<uint32_t>(s1),
+                         static_cast<uint32_t>(s1 >> 32)};
+  uint32_t acc[4] = {0, 0, 0, 0};
+  for (int d = 0; d < 4; ++d)
+    for (int k = 0; k < 8; ++k) {
+      const uint32_t* e = tab + ((d * 8 + k) * 16 + ((w[d] >> (4 * k)) & 15u)) * 4;
+      for (int i = 0; i < 4; ++i) acc[i] ^= e[i];
+    }
+  s0 = (static_cast<uint64_t>(acc[1]) << 32) | acc[0];
+  s1 = (static_cast<uint64_t>(acc[3]) << 32) | acc[2];
+}
 
 }  // namespace bkd

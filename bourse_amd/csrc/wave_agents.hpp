@@ -1,0 +1,357 @@
+// wave_agents.hpp — k_agents_wave: the RNG-serial half of a book-step (RandomAgents::update for every group +
+// the Fisher-Yates shuffle of Env::step) with ONE WAVE PER BOOK and the book's RNG stream decoded 64 draws at a time.
+//
+// Why: the lane-per-book k_agents_fsm walks ~600 dependent draws per book-step at the ~6.5 clocks a lone wave gets per
+// instruction — a 140 us floor per step however few books there are, which is what strong scaling over
+// 8 GPUs (8 192 books per GPU) runs into.  Here the stream itself is parallel:
+//
+//   * xoroshiro128** is F2-linear: lane j keeps the generator state 4 j draws ahead of the block
+//     start, produces its 4 draws independently, and the 64 lane states move to the next 256-draw block by T^256,
+//     applied as the XOR of 32 entries of a nibble-indexed table (8 KB of LDS per workgroup; host_math.hpp builds it,
+//     tests/cpp/host_math_test.cpp checks it against single steps).
+//   * consumption order is data dependent (rejection sampling; an agent that holds an Active order cancels instead of
+//     drawing side / tick / vol: ref crates/step_sim/src/agents/random_agent.rs:91-101).  Per 64-draw window the wave
+//     builds ballot masks (activity hit, accept for range 2 / tick range / vol range), every lane p precomputes where
+//     the stream would stand after a placement STARTING at p (three first-set-bit searches over a 128-draw look-ahead)
+//     and what that order would be; a scalar walk then only visits the activity HITS (s_ff1 skips the runs of
+//     inactive agents) and consumes one cancellation or one whole placement per iteration.
+//   * the shuffle's acceptance test depends on how many earlier draws were accepted (the range i + 1 shrinks,
+//     env.rs:121 / rand SliceRandom::shuffle): a fixed-point iteration over the window's accept mask — exact, because
+//     lane 0's count is always right and correctness spreads left to right — then the swaps in order.
+//   A placement whose draws run past the look-ahead (probability ~2^-60 at the shipped 64; forced in tests by a tiny
+//   look-ahead) is resolved draw by draw on the scalar path.
+//
+// Output: the same per-book step batch k_agents_fsm writes (book_device.hpp "step batch layout"), consumed by
+// k_step_batch unchanged.  tools/wave_decode_proto.py is the plain-Python model of this file (CPU test).
+#pragma once
+#include "book_device.hpp"
+
+namespace bkd {
+
+constexpr uint32_t WV_K = 4;                   // draws per lane per block
+constexpr uint32_t WV_BLOCK = 64 * WV_K;       // 256 draws
+constexpr uint32_t WV_RING = 2 * WV_BLOCK;     // generated draws kept in LDS
+constexpr uint32_t WC_HDR = 64;                // cache record: 64 header dwords (lane i holds dword i) + 64 x uint4 states
+constexpr uint32_t WC_STRIDE = WC_HDR + 256;   // dwords per book
+constexpr uint32_t WC_MAGIC = 0x45564157u;     // "WAVE"
+enum WcHdr : int { WC_S0_LO = 0, WC_S0_HI, WC_S1_LO, WC_S1_HI, WC_OFF, WC_TAG };
+constexpr uint32_t WV_NONE = 0xFFFFu;          // "placement not resolvable inside the look-ahead"
+
+struct WaveArgs {
+  const uint4* jt_block;  // T^256: 32 x 16 entries
+  const uint4* jt_lane;   // T^(4 << b), b = 0..5: lane offsets when the cached lane states do not match the book's RNG
+  uint32_t* wcache;       // [n_books][WC_STRIDE]: lane states of the block the book's RNG stands in + offset
+  uint32_t lookahead;     // draws beyond the window a placement may use on the vector path (1..64)
+};
+
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+// T^n applied to the lane's state {s0_lo, s0_hi, s1_lo, s1_hi}: XOR of one table entry per state nibble
+__device__ __forceinline__ uint4 wv_jump(const uint4* __restrict__ tab, uint4 s) {
+  const uint32_t w[4] = {s.x, s.y, s.z, s.w};
+  uint4 acc = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+  for (int d = 0; d < 4; ++d) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const uint32_t idx = (w[d] >> (4 * k)) & 15u;
+      const uint4 e = tab[(d * 8 + k) * 16 + idx];
+      acc.x ^= e.x;
+      acc.y ^= e.y;
+      acc.z ^= e.z;
+      acc.w ^= e.w;
+    }
+  }
+  return acc;
+}
+
+// index of the first set bit ABOVE position i in the 128-bit mask hi:lo (i per lane); >= 128 if there is none
+__device__ __forceinline__ uint32_t first_above(uint64_t lo, uint64_t hi, uint32_t i) {
+  const uint32_t n = i + 1u;
+  const uint64_t l = n < 64u ? (lo >> n) : 0ull;
+  const uint64_t h = n < 64u ? hi : (n < 128u ? (hi >> (n - 64u)) : 0ull);
+  const uint32_t hb = n < 64u ? 64u : n;
+  const uint32_t ql = n + (uint32_t)__builtin_ctzll(l | (1ull << 63));
+  const uint32_t qh = hb + (uint32_t)__builtin_ctzll(h | (1ull << 63));
+  return l ? ql : (h ? qh : 256u);
+}
+
+template <int R>
+__global__ __launch_bounds__(256, 8) void k_agents_wave(DevArgs a, WaveArgs wa) {
+  __shared__ uint4 tab[512];
+  __shared__ uint32_t ring_s[4][WV_RING];
+  __shared__ uint16_t evl_s[4][64 * R];
+  __shared__ uint32_t pm_s[4][2 * R], sm_s[4][2 * R];
+  const int lane = threadIdx.x & 63;
+  const int wv = threadIdx.x >> 6;
+  for (int i = threadIdx.x; i < 512; i += 256) tab[i] = wa.jt_block[i];
+  __syncthreads();
+  const uint32_t book = rfl(a.book_begin + blockIdx.x * 4 + wv);
+  if (book >= a.book_end) return;
+  uint32_t* st = a.state + (size_t)book * a.state_stride;
+  uint32_t* bt = a.batch + (size_t)book * a.batch_stride;
+  uint32_t* wc = wa.wcache + (size_t)book * WC_STRIDE;
+  uint32_t* ring = ring_s[wv];
+  uint4* ring4 = reinterpret_cast<uint4*>(ring);
+  uint16_t* evl = evl_s[wv];
+  uint32_t* pm = pm_s[wv];
+  uint32_t* sm = sm_s[wv];
+  uint2* pv = reinterpret_cast<uint2*>(bt + BT_EV + 32 * R);
+
+  // ---- the book's RNG state and live masks (header), the cached lane states
+  const uint32_t hdr = st[lane];
+  const uint32_t wch = wc[lane];
+  uint4 cs = reinterpret_cast<const uint4*>(wc + WC_HDR)[lane];  // chunk-start state of this lane in the cached block
+  const uint32_t s0l = rdl(hdr, H_S0_LO), s0h = rdl(hdr, H_S0_HI), s1l = rdl(hdr, H_S1_LO), s1h = rdl(hdr, H_S1_HI);
+  uint64_t live[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) live[r] = mk64(rdl(hdr, H_LIVE0 + 2 * r), rdl(hdr, H_LIVE0 + 2 * r + 1));
+  if (lane < 2 * R) {
+    pm[lane] = 0;
+    sm[lane] = 0;
+  }
+  uint32_t pos = rdl(wch, WC_OFF);  // stream position inside the cached block (0..255)
+  const bool cached = rdl(wch, WC_TAG) == WC_MAGIC && rdl(wch, WC_S0_LO) == s0l && rdl(wch, WC_S0_HI) == s0h &&
+                      rdl(wch, WC_S1_LO) == s1l && rdl(wch, WC_S1_HI) == s1h && pos < WV_BLOCK;
+  if (!cached) {
+    // another pipeline (or a restore / a fresh env) moved the RNG: lane j = T^(4 j) of the book's state, by doubling
+    cs = make_uint4(s0l, s0h, s1l, s1h);
+    for (int b = 0; b < 6; ++b) {
+      const uint4 j = wv_jump(wa.jt_lane + b * 512, cs);
+      const bool take = (lane >> b) & 1;
+      cs.x = take ? j.x : cs.x;
+      cs.y = take ? j.y : cs.y;
+      cs.z = take ? j.z : cs.z;
+      cs.w = take ? j.w : cs.w;
+    }
+    pos = 0;
+  }
+  uint4* wcs = reinterpret_cast<uint4*>(wc + WC_HDR);
+  uint32_t gen_end = 0;      // draws generated so far (this launch's stream origin = start of the cached block)
+
+  auto gen_block = [&]() {   // next 256 draws into the ring; cs = chunk-start states of the block just generated
+    if (gen_end != 0) {
+      // the stream position may still lie in the block being left when the launch ends (look-ahead): its chunk-start
+      // states go to the cache record now (a fire-and-forget 1 KB store instead of four live registers)
+      wcs[lane] = cs;
+      cs = wv_jump(tab, cs);
+    }
+    RngLane t{cs.x, cs.y, cs.z, cs.w};
+    uint4 x;
+    x.x = t.next_u32();
+    x.y = t.next_u32();
+    x.z = t.next_u32();
+    x.w = t.next_u32();
+    ring4[((gen_end >> 2) + lane) & (WV_RING / 4 - 1)] = x;
+    gen_end += WV_BLOCK;
+    wave_sync();
+  };
+  auto ensure = [&](uint32_t upto) {
+    while (gen_end < upto) gen_block();
+  };
+
+  // ================= agents.update: groups in declaration order (crates/macros/src/lib.rs:57-73) =================
+  const uint32_t lim = 64u + (wa.lookahead < 1u ? 1u : (wa.lookahead > 64u ? 64u : wa.lookahead));
+  uint32_t n_ev = 0, ag = 0, gbase = 0;
+  for (uint32_t g = 0; g < a.n_groups; ++g) {
+    const Group G = a.groups[g];
+    const uint32_t gend = gbase + G.n;
+    gbase = gend;
+    while (ag < gend) {
+      // ---- window [w0, w0 + 64) of the stream + 64 draws of look-ahead
+      const uint32_t w0 = pos & ~63u;
+      ensure(w0 + 128u);
+      const uint32_t xc = ring[(w0 + lane) & (WV_RING - 1)], xn = ring[(w0 + 64u + lane) & (WV_RING - 1)];
+      // p = gen::<f32>() < activity_rate (random_agent.rs:91-93) as an integer threshold (host_math.hpp)
+      const uint64_t H = __ballot((xc >> 8) < G.thr);
+      // UniformInt<u32>::sample_single: accept iff lo32(x * range) <= zone.  range 2: bit 30 clear.
+      const uint64_t A2l = __ballot((xc & 0x40000000u) == 0u), A2h = __ballot((xn & 0x40000000u) == 0u);
+      const uint64_t ATl = __ballot(xc * G.tick_rng <= G.tick_zone), ATh = __ballot(xn * G.tick_rng <= G.tick_zone);
+      const uint64_t AVl = __ballot(xc * G.vol_rng <= G.vol_zone), AVh = __ballot(xn * G.vol_rng <= G.vol_zone);
+      // lane p: the placement that starts if the activity draw at p hits and the agent holds no Active order:
+      // side = [Ask, Bid].choose, tick, vol in that order (random_agent.rs:99-101)
+      const uint32_t q1 = first_above(A2l, A2h, (uint32_t)lane);
+      const uint32_t q2 = first_above(ATl, ATh, q1);
+      const uint32_t q3 = first_above(AVl, AVh, q2);
+      const uint32_t fpos = q3 < lim ? q3 + 1u : WV_NONE;
+      const uint32_t x1 = ring[(w0 + q1) & (WV_RING - 1)], x2 = ring[(w0 + q2) & (WV_RING - 1)],
+                     x3 = ring[(w0 + q3) & (WV_RING - 1)];
+      const uint32_t fside = x1 >> 31;  // hi32(x * 2): 0 = Ask, 1 = Bid
+      const uint32_t fprice = (G.tick_lo + __umulhi(x2, G.tick_rng)) * G.tick_size;
+      const uint32_t fvol = G.vol_lo + __umulhi(x3, G.vol_rng);
+
+      // ---- scalar walk over the activity hits of this window
+      uint32_t p = pos - w0;
+      uint64_t acted = 0, placed = 0;
+      uint32_t agw = 0, evi = 0;
+      while (p < 64u && ag < gend) {
+        const uint64_t m = H >> p;
+        if (m == 0) {  // no further hit in the window: the remaining draws are inactive agents'
+          const uint32_t adv = (64u - p) < (gend - ag) ? (64u - p) : (gend - ag);
+          ag += adv;
+          p += adv;
+          break;
+        }
+        const uint32_t d = (uint32_t)__builtin_ctzll(m);
+        if (ag + d >= gend) {  // the group ends before the next hit
+          p += gend - ag;
+          ag = gend;
+          break;
+        }
+        ag += d;
+        p += d;
+        const uint64_t bit = 1ull << p;
+        if (mask_test<R>(live, ag)) {  // holds an Active order: queue its cancellation (random_agent.rs:95-97)
+          agw = wrl(ag, p, agw);
+          evi = wrl(n_ev, p, evi);
+          acted |= bit;
+          n_ev += 1;
+          ag += 1;
+          p += 1;
+          continue;
+        }
+        const uint32_t fp = rdl(fpos, p);
+        if (fp != WV_NONE) {
+          agw = wrl(ag | EV_NEW, p, agw);
+          evi = wrl(n_ev, p, evi);
+          acted |= bit;
+          placed |= bit;
+          n_ev += 1;
+          ag += 1;
+          p = fp;
+          continue;
+        }
+        // slow path: the placement's draws run past the look-ahead; resolve it draw by draw (generating as needed:
+        // the window's draws are already in registers, the ring may move on)
+        uint32_t q = w0 + p + 1u, val[3];
+        const uint32_t rng3[3] = {2u, G.tick_rng, G.vol_rng}, zone3[3] = {0x7FFFFFFFu, G.tick_zone, G.vol_zone};
+#pragma unroll
+        for (int sgi = 0; sgi < 3; ++sgi) {
+          for (;;) {
+            ensure(q + 1u);
+            const uint32_t x = rfl(ring[q & (WV_RING - 1)]);
+            ++q;
+            const uint64_t mm = (uint64_t)x * rng3[sgi];
+            if ((uint32_t)mm <= zone3[sgi]) {
+              val[sgi] = (uint32_t)(mm >> 32);
+              break;
+            }
+          }
+        }
+        if (lane == 0) {
+          evl[n_ev] = (uint16_t)(ag | EV_NEW | (val[0] << 14));
+          pv[ag] = make_uint2((G.tick_lo + val[1]) * G.tick_size, G.vol_lo + val[2]);
+          atomicOr(&pm[ag >> 5], 1u << (ag & 31u));
+          atomicOr(&sm[ag >> 5], val[0] << (ag & 31u));
+        }
+        n_ev += 1;
+        ag += 1;
+        p = q - w0;
+        break;
+      }
+      // ---- the window's events, one lane each: list entry (agent order = stream order) and the new order's fields
+      if (lane_bit(acted)) evl[evi] = (uint16_t)(agw | (lane_bit(placed) ? (fside << 14) : 0u));
+      if (lane_bit(placed)) {
+        const uint32_t slot = agw & EV_SLOT;
+        pv[slot] = make_uint2(fprice, fvol);
+        atomicOr(&pm[slot >> 5], 1u << (slot & 31u));
+        atomicOr(&sm[slot >> 5], fside << (slot & 31u));
+      }
+      pos = w0 + p;
+    }
+  }
+  wave_sync();
+
+  // ================= transactions.shuffle(rng) (env.rs:121): for i in (1..n).rev() swap(i, gen_range(0..i+1)) =====
+  {
+    uint32_t i = n_ev > 0 ? n_ev - 1u : 0u;
+    while (i >= 1u) {
+      const uint32_t w0 = pos & ~63u, p0 = pos - w0;
+      ensure(w0 + 64u);
+      const uint32_t x = ring[(w0 + lane) & (WV_RING - 1)];
+      const uint64_t valid = ~0ull << p0;
+      const bool is_valid = (uint32_t)lane >= p0;
+      // draw p serves index i - (#accepted draws before p): iterate the accept mask to its (unique) fixed point
+      uint64_t acc = valid;
+      uint32_t ii = 0, jj = 0;
+      for (;;) {
+        const uint32_t k = __builtin_amdgcn_mbcnt_hi((uint32_t)(acc >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)acc, 0u));
+        ii = i - k;                                  // <= 0 (wrapped): past the end of the shuffle
+        const uint32_t r = ii + 1u;                  // range i + 1
+        const bool in_range = is_valid && k < i;     // ii >= 1
+        const uint32_t zone = (r << __builtin_clz(r | 1u)) - 1u;
+        const uint64_t mm = (uint64_t)x * r;
+        jj = (uint32_t)(mm >> 32);
+        const uint64_t nacc = __ballot(in_range && (uint32_t)mm <= zone);
+        if (nacc == acc) break;
+        acc = nacc;
+      }
+      const uint32_t cnt = (uint32_t)__builtin_popcountll(acc);
+      // the swaps, in stream order (uniform addresses: every lane reads the same pair, every lane writes the same values)
+      uint64_t todo = acc;
+      while (todo) {
+        const uint32_t l = (uint32_t)__builtin_ctzll(todo);
+        todo &= todo - 1ull;
+        const uint32_t si = rdl(ii, l), sj = rdl(jj, l);
+        const uint16_t ea = evl[si], eb = evl[sj];
+        wave_sync();
+        evl[si] = eb;
+        evl[sj] = ea;
+        wave_sync();
+      }
+      i -= cnt;  // cnt <= i by construction
+      // draws consumed: up to the accepted draw that served index 1, else the whole window
+      pos = w0 + ((i < 1u && acc) ? (64u - (uint32_t)__builtin_clzll(acc)) : 64u);
+    }
+  }
+
+  // ================= publish: RNG state, lane-state cache, step batch =================
+  {
+    const bool in_last = pos + WV_BLOCK >= gen_end;  // pos lies in the last generated block (or at its end)
+    uint4 bs = cs;
+    if (!in_last) bs = wcs[lane];  // the block before the last generated one: stored when it was left (same lane)
+    uint32_t c2 = pos - (in_last ? gen_end - WV_BLOCK : gen_end - 2u * WV_BLOCK);
+    if (gen_end == 0) c2 = pos;  // nothing generated (no agents, no events): the cached block start is still `cs`
+    if (c2 == WV_BLOCK) {        // exactly at the block end: the cache describes the next block
+      bs = wv_jump(tab, bs);
+      c2 = 0;
+    }
+    RngLane t{bs.x, bs.y, bs.z, bs.w};
+    const uint32_t nst = c2 & (WV_K - 1u);
+    for (uint32_t s = 0; s < nst; ++s) (void)t.next_u32();
+    const uint32_t src = c2 >> 2;
+    const uint32_t n0 = rdl(t.a0, src), n1 = rdl(t.a1, src), n2 = rdl(t.b0, src), n3 = rdl(t.b1, src);
+    uint32_t hv = lane == 0 ? n0 : (lane == 1 ? n1 : (lane == 2 ? n2 : n3));
+    if (lane < 4) st[H_S0_LO + lane] = hv;
+    uint32_t cw = 0;
+    cw = lane == WC_S0_LO ? n0 : cw;
+    cw = lane == WC_S0_HI ? n1 : cw;
+    cw = lane == WC_S1_LO ? n2 : cw;
+    cw = lane == WC_S1_HI ? n3 : cw;
+    cw = lane == WC_OFF ? c2 : cw;
+    cw = lane == WC_TAG ? WC_MAGIC : cw;
+    wc[lane] = cw;
+    wcs[lane] = bs;
+  }
+  {
+    uint32_t hb = 0;
+    hb = lane == BT_NEV ? n_ev : hb;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      hb = lane == BT_PEND + 2 * r ? pm[2 * r] : hb;
+      hb = lane == BT_PEND + 2 * r + 1 ? pm[2 * r + 1] : hb;
+      hb = lane == BT_SIDE + 2 * r ? sm[2 * r] : hb;
+      hb = lane == BT_SIDE + 2 * r + 1 ? sm[2 * r + 1] : hb;
+    }
+    bt[lane] = hb;
+    for (uint32_t k = lane; k < 32u * R; k += 64u) {
+      const uint32_t lo = 2u * k < n_ev ? evl[2u * k] : 0u, hi = 2u * k + 1u < n_ev ? evl[2u * k + 1u] : 0u;
+      bt[BT_EV + k] = lo | (hi << 16);
+    }
+  }
+}
+
+}  // namespace bkd

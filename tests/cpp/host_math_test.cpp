@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstring>
 #include <random>
+#include <vector>
 
 #include "../../bourse_amd/csrc/host_math.hpp"
 
@@ -53,6 +54,28 @@ int main(int argc, char** argv) {
     const int lz = __builtin_clz(range);
     if (z != ((range << lz) - 1u)) return 2;
     if (z < range - 1u) return 2;  // at least one full period of residues is accepted
+  }
+  // jump tables of the wave-parallel RNG decode: T^n by table == n single steps, for the block jump (256), the lane
+  // offsets (4 << b) and a few odd counts, on random states; and the published xoroshiro128** vector for the step itself
+  {
+    uint64_t a0 = 1, a1 = 2;  // outputs 5760, 97769243520, ... from state (1, 2)
+    const uint64_t r0 = ((a0 * 5) << 7 | (a0 * 5) >> 57) * 9;
+    if (r0 != 5760ull) return 4;
+    bkd::xoroshiro_step(a0, a1);
+    const uint64_t x = a0 * 5, r1 = ((x << 7) | (x >> 57)) * 9;
+    if (r1 != 97769243520ull) return 4;
+    for (uint64_t n : {0ull, 1ull, 4ull, 8ull, 16ull, 32ull, 64ull, 128ull, 256ull, 1000ull}) {
+      const std::vector<uint32_t> tab = bkd::xoroshiro_jump_table(n);
+      for (int rep = 0; rep < 50; ++rep) {
+        uint64_t s0 = rng(), s1 = rng();
+        if (rep == 0) { s0 = 0; s1 = 0; }
+        if (rep == 1) { s0 = ~0ull; s1 = ~0ull; }
+        uint64_t j0 = s0, j1 = s1, t0 = s0, t1 = s1;
+        bkd::xoroshiro_jump_apply(tab.data(), j0, j1);
+        for (uint64_t i = 0; i < n; ++i) bkd::xoroshiro_step(t0, t1);
+        if (j0 != t0 || j1 != t1) { std::printf("jump table n=%llu mismatch\n", (unsigned long long)n); return 4; }
+      }
+    }
   }
   uint64_t s0, s1;
   bkd::seed_from_u64(101, s0, s1);

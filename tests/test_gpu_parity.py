@@ -45,7 +45,7 @@ def test_dpp_reductions(bk):
 
 
 def _compare_random(bk, oracle, n_books, groups, levels, n_steps, seed=101, tick=2, step_size=100_000, chunks=None,
-                    max_live=None, trade_cap=None, pipeline="fused"):
+                    max_live=None, trade_cap=None, pipeline="fused", lookahead=None, wave_parts=0):
     n_agents = sum(g[0] for g in groups)
     if chunks:
         n_steps = sum(chunks)
@@ -53,9 +53,11 @@ def _compare_random(bk, oracle, n_books, groups, levels, n_steps, seed=101, tick
                          max_live_orders=max_live or n_agents, trade_capacity=trade_cap or 2 * n_agents * n_steps,
                          history_capacity=n_steps)
     env.set_random_agents(groups)
+    if lookahead is not None:
+        env.set_wave_options(lookahead, wave_parts)
     for i, c in enumerate(chunks or [n_steps]):
-        # "mixed": alternate the two kernel pipelines between launches — they share the device state
-        env.set_pipeline(("fused", "split")[i % 2] if pipeline == "mixed" else pipeline)
+        # "mixed": alternate the kernel pipelines between launches — they share the device state
+        env.set_pipeline(("fused", "wave", "split", "wave")[i % 4] if pipeline == "mixed" else pipeline)
         env.run(c)
     ref = oracle.ManyBooks(n_books, seed, 0, tick, step_size, True, levels, groups)
     ref.run(n_steps, n_threads=4)
@@ -97,7 +99,9 @@ def _compare_random(bk, oracle, n_books, groups, levels, n_steps, seed=101, tick
     return hist
 
 
-PIPELINES = ["fused", "split"]  # one wave per book for everything / RNG phases one lane per book + event kernel
+# one wave per book for everything / RNG phases one lane per book + event kernel / RNG phases one wave per book with the
+# wave-parallel stream decode (k_agents_wave) + event kernel
+PIPELINES = ["fused", "split", "wave"]
 
 
 @pytest.mark.parametrize("pipeline", PIPELINES)
@@ -145,6 +149,28 @@ def test_chunked_launches_equal_one_launch(bk, oracle, pipeline):
     assert np.array_equal(a, b)
 
 
+@pytest.mark.parametrize("lookahead", [1, 2, 7, 33])
+def test_wave_decode_slow_path_small_lookahead(bk, oracle, lookahead):
+    """k_agents_wave resolves a placement on its vector path only if its side / tick / vol draws end inside the
+    look-ahead; otherwise draw by draw on the scalar path.  A tiny look-ahead sends most placements there: the
+    results must not change (nor across launch chunkings, which restart from the cached lane states)."""
+    _compare_random(bk, oracle, n_books=70, groups=C3_GROUPS, levels=32, n_steps=30, pipeline="wave", lookahead=lookahead,
+                    chunks=[1, 4, 25])
+    _compare_random(bk, oracle, n_books=9, groups=[(5, (10, 14), (1, 3), 3, 0.0), (37, (10, 14), (1, 3), 3, 1.0),
+                                                    (23, (9, 13), (1, 2), 6, 0.5)], levels=4, n_steps=40, tick=3,
+                    pipeline="wave", lookahead=lookahead)
+
+
+def test_wave_decode_many_parts_and_odd_batches(bk, oracle):
+    # more parts than the default, book counts that are not multiples of 4 (the workgroup holds four books)
+    for nb, parts in ((5, 2), (130, 3), (257, 8)):
+        _compare_random(bk, oracle, n_books=nb, groups=C2_GROUPS, levels=16, n_steps=16, pipeline="wave", lookahead=64,
+                        wave_parts=parts)
+    # every agent acts every step (rate 1): the longest streams, group boundaries in every window
+    _compare_random(bk, oracle, n_books=33, groups=[(100, (10, 100), (1, 2), 1, 1.0), (28, (50, 51), (5, 6), 1, 1.0)], levels=10,
+                    n_steps=25, tick=1, pipeline="wave")
+
+
 def test_book_offset_sharding_is_seed_transparent(bk):
     # books [4, 12) of a 16-book run equal an 8-book env created with book_offset=4 (multi-GPU sharding rule)
     full = bk.ManyBookEnv(16, 101, 0, 2, 100_000, levels=16, max_live_orders=64, trade_capacity=4096, history_capacity=20)
@@ -180,6 +206,7 @@ def test_trade_capacity_overflow_is_flagged_not_silent(bk, oracle):
         got, exp = env.trades(b, first=0, n=8), ref.book(b).trades_array()[:8]
         for f in got.dtype.names:
             assert np.array_equal(got[f], exp[f]), (b, f)
+    env.strict = False  # the flag is sticky: a strict env would raise again
     env.run(5)  # the L2 history is a ring of the last 30 steps: stepping on is fine ...
     first, n = env.history_len()
     assert (first, n) == (5, 30)
@@ -653,7 +680,7 @@ def _compare_members(bk, oracle, n_books, members, levels, n_steps, tick=1, step
     return hist
 
 
-@pytest.mark.parametrize("pipeline", PIPELINES + ["split_wave"])
+@pytest.mark.parametrize("pipeline", ["fused", "split", "split_wave"])
 def test_noise_agents_on_device(bk, oracle, pipeline):
     _compare_members(bk, oracle, 24, [("noise", 0, 20, NOISE_P)], levels=10, n_steps=80, pipeline=pipeline)
     _compare_members(bk, oracle, 5, [("noise", 3, 50, dict(NOISE_P, p_limit=0.6, p_market=0.1, p_cancel=0.3, price_dist_sigma=2.5,
