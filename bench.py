@@ -142,7 +142,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--l1-gather", action="store_true", help="also all-gather every book's L1 record per launch (SURVEY 8e ii)")
     ap.add_argument("--no-history", action="store_true", help="keep only the latest L2 record (diagnostic)")
-    ap.add_argument("--pipeline", default="auto", choices=["auto", "fused", "split"])
+    ap.add_argument("--pipeline", default="auto", choices=["auto", "fused", "split", "wave_split", "wave"])
+    ap.add_argument("--wave-parts", type=int, default=0, help="parts the wave pipeline cuts the batch in (0 = library default)")
     ap.add_argument("--profile-every", type=int, default=8, help="HIP-event-time every Nth step's kernels (0 = none)")
     ap.add_argument("--repeats", type=int, default=4, help="extra timed regions of --steps after the reported one (median in `runs`)")
     args = ap.parse_args()
@@ -196,6 +197,9 @@ def main():
     else:
         env.set_random_agents(groups)
     env.set_pipeline(args.pipeline)
+    if args.wave_parts:
+        env.set_wave_options(64, args.wave_parts)
+    pipe, parts = env.pipeline()
     gather = parallel.StatsGather(env, dist) if dist is not None else None
     if args.l1_gather and books_total != world * B:
         raise SystemExit("--l1-gather needs equal shards (all_gather_into_tensor)")
@@ -229,8 +233,8 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
     env.profile(False)
-    kind0 = "k_run_mixed" if mixed else "k_run_random"
-    kind1 = "k_agents_mixed_lanes" if mixed else "k_agents_fsm"
+    kind0 = "k_run_mixed" if mixed else ("k_run_wave" if pipe == "wave" else "k_run_random")
+    kind1 = "k_agents_mixed_lanes" if mixed else ("k_agents_wave" if pipe == "wave_split" else "k_agents_fsm")
     per_kind = {k: env.profile_read_kind(i) for i, k in enumerate((kind0, kind1, "k_step_batch", "k_step_events"))}
     env.profile_read()
     if dist is not None:
@@ -256,17 +260,22 @@ def main():
     tr_per_bs = n_trades / (B * args.steps)
     ev_per_bs = st["sum_events"] / (B * (args.steps + args.warmup))
     new_per_bs = n_new / (B * args.steps)
-    pipe, parts = env.pipeline()
     per_bs = {
-        kind0: 2.0 * S / spl + W4 + 32.0 * tr_per_bs,
+        # fused kernels: the book block in and out once per launch, the L2 record and the trade records every step;
+        # k_run_wave adds its lane-state record (1.3 KB in / out per launch, ~2.5 KB of block-start spills per step)
+        kind0: 2.0 * S / spl + W4 + 32.0 * tr_per_bs + ((2.0 * 1280.0 / spl + 2.5 * 1024.0) if pipe == "wave" else 0.0),
         "k_agents_fsm": 32.0 + 96.0 + 2.0 * ev_per_bs + 8.0 * new_per_bs,
+        # wave-per-book decode: header line + lane-state record (64 x 16 B + 256 B) in; record out, ~2.5 block-start
+        # spills of 1 KB (one per 256-draw block crossed), RNG state, step batch (256 B header + list + new orders) out
+        "k_agents_wave": 256.0 + 1280.0 + 1280.0 + 2.5 * 1024.0 + 16.0 + 256.0 + 2.0 * ev_per_bs + 8.0 * new_per_bs,
         # lane-per-book members' update: RNG + live-mask line + touches in; the members' lists in and out (2-byte slots,
         # about one entry per resting order ~ events), 16 B per new order into the pool, the shuffled event list out
         "k_agents_mixed_lanes": 192.0 + 4.0 * ev_per_bs + 16.0 * new_per_bs + 2.0 * ev_per_bs,
         "k_step_batch": 2.0 * S + 64.0 + 2.0 * ev_per_bs + 8.0 * new_per_bs + W4 + 32.0 * tr_per_bs,
         "k_step_events": 2.0 * S + 2.0 * W4 + 20.0 * ev_per_bs + 32.0 * tr_per_bs,
     }
-    bs_per_launch = {kind0: B * spl, "k_agents_fsm": B / parts, "k_agents_mixed_lanes": B / parts, "k_step_batch": B / parts,
+    bs_per_launch = {kind0: B * spl, "k_agents_fsm": B / parts, "k_agents_wave": B / parts, "k_agents_mixed_lanes": B / parts,
+                     "k_step_batch": B / parts,
                      "k_step_events": B}
     # PMC figures (HBM traffic, instruction counts) cannot be collected inside this process: they are rocprofv3 --pmc
     # passes of this same command (scripts/profile_round.sh), committed under profiles/ and REPLAYED here, keyed by
@@ -327,8 +336,8 @@ def main():
                            f"collective, 64 B stats all-gather per launch" if world > 1 else "single GPU",
             "trades_per_book_step": tr_per_bs, "events_per_book_step": ev_per_bs,
             "events_per_s": ev_per_bs * value, "trades_per_s": tr_per_bs * value,
-            "pipeline": f"split ({kind1} + k_step_batch per step, {parts} book parts on separate streams)"
-            if pipe == "split" else f"fused ({kind0})",
+            "pipeline": f"{pipe} ({kind1} + k_step_batch per step, {parts} book parts on separate streams)"
+            if pipe in ("split", "wave_split") else f"fused ({kind0})",
         },
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -367,8 +376,10 @@ def main():
     R["peak_node"] = HBM_PEAK_GBPS * world
     R["frac_node"] = R["achieved_node"] / R["peak_node"]
     R["traffic_source"] = pmc_src if traffic is not None else None
-    if pipe == "split" and parts > 1:
+    if pipe in ("split", "wave_split") and parts > 1:
         env.set_split_parts(1, 64)
+        if pipe == "wave_split":
+            env.set_wave_options(64, 1)
         env.profile(1)
         run_steps(min(16, args.steps))
         env.sync()
@@ -376,6 +387,8 @@ def main():
         ms1, n1 = env.profile_read_kind(2)
         env.profile_read()
         env.set_split_parts(3, 4096)
+        if pipe == "wave_split":
+            env.set_wave_options(64, args.wave_parts)
         if n1:
             a1 = per_bs["k_step_batch"] * B / (ms1 / n1 * 1e-3) / 1e9
             R["standalone"] = {"kernel": "k_step_batch", "book_steps_per_launch": B, "avg_launch_ms": ms1 / n1, "launches": n1,

@@ -115,14 +115,17 @@ struct bk_env {
   HostEvent* ev_stage = nullptr;  // pinned staging of the same (uploaded at link speed)
   uint32_t* off_stage = nullptr;
   uint32_t batch_stride = 0;
-  int pipeline = 0;  // 0 auto, 1 fused (k_run_random), 2 split (k_agents_fsm + k_step_batch), 4 wave (k_agents_wave + k_step_batch)
+  // 0 auto, 1 fused (k_run_random), 2 split (k_agents_fsm + k_step_batch), 3 split with wave-per-book AgentSet members,
+  // 4 wave_split (k_agents_wave + k_step_batch), 5 wave (k_run_wave: wave-parallel decode + events, persistent)
+  int pipeline = 0;
   DevBuf<uint4> jump_tabs;      // k_agents_wave: T^256 (block jump) then T^(4 << b), b = 0..5 (lane offsets): 7 x 8 KB
   DevBuf<uint32_t> wcache;      // k_agents_wave: per-book lane states of the RNG block in progress
   uint32_t wave_lookahead = 64;
   int wave_parts = 0;           // 0 = as the lane split (n_parts / min_part)
-  bool use_wave() const {       // the pipeline bk_run takes for RandomAgents books
-    if (n_mixed || M > 1 || groups.empty()) return false;
-    return pipeline == 4 || (pipeline == 0 && cfg.n_books >= WAVE_MIN_BOOKS && cfg.n_books <= WAVE_MAX_BOOKS);
+  bool wave_ok() const { return !n_mixed && M == 1 && !groups.empty(); }  // RandomAgents on independent books
+  bool use_wave() const { return wave_ok() && pipeline == 4; }              // split form
+  bool use_wave_fused() const {                                             // persistent fused form
+    return wave_ok() && (pipeline == 5 || (pipeline == 0 && cfg.n_books >= WAVE_MIN_BOOKS && cfg.n_books <= WAVE_MAX_BOOKS));
   }
   // split pipeline: the batch is cut into n_parts contiguous parts, each on its own stream and started one
   // k_agents_fsm apart, so the latency-bound lane-per-book kernel of one part runs under the issue-bound
@@ -280,6 +283,37 @@ int launch_mixed(bk_env* env, const DevArgs& a, uint64_t first_step, uint32_t n_
   return BK_OK;
 }
 
+// jump tables (T^256, then T^(4 << b)) and the per-book lane-state cache of the wave-parallel decode, on first use
+int wave_args(bk_env* env, WaveArgs* wva) {
+  if (!env->jump_tabs.p) {
+    std::vector<uint32_t> all;
+    for (int t = 0; t < 7; ++t) {
+      const std::vector<uint32_t> tab = xoroshiro_jump_table(t == 0 ? WV_BLOCK : static_cast<uint64_t>(WV_K) << (t - 1));
+      all.insert(all.end(), tab.begin(), tab.end());
+    }
+    HIPCHK(env->jump_tabs.alloc(all.size() / 4));
+    HIPCHK(hipMemcpy(env->jump_tabs.p, all.data(), all.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(env->wcache.alloc(static_cast<size_t>(env->cfg.n_books) * WC_STRIDE));
+    HIPCHK(hipMemset(env->wcache.p, 0, static_cast<size_t>(env->cfg.n_books) * WC_STRIDE * 4));
+  }
+  wva->jt_block = env->jump_tabs.p;
+  wva->jt_lane = env->jump_tabs.p + 512;
+  wva->wcache = env->wcache.p;
+  wva->lookahead = env->wave_lookahead;
+  return BK_OK;
+}
+
+template <int R>
+int launch_wave_fused(bk_env* env, const DevArgs& a, uint64_t first_step, uint32_t n_steps) {
+  WaveArgs wva{};
+  if (int rc = wave_args(env, &wva)) return rc;
+  env->prof_now = env->profile > 0;
+  ProfScope ps(env, 0);
+  hipLaunchKernelGGL(k_run_wave<R>, dim3((env->cfg.n_books + 7) / 8), dim3(512), 0, env->stream, a, wva, first_step, n_steps);
+  HIPCHK(hipGetLastError());
+  return BK_OK;
+}
+
 // split pipeline: per step and per part one lane-per-book launch (RNG-serial phases) + one wave-per-book launch
 // MIXED: 0 RandomAgents groups (k_agents_fsm), 1 AgentSet members one wave per book (k_agents_mixed), 2 members one lane
 // per book (k_agents_mixed_lanes)
@@ -313,23 +347,8 @@ int launch_split(bk_env* env, const DevArgs& a0, uint64_t first_step, uint32_t n
   const MixedLists ml = env->lists();
   const bool wave = MIXED == 0 && env->use_wave();
   WaveArgs wva{};
-  if (wave) {
-    if (!env->jump_tabs.p) {
-      std::vector<uint32_t> all;
-      for (int t = 0; t < 7; ++t) {
-        const std::vector<uint32_t> tab = xoroshiro_jump_table(t == 0 ? WV_BLOCK : static_cast<uint64_t>(WV_K) << (t - 1));
-        all.insert(all.end(), tab.begin(), tab.end());
-      }
-      HIPCHK(env->jump_tabs.alloc(all.size() / 4));
-      HIPCHK(hipMemcpy(env->jump_tabs.p, all.data(), all.size() * 4, hipMemcpyHostToDevice));
-      HIPCHK(env->wcache.alloc(static_cast<size_t>(env->cfg.n_books) * WC_STRIDE));
-      HIPCHK(hipMemset(env->wcache.p, 0, static_cast<size_t>(env->cfg.n_books) * WC_STRIDE * 4));
-    }
-    wva.jt_block = env->jump_tabs.p;
-    wva.jt_lane = env->jump_tabs.p + 512;
-    wva.wcache = env->wcache.p;
-    wva.lookahead = env->wave_lookahead;
-  }
+  if (wave)
+    if (int rc = wave_args(env, &wva)) return rc;
   const uint32_t M = env->M;
   const uint32_t B = env->cfg.n_books / M;  // units the parts are cut in: books, or markets of M books
   // small batches: one part on the caller's stream
@@ -540,7 +559,8 @@ int bk_env_create(const bk_config* cfg, bk_env** out) {
   if (const char* pm = std::getenv("BOURSE_AMD_PIPELINE")) {
     if (std::strcmp(pm, "fused") == 0) env->pipeline = 1;
     if (std::strcmp(pm, "split") == 0) env->pipeline = 2;
-    if (std::strcmp(pm, "wave") == 0) env->pipeline = 4;
+    if (std::strcmp(pm, "wave_split") == 0) env->pipeline = 4;
+    if (std::strcmp(pm, "wave") == 0) env->pipeline = 5;
   }
   if (const char* np = std::getenv("BOURSE_AMD_SPLIT_PARTS")) {
     const int v = std::atoi(np);
@@ -1057,7 +1077,18 @@ int bk_run(bk_env* env, uint64_t n_steps) {
   // phases on the scalar unit of ONE wave per book; the split pipeline runs them one lane per book and needs
   // >= 64 books per wave to pay off.  auto: split once the batch fills the chip several times over.
   // Markets always take the split pipeline: the market's RNG-serial phase is one lane, its books are M waves.
-  const bool split = env->pipeline >= 2 || env->M > 1 || env->use_wave() ||
+  if (env->use_wave_fused()) {
+    switch (env->R) {
+      case 1: rc = launch_wave_fused<1>(env, a, env->steps_done, ns); break;
+      case 2: rc = launch_wave_fused<2>(env, a, env->steps_done, ns); break;
+      case 4: rc = launch_wave_fused<4>(env, a, env->steps_done, ns); break;
+      default: rc = launch_wave_fused<8>(env, a, env->steps_done, ns); break;
+    }
+    if (rc != BK_OK) return rc;
+    env->steps_done += n_steps;
+    return BK_OK;
+  }
+  const bool split = (env->pipeline >= 2 && env->pipeline != 5) || env->M > 1 ||
                      (env->pipeline == 0 && env->cfg.n_books >= RANDOM_SPLIT_MIN_BOOKS && a.n_groups > 0);
   if (split) {
     switch (env->R) {
@@ -1586,8 +1617,13 @@ int bk_profile_read_kind(bk_env* env, int kind, double* total_ms, uint64_t* n_la
 
 int bk_get_pipeline(bk_env* env, int* split, int* n_parts) {
   if (!env) return fail(BK_INVALID_ARGUMENT, "null env");
+  if (env->use_wave_fused()) {
+    if (split) *split = 3;
+    if (n_parts) *n_parts = 1;
+    return BK_OK;
+  }
   const bool wv = env->use_wave();
-  const bool sp = wv || env->pipeline >= 2 || env->M > 1 ||
+  const bool sp = wv || (env->pipeline >= 2 && env->pipeline != 5) || env->M > 1 ||
                   (env->pipeline == 0 && (env->n_mixed ? env->cfg.n_books >= MIXED_SPLIT_MIN_BOOKS
                                                        : env->cfg.n_books >= RANDOM_SPLIT_MIN_BOOKS && !env->groups.empty()));
   const int P = (wv && env->wave_parts > 0)
@@ -1599,10 +1635,10 @@ int bk_get_pipeline(bk_env* env, int* split, int* n_parts) {
 }
 
 int bk_set_pipeline(bk_env* env, int mode) {
-  if (!env || mode < 0 || mode > 4)
+  if (!env || mode < 0 || mode > 5)
     return fail(BK_INVALID_ARGUMENT,
-                "pipeline mode must be 0 (auto), 1 (fused), 2 (split), 3 (split, wave-per-book AgentSet members) or 4 (wave: "
-                "wave-parallel RNG decode + event kernel, RandomAgents books)");
+                "pipeline mode must be 0 (auto), 1 (fused), 2 (split), 3 (split, wave-per-book AgentSet members), 4 (wave_split: "
+                "wave-parallel RNG decode kernel + event kernel) or 5 (wave: both fused in one persistent kernel)");
   env->pipeline = mode;
   return BK_OK;
 }

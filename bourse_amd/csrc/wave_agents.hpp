@@ -36,6 +36,7 @@ constexpr uint32_t WC_STRIDE = WC_HDR + 256;   // dwords per book
 constexpr uint32_t WC_MAGIC = 0x45564157u;     // "WAVE"
 enum WcHdr : int { WC_S0_LO = 0, WC_S0_HI, WC_S1_LO, WC_S1_HI, WC_OFF, WC_TAG };
 constexpr uint32_t WV_NONE = 0xFFFFu;          // "placement not resolvable inside the look-ahead"
+constexpr uint32_t WV_ACTED = 0x10000u;        // marker bit of a lane's event word (above the 16 bits that are stored)
 
 struct WaveArgs {
   const uint4* jt_block;  // T^256: 32 x 16 entries
@@ -79,60 +80,46 @@ __device__ __forceinline__ uint32_t first_above(uint64_t lo, uint64_t hi, uint32
   return l ? ql : (h ? qh : 256u);
 }
 
+// The decoder state of one wave (= one book).  All pointers are wave-uniform; `pv` (new orders {price, vol} by pool
+// slot) is global memory for the split pipeline (the step batch) and LDS for the fused kernel.
 template <int R>
-__global__ __launch_bounds__(256, 8) void k_agents_wave(DevArgs a, WaveArgs wa) {
-  __shared__ uint4 tab[512];
-  __shared__ uint32_t ring_s[4][WV_RING];
-  __shared__ uint16_t evl_s[4][64 * R];
-  __shared__ uint32_t pm_s[4][2 * R], sm_s[4][2 * R];
-  const int lane = threadIdx.x & 63;
-  const int wv = threadIdx.x >> 6;
-  for (int i = threadIdx.x; i < 512; i += 256) tab[i] = wa.jt_block[i];
-  __syncthreads();
-  const uint32_t book = rfl(a.book_begin + blockIdx.x * 4 + wv);
-  if (book >= a.book_end) return;
-  uint32_t* st = a.state + (size_t)book * a.state_stride;
-  uint32_t* bt = a.batch + (size_t)book * a.batch_stride;
-  uint32_t* wc = wa.wcache + (size_t)book * WC_STRIDE;
-  uint32_t* ring = ring_s[wv];
-  uint4* ring4 = reinterpret_cast<uint4*>(ring);
-  uint16_t* evl = evl_s[wv];
-  uint32_t* pm = pm_s[wv];
-  uint32_t* sm = sm_s[wv];
-  uint2* pv = reinterpret_cast<uint2*>(bt + BT_EV + 32 * R);
+struct WaveDecoder {
+  const uint4* tab;    // LDS: T^256 table
+  uint32_t* ring;      // LDS: the last WV_RING generated draws, ring[q & (WV_RING - 1)] = draw q of this launch's stream
+  uint16_t* evl;       // LDS: this step's event list (event words, book_device.hpp EV_*)
+  uint32_t* pm;        // LDS: placing-agents mask, 2 R words
+  uint32_t* sm;        // LDS: bid-side mask of the placements, 2 R words
+  uint2* pv;           // new orders by slot
+  uint4* wcs;          // global: the 64 lane states of the cache record
+  int lane;
+  uint4 cs;            // this lane's chunk-start state in the last generated block
+  uint32_t gen_end;    // draws generated so far (stream origin = start of the cached block)
+  uint32_t pos;        // stream position: draws consumed so far
 
-  // ---- the book's RNG state and live masks (header), the cached lane states
-  const uint32_t hdr = st[lane];
-  const uint32_t wch = wc[lane];
-  uint4 cs = reinterpret_cast<const uint4*>(wc + WC_HDR)[lane];  // chunk-start state of this lane in the cached block
-  const uint32_t s0l = rdl(hdr, H_S0_LO), s0h = rdl(hdr, H_S0_HI), s1l = rdl(hdr, H_S1_LO), s1h = rdl(hdr, H_S1_HI);
-  uint64_t live[R];
-#pragma unroll
-  for (int r = 0; r < R; ++r) live[r] = mk64(rdl(hdr, H_LIVE0 + 2 * r), rdl(hdr, H_LIVE0 + 2 * r + 1));
-  if (lane < 2 * R) {
-    pm[lane] = 0;
-    sm[lane] = 0;
-  }
-  uint32_t pos = rdl(wch, WC_OFF);  // stream position inside the cached block (0..255)
-  const bool cached = rdl(wch, WC_TAG) == WC_MAGIC && rdl(wch, WC_S0_LO) == s0l && rdl(wch, WC_S0_HI) == s0h &&
-                      rdl(wch, WC_S1_LO) == s1l && rdl(wch, WC_S1_HI) == s1h && pos < WV_BLOCK;
-  if (!cached) {
-    // another pipeline (or a restore / a fresh env) moved the RNG: lane j = T^(4 j) of the book's state, by doubling
-    cs = make_uint4(s0l, s0h, s1l, s1h);
-    for (int b = 0; b < 6; ++b) {
-      const uint4 j = wv_jump(wa.jt_lane + b * 512, cs);
-      const bool take = (lane >> b) & 1;
-      cs.x = take ? j.x : cs.x;
-      cs.y = take ? j.y : cs.y;
-      cs.z = take ? j.z : cs.z;
-      cs.w = take ? j.w : cs.w;
+  // cached lane states valid for the book's RNG state (s0l..s1h)?  else lane j = T^(4 j) of it, by doubling
+  __device__ __forceinline__ void load_cache(const uint32_t* wc, uint32_t s0l, uint32_t s0h, uint32_t s1l, uint32_t s1h,
+                                             const uint4* jt_lane) {
+    const uint32_t wch = wc[lane];
+    cs = reinterpret_cast<const uint4*>(wc + WC_HDR)[lane];
+    pos = rdl(wch, WC_OFF);
+    const bool cached = rdl(wch, WC_TAG) == WC_MAGIC && rdl(wch, WC_S0_LO) == s0l && rdl(wch, WC_S0_HI) == s0h &&
+                        rdl(wch, WC_S1_LO) == s1l && rdl(wch, WC_S1_HI) == s1h && pos < WV_BLOCK;
+    if (!cached) {  // another pipeline (or a restore / a fresh env) moved the RNG
+      cs = make_uint4(s0l, s0h, s1l, s1h);
+      for (int b = 0; b < 6; ++b) {
+        const uint4 j = wv_jump(jt_lane + b * 512, cs);
+        const bool take = (lane >> b) & 1;
+        cs.x = take ? j.x : cs.x;
+        cs.y = take ? j.y : cs.y;
+        cs.z = take ? j.z : cs.z;
+        cs.w = take ? j.w : cs.w;
+      }
+      pos = 0;
     }
-    pos = 0;
+    gen_end = 0;
   }
-  uint4* wcs = reinterpret_cast<uint4*>(wc + WC_HDR);
-  uint32_t gen_end = 0;      // draws generated so far (this launch's stream origin = start of the cached block)
 
-  auto gen_block = [&]() {   // next 256 draws into the ring; cs = chunk-start states of the block just generated
+  __device__ __forceinline__ void gen_block() {  // next 256 draws into the ring
     if (gen_end != 0) {
       // the stream position may still lie in the block being left when the launch ends (look-ahead): its chunk-start
       // states go to the cache record now (a fire-and-forget 1 KB store instead of four live registers)
@@ -145,128 +132,135 @@ __global__ __launch_bounds__(256, 8) void k_agents_wave(DevArgs a, WaveArgs wa) 
     x.y = t.next_u32();
     x.z = t.next_u32();
     x.w = t.next_u32();
-    ring4[((gen_end >> 2) + lane) & (WV_RING / 4 - 1)] = x;
+    reinterpret_cast<uint4*>(ring)[((gen_end >> 2) + lane) & (WV_RING / 4 - 1)] = x;
     gen_end += WV_BLOCK;
     wave_sync();
-  };
-  auto ensure = [&](uint32_t upto) {
+  }
+  __device__ __forceinline__ void ensure(uint32_t upto) {
     while (gen_end < upto) gen_block();
-  };
+  }
 
   // ================= agents.update: groups in declaration order (crates/macros/src/lib.rs:57-73) =================
-  const uint32_t lim = 64u + (wa.lookahead < 1u ? 1u : (wa.lookahead > 64u ? 64u : wa.lookahead));
-  uint32_t n_ev = 0, ag = 0, gbase = 0;
-  for (uint32_t g = 0; g < a.n_groups; ++g) {
-    const Group G = a.groups[g];
-    const uint32_t gend = gbase + G.n;
-    gbase = gend;
-    while (ag < gend) {
-      // ---- window [w0, w0 + 64) of the stream + 64 draws of look-ahead
-      const uint32_t w0 = pos & ~63u;
-      ensure(w0 + 128u);
-      const uint32_t xc = ring[(w0 + lane) & (WV_RING - 1)], xn = ring[(w0 + 64u + lane) & (WV_RING - 1)];
-      // p = gen::<f32>() < activity_rate (random_agent.rs:91-93) as an integer threshold (host_math.hpp)
-      const uint64_t H = __ballot((xc >> 8) < G.thr);
-      // UniformInt<u32>::sample_single: accept iff lo32(x * range) <= zone.  range 2: bit 30 clear.
-      const uint64_t A2l = __ballot((xc & 0x40000000u) == 0u), A2h = __ballot((xn & 0x40000000u) == 0u);
-      const uint64_t ATl = __ballot(xc * G.tick_rng <= G.tick_zone), ATh = __ballot(xn * G.tick_rng <= G.tick_zone);
-      const uint64_t AVl = __ballot(xc * G.vol_rng <= G.vol_zone), AVh = __ballot(xn * G.vol_rng <= G.vol_zone);
-      // lane p: the placement that starts if the activity draw at p hits and the agent holds no Active order:
-      // side = [Ask, Bid].choose, tick, vol in that order (random_agent.rs:99-101)
-      const uint32_t q1 = first_above(A2l, A2h, (uint32_t)lane);
-      const uint32_t q2 = first_above(ATl, ATh, q1);
-      const uint32_t q3 = first_above(AVl, AVh, q2);
-      const uint32_t fpos = q3 < lim ? q3 + 1u : WV_NONE;
-      const uint32_t x1 = ring[(w0 + q1) & (WV_RING - 1)], x2 = ring[(w0 + q2) & (WV_RING - 1)],
-                     x3 = ring[(w0 + q3) & (WV_RING - 1)];
-      const uint32_t fside = x1 >> 31;  // hi32(x * 2): 0 = Ask, 1 = Bid
-      const uint32_t fprice = (G.tick_lo + __umulhi(x2, G.tick_rng)) * G.tick_size;
-      const uint32_t fvol = G.vol_lo + __umulhi(x3, G.vol_rng);
+  // livev: lane live_base + w holds bits [32 w, 32 w + 32) of the pool's live mask.  Returns the number of events.
+  __device__ __forceinline__ uint32_t agents(const DevArgs& a, uint32_t lim, uint32_t livev, uint32_t live_base) {
+    uint32_t n_ev = 0, ag = 0, gbase = 0;
+    for (uint32_t g = 0; g < a.n_groups; ++g) {
+      const Group G = a.groups[g];
+      const uint32_t gend = gbase + G.n;
+      gbase = gend;
+      while (ag < gend) {
+        // ---- window [w0, w0 + 64) of the stream + 64 draws of look-ahead
+        const uint32_t w0 = pos & ~63u;
+        ensure(w0 + 128u);
+        const uint32_t xc = ring[(w0 + lane) & (WV_RING - 1)], xn = ring[(w0 + 64u + lane) & (WV_RING - 1)];
+        // p = gen::<f32>() < activity_rate (random_agent.rs:91-93) as an integer threshold (host_math.hpp)
+        const uint64_t H = __ballot((xc >> 8) < G.thr);
+        // UniformInt<u32>::sample_single: accept iff lo32(x * range) <= zone.  range 2: bit 30 clear.
+        const uint64_t A2l = __ballot((xc & 0x40000000u) == 0u), A2h = __ballot((xn & 0x40000000u) == 0u);
+        const uint64_t ATl = __ballot(xc * G.tick_rng <= G.tick_zone), ATh = __ballot(xn * G.tick_rng <= G.tick_zone);
+        const uint64_t AVl = __ballot(xc * G.vol_rng <= G.vol_zone), AVh = __ballot(xn * G.vol_rng <= G.vol_zone);
+        // lane p: the placement that starts if the activity draw at p hits and the agent holds no Active order:
+        // side = [Ask, Bid].choose, tick, vol in that order (random_agent.rs:99-101)
+        const uint32_t q1 = first_above(A2l, A2h, (uint32_t)lane);
+        const uint32_t q2 = first_above(ATl, ATh, q1);
+        const uint32_t q3 = first_above(AVl, AVh, q2);
+        const uint32_t fpos = q3 < lim ? q3 + 1u : WV_NONE;
+        const uint32_t x1 = ring[(w0 + q1) & (WV_RING - 1)], x2 = ring[(w0 + q2) & (WV_RING - 1)],
+                       x3 = ring[(w0 + q3) & (WV_RING - 1)];
+        const uint32_t fside = x1 >> 31;  // hi32(x * 2): 0 = Ask, 1 = Bid
+        const uint32_t fprice = (G.tick_lo + __umulhi(x2, G.tick_rng)) * G.tick_size;
+        const uint32_t fvol = G.vol_lo + __umulhi(x3, G.vol_rng);
 
-      // ---- scalar walk over the activity hits of this window
-      uint32_t p = pos - w0;
-      uint64_t acted = 0, placed = 0;
-      uint32_t agw = 0, evi = 0;
-      while (p < 64u && ag < gend) {
-        const uint64_t m = H >> p;
-        if (m == 0) {  // no further hit in the window: the remaining draws are inactive agents'
-          const uint32_t adv = (64u - p) < (gend - ag) ? (64u - p) : (gend - ag);
-          ag += adv;
-          p += adv;
-          break;
-        }
-        const uint32_t d = (uint32_t)__builtin_ctzll(m);
-        if (ag + d >= gend) {  // the group ends before the next hit
-          p += gend - ag;
-          ag = gend;
-          break;
-        }
-        ag += d;
-        p += d;
-        const uint64_t bit = 1ull << p;
-        if (mask_test<R>(live, ag)) {  // holds an Active order: queue its cancellation (random_agent.rs:95-97)
-          agw = wrl(ag, p, agw);
-          evi = wrl(n_ev, p, evi);
-          acted |= bit;
-          n_ev += 1;
-          ag += 1;
-          p += 1;
-          continue;
-        }
-        const uint32_t fp = rdl(fpos, p);
-        if (fp != WV_NONE) {
-          agw = wrl(ag | EV_NEW, p, agw);
-          evi = wrl(n_ev, p, evi);
-          acted |= bit;
-          placed |= bit;
-          n_ev += 1;
-          ag += 1;
-          p = fp;
-          continue;
-        }
-        // slow path: the placement's draws run past the look-ahead; resolve it draw by draw (generating as needed:
-        // the window's draws are already in registers, the ring may move on)
-        uint32_t q = w0 + p + 1u, val[3];
-        const uint32_t rng3[3] = {2u, G.tick_rng, G.vol_rng}, zone3[3] = {0x7FFFFFFFu, G.tick_zone, G.vol_zone};
-#pragma unroll
-        for (int sgi = 0; sgi < 3; ++sgi) {
-          for (;;) {
-            ensure(q + 1u);
-            const uint32_t x = rfl(ring[q & (WV_RING - 1)]);
-            ++q;
-            const uint64_t mm = (uint64_t)x * rng3[sgi];
-            if ((uint32_t)mm <= zone3[sgi]) {
-              val[sgi] = (uint32_t)(mm >> 32);
+        // ---- scalar walk over the activity hits of this window (p < 64 and ag < gend on entry).  Each acting lane
+        // gets its event word (slot, EV_NEW, marker bit 16) by v_writelane; list positions follow from the lane order
+        // at the flush below (events of a window are in stream order = agent order).
+        uint32_t p = pos - w0;
+        uint32_t agw = 0;
+        bool slow = false;
+        for (;;) {
+          const uint64_t m = H >> p;
+          if (m == 0) {  // no further hit in the window: the remaining draws are inactive agents'
+            const uint32_t adv = (64u - p) < (gend - ag) ? (64u - p) : (gend - ag);
+            ag += adv;
+            p += adv;
+            break;
+          }
+          const uint32_t d = (uint32_t)__builtin_ctzll(m);
+          const uint32_t na = ag + d;
+          if (na >= gend) {  // the group ends before the next hit
+            p += gend - ag;
+            ag = gend;
+            break;
+          }
+          p += d;
+          ag = na + 1u;
+          if ((rdl(livev, live_base + (na >> 5)) >> (na & 31u)) & 1u) {  // holds an Active order: cancel it (:95-97)
+            agw = wrl(na | WV_ACTED, p, agw);
+            p += 1u;
+          } else {
+            const uint32_t fp = rdl(fpos, p);
+            if (fp == WV_NONE) {
+              ag = na;
+              slow = true;
               break;
             }
+            agw = wrl(na | (EV_NEW | WV_ACTED), p, agw);
+            p = fp;
           }
+          if (p >= 64u) break;
         }
-        if (lane == 0) {
-          evl[n_ev] = (uint16_t)(ag | EV_NEW | (val[0] << 14));
-          pv[ag] = make_uint2((G.tick_lo + val[1]) * G.tick_size, G.vol_lo + val[2]);
-          atomicOr(&pm[ag >> 5], 1u << (ag & 31u));
-          atomicOr(&sm[ag >> 5], val[0] << (ag & 31u));
+        // ---- the window's events, one lane each: list entry and the new order's fields
+        {
+          const bool acted = (agw & WV_ACTED) != 0, placed = (agw & EV_NEW) != 0;
+          const uint64_t am = __ballot(acted);
+          const uint32_t evi =
+              n_ev + __builtin_amdgcn_mbcnt_hi((uint32_t)(am >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)am, 0u));
+          if (acted) evl[evi] = (uint16_t)(agw | (placed ? (fside << 14) : 0u));
+          if (placed) {
+            const uint32_t slot = agw & EV_SLOT;
+            pv[slot] = make_uint2(fprice, fvol);
+            atomicOr(&pm[slot >> 5], 1u << (slot & 31u));
+            atomicOr(&sm[slot >> 5], fside << (slot & 31u));
+          }
+          n_ev += (uint32_t)__builtin_popcountll(am);
         }
-        n_ev += 1;
-        ag += 1;
-        p = q - w0;
-        break;
+        if (slow) {
+          // slow path: the placement's draws run past the look-ahead; resolve it draw by draw (generating as needed:
+          // the window's draws are already in registers, the ring may move on)
+          uint32_t q = w0 + p + 1u, val[3];
+          const uint32_t rng3[3] = {2u, G.tick_rng, G.vol_rng}, zone3[3] = {0x7FFFFFFFu, G.tick_zone, G.vol_zone};
+#pragma unroll
+          for (int sgi = 0; sgi < 3; ++sgi) {
+            for (;;) {
+              ensure(q + 1u);
+              const uint32_t x = rfl(ring[q & (WV_RING - 1)]);
+              ++q;
+              const uint64_t mm = (uint64_t)x * rng3[sgi];
+              if ((uint32_t)mm <= zone3[sgi]) {
+                val[sgi] = (uint32_t)(mm >> 32);
+                break;
+              }
+            }
+          }
+          if (lane == 0) {
+            evl[n_ev] = (uint16_t)(ag | EV_NEW | (val[0] << 14));
+            pv[ag] = make_uint2((G.tick_lo + val[1]) * G.tick_size, G.vol_lo + val[2]);
+            atomicOr(&pm[ag >> 5], 1u << (ag & 31u));
+            atomicOr(&sm[ag >> 5], val[0] << (ag & 31u));
+          }
+          n_ev += 1;
+          ag += 1;
+          p = q - w0;
+        }
+        pos = w0 + p;
       }
-      // ---- the window's events, one lane each: list entry (agent order = stream order) and the new order's fields
-      if (lane_bit(acted)) evl[evi] = (uint16_t)(agw | (lane_bit(placed) ? (fside << 14) : 0u));
-      if (lane_bit(placed)) {
-        const uint32_t slot = agw & EV_SLOT;
-        pv[slot] = make_uint2(fprice, fvol);
-        atomicOr(&pm[slot >> 5], 1u << (slot & 31u));
-        atomicOr(&sm[slot >> 5], fside << (slot & 31u));
-      }
-      pos = w0 + p;
     }
+    wave_sync();
+    return n_ev;
   }
-  wave_sync();
 
-  // ================= transactions.shuffle(rng) (env.rs:121): for i in (1..n).rev() swap(i, gen_range(0..i+1)) =====
-  {
+  // ============ transactions.shuffle(rng) (env.rs:121): for i in (1..n).rev() swap(i, gen_range(0..i+1)) ============
+  __device__ __forceinline__ void shuffle(uint32_t n_ev) {
     uint32_t i = n_ev > 0 ? n_ev - 1u : 0u;
     while (i >= 1u) {
       const uint32_t w0 = pos & ~63u, p0 = pos - w0;
@@ -308,8 +302,9 @@ __global__ __launch_bounds__(256, 8) void k_agents_wave(DevArgs a, WaveArgs wa) 
     }
   }
 
-  // ================= publish: RNG state, lane-state cache, step batch =================
-  {
+  // The generator state at `pos` (= what the reference's RNG holds now), and the cache record for the next launch:
+  // chunk-start states of the block `pos` lies in + the offset inside it.
+  __device__ __forceinline__ void finish(uint32_t* wc, uint32_t& n0, uint32_t& n1, uint32_t& n2, uint32_t& n3) {
     const bool in_last = pos + WV_BLOCK >= gen_end;  // pos lies in the last generated block (or at its end)
     uint4 bs = cs;
     if (!in_last) bs = wcs[lane];  // the block before the last generated one: stored when it was left (same lane)
@@ -323,9 +318,7 @@ __global__ __launch_bounds__(256, 8) void k_agents_wave(DevArgs a, WaveArgs wa) 
     const uint32_t nst = c2 & (WV_K - 1u);
     for (uint32_t s = 0; s < nst; ++s) (void)t.next_u32();
     const uint32_t src = c2 >> 2;
-    const uint32_t n0 = rdl(t.a0, src), n1 = rdl(t.a1, src), n2 = rdl(t.b0, src), n3 = rdl(t.b1, src);
-    uint32_t hv = lane == 0 ? n0 : (lane == 1 ? n1 : (lane == 2 ? n2 : n3));
-    if (lane < 4) st[H_S0_LO + lane] = hv;
+    n0 = rdl(t.a0, src), n1 = rdl(t.a1, src), n2 = rdl(t.b0, src), n3 = rdl(t.b1, src);
     uint32_t cw = 0;
     cw = lane == WC_S0_LO ? n0 : cw;
     cw = lane == WC_S0_HI ? n1 : cw;
@@ -336,22 +329,156 @@ __global__ __launch_bounds__(256, 8) void k_agents_wave(DevArgs a, WaveArgs wa) 
     wc[lane] = cw;
     wcs[lane] = bs;
   }
-  {
-    uint32_t hb = 0;
-    hb = lane == BT_NEV ? n_ev : hb;
+};
+
+// ==================================================================================
+// Split form: k_agents_wave writes the step batch, k_step_batch (book_device.hpp) consumes it.
+// ==================================================================================
+template <int R>
+__global__ __launch_bounds__(256, 8) void k_agents_wave(DevArgs a, WaveArgs wa) {
+  __shared__ uint4 tab[512];
+  __shared__ uint32_t ring_s[4][WV_RING];
+  __shared__ uint16_t evl_s[4][64 * R];
+  __shared__ uint32_t pm_s[4][2 * R], sm_s[4][2 * R];
+  const int lane = threadIdx.x & 63;
+  const int wv = (int)rfl(threadIdx.x >> 6);  // wave-uniform: the per-wave LDS regions get scalar base addresses
+  for (int i = threadIdx.x; i < 512; i += 256) tab[i] = wa.jt_block[i];
+  __syncthreads();
+  const uint32_t book = rfl(a.book_begin + blockIdx.x * 4 + wv);
+  if (book >= a.book_end) return;
+  uint32_t* st = a.state + (size_t)book * a.state_stride;
+  uint32_t* bt = a.batch + (size_t)book * a.batch_stride;
+  uint32_t* wc = wa.wcache + (size_t)book * WC_STRIDE;
+
+  WaveDecoder<R> D;
+  D.tab = tab;
+  D.ring = ring_s[wv];
+  D.evl = evl_s[wv];
+  D.pm = pm_s[wv];
+  D.sm = sm_s[wv];
+  D.pv = reinterpret_cast<uint2*>(bt + BT_EV + 32 * R);
+  D.wcs = reinterpret_cast<uint4*>(wc + WC_HDR);
+  D.lane = lane;
+  // the book's RNG state and live masks (header dwords H_LIVE0 + w hold bits [32 w, 32 w + 32) of the pool's live mask)
+  const uint32_t hdr = st[lane];
+  D.load_cache(wc, rdl(hdr, H_S0_LO), rdl(hdr, H_S0_HI), rdl(hdr, H_S1_LO), rdl(hdr, H_S1_HI), wa.jt_lane);
+  if (lane < 2 * R) {
+    D.pm[lane] = 0;
+    D.sm[lane] = 0;
+  }
+  const uint32_t lim = 64u + (wa.lookahead < 1u ? 1u : (wa.lookahead > 64u ? 64u : wa.lookahead));
+  const uint32_t n_ev = D.agents(a, lim, hdr, H_LIVE0);
+  D.shuffle(n_ev);
+
+  // ---- publish: RNG state, lane-state cache, step batch
+  uint32_t n0, n1, n2, n3;
+  D.finish(wc, n0, n1, n2, n3);
+  const uint32_t hv = lane == 0 ? n0 : (lane == 1 ? n1 : (lane == 2 ? n2 : n3));
+  if (lane < 4) st[H_S0_LO + lane] = hv;
+  uint32_t hb = 0;
+  hb = lane == BT_NEV ? n_ev : hb;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    hb = lane == BT_PEND + 2 * r ? D.pm[2 * r] : hb;
+    hb = lane == BT_PEND + 2 * r + 1 ? D.pm[2 * r + 1] : hb;
+    hb = lane == BT_SIDE + 2 * r ? D.sm[2 * r] : hb;
+    hb = lane == BT_SIDE + 2 * r + 1 ? D.sm[2 * r + 1] : hb;
+  }
+  bt[lane] = hb;
+  for (uint32_t k = lane; k < 32u * R; k += 64u) {
+    const uint32_t lo = 2u * k < n_ev ? D.evl[2u * k] : 0u, hi = 2u * k + 1u < n_ev ? D.evl[2u * k + 1u] : 0u;
+    bt[BT_EV + k] = lo | (hi << 16);
+  }
+}
+
+// ==================================================================================
+// Fused form: n_steps x { agents.update (wave-parallel decode); Env::step } per book with the book in registers and the
+// generated draws in LDS across all steps of the launch (sim_runner, runner.rs:53-68) - no per-step launches, no state
+// round trips; for batches that fit the chip once or twice (8 192 books = one resident wave per book).
+// ==================================================================================
+template <int R>
+__global__ __launch_bounds__(512, 8) void k_run_wave(DevArgs a, WaveArgs wa, uint64_t first_step, uint32_t n_steps) {
+  constexpr int WPB = 8;                                       // books (waves) per workgroup
+  constexpr int STAGE_DW = 128 * R > 256 ? 128 * R : 256;      // new orders {price, vol} by slot, then the level bins
+  __shared__ uint4 tab[512];
+  __shared__ uint32_t ring_s[WPB][WV_RING];
+  __shared__ uint16_t evl_s[WPB][64 * R];
+  __shared__ uint32_t pm_s[WPB][2 * R], sm_s[WPB][2 * R];
+  __shared__ uint32_t stage_s[WPB][STAGE_DW];
+  const int lane = threadIdx.x & 63;
+  const int wv = (int)rfl(threadIdx.x >> 6);
+  for (int i = threadIdx.x; i < 512; i += 512) tab[i] = wa.jt_block[i];
+  __syncthreads();
+  const uint32_t book = rfl(blockIdx.x * WPB + wv);
+  if (book >= a.n_books) return;
+  uint32_t* st = a.state + (size_t)book * a.state_stride;
+  uint32_t* wc = wa.wcache + (size_t)book * WC_STRIDE;
+  uint32_t* stage = stage_s[wv];
+
+  Book<R> B;
+  Rng rng;
+  load_book<R>(B, rng, st, lane);
+  WaveDecoder<R> D;
+  D.tab = tab;
+  D.ring = ring_s[wv];
+  D.evl = evl_s[wv];
+  D.pm = pm_s[wv];
+  D.sm = sm_s[wv];
+  D.pv = reinterpret_cast<uint2*>(stage);
+  D.wcs = reinterpret_cast<uint4*>(wc + WC_HDR);
+  D.lane = lane;
+  D.load_cache(wc, (uint32_t)rng.s0, (uint32_t)(rng.s0 >> 32), (uint32_t)rng.s1, (uint32_t)(rng.s1 >> 32), wa.jt_lane);
+  const uint32_t lim = 64u + (wa.lookahead < 1u ? 1u : (wa.lookahead > 64u ? 64u : wa.lookahead));
+  uint64_t all[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) all[r] = ~0ull;
+  uint32_t last_ntr = 0, last_nev = 0;
+
+  for (uint32_t s = 0; s < n_steps; ++s) {
+    // ---------------- agents.update(env, rng) + the shuffle of Env::step ----------------
+    uint32_t livev = 0;  // lane w: bits [32 w, 32 w + 32) of the pool's live mask
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      hb = lane == BT_PEND + 2 * r ? pm[2 * r] : hb;
-      hb = lane == BT_PEND + 2 * r + 1 ? pm[2 * r + 1] : hb;
-      hb = lane == BT_SIDE + 2 * r ? sm[2 * r] : hb;
-      hb = lane == BT_SIDE + 2 * r + 1 ? sm[2 * r + 1] : hb;
+      livev = wrl((uint32_t)B.live[r], 2 * r, livev);
+      livev = wrl((uint32_t)(B.live[r] >> 32), 2 * r + 1, livev);
     }
-    bt[lane] = hb;
-    for (uint32_t k = lane; k < 32u * R; k += 64u) {
-      const uint32_t lo = 2u * k < n_ev ? evl[2u * k] : 0u, hi = 2u * k + 1u < n_ev ? evl[2u * k + 1u] : 0u;
-      bt[BT_EV + k] = lo | (hi << 16);
+    if (lane < 2 * R) {
+      D.pm[lane] = 0;
+      D.sm[lane] = 0;
     }
+    wave_sync();
+    const uint32_t n_ev = D.agents(a, lim, livev, 0u);
+    D.shuffle(n_ev);
+    // ---------------- the step's new orders into the pool (create_order ids: dense, agent order) -------------
+    uint32_t ev[R];
+    uint32_t base = B.next_id;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const uint64_t pend = mk64(rfl(D.pm[2 * r]), rfl(D.pm[2 * r + 1]));
+      const uint64_t side = mk64(rfl(D.sm[2 * r]), rfl(D.sm[2 * r + 1]));
+      ev[r] = D.evl[r * 64 + lane];
+      const uint2 pvv = D.pv[r * 64 + lane];
+      B.price[r] = sel(pend, pvv.x, B.price[r]);
+      B.vol[r] = sel(pend, pvv.y, B.vol[r]);
+      const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(pend >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pend, 0u));
+      B.id[r] = sel(pend, base + rank, B.id[r]);
+      base += __builtin_popcountll(pend);
+      B.bid[r] = (B.bid[r] & ~pend) | (side & pend);
+      B.pend[r] = 0;  // the event words classify themselves (EV_NEW)
+    }
+    B.next_id = base;
+    wave_sync();  // the staging area becomes the snapshot's level bins
+    // ---------------- Env::step: events at t0 + k, clock, level-2 record, trades ----------------
+    last_ntr = step_from_list<R, false, false, true>(B, a, book, lane, ev, n_ev, stage,
+                                                     a.hist_cap ? (a.hist_slot0 + s) % a.hist_cap : 0u,
+                                                     s + 1 == n_steps || a.hist_cap == 0, a.tick_size, all, last_nev);
+    wave_sync();
   }
+  uint32_t n0, n1, n2, n3;
+  D.finish(wc, n0, n1, n2, n3);
+  rng.s0 = mk64(n0, n1);
+  rng.s1 = mk64(n2, n3);
+  store_book<R>(B, rng, st, lane, first_step + n_steps, last_ntr, last_nev);
 }
 
 }  // namespace bkd

@@ -600,10 +600,11 @@ class ManyBookEnv:
         return float(ms.value), int(n.value)
 
     def set_pipeline(self, mode: str):
-        """'auto' | 'fused' | 'split' | 'split_wave' | 'wave' — kernel pipeline of run(); results are identical.  ('wave':
-        RandomAgents books, the RNG-serial phases one wave per book with a wave-parallel stream decode.)  ('split_wave':
+        """'auto' | 'fused' | 'split' | 'split_wave' | 'wave_split' | 'wave' — kernel pipeline of run(); results are
+        identical.  ('wave' / 'wave_split': RandomAgents books, the RNG-serial phases one wave per book with a
+        wave-parallel stream decode, fused with the event phase in one persistent kernel / as a kernel of its own.)  ('split_wave':
         AgentSets with Noise/Momentum members keep their update one wave per book; for RandomAgents it equals 'split'.)"""
-        check(self._L.bk_set_pipeline(self._h, {"auto": 0, "fused": 1, "split": 2, "split_wave": 3, "wave": 4}[mode]))
+        check(self._L.bk_set_pipeline(self._h, {"auto": 0, "fused": 1, "split": 2, "split_wave": 3, "wave_split": 4, "wave": 5}[mode]))
 
     def set_wave_options(self, lookahead: int = 64, parts: int = 0):
         """'wave' pipeline knobs: look-ahead of the vector decode path (1..64; small = exercise the scalar slow path)
@@ -615,10 +616,10 @@ class ManyBookEnv:
         check(self._L.bk_set_split_parts(self._h, int(n_parts), int(min_part)))
 
     def pipeline(self) -> Tuple[str, int]:
-        """('fused' | 'split' | 'wave', number of book parts launched on separate streams) that run() will use."""
+        """('fused' | 'split' | 'wave_split' | 'wave', number of book parts on separate streams) that run() will use."""
         a, b = C.c_int(0), C.c_int(1)
         check(self._L.bk_get_pipeline(self._h, C.byref(a), C.byref(b)))
-        return ("fused", "split", "wave")[a.value], int(b.value)
+        return ("fused", "split", "wave_split", "wave")[a.value], int(b.value)
 
     def checkpoint(self) -> np.ndarray:
         """Complete simulation state (pool, clock, counters, RNG of every book) as a byte array."""

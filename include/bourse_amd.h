@@ -275,13 +275,15 @@ int bk_profile_read_kind(bk_env* env, int kind, double* total_ms, uint64_t* n_la
 /* bk_run kernel pipeline: 0 auto, 1 fused (one wave per book, all phases), 2 split (RNG-serial phases one lane per
  * book + event phase one wave per book).  Results are identical; only speed differs. */
 int bk_set_pipeline(bk_env* env, int mode);
-/* mode 4 ("wave", RandomAgents books; auto for 1 024..24 576 books): the RNG-serial phases run one WAVE per book with the
- * book's xoroshiro stream decoded 64 draws at a time (jump-ahead lane states + ballot/prefix resolution), in front of
- * the same event kernel.  bk_set_wave_options: look-ahead of its vector path (1..64 draws, default 64; smaller values
- * push placements onto its scalar slow path - a test knob) and the number of parts it cuts the batch in (0 = default). */
+/* modes 4 ("wave_split") and 5 ("wave"; auto for 1 024..24 576 RandomAgents books): the RNG-serial phases run one WAVE per
+ * book with the book's xoroshiro stream decoded 64 draws at a time (jump-ahead lane states + ballot/prefix resolution) -
+ * as a kernel of its own in front of the event kernel (4), or fused with the event phase in one persistent kernel that
+ * keeps the book in registers across all steps of a bk_run (5).  bk_set_wave_options: look-ahead of the decode's vector
+ * path (1..64 draws, default 64; smaller values push placements onto its scalar slow path - a test knob) and the number
+ * of parts mode 4 cuts the batch in (0 = default). */
 int bk_set_wave_options(bk_env* env, uint32_t lookahead, int parts);
-/* the pipeline bk_run will use: *split = 0 fused / 1 split (lane-per-book agents) / 2 wave; *n_parts = contiguous book
- * parts launched on separate streams */
+/* the pipeline bk_run will use: *split = 0 fused / 1 split (lane-per-book agents) / 2 wave_split / 3 wave; *n_parts =
+ * contiguous book parts launched on separate streams */
 int bk_get_pipeline(bk_env* env, int* split, int* n_parts);
 uint64_t bk_state_bytes_per_book(const bk_env* env);
 /* split-pipeline geometry: the batch is cut in min(n_parts, books / min_part) contiguous parts, each on its own HIP

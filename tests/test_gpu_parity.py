@@ -57,7 +57,7 @@ def _compare_random(bk, oracle, n_books, groups, levels, n_steps, seed=101, tick
         env.set_wave_options(lookahead, wave_parts)
     for i, c in enumerate(chunks or [n_steps]):
         # "mixed": alternate the kernel pipelines between launches — they share the device state
-        env.set_pipeline(("fused", "wave", "split", "wave")[i % 4] if pipeline == "mixed" else pipeline)
+        env.set_pipeline(("fused", "wave", "split", "wave_split")[i % 4] if pipeline == "mixed" else pipeline)
         env.run(c)
     ref = oracle.ManyBooks(n_books, seed, 0, tick, step_size, True, levels, groups)
     ref.run(n_steps, n_threads=4)
@@ -101,7 +101,7 @@ def _compare_random(bk, oracle, n_books, groups, levels, n_steps, seed=101, tick
 
 # one wave per book for everything / RNG phases one lane per book + event kernel / RNG phases one wave per book with the
 # wave-parallel stream decode (k_agents_wave) + event kernel
-PIPELINES = ["fused", "split", "wave"]
+PIPELINES = ["fused", "split", "wave_split", "wave"]
 
 
 @pytest.mark.parametrize("pipeline", PIPELINES)
@@ -149,26 +149,29 @@ def test_chunked_launches_equal_one_launch(bk, oracle, pipeline):
     assert np.array_equal(a, b)
 
 
+@pytest.mark.parametrize("pipeline", ["wave_split", "wave"])
 @pytest.mark.parametrize("lookahead", [1, 2, 7, 33])
-def test_wave_decode_slow_path_small_lookahead(bk, oracle, lookahead):
+def test_wave_decode_slow_path_small_lookahead(bk, oracle, lookahead, pipeline):
     """k_agents_wave resolves a placement on its vector path only if its side / tick / vol draws end inside the
     look-ahead; otherwise draw by draw on the scalar path.  A tiny look-ahead sends most placements there: the
     results must not change (nor across launch chunkings, which restart from the cached lane states)."""
-    _compare_random(bk, oracle, n_books=70, groups=C3_GROUPS, levels=32, n_steps=30, pipeline="wave", lookahead=lookahead,
+    _compare_random(bk, oracle, n_books=70, groups=C3_GROUPS, levels=32, n_steps=30, pipeline=pipeline, lookahead=lookahead,
                     chunks=[1, 4, 25])
     _compare_random(bk, oracle, n_books=9, groups=[(5, (10, 14), (1, 3), 3, 0.0), (37, (10, 14), (1, 3), 3, 1.0),
                                                     (23, (9, 13), (1, 2), 6, 0.5)], levels=4, n_steps=40, tick=3,
-                    pipeline="wave", lookahead=lookahead)
+                    pipeline=pipeline, lookahead=lookahead)
 
 
 def test_wave_decode_many_parts_and_odd_batches(bk, oracle):
     # more parts than the default, book counts that are not multiples of 4 (the workgroup holds four books)
     for nb, parts in ((5, 2), (130, 3), (257, 8)):
-        _compare_random(bk, oracle, n_books=nb, groups=C2_GROUPS, levels=16, n_steps=16, pipeline="wave", lookahead=64,
+        _compare_random(bk, oracle, n_books=nb, groups=C2_GROUPS, levels=16, n_steps=16, pipeline="wave_split", lookahead=64,
                         wave_parts=parts)
+        _compare_random(bk, oracle, n_books=nb, groups=C2_GROUPS, levels=16, n_steps=16, pipeline="wave")
     # every agent acts every step (rate 1): the longest streams, group boundaries in every window
-    _compare_random(bk, oracle, n_books=33, groups=[(100, (10, 100), (1, 2), 1, 1.0), (28, (50, 51), (5, 6), 1, 1.0)], levels=10,
-                    n_steps=25, tick=1, pipeline="wave")
+    for pipe in ("wave_split", "wave"):
+        _compare_random(bk, oracle, n_books=33, groups=[(100, (10, 100), (1, 2), 1, 1.0), (28, (50, 51), (5, 6), 1, 1.0)],
+                        levels=10, n_steps=25, tick=1, pipeline=pipe)
 
 
 def test_book_offset_sharding_is_seed_transparent(bk):
