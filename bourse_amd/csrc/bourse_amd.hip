@@ -62,10 +62,12 @@ uint64_t fnv1a(const void* p, size_t n, uint64_t h = 1469598103934665603ull) {
 // batch sizes from which bk_run's auto mode takes the split pipeline (measured crossovers: scripts/size_sweep.py,
 // scripts/parts_size_sweep.py, scripts/c5m_sweep.sh)
 constexpr uint32_t RANDOM_SPLIT_MIN_BOOKS = 8192, MIXED_SPLIT_MIN_BOOKS = 4096;
-// RandomAgents batches in [WAVE_MIN_BOOKS, WAVE_MAX_BOOKS] take the wave-parallel RNG decode (k_agents_wave) in front of
-// k_step_batch: below, the fused kernel's single launch per run wins; above, the lane-per-book k_agents_fsm costs fewer
-// issue slots per book-step and its latency is hidden by the other parts (scripts/size_sweep.py)
-constexpr uint32_t WAVE_MIN_BOOKS = 1024, WAVE_MAX_BOOKS = 24576;
+// RandomAgents batches of up to WAVE_MAX_BOOKS books take the wave-parallel RNG decode: fused with the event phase in
+// one persistent kernel (k_run_wave) below WAVE_FUSED_MAX_BOOKS, as k_agents_wave in front of k_step_batch (three parts
+// whose kernels overlap) from there; above WAVE_MAX_BOOKS the lane-per-book k_agents_fsm costs far fewer issue slots per
+// book-step and its latency is hidden by the other parts (scripts/size_sweep.py: 2 048 / 4 096 / 8 192 / 16 384 / 32 768
+// books: k_run_wave 33 / 53 / 74 / 76 / 79 M, wave_split 32 / 50 / 85 / 97 / 99 M, lane split - / 22 / 41 / 69 / 121 M)
+constexpr uint32_t WAVE_FUSED_MAX_BOOKS = 6144, WAVE_MAX_BOOKS = 24576;
 
 struct HostOrder {  // immutable half of an order, fixed at create_order (orderbook.rs:356-396)
   uint8_t bid;
@@ -123,9 +125,16 @@ struct bk_env {
   uint32_t wave_lookahead = 64;
   int wave_parts = 0;           // 0 = as the lane split (n_parts / min_part)
   bool wave_ok() const { return !n_mixed && M == 1 && !groups.empty(); }  // RandomAgents on independent books
-  bool use_wave() const { return wave_ok() && pipeline == 4; }              // split form
-  bool use_wave_fused() const {                                             // persistent fused form
-    return wave_ok() && (pipeline == 5 || (pipeline == 0 && cfg.n_books >= WAVE_MIN_BOOKS && cfg.n_books <= WAVE_MAX_BOOKS));
+  bool use_wave() const {        // split form: k_agents_wave + k_step_batch
+    return wave_ok() && (pipeline == 4 || (pipeline == 0 && cfg.n_books >= WAVE_FUSED_MAX_BOOKS && cfg.n_books <= WAVE_MAX_BOOKS));
+  }
+  bool use_wave_fused() const {  // persistent fused form: k_run_wave
+    return wave_ok() && (pipeline == 5 || (pipeline == 0 && cfg.n_books < WAVE_FUSED_MAX_BOOKS));
+  }
+  int wave_split_parts() const {
+    if (wave_parts > 0)  // set explicitly (tests, sweeps): any batch of >= 64 books per part
+      return static_cast<int>(std::max(1u, std::min(static_cast<uint32_t>(wave_parts), cfg.n_books / 64u)));
+    return static_cast<int>(std::max(1u, std::min(3u, cfg.n_books / 2048u)));
   }
   // split pipeline: the batch is cut into n_parts contiguous parts, each on its own stream and started one
   // k_agents_fsm apart, so the latency-bound lane-per-book kernel of one part runs under the issue-bound
@@ -352,9 +361,7 @@ int launch_split(bk_env* env, const DevArgs& a0, uint64_t first_step, uint32_t n
   const uint32_t M = env->M;
   const uint32_t B = env->cfg.n_books / M;  // units the parts are cut in: books, or markets of M books
   // small batches: one part on the caller's stream
-  const int P = (wave && env->wave_parts > 0)
-                    ? static_cast<int>(std::max(1u, std::min<uint32_t>(env->wave_parts, env->cfg.n_books / 64u)))
-                    : env->parts();
+  const int P = wave ? env->wave_split_parts() : env->parts();
   if (P > 1 && !env->ev_fork) {
     HIPCHK(hipEventCreateWithFlags(&env->ev_fork, hipEventDisableTiming));
     for (int i = 0; i < bk_env::MAX_PARTS; ++i) {
@@ -1088,7 +1095,7 @@ int bk_run(bk_env* env, uint64_t n_steps) {
     env->steps_done += n_steps;
     return BK_OK;
   }
-  const bool split = (env->pipeline >= 2 && env->pipeline != 5) || env->M > 1 ||
+  const bool split = (env->pipeline >= 2 && env->pipeline != 5) || env->M > 1 || env->use_wave() ||
                      (env->pipeline == 0 && env->cfg.n_books >= RANDOM_SPLIT_MIN_BOOKS && a.n_groups > 0);
   if (split) {
     switch (env->R) {
@@ -1626,9 +1633,7 @@ int bk_get_pipeline(bk_env* env, int* split, int* n_parts) {
   const bool sp = wv || (env->pipeline >= 2 && env->pipeline != 5) || env->M > 1 ||
                   (env->pipeline == 0 && (env->n_mixed ? env->cfg.n_books >= MIXED_SPLIT_MIN_BOOKS
                                                        : env->cfg.n_books >= RANDOM_SPLIT_MIN_BOOKS && !env->groups.empty()));
-  const int P = (wv && env->wave_parts > 0)
-                    ? static_cast<int>(std::max(1u, std::min<uint32_t>(env->wave_parts, env->cfg.n_books / 64u)))
-                    : env->parts();
+  const int P = wv ? env->wave_split_parts() : env->parts();
   if (split) *split = wv ? 2 : (sp ? 1 : 0);
   if (n_parts) *n_parts = sp ? P : 1;
   return BK_OK;
