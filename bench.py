@@ -57,7 +57,11 @@ def cpu_baseline(groups, levels, n_books, budget_s=12.0):
 def _cpu_baseline(agents_kw, levels, n_books, budget_s=12.0):
     """Time the CPU oracle (kind "port": C++ restatement of the reference algorithm, ordered maps per
     side, one Env per book) on all host cores, on a bounded sample of the same workload: the workload's own number of
-    books (so that the working set is the real one, not a cache-resident toy), a few steps, three timed repetitions."""
+    books (so that the working set is the real one, not a cache-resident toy), a few steps, three timed repetitions.
+    Books are constructed by the threads that step them (per-thread allocator arenas, first-touch placement).  For
+    RandomAgents workloads the batched SoA CPU implementation (oracle/bourse_soa.cpp: ladder + per-level FIFO, checked
+    equal to the oracle by tests/test_soa_cpu.py) is timed beside it under "soa": the oracle measures the reference's
+    ALGORITHM, the SoA figure what the same host does with the kernel's data structure."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import pyoracle
 
@@ -70,18 +74,53 @@ def _cpu_baseline(agents_kw, levels, n_books, budget_s=12.0):
     est = rate1 * min(cores, books) * 0.04  # measured: 256 hardware threads deliver ~9x one thread on this workload
     warm = 10
     steps = int(max(5, min(100, est * budget_s / 3.0 / books - warm / 3.0)))
-    many = pyoracle.ManyBooks(books, SEED, 0, TICK, STEP_SIZE, True, levels, **agents_kw)
+    many = pyoracle.ManyBooks(books, SEED, 0, TICK, STEP_SIZE, True, levels, build_threads=cores, **agents_kw)
     many.run(warm, cores)
     vals = []
     for _ in range(3):
         t = time.perf_counter()
         many.run(steps, cores)
         vals.append(books * steps / (time.perf_counter() - t))
-    return {
+    del many
+    out = {
         "value": float(np.median(vals)), "unit": "book-steps/s", "cores": cores, "kind": "port",
         "sample": f"{books} books x {steps} steps, median of 3 repetitions after {warm} warm-up steps, same agents/levels/"
-                  f"seeds, {cores} host threads (books statically partitioned), oracle/libbourse_oracle.so -O3",
+                  f"seeds, {cores} host threads (books statically partitioned, built by their own threads), "
+                  f"oracle/libbourse_oracle.so -O3",
         "values": vals, "single_thread_probe": rate1,
+        "thread_efficiency": float(np.median(vals)) / (rate1 * cores),
+    }
+    if "groups" in agents_kw:
+        try:
+            out["soa"] = _cpu_baseline_soa(pyoracle, agents_kw["groups"], levels, books, cores)
+        except Exception as e:  # the SoA engine covers bounded-grid RandomAgents shapes only
+            out["soa"] = {"error": str(e)}
+    return out
+
+
+def _cpu_baseline_soa(pyoracle, groups, levels, books, cores, budget_s=6.0):
+    steps1 = 20
+    p1 = pyoracle.SoaBooks(256, SEED, 0, TICK, STEP_SIZE, levels, groups, history_capacity=steps1, trade_reserve=0, threads=1)
+    p1.run(steps1)          # touches the trade / history memory
+    p1.clear_trades()
+    t = time.perf_counter()
+    p1.run(steps1)
+    rate1 = 256 * steps1 / (time.perf_counter() - t)
+    steps = int(max(5, min(50, rate1 * min(cores, books) * 0.3 * budget_s / 4.0 / books)))
+    soa = pyoracle.SoaBooks(books, SEED, 0, TICK, STEP_SIZE, levels, groups, history_capacity=steps, trade_reserve=0,
+                            threads=cores)
+    soa.run(steps)          # warm-up of the same length: every page the timed passes write is resident
+    vals = []
+    for _ in range(3):
+        soa.clear_trades()  # the consumer has drained the records (as the GPU bench does per launch)
+        t = time.perf_counter()
+        soa.run(steps)
+        vals.append(books * steps / (time.perf_counter() - t))
+    return {
+        "value": float(np.median(vals)), "unit": "book-steps/s", "cores": cores, "kind": "soa",
+        "sample": f"{books} books x {steps} steps, median of 3 repetitions after {steps} warm-up steps, L2 record of every "
+                  f"step and all trade records kept; {cores} host threads, oracle/libbourse_soa.so -O3",
+        "values": vals, "single_thread_probe": rate1, "thread_efficiency": float(np.median(vals)) / (rate1 * cores),
     }
 
 

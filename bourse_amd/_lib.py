@@ -182,6 +182,8 @@ def load() -> C.CDLL:
         fn.argtypes = args
     L.bk_selftest_reduce.restype = _i32
     L.bk_selftest_reduce.argtypes = [_p32, _u32, _p32]
+    L.bk_selftest_math.restype = _i32
+    L.bk_selftest_math.argtypes = [_i32, C.POINTER(C.c_double), _u64, C.POINTER(C.c_double)]
     _lib = L
     return L
 

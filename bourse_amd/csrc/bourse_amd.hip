@@ -1766,4 +1766,22 @@ int bk_selftest_reduce(const uint32_t* in_host, uint32_t n_waves, uint32_t* out_
   return BK_OK;
 }
 
+// pm_math.hpp on the device (tests only): out[i] = f(in[i]), op 0 pm::exp, 1 pm::log, 2 pm::tanh - the routines the
+// Noise/Momentum members' log-normal offsets and momentum signal go through (agents/common.rs:104,137;
+// momentum_agent.rs:156); tests compare them with the host build of the same header bit for bit and with libm in ulps
+int bk_selftest_math(int op, const double* in_host, uint64_t n, double* out_host) {
+  if (!in_host || !out_host || op < 0 || op > 2) return fail(BK_INVALID_ARGUMENT, "bad argument");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(BK_NO_DEVICE, "no HIP device available");
+  DevBuf<double> in, out;
+  HIPCHK(in.alloc(n));
+  HIPCHK(out.alloc(n));
+  HIPCHK(hipMemcpy(in.p, in_host, n * sizeof(double), hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_selftest_math, dim3(static_cast<uint32_t>((n + 255) / 256)), dim3(256), 0, nullptr, op, in.p, out.p, n);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpy(out_host, out.p, n * sizeof(double), hipMemcpyDeviceToHost));
+  return BK_OK;
+}
+
 }  // extern "C"

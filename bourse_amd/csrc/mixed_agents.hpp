@@ -865,4 +865,12 @@ __global__ __launch_bounds__(256) void k_mixed_lists_rebuild(DevArgs a, MixedArg
   }
 }
 
+// pm_math.hpp routines on the device, element-wise (tests only)
+__global__ void k_selftest_math(int op, const double* in, double* out, uint64_t n) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double x = in[i];
+  out[i] = op == 0 ? pm::exp(x) : (op == 1 ? pm::log(x) : pm::tanh(x));
+}
+
 }  // namespace bkd

@@ -1,5 +1,6 @@
 // bourse_oracle_capi.cpp — C ABI over the CPU ORACLE, for ctypes (tests/, smoke(),
 // bench.py cpu_baseline only — see bourse_oracle.hpp).  Test infrastructure.
+#include <algorithm>
 #include <atomic>
 #include <cstring>
 #include <memory>
@@ -467,12 +468,35 @@ int orc_sim_run(void* e, void* a, uint64_t* st, uint64_t n_steps) {
 // ---------------------------------------------- many independent books -----
 // B independent (Env, agents, rng) triples, book b seeded seed_base + b.
 // groups: n_groups rows of {n, tick_lo, tick_hi, vol_lo, vol_hi, tick_size, rate_bits(f32)}
+// Threads that CONSTRUCT the books of the next orc_many_new* call (default 1).  With n > 1 the books are built by the same
+// static partition orc_many_run(.., n) steps them with: every book's maps and vectors then live in the allocator arena of
+// (and are first touched by) the thread that works on them, instead of all in the main thread's arena - the timed CPU
+// baseline of bench.py uses it; results do not depend on it.
+static int g_build_threads = 1;
+void orc_many_set_build_threads(int n) { g_build_threads = n < 1 ? 1 : n; }
+}  // extern "C"
+template <class F>
+static void build_books(OrcMany* m, uint32_t n_books, F&& make) {
+  m->books.resize(n_books);
+  const int nt = std::min<int>(g_build_threads, std::max<uint32_t>(1u, n_books));
+  auto work = [&](size_t lo, size_t hi) {
+    for (size_t b = lo; b < hi; ++b) m->books[b] = make(static_cast<uint32_t>(b));
+  };
+  if (nt == 1) {
+    work(0, n_books);
+    return;
+  }
+  std::vector<std::thread> th;
+  for (int t = 0; t < nt; ++t) th.emplace_back(work, static_cast<size_t>(n_books) * t / nt, static_cast<size_t>(n_books) * (t + 1) / nt);
+  for (auto& t : th) t.join();
+}
+extern "C" {
+
 void* orc_many_new(uint32_t n_books, uint64_t seed_base, uint64_t start, uint32_t tick, uint64_t step,
                    int trading, int levels, int n_groups, const uint32_t* groups) {
   auto* m = new OrcMany();
   m->levels = levels;
-  m->books.reserve(n_books);
-  for (uint32_t b = 0; b < n_books; ++b) {
+  build_books(m, n_books, [&](uint32_t b) {
     auto bk = std::make_unique<ManyBook>(start, tick, step, trading != 0, levels, seed_base + b);
     for (int g = 0; g < n_groups; ++g) {
       const uint32_t* r = groups + 7 * g;
@@ -481,8 +505,8 @@ void* orc_many_new(uint32_t n_books, uint64_t seed_base, uint64_t start, uint32_
       bk->agents.groups.push_back(
           std::make_unique<RandomAgentsBox>(RandomAgents(r[0], r[1], r[2], r[3], r[4], r[5], rate)));
     }
-    m->books.push_back(std::move(bk));
-  }
+    return bk;
+  });
   return m;
 }
 // same with an arbitrary AgentSet given as n_desc OrcAgentDesc records
@@ -490,13 +514,12 @@ void* orc_many_new_mixed(uint32_t n_books, uint64_t seed_base, uint64_t start, u
                          int trading, int levels, int n_desc, const void* descs) {
   auto* m = new OrcMany();
   m->levels = levels;
-  m->books.reserve(n_books);
   const OrcAgentDesc* d = static_cast<const OrcAgentDesc*>(descs);
-  for (uint32_t b = 0; b < n_books; ++b) {
+  build_books(m, n_books, [&](uint32_t b) {
     auto bk = std::make_unique<ManyBook>(start, tick, step, trading != 0, levels, seed_base + b);
     for (int g = 0; g < n_desc; ++g) add_from_desc(bk->agents, d[g]);
-    m->books.push_back(std::move(bk));
-  }
+    return bk;
+  });
   return m;
 }
 void orc_many_free(void* m) { delete static_cast<OrcMany*>(m); }

@@ -24,6 +24,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libbourse_oracle.so")
+_SOA_PATH = os.path.join(_HERE, "libbourse_soa.so")
 
 U64_MAX = 2**64 - 1
 MAX_PRICE = 2**32 - 1
@@ -56,6 +57,9 @@ def build(force: bool = False) -> str:
     )
     if stale:
         subprocess.run(["make", "-C", _HERE, "libbourse_oracle.so"], check=True, capture_output=True)
+    soa_src = os.path.join(_HERE, "bourse_soa.cpp")
+    if force or not os.path.exists(_SOA_PATH) or os.path.getmtime(soa_src) > os.path.getmtime(_SOA_PATH):
+        subprocess.run(["make", "-C", _HERE, "libbourse_soa.so"], check=True, capture_output=True)
     return _LIB_PATH
 
 
@@ -76,6 +80,7 @@ def lib() -> C.CDLL:
         fn.restype = res
         fn.argtypes = list(args)
 
+    sig("orc_many_set_build_threads", None, i32)
     sig("orc_rng_seed", None, u64, p64)
     sig("orc_rng_next_u64", u64, p64)
     sig("orc_rng_next_u32", u32, p64)
@@ -800,8 +805,10 @@ def sim_runner(env, agents, seed, n_steps, rng_state=None):
 class ManyBooks:
     """B independent (Env, RandomAgents groups, RNG) simulations; book b seeded seed + b."""
 
-    def __init__(self, n_books, seed, start_time, tick_size, step_size, trading, levels, groups=None, members=None):
+    def __init__(self, n_books, seed, start_time, tick_size, step_size, trading, levels, groups=None, members=None,
+                 build_threads=1):
         self.n_books, self.levels, self.tick = int(n_books), int(levels), int(tick_size)
+        lib().orc_many_set_build_threads(int(build_threads))
         if members is not None:  # arbitrary AgentSet (see agent_descs)
             d = agent_descs(members)
             self._m = lib().orc_many_new_mixed(self.n_books, int(seed), int(start_time), int(tick_size),
@@ -935,3 +942,113 @@ class ManyMarkets:
         for b in range(self.n_markets):
             lib().orc_mkts_rng_state(self._m, b, _p64(out[b]))
         return out
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Batched SoA CPU implementation (oracle/bourse_soa.cpp): ladder + per-level FIFO instead of ordered maps.  Test and
+# measurement infrastructure like the rest of this directory; tests/test_soa_cpu.py checks it equal to ManyBooks.
+_soa = None
+
+
+def soa_lib() -> C.CDLL:
+    global _soa
+    if _soa is not None:
+        return _soa
+    build()
+    L = C.CDLL(_SOA_PATH)
+    u64, u32, i32, vp = C.c_uint64, C.c_uint32, C.c_int, C.c_void_p
+    p64, p32 = C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)
+    L.soa_new.restype = vp
+    L.soa_new.argtypes = [u32, u64, u64, u32, u64, u32, i32, p32, u64, u32, i32, i32]
+    L.soa_free.restype = None
+    L.soa_free.argtypes = [vp]
+    L.soa_run.restype = i32
+    L.soa_run.argtypes = [vp, u64, i32]
+    L.soa_steps_done.restype = u64
+    L.soa_steps_done.argtypes = [vp]
+    L.soa_history.restype = None
+    L.soa_history.argtypes = [vp, u64, u64, p32]
+    for name in ("soa_trade_counts", "soa_event_counts", "soa_rng_states"):
+        getattr(L, name).restype = None
+        getattr(L, name).argtypes = [vp, p64]
+    L.soa_trades_retained.restype = u64
+    L.soa_trades_retained.argtypes = [vp, u32]
+    L.soa_trades.restype = None
+    L.soa_trades.argtypes = [vp, u32, vp]
+    L.soa_clear_trades.restype = None
+    L.soa_clear_trades.argtypes = [vp]
+    _soa = L
+    return L
+
+
+def activity_threshold(rate) -> int:
+    """`gen::<f32>() < rate` as a threshold on (u32 >> 8): ceil(f32(rate) * 2^24) clamped to [0, 2^24] (the integer the
+    device uses, bourse_amd/csrc/host_math.hpp; exact in double)."""
+    import math
+
+    r = float(np.float32(rate))
+    if not (r > 0.0):
+        return 0
+    x = r * 16777216.0
+    return 16777216 if x >= 16777216.0 else int(math.ceil(x))
+
+
+class SoaBooks:
+    """B independent RandomAgents books on the SoA CPU engine; same constructor meaning as ManyBooks (trading enabled)."""
+
+    def __init__(self, n_books, seed, start_time, tick_size, step_size, levels, groups, history_capacity, trade_reserve=0,
+                 keep_trades=True, threads=1):
+        self.n_books, self.levels, self.threads = int(n_books), int(levels), int(threads)
+        self.hist_cap = int(history_capacity)
+        g = np.zeros((len(groups), 7), dtype=np.uint32)
+        for i, (n, tr, vr, ts, rate) in enumerate(groups):
+            g[i] = (n, tr[0], tr[1], vr[0], vr[1], ts, activity_threshold(rate))
+        self._m = soa_lib().soa_new(self.n_books, int(seed), int(start_time), int(tick_size), int(step_size), self.levels,
+                                    len(groups), _p32(g), self.hist_cap, int(trade_reserve), int(bool(keep_trades)),
+                                    self.threads)
+        if not self._m:
+            raise ValueError("shape outside the SoA engine's ladder (tick grid / window / agent count)")
+
+    def __del__(self):
+        if getattr(self, "_m", None):
+            soa_lib().soa_free(self._m)
+            self._m = None
+
+    def run(self, n_steps, n_threads=None):
+        soa_lib().soa_run(self._m, int(n_steps), int(n_threads or self.threads))
+
+    def history(self, first_step=None, n=None):
+        done = int(soa_lib().soa_steps_done(self._m))
+        if first_step is None:
+            first_step = max(0, done - self.hist_cap)
+        if n is None:
+            n = done - first_step
+        o = np.zeros((n, self.n_books, 5 + 4 * self.levels), dtype=np.uint32)
+        if n:
+            soa_lib().soa_history(self._m, int(first_step), int(n), _p32(o))
+        return o
+
+    def trade_counts(self):
+        out = np.zeros(self.n_books, dtype=np.uint64)
+        soa_lib().soa_trade_counts(self._m, _p64(out))
+        return out
+
+    def event_counts(self):
+        out = np.zeros(self.n_books, dtype=np.uint64)
+        soa_lib().soa_event_counts(self._m, _p64(out))
+        return out
+
+    def rng_states(self):
+        out = np.zeros((self.n_books, 2), dtype=np.uint64)
+        soa_lib().soa_rng_states(self._m, _p64(out))
+        return out
+
+    def trades(self, book):
+        n = int(soa_lib().soa_trades_retained(self._m, int(book)))
+        a = np.zeros(n, dtype=TRADE_DTYPE)
+        if n:
+            soa_lib().soa_trades(self._m, int(book), a.ctypes.data_as(C.c_void_p))
+        return a
+
+    def clear_trades(self):
+        soa_lib().soa_clear_trades(self._m)
