@@ -48,6 +48,27 @@ WORKLOADS["C5M"] = (8192, 64, [("momentum", 0, 256, MOM_P), ("noise", 256, 256, 
 TICK, STEP_SIZE, SEED = 2, 100_000, 101
 
 
+def effective_cores():
+    """Host threads this process can really run at once: the scheduler affinity capped by the cgroup CPU quota (the GPU
+    boxes show 256 logical CPUs but cap the container at 16 CPUs' worth of time - 256 threads then only thrash)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]  # cgroup v2: "<quota|max> <period>"
+        if q != "max":
+            quota = int(q) / int(per)
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except Exception:
+            pass
+    used = max(1, min(n, int(quota))) if quota else n
+    return used, n, quota
+
+
 def cpu_baseline(groups, levels, n_books, budget_s=12.0):
     if any(isinstance(g[0], str) for g in groups):
         return _cpu_baseline(dict(members=groups), levels, n_books, budget_s)
@@ -65,13 +86,13 @@ def _cpu_baseline(agents_kw, levels, n_books, budget_s=12.0):
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import pyoracle
 
-    cores = os.cpu_count() or 1
+    cores, visible, quota = effective_cores()
     probe = pyoracle.ManyBooks(64, SEED, 0, TICK, STEP_SIZE, True, levels, **agents_kw)
     t = time.perf_counter()
     probe.run(30, 1)
     rate1 = 64 * 30 / (time.perf_counter() - t)
     books = int(min(n_books, 65536))
-    est = rate1 * min(cores, books) * 0.04  # measured: 256 hardware threads deliver ~9x one thread on this workload
+    est = rate1 * min(cores, books) * 0.5
     warm = 10
     steps = int(max(5, min(100, est * budget_s / 3.0 / books - warm / 3.0)))
     many = pyoracle.ManyBooks(books, SEED, 0, TICK, STEP_SIZE, True, levels, build_threads=cores, **agents_kw)
@@ -89,6 +110,7 @@ def _cpu_baseline(agents_kw, levels, n_books, budget_s=12.0):
                   f"oracle/libbourse_oracle.so -O3",
         "values": vals, "single_thread_probe": rate1,
         "thread_efficiency": float(np.median(vals)) / (rate1 * cores),
+        "host": f"{visible} logical CPUs visible, cgroup CPU quota {quota if quota else 'none'}: {cores} threads used",
     }
     if "groups" in agents_kw:
         try:

@@ -147,6 +147,7 @@ SIGNATURES = {
     "bk_state_bytes_per_book": (_u64, [_vp]),
     "bk_set_split_parts": (_i32, [_vp, _i32, _u32]),
     "bk_set_wave_options": (_i32, [_vp, _u32, _i32]),
+    "bk_pipeline_fallbacks": (_i32, [_vp, _p64]),
     "bk_order_counts": (_i32, [_vp, _p64]),
     "bk_checkpoint_bytes": (_u64, [_vp]),
     "bk_checkpoint_save": (_i32, [_vp, _vp, _u64]),

@@ -1155,6 +1155,15 @@ __global__ void k_book_service(uint32_t* state, uint32_t stride, uint32_t n_book
   }
 }
 
+// books whose sticky flags gained a bit of `mask` relative to the snapshot taken before a guarded launch
+__global__ void k_count_new_flags(const uint32_t* state, const uint32_t* snap, uint32_t stride, uint32_t n_books,
+                                  uint32_t mask, uint32_t* count) {
+  const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= n_books) return;
+  const uint32_t now = state[(size_t)b * stride + H_FLAGS], was = snap[(size_t)b * stride + H_FLAGS];
+  if (now & ~was & mask) atomicAdd(count, 1u);
+}
+
 struct DevStats {  // == bk_stats
   unsigned long long n_books, sum_trade_vol, sum_trades, sum_events, sum_bid_vol, sum_ask_vol;
   uint32_t min_bid, max_bid, min_ask, max_ask;

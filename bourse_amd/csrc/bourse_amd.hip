@@ -120,6 +120,8 @@ struct bk_env {
   // 0 auto, 1 fused (k_run_random), 2 split (k_agents_fsm + k_step_batch), 3 split with wave-per-book AgentSet members,
   // 4 wave_split (k_agents_wave + k_step_batch), 5 wave (k_run_wave: wave-parallel decode + events, persistent)
   int pipeline = 0;
+  DevBuf<uint32_t> snap, snap_count;  // guarded launches (auto pipeline, AgentSets): state + L2 copy, new-flag counter
+  uint64_t n_fallbacks = 0;           // guarded launches that were rolled back and redone on the fused kernel
   DevBuf<uint4> jump_tabs;      // k_agents_wave: T^256 (block jump) then T^(4 << b), b = 0..5 (lane offsets): 7 x 8 KB
   DevBuf<uint32_t> wcache;      // k_agents_wave: per-book lane states of the RNG block in progress
   uint32_t wave_lookahead = 64;
@@ -1053,12 +1055,51 @@ int bk_run(bk_env* env, uint64_t n_steps) {
     // overtakes the fused kernel, scripts/c5m_sweep.sh) the members' update runs one LANE per book in front of the lean
     // event kernel, the batch cut in parts that overlap.  Mode 3 keeps the wave-per-book members' update selectable.
     const bool mlanes = env->pipeline == 2 || env->M > 1 || (env->pipeline == 0 && env->cfg.n_books >= MIXED_SPLIT_MIN_BOOKS);
+    // The lane-per-book members' update keeps a filled order's pool slot reserved until its member's next update, so a
+    // pool the wave-per-book kernels just fit can overflow there.  A pipeline CHOSEN BY THE LIBRARY must not change
+    // results: in auto mode (independent books) the launch is guarded - state and level-2 records are copied aside, and
+    // if the launch newly raised BK_FLAG_POOL_OVERFLOW on any book it is rolled back and redone on the fused kernel
+    // (same history slots, same trade-record positions: nothing of the first attempt survives).  Costs one device-to-
+    // device copy and one host sync per bk_run; a pipeline requested explicitly runs unguarded.
+    const bool guarded = mlanes && env->pipeline == 0 && env->M == 1;
+    if (guarded) {
+      const size_t sb = static_cast<size_t>(env->cfg.n_books) * env->stride, lb = static_cast<size_t>(env->cfg.n_books) * env->W;
+      if (!env->snap.p) {
+        HIPCHK(env->snap.alloc(sb + lb));
+        HIPCHK(env->snap_count.alloc(1));
+      }
+      HIPCHK(hipMemcpyAsync(env->snap.p, env->state.p, sb * 4, hipMemcpyDeviceToDevice, env->stream));
+      HIPCHK(hipMemcpyAsync(env->snap.p + sb, env->l2_last.p, lb * 4, hipMemcpyDeviceToDevice, env->stream));
+    }
     if (mlanes) {
       switch (env->R) {
         case 1: rc = launch_split<1, 2>(env, a, env->steps_done, ns); break;
         case 2: rc = launch_split<2, 2>(env, a, env->steps_done, ns); break;
         case 4: rc = launch_split<4, 2>(env, a, env->steps_done, ns); break;
         default: rc = launch_split<8, 2>(env, a, env->steps_done, ns); break;
+      }
+      if (rc == BK_OK && guarded) {
+        const uint32_t B = env->cfg.n_books;
+        const size_t sb = static_cast<size_t>(B) * env->stride, lb = static_cast<size_t>(B) * env->W;
+        HIPCHK(hipMemsetAsync(env->snap_count.p, 0, 4, env->stream));
+        hipLaunchKernelGGL(k_count_new_flags, dim3((B + 255) / 256), dim3(256), 0, env->stream, env->state.p, env->snap.p,
+                           env->stride, B, FLAG_POOL_OVERFLOW, env->snap_count.p);
+        HIPCHK(hipGetLastError());
+        uint32_t n_new = 0;
+        HIPCHK(hipMemcpyAsync(&n_new, env->snap_count.p, 4, hipMemcpyDeviceToHost, env->stream));
+        HIPCHK(hipStreamSynchronize(env->stream));
+        if (n_new) {  // roll back and redo this launch one wave per book
+          HIPCHK(hipMemcpyAsync(env->state.p, env->snap.p, sb * 4, hipMemcpyDeviceToDevice, env->stream));
+          HIPCHK(hipMemcpyAsync(env->l2_last.p, env->snap.p + sb, lb * 4, hipMemcpyDeviceToDevice, env->stream));
+          env->ml_valid = false;
+          env->n_fallbacks += 1;
+          switch (env->R) {
+            case 1: rc = launch_mixed<1>(env, a, env->steps_done, ns); break;
+            case 2: rc = launch_mixed<2>(env, a, env->steps_done, ns); break;
+            case 4: rc = launch_mixed<4>(env, a, env->steps_done, ns); break;
+            default: rc = launch_mixed<8>(env, a, env->steps_done, ns); break;
+          }
+        }
       }
     } else if (env->pipeline == 3) {
       switch (env->R) {
@@ -1645,6 +1686,14 @@ int bk_set_pipeline(bk_env* env, int mode) {
                 "pipeline mode must be 0 (auto), 1 (fused), 2 (split), 3 (split, wave-per-book AgentSet members), 4 (wave_split: "
                 "wave-parallel RNG decode kernel + event kernel) or 5 (wave: both fused in one persistent kernel)");
   env->pipeline = mode;
+  return BK_OK;
+}
+
+// number of bk_run launches the auto pipeline rolled back and redid on the fused kernel (pool overflow on the lane-per-book
+// members' update that the wave-per-book kernels avoid)
+int bk_pipeline_fallbacks(bk_env* env, uint64_t* out) {
+  if (!env || !out) return fail(BK_INVALID_ARGUMENT, "null argument");
+  *out = env->n_fallbacks;
   return BK_OK;
 }
 

@@ -615,6 +615,12 @@ class ManyBookEnv:
         """Split pipeline: cut the batch in ``min(n_parts, books / min_part)`` parts on separate streams."""
         check(self._L.bk_set_split_parts(self._h, int(n_parts), int(min_part)))
 
+    def pipeline_fallbacks(self) -> int:
+        """bk_run launches the auto pipeline rolled back and redid on the fused kernel (AgentSets, pool at capacity)."""
+        out = C.c_uint64(0)
+        check(self._L.bk_pipeline_fallbacks(self._h, C.byref(out)))
+        return int(out.value)
+
     def pipeline(self) -> Tuple[str, int]:
         """('fused' | 'split' | 'wave_split' | 'wave', number of book parts on separate streams) that run() will use."""
         a, b = C.c_int(0), C.c_int(1)

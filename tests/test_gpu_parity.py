@@ -1730,3 +1730,30 @@ def test_step_env_history_outlives_the_device_ring(bk, oracle):
         for x, y in zip(g, w):
             assert len(x) == 11 and np.array_equal(x, y), name
     assert all(np.array_equal(v, ref.get_market_data()[k]) for k, v in env.get_market_data().items())
+
+
+def test_auto_pipeline_does_not_change_results_at_the_pool_capacity_edge(bk):
+    """The lane-per-book members' update (the auto pipeline's choice from 4 096 books) keeps a filled order's pool slot
+    until its member's next update, so it overflows a nearly full pool where the wave-per-book kernels still fit (1 of
+    60 000 fuzz draws in round 1).  A pipeline chosen BY THE LIBRARY must not change results: the guarded launch is
+    rolled back and redone on the fused kernel.  Configurations found with scripts/find_capacity_edge.py."""
+    B, T = 4096, 30
+    worse = 0
+    for n, pl, pm_, pc in ((125, 0.3, 0.2, 0.7), (120, 0.4, 0.3, 0.6)):
+        P = dict(tick_size=1, p_limit=pl, p_market=pm_, p_cancel=pc, trade_vol=10, price_dist_mu=0.0, price_dist_sigma=1.0)
+        res = {}
+        for pipe in ("split", "fused", "auto"):
+            e = bk.ManyBookEnv(B, 11, 0, 1, 1_000_000, True, levels=8, max_live_orders=128, trade_capacity=128 * T,
+                               history_capacity=T, strict=False)
+            e.set_agents([("noise", 0, n, P)])
+            e.set_pipeline(pipe)
+            for c in (T // 3, T - T // 3):
+                e.run(c)
+            res[pipe] = (e.flags() & 1, e.pipeline_fallbacks(), e.history(), e.trade_counts(), [e.rng_state(b) for b in (0, 77, B - 1)])
+            e.close()
+        assert res["auto"][1] >= 1 and res["split"][1] == 0 and res["fused"][1] == 0   # only the library's own choice is guarded
+        for k in (0, 2, 3):
+            assert np.array_equal(res["auto"][k], res["fused"][k]), (n, k)
+        assert res["auto"][4] == res["fused"][4]
+        worse += int(res["split"][0].sum()) > int(res["fused"][0].sum())
+    assert worse >= 1  # the edge exists: unguarded, the lane pipeline flags books the fused kernel does not
