@@ -171,43 +171,68 @@ struct WaveDecoder {
         const uint32_t fprice = (G.tick_lo + __umulhi(x2, G.tick_rng)) * G.tick_size;
         const uint32_t fvol = G.vol_lo + __umulhi(x3, G.vol_rng);
 
+        // ---- per lane p, both continuations of the walk from a hit at p, packed in one word so that the scalar walk
+        // needs a single v_readlane per hit: after a cancellation (or any one-draw outcome) the next hit is the first
+        // set bit of H above p; after a placement the stream stands at f = fpos(p) and the next hit is the first set
+        // bit of H at or above f (f itself when the placement leaves the window).  Inactive agents in between are
+        // skipped by position arithmetic: one agent per activity draw.
+        //   bits 0..6 next hit after a cancellation (1..64) | 7..14 next position after a placement (<= 128) |
+        //   15..22 f | 23..29 agents consumed by the placement path | 31 placement not resolvable in the look-ahead
+        uint32_t pack;
+        {
+          const uint64_t hc = (uint32_t)lane < 63u ? (H >> (lane + 1)) : 0ull;
+          const uint32_t nC = hc ? (uint32_t)lane + 1u + (uint32_t)__builtin_ctzll(hc) : 64u;
+          const uint32_t fq = fpos < 64u ? fpos : 0u;
+          const uint64_t hp = H >> fq;
+          const uint32_t nP = fpos < 64u ? (hp ? fq + (uint32_t)__builtin_ctzll(hp) : 64u) : fpos;
+          const uint32_t dP = fpos < 64u ? 1u + nP - fpos : 1u;
+          pack = nC | (fpos == WV_NONE ? 0x80000000u : ((nP << 7) | (fpos << 15) | (dP << 23)));
+        }
         // ---- scalar walk over the activity hits of this window (p < 64 and ag < gend on entry).  Each acting lane
         // gets its event word (slot, EV_NEW, marker bit 16) by v_writelane; list positions follow from the lane order
         // at the flush below (events of a window are in stream order = agent order).
         uint32_t p = pos - w0;
         uint32_t agw = 0;
         bool slow = false;
-        for (;;) {
+        {
+          // to the first hit at or after p (or the end of the window / group)
           const uint64_t m = H >> p;
-          if (m == 0) {  // no further hit in the window: the remaining draws are inactive agents'
-            const uint32_t adv = (64u - p) < (gend - ag) ? (64u - p) : (gend - ag);
-            ag += adv;
+          const uint32_t d = m ? (uint32_t)__builtin_ctzll(m) : 64u - p;
+          if (ag + d >= gend || m == 0) {
+            const uint32_t adv = d < gend - ag ? d : gend - ag;
             p += adv;
-            break;
-          }
-          const uint32_t d = (uint32_t)__builtin_ctzll(m);
-          const uint32_t na = ag + d;
-          if (na >= gend) {  // the group ends before the next hit
-            p += gend - ag;
-            ag = gend;
-            break;
-          }
-          p += d;
-          ag = na + 1u;
-          if ((rdl(livev, live_base + (na >> 5)) >> (na & 31u)) & 1u) {  // holds an Active order: cancel it (:95-97)
-            agw = wrl(na | WV_ACTED, p, agw);
-            p += 1u;
+            ag += adv;
           } else {
-            const uint32_t fp = rdl(fpos, p);
-            if (fp == WV_NONE) {
+            p += d;
+            ag += d;
+            for (;;) {  // p: a hit inside the window, ag < gend: its agent
+              const uint32_t w = rdl(pack, p);
+              uint32_t np, na;
+              const bool holds = (rdl(livev, live_base + (ag >> 5)) >> (ag & 31u)) & 1u;
+              if (holds) {  // an Active order: queue its cancellation (random_agent.rs:95-97)
+                agw = wrl(ag | WV_ACTED, p, agw);
+                np = w & 0x7Fu;
+                na = ag + (np - p);
+              } else {
+                if (w >> 31) {
+                  slow = true;
+                  break;
+                }
+                agw = wrl(ag | (EV_NEW | WV_ACTED), p, agw);
+                np = (w >> 7) & 0xFFu;
+                na = ag + ((w >> 23) & 0x7Fu);
+              }
+              if (na >= gend) {  // the group ends before the next hit: agent `gend`'s activity draw is where the run
+                const uint32_t rs = holds ? p + 1u : ((w >> 15) & 0xFFu);  // of one-draw agents that starts at rs gets to
+                p = rs + (gend - ag - 1u);
+                ag = gend;
+                break;
+              }
+              p = np;
               ag = na;
-              slow = true;
-              break;
+              if (p >= 64u) break;
             }
-            agw = wrl(na | (EV_NEW | WV_ACTED), p, agw);
-            p = fp;
           }
-          if (p >= 64u) break;
         }
         // ---- the window's events, one lane each: list entry and the new order's fields
         {
