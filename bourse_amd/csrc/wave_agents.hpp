@@ -90,6 +90,8 @@ struct WaveDecoder {
   uint32_t* pm;        // LDS: placing-agents mask, 2 R words
   uint32_t* sm;        // LDS: bid-side mask of the placements, 2 R words
   uint2* pv;           // new orders by slot
+  uint16_t* jarr;      // LDS: shuffle targets, jarr[i] = gen_range(0..i+1) of step i (64 R entries)
+  uint4* wmask;        // LDS (R <= 2): 128 x 128-bit "steps that target this position" masks of the shuffle resolution
   uint4* wcs;          // global: the 64 lane states of the cache record
   int lane;
   uint4 cs;            // this lane's chunk-start state in the last generated block
@@ -309,21 +311,71 @@ struct WaveDecoder {
         acc = nacc;
       }
       const uint32_t cnt = (uint32_t)__builtin_popcountll(acc);
-      // the swaps, in stream order (uniform addresses: every lane reads the same pair, every lane writes the same values)
-      uint64_t todo = acc;
-      while (todo) {
-        const uint32_t l = (uint32_t)__builtin_ctzll(todo);
-        todo &= todo - 1ull;
-        const uint32_t si = rdl(ii, l), sj = rdl(jj, l);
-        const uint16_t ea = evl[si], eb = evl[sj];
-        wave_sync();
-        evl[si] = eb;
-        evl[sj] = ea;
-        wave_sync();
+      if constexpr (R <= 2) {
+        if (lane_bit(acc)) jarr[ii] = (uint16_t)jj;  // resolved in one go below
+      } else {
+        // the swaps, in stream order (uniform addresses: every lane reads the same pair and writes the same values)
+        uint64_t todo = acc;
+        while (todo) {
+          const uint32_t l = (uint32_t)__builtin_ctzll(todo);
+          todo &= todo - 1ull;
+          const uint32_t si = rdl(ii, l), sj = rdl(jj, l);
+          const uint16_t ea = evl[si], eb = evl[sj];
+          wave_sync();
+          evl[si] = eb;
+          evl[sj] = ea;
+          wave_sync();
+        }
       }
       i -= cnt;  // cnt <= i by construction
       // draws consumed: up to the accepted draw that served index 1, else the whole window
       pos = w0 + ((i < 1u && acc) ? (64u - (uint32_t)__builtin_clzll(acc)) : 64u);
+    }
+    if constexpr (R <= 2) {
+      // All swap targets j_i are known: resolve the whole Fisher-Yates in parallel instead of n dependent LDS round
+      // trips.  Steps run i = n-1 .. 1; the value that ends at position x was at position j_x just before step x, and a
+      // position y holds, before step t, what the most recent earlier step s* = min{s > t : j_s = y} moved there - the
+      // value position s* held before step s* - or its original entry if there is none.  One 128-bit mask per position
+      // ("steps that target it"), a first-set-bit search per hop, every position chased by its own lane
+      // (tools/wave_decode_proto.py checks the rule against sequential swaps).
+      if (n_ev >= 2u) {
+        wave_sync();
+        wmask[lane] = make_uint4(0u, 0u, 0u, 0u);
+        wmask[lane + 64] = make_uint4(0u, 0u, 0u, 0u);
+        wave_sync();
+        uint32_t* w32 = reinterpret_cast<uint32_t*>(wmask);
+        uint32_t jx[2];
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+          const uint32_t x = (uint32_t)lane + 64u * g;
+          jx[g] = (x >= 1u && x < n_ev) ? jarr[x] : x;
+          if (jx[g] != x) atomicOr(&w32[jx[g] * 4u + (x >> 5)], 1u << (x & 31u));  // a self-swap moves nothing
+        }
+        wave_sync();
+        uint32_t val[2];
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+          const uint32_t x = (uint32_t)lane + 64u * g;
+          uint32_t y = jx[g], t = x;
+          bool go = x < n_ev;
+          while (__ballot(go)) {
+            const uint4 m = wmask[y & 127u];
+            const uint32_t sx = first_above(mk64(m.x, m.y), mk64(m.z, m.w), t);
+            const bool hop = go && sx < 128u;
+            y = hop ? sx : y;
+            t = hop ? sx : t;
+            go = hop;
+          }
+          val[g] = evl[y & (64u * R - 1u)];
+        }
+        wave_sync();
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+          const uint32_t x = (uint32_t)lane + 64u * g;
+          if (x < n_ev) evl[x] = (uint16_t)val[g];
+        }
+        wave_sync();
+      }
     }
   }
 
@@ -365,6 +417,7 @@ __global__ __launch_bounds__(256, 8) void k_agents_wave(DevArgs a, WaveArgs wa) 
   __shared__ uint32_t ring_s[4][WV_RING];
   __shared__ uint16_t evl_s[4][64 * R];
   __shared__ uint32_t pm_s[4][2 * R], sm_s[4][2 * R];
+  __shared__ uint16_t jarr_s[4][64 * R];
   const int lane = threadIdx.x & 63;
   const int wv = (int)rfl(threadIdx.x >> 6);  // wave-uniform: the per-wave LDS regions get scalar base addresses
   for (int i = threadIdx.x; i < 512; i += 256) tab[i] = wa.jt_block[i];
@@ -382,6 +435,8 @@ __global__ __launch_bounds__(256, 8) void k_agents_wave(DevArgs a, WaveArgs wa) 
   D.pm = pm_s[wv];
   D.sm = sm_s[wv];
   D.pv = reinterpret_cast<uint2*>(bt + BT_EV + 32 * R);
+  D.jarr = jarr_s[wv];
+  D.wmask = reinterpret_cast<uint4*>(ring_s[wv]);  // the generated draws are dead once the shuffle's windows are resolved
   D.wcs = reinterpret_cast<uint4*>(wc + WC_HDR);
   D.lane = lane;
   // the book's RNG state and live masks (header dwords H_LIVE0 + w hold bits [32 w, 32 w + 32) of the pool's live mask)
@@ -422,7 +477,7 @@ __global__ __launch_bounds__(256, 8) void k_agents_wave(DevArgs a, WaveArgs wa) 
 // round trips; for batches that fit the chip once or twice (8 192 books = one resident wave per book).
 // ==================================================================================
 template <int R>
-__global__ __launch_bounds__(512, 8) void k_run_wave(DevArgs a, WaveArgs wa, uint64_t first_step, uint32_t n_steps) {
+__global__ __launch_bounds__(512, 6) void k_run_wave(DevArgs a, WaveArgs wa, uint64_t first_step, uint32_t n_steps) {
   constexpr int WPB = 8;                                       // books (waves) per workgroup
   constexpr int STAGE_DW = 128 * R > 256 ? 128 * R : 256;      // new orders {price, vol} by slot, then the level bins
   __shared__ uint4 tab[512];
@@ -430,6 +485,8 @@ __global__ __launch_bounds__(512, 8) void k_run_wave(DevArgs a, WaveArgs wa, uin
   __shared__ uint16_t evl_s[WPB][64 * R];
   __shared__ uint32_t pm_s[WPB][2 * R], sm_s[WPB][2 * R];
   __shared__ uint32_t stage_s[WPB][STAGE_DW];
+  __shared__ uint16_t jarr_s[WPB][64 * R];
+  __shared__ uint4 wmask_s[WPB][R <= 2 ? 128 : 1];  // the ring stays live across steps here: the masks get their own 2 KB
   const int lane = threadIdx.x & 63;
   const int wv = (int)rfl(threadIdx.x >> 6);
   for (int i = threadIdx.x; i < 512; i += 512) tab[i] = wa.jt_block[i];
@@ -450,6 +507,8 @@ __global__ __launch_bounds__(512, 8) void k_run_wave(DevArgs a, WaveArgs wa, uin
   D.pm = pm_s[wv];
   D.sm = sm_s[wv];
   D.pv = reinterpret_cast<uint2*>(stage);
+  D.jarr = jarr_s[wv];
+  D.wmask = wmask_s[wv];
   D.wcs = reinterpret_cast<uint4*>(wc + WC_HDR);
   D.lane = lane;
   D.load_cache(wc, (uint32_t)rng.s0, (uint32_t)(rng.s0 >> 32), (uint32_t)rng.s1, (uint32_t)(rng.s1 >> 32), wa.jt_lane);

@@ -34,3 +34,18 @@ def test_jump_tables_model():
     a, b, x0 = w.step(1, 2)
     a, b, x1 = w.step(a, b)
     assert (x0, x1) == (5760, 97769243520 & 0xFFFFFFFF)
+
+
+def test_parallel_fisher_yates_resolution_equals_sequential_swaps():
+    import random
+
+    import wave_decode_proto as w
+
+    rnd = random.Random(5)
+    for _ in range(2000):
+        n = rnd.randrange(1, 129)
+        j = [0] + [rnd.randrange(0, i + 1) for i in range(1, n)]
+        assert w.fisher_yates_parallel(n, j) == w.fisher_yates_serial(n, j)
+    for n in (1, 2, 128):  # all self-swaps / all to position 0
+        assert w.fisher_yates_parallel(n, list(range(n))) == list(range(n))
+        assert w.fisher_yates_parallel(n, [0] * n) == w.fisher_yates_serial(n, [0] * n)

@@ -301,6 +301,35 @@ def wave_step(s0, s1, groups, live, tab_block, lane_tabs, lookahead=64, stats=No
     return c0, c1, ev, orders, lst, pos
 
 
+def fisher_yates_serial(n, j):
+    """positions after `for i in (1..n).rev(): swap(i, j[i])` applied to the identity"""
+    a = list(range(n))
+    for i in range(n - 1, 0, -1):
+        a[i], a[j[i]] = a[j[i]], a[i]
+    return a
+
+
+def fisher_yates_parallel(n, j):
+    """The same permutation, every position resolved independently (k_agents_wave's shuffle, R <= 2): W[y] = mask of
+    the steps that target position y; the value that ends at x sat at j[x] just before step x; position y holds, before
+    step t, what the most recent earlier step s* = min{s > t : j[s] == y} moved there - the value position s* held
+    before step s* - or its original entry when there is none."""
+    W = [0] * n
+    for s in range(1, n):
+        if j[s] != s:
+            W[j[s]] |= 1 << s
+    out = [0] * n
+    for x in range(n):
+        y, t = (j[x], x) if x >= 1 else (0, 0)
+        while True:
+            m = W[y] >> (t + 1)
+            if m == 0:
+                break
+            y = t = t + 1 + ((m & -m).bit_length() - 1)
+        out[x] = y
+    return out
+
+
 def selftest(n_cases=60, seed=1, lookahead=64, verbose=False):
     rnd = random.Random(seed)
     tab_block = build_jump_tables(BLOCK)
