@@ -344,11 +344,11 @@ def main():
     pmc, pmc_src = {}, None
     try:
         allp = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-        pmc = allp.get(args.workload, {})
-        pmc_src = "profiles/pmc_traffic.json[%s] (rocprofv3 --pmc passes of `bench.py --workload %s`; replayed, not measured in this run)" % (
-            args.workload, args.workload)
-        if B != books_default:
-            pmc, pmc_src = {}, None  # another batch size: the per-book-step PMC figures of the profiled shape do not carry over
+        # keyed by workload and books per GPU: per-book-step PMC figures of one batch size do not carry over to another
+        key = args.workload if B == books_default else f"{args.workload}/{B}"
+        pmc = allp.get(key, {})
+        pmc_src = "profiles/pmc_traffic.json[%s] (rocprofv3 --pmc passes of `bench.py --workload %s --books %d`, scripts/profile_round.sh; replayed, not measured in this run)" % (
+            key, args.workload, B) if pmc else None
     except Exception:
         pass
     kernels = {}
