@@ -21,6 +21,14 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "event_asm.hpp"
+
+// 1: the event loop of a 128-slot pool runs the hand-written gfx950 code of event_asm.hpp; 0: the compiled C++ below
+// (same semantics; the parity suite passes on both - build with -DBOURSE_AMD_ASM_EVENTS=0 to compare)
+#ifndef BOURSE_AMD_ASM_EVENTS
+#define BOURSE_AMD_ASM_EVENTS 1
+#endif
+
 namespace bkd {
 
 constexpr int HDR_DW = 64;  // per-book header: 64 dwords, lane i holds dword i
@@ -639,6 +647,15 @@ __device__ __forceinline__ uint32_t step_from_list(Book<R>& B, const DevArgs& a,
   const uint64_t trades_before = B.n_trades;
   // step_size 0 = immediate mode (the clock is the caller's, OrderBook::set_time): no step window to overflow
   if (step_size != 0 && (uint64_t)n_ev >= step_size) B.flags |= FLAG_STEP_SIZE;
+  if constexpr (R == 2 && !MKT && CLS && BOURSE_AMD_ASM_EVENTS) {
+    // hand-written event loop (event_asm.hpp); it returns whenever the 64-record trade buffer is full
+    uint32_t k = 0;
+    const uint32_t nev = rfl(n_ev), tmask = B.trading ? 0xFFFFFFFFu : 0u;
+    while (events_asm_r2(k, nev, tmask, B.tr_n, B.seq_ctr, B.trade_vol, B.live[0], B.live[1], B.bid[0], B.bid[1],
+                         B.price[0], B.price[1], B.vol[0], B.vol[1], B.id[0], B.id[1], B.seq[0], B.seq[1], ev[0], ev[1],
+                         B.tr_k, B.tr_price, B.tr_vol, B.tr_act, B.tr_pas))
+      flush_trades<R>(B, a, book, t0, lane);
+  } else
 #pragma unroll
   for (int re = 0; re < R; ++re) {  // events at t0 + k (env.rs:123-127); entry k lives in lane k & 63 of ev[k >> 6]
     const uint32_t kb = re * 64;
@@ -770,6 +787,10 @@ __global__ __launch_bounds__(64) void k_agents_fsm(DevArgs a) {
   // (one ds_or per new order instead of ~20 VALU of per-lane 64-bit mask arithmetic in the hot loop)
   __shared__ uint32_t pmask[2 * R * 64], smask[2 * R * 64];
   const int lane = threadIdx.x;
+  // This kernel is a dependent chain of ~600 iterations on ONE wave per SIMD, co-resident with up to 7 waves of the
+  // issue-bound event kernel of another part: top issue priority lets the chain run at its lone-wave pace (the part's
+  // next k_step_batch cannot start before it ends) at no cost to the event kernel's throughput
+  __builtin_amdgcn_s_setprio(3);
   // MarketEnv mode (assets = M > 1): the lane owns a MARKET = books [b*M, b*M + M) with one RNG stream and one event
   // queue (market_env.rs:110-121, runner.rs:108-131); RandomMarketAgents::update is RandomAgents::update addressed to
   // the group's asset (random_agent.rs:204-247), so the state machine below is unchanged.

@@ -374,7 +374,9 @@ int launch_split(bk_env* env, const DevArgs& a0, uint64_t first_step, uint32_t n
   }
   if (P > 1) {
     HIPCHK(hipEventRecord(env->ev_fork, env->stream));
-    for (int i = 0; i < P; ++i) HIPCHK(hipStreamWaitEvent(env->part_stream[i], env->ev_fork, 0));
+    // part 0 runs on the caller's stream itself: P streams in all, so that four parts still map onto HIP's four
+    // hardware queues one to one (a fifth stream would share a queue with another part and serialise with it)
+    for (int i = 1; i < P; ++i) HIPCHK(hipStreamWaitEvent(env->part_stream[i], env->ev_fork, 0));
   }
   for (uint32_t s = 0; s < n_steps; ++s) {
     env->prof_now = env->profile > 0 && (env->prof_tick++ % env->profile) == 0;
@@ -384,7 +386,7 @@ int launch_split(bk_env* env, const DevArgs& a0, uint64_t first_step, uint32_t n
       a.book_end = (i + 1 == P) ? B : (static_cast<uint32_t>(static_cast<uint64_t>(B) * (i + 1) / P) & ~3u);
       a.hist_slot0 = a.hist_cap ? static_cast<uint32_t>((first_step + s) % a.hist_cap) : 0u;
       const uint32_t nb = a.book_end - a.book_begin;
-      hipStream_t st = P > 1 ? env->part_stream[i] : env->stream;
+      hipStream_t st = (P > 1 && i > 0) ? env->part_stream[i] : env->stream;
       if (P > 1 && s == 0 && i > 0) HIPCHK(hipStreamWaitEvent(st, env->ev_first[i - 1], 0));  // stagger the parts
       {
         ProfScope ps(env, 1, st);
@@ -420,6 +422,7 @@ int launch_split(bk_env* env, const DevArgs& a0, uint64_t first_step, uint32_t n
   HIPCHK(hipGetLastError());
   if (P > 1) {
     for (int i = 0; i < P; ++i) {
+      if (i == 0) continue;
       HIPCHK(hipEventRecord(env->ev_join[i], env->part_stream[i]));
       HIPCHK(hipStreamWaitEvent(env->stream, env->ev_join[i], 0));
     }

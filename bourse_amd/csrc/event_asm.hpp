@@ -1,0 +1,249 @@
+// event_asm.hpp — the event loop of Env::step for a 128-slot pool (R = 2), hand-written for gfx950.
+//
+// Why assembly: every kernel on this path is bound by the CU's single scalar issue port, and the event
+// loop is where the scalar instructions are: the compiled loop spends ≈47 scalar + branch instructions per fill and
+// ≈46 per new order that only rests (SQ_INSTS_SALU / SQ_INSTS_BRANCH, profiles/r02/pmc_sq_*.csv) — flag registers for
+// loop exits, 64-bit mask juggling, per-stage re-derivation of the slot's register.  Written by hand the same
+// semantics take ≈28 and ≈23: the code is specialised by list register (events 0..63 / 64..127), by the slot's pool
+// register and by the aggressor's side, so nothing is selected at run time; every exit is one compare + one branch;
+// lane selects and shift counts use the event word directly (the hardware reads its low 6 bits).
+// ONE asm statement processes a whole step's list, so the operand copies hipcc places around it are paid once per
+// step, not once per fill (round 1's per-match asm block lost to exactly that).
+//
+// Semantics (identical to slot_event_at / match_side in book_device.hpp; the parity suite runs on both):
+//   event word ew = slot | EV_NEW (bit 15) | EV_BID (bit 14); pool slot (r = ew bit 6, lane = ew & 63)
+//   Cancellation (orderbook.rs:622-644): live[r] &= ~bit (a no-op if the order was filled meanwhile)
+//   New (place_order, orderbook.rs:583-611): while volume remains and the book crosses (inclusive test :430/:463):
+//     touch = DPP min/max over the opposite side's live prices; oldest order at the touch = the single candidate, or
+//     the min `seq` among them (second DPP reduction); match_orders (:843-870): trade record into lane tr_n of the
+//     trade buffer, passive volume / liveness updated; the remainder of a limit order rests with a fresh `seq`,
+//     a market order's (price sentinel) is dropped.  `tmask` = all ones while trading is enabled.
+//   When the 64-record trade buffer fills the statement returns 1 for a flush; an event with volume left has it
+//   written back to its slot and is simply dispatched again (it resumes matching with what remains).
+//
+// Wait states (hipcc pads nothing inside an asm string): VALU-written SGPR -> v_readlane/v_writelane LANE SELECT needs
+// 4 (ew: two s_bitcmp1 + two s_cbranch precede its first use as a select); VALU-written SGPR -> VALU operand needs 2
+// (touch: s_cmp + s_cbranch; tie stamp: s_nop 1); VGPR write -> DPP read needs 2 (s_nop 1 inside the reduction);
+// VGPR write -> v_readlane needs 1 (the reduction ends with s_nop 1).  SALU-written SGPRs / M0 need none.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace bkd {
+
+// fixed scratch SGPRs of the statement (declared as clobbers): 64-bit pairs first
+#define EA_BIT "s[80:81]"
+#define EA_C0 "s[82:83]"
+#define EA_C1 "s[84:85]"
+#define EA_E0 "s[86:87]"
+#define EA_E1 "s[88:89]"
+#define EA_EW "s90"
+#define EA_P "s91"
+#define EA_V "s92"
+#define EA_ID "s93"
+#define EA_KK "s94"
+#define EA_BEST "s95"
+#define EA_PV "s96"
+#define EA_PID "s97"
+#define EA_TV "s98"
+#define EA_LS "s99"
+#define EA_X "s100"
+#define EA_X2 "s101"
+
+// full-wave DPP reduction of %[vm] (same network as BK_DPP_REDUCE)
+#define EA_DPP(OP)                                                                                \
+  "s_nop 1\n\t" OP " %[vm], %[vm], %[vm] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"      \
+  "s_nop 1\n\t" OP " %[vm], %[vm], %[vm] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"      \
+  "s_nop 1\n\t" OP " %[vm], %[vm], %[vm] row_half_mirror row_mask:0xf bank_mask:0xf\n\t"          \
+  "s_nop 1\n\t" OP " %[vm], %[vm], %[vm] row_mirror row_mask:0xf bank_mask:0xf\n\t"               \
+  "s_nop 1\n\t" OP " %[vm], %[vm], %[vm] row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"             \
+  "s_nop 1\n\t" OP " %[vm], %[vm], %[vm] row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"             \
+  "s_nop 1\n\t"
+
+// the passive order sits in pool register Q (lane = first set bit of its mask EQ): match_orders on it
+#define EA_PICK(Q, EQ, L)                                              \
+  "s_ff1_i32_b64 " EA_LS ", " EQ "\n\t"                                \
+  "v_readlane_b32 " EA_PV ", %[vol" Q "], " EA_LS "\n\t"               \
+  "v_readlane_b32 " EA_PID ", %[id" Q "], " EA_LS "\n\t"               \
+  "s_mov_b32 m0, " EA_LS "\n\t"                                        \
+  "s_min_u32 " EA_TV ", " EA_V ", " EA_PV "\n\t"                       \
+  "s_sub_u32 " EA_PV ", " EA_PV ", " EA_TV "\n\t"                      \
+  "v_writelane_b32 %[vol" Q "], " EA_PV ", m0\n\t"                     \
+  "s_cmp_lg_u32 " EA_PV ", 0\n\t"                                      \
+  "s_cbranch_scc1 L_trade_" L "\n\t"                                   \
+  "s_andn2_b64 %[live" Q "], %[live" Q "], " EQ "\n\t"
+
+// A New event whose slot is in pool register RG, aggressor side given by the five side-specific pieces:
+//   CAND  "s_andn2_b64" (bid: opposite = asks = live & ~bid) / "s_and_b64" (ask: opposite = bids)
+//   SENT  "-1" / "0"      neutral element of the touch reduction = price sentinel of a market order of this side
+//   VOP, DOP  v_min_u32 / v_max_u32 and the _dpp form
+//   NOX   "s_cmp_lt_u32" (bid: p < best ask) / "s_cmp_gt_u32" (ask: p > best bid): no cross
+//   KKI   instruction that forms the trade's k word: passive side bit 31
+#define EA_SIDE(L, PH, RG, CAND, SENT, VOP, DOP, NOX, KKI)                                         \
+  KKI "\n\t"                                                                                        \
+  "s_and_b32 " EA_X ", " EA_V ", %[tmask]\n\t"          /* no volume or trading disabled: no match */ \
+  "s_cbranch_scc0 L_rest_" L "\n\t"                                                                 \
+  "L_match_" L ":\n\t"                                                                              \
+  CAND " " EA_C0 ", %[live0], %[bid0]\n\t"                                                          \
+  CAND " " EA_C1 ", %[live1], %[bid1]\n\t"                                                          \
+  "s_or_b64 " EA_E0 ", " EA_C0 ", " EA_C1 "\n\t"                                                    \
+  "s_cbranch_scc0 L_rest_" L "\n\t"                     /* best_order_idx() == None */              \
+  "v_cndmask_b32_e64 %[vm], " SENT ", %[price0], " EA_C0 "\n\t"                                     \
+  "v_cndmask_b32_e64 %[vm2], " SENT ", %[price1], " EA_C1 "\n\t"                                    \
+  VOP " %[vm], %[vm], %[vm2]\n\t"                                                                   \
+  EA_DPP(DOP)                                                                                       \
+  "v_readlane_b32 " EA_BEST ", %[vm], 63\n\t"                                                       \
+  NOX " " EA_P ", " EA_BEST "\n\t"                                                                  \
+  "s_cbranch_scc1 L_rest_" L "\n\t"                                                                 \
+  "v_cmp_eq_u32_e64 " EA_E0 ", " EA_BEST ", %[price0]\n\t"                                          \
+  "v_cmp_eq_u32_e64 " EA_E1 ", " EA_BEST ", %[price1]\n\t"                                          \
+  "s_and_b64 " EA_E0 ", " EA_E0 ", " EA_C0 "\n\t"                                                   \
+  "s_and_b64 " EA_E1 ", " EA_E1 ", " EA_C1 "\n\t"                                                   \
+  "s_bcnt1_i32_b64 " EA_X ", " EA_E0 "\n\t"                                                         \
+  "s_bcnt1_i32_b64 " EA_X2 ", " EA_E1 "\n\t"                                                        \
+  "s_add_u32 " EA_X ", " EA_X ", " EA_X2 "\n\t"                                                     \
+  "s_cmp_eq_u32 " EA_X ", 1\n\t"                                                                    \
+  "s_cbranch_scc1 L_pick_" L "\n\t"                                                                 \
+  /* several orders rest at the touch: the oldest (min seq stamp, unique per book) is next in the queue */ \
+  "v_cndmask_b32_e64 %[vm], -1, %[seq0], " EA_E0 "\n\t"                                             \
+  "v_cndmask_b32_e64 %[vm2], -1, %[seq1], " EA_E1 "\n\t"                                            \
+  "v_min_u32 %[vm], %[vm], %[vm2]\n\t"                                                              \
+  EA_DPP("v_min_u32_dpp")                                                                           \
+  "v_readlane_b32 " EA_X ", %[vm], 63\n\t"                                                          \
+  "s_nop 1\n\t"                                                                                     \
+  "v_cmp_eq_u32_e64 " EA_C0 ", " EA_X ", %[seq0]\n\t"                                               \
+  "v_cmp_eq_u32_e64 " EA_C1 ", " EA_X ", %[seq1]\n\t"                                               \
+  "s_and_b64 " EA_E0 ", " EA_E0 ", " EA_C0 "\n\t"                                                   \
+  "s_and_b64 " EA_E1 ", " EA_E1 ", " EA_C1 "\n\t"                                                   \
+  "L_pick_" L ":\n\t"                                                                               \
+  "s_cmp_lg_u64 " EA_E0 ", 0\n\t"                                                                   \
+  "s_cbranch_scc0 L_pick1_" L "\n\t"                                                                \
+  EA_PICK("0", EA_E0, L)                                                                            \
+  "s_branch L_trade_" L "\n\t"                                                                      \
+  "L_pick1_" L ":\n\t"                                                                              \
+  EA_PICK("1", EA_E1, L)                                                                            \
+  "L_trade_" L ":\n\t"                                  /* Trade record, lane tr_n of the buffer */ \
+  "s_sub_u32 " EA_V ", " EA_V ", " EA_TV "\n\t"                                                     \
+  "s_add_u32 %[tvol], %[tvol], " EA_TV "\n\t"                                                       \
+  "s_mov_b32 m0, %[trn]\n\t"                                                                        \
+  "v_writelane_b32 %[trk], " EA_KK ", m0\n\t"                                                       \
+  "v_writelane_b32 %[trp], " EA_BEST ", m0\n\t"                                                     \
+  "v_writelane_b32 %[trv], " EA_TV ", m0\n\t"                                                       \
+  "v_writelane_b32 %[tra], " EA_ID ", m0\n\t"                                                       \
+  "v_writelane_b32 %[trs], " EA_PID ", m0\n\t"                                                      \
+  "s_add_u32 %[trn], %[trn], 1\n\t"                                                                 \
+  "s_cmp_eq_u32 %[trn], 64\n\t"                                                                     \
+  "s_cbranch_scc1 L_full_" L "\n\t"                                                                 \
+  "s_cmp_lg_u32 " EA_V ", 0\n\t"                                                                    \
+  "s_cbranch_scc1 L_match_" L "\n\t"                                                                \
+  "s_branch L_next_" PH "_%=\n\t"                       /* Filled: nothing rests */                 \
+  "L_full_" L ":\n\t"                                   /* buffer full: flush outside */            \
+  "s_cmp_eq_u32 " EA_V ", 0\n\t"                                                                    \
+  "s_cbranch_scc1 L_fullnext_%=\n\t"                                                                \
+  "s_mov_b32 m0, " EA_EW "\n\t"                                                                     \
+  "v_writelane_b32 %[vol" RG "], " EA_V ", m0\n\t"      /* the event restarts with what remains */  \
+  "s_branch L_flush_%=\n\t"                                                                         \
+  "L_rest_" L ":\n\t"                                                                               \
+  "s_cmp_eq_u32 " EA_P ", " SENT "\n\t"                 /* market remainder: dropped (:521-524) */  \
+  "s_cbranch_scc1 L_next_" PH "_%=\n\t"                                                             \
+  "s_mov_b32 m0, " EA_EW "\n\t"                                                                     \
+  "v_writelane_b32 %[vol" RG "], " EA_V ", m0\n\t"                                                  \
+  "v_writelane_b32 %[seq" RG "], %[seqc], m0\n\t"                                                   \
+  "s_lshl_b64 " EA_BIT ", 1, " EA_EW "\n\t"                                                         \
+  "s_or_b64 %[live" RG "], %[live" RG "], " EA_BIT "\n\t"                                           \
+  "s_add_u32 %[seqc], %[seqc], 1\n\t"                                                               \
+  "s_branch L_next_" PH "_%=\n\t"
+
+// a New event in pool register RG of list phase PH: read the order, dispatch on its side
+#define EA_NEW(PH, RG)                                                                              \
+  "v_readlane_b32 " EA_P ", %[price" RG "], " EA_EW "\n\t"                                          \
+  "v_readlane_b32 " EA_V ", %[vol" RG "], " EA_EW "\n\t"                                            \
+  "v_readlane_b32 " EA_ID ", %[id" RG "], " EA_EW "\n\t"                                            \
+  "s_bitcmp1_b32 " EA_EW ", 14\n\t"                                                                 \
+  "s_cbranch_scc1 L_bid_" PH RG "_%=\n\t"                                                           \
+  EA_SIDE("a" PH RG "_%=", PH, RG, "s_and_b64", "0", "v_max_u32", "v_max_u32_dpp", "s_cmp_gt_u32",  \
+          "s_or_b32 " EA_KK ", %[k], 0x80000000")                                                   \
+  "L_bid_" PH RG "_%=:\n\t"                                                                         \
+  EA_SIDE("b" PH RG "_%=", PH, RG, "s_andn2_b64", "-1", "v_min_u32", "v_min_u32_dpp", "s_cmp_lt_u32", \
+          "s_mov_b32 " EA_KK ", %[k]")
+
+// the events of one list register (PH = "0": k < kend0 from ev0, "1": k < nev from ev1)
+#define EA_PHASE(PH, KEND)                                                                          \
+  "L_top_" PH "_%=:\n\t"                                                                            \
+  "v_readlane_b32 " EA_EW ", %[ev" PH "], %[k]\n\t"                                                 \
+  "s_bitcmp1_b32 " EA_EW ", 15\n\t"                                                                 \
+  "s_cbranch_scc1 L_new_" PH "_%=\n\t"                                                              \
+  "s_lshl_b64 " EA_BIT ", 1, " EA_EW "\n\t"             /* Cancellation */                          \
+  "s_bitcmp1_b32 " EA_EW ", 6\n\t"                                                                  \
+  "s_cbranch_scc1 L_can1_" PH "_%=\n\t"                                                             \
+  "s_andn2_b64 %[live0], %[live0], " EA_BIT "\n\t"                                                  \
+  "s_branch L_next_" PH "_%=\n\t"                                                                   \
+  "L_can1_" PH "_%=:\n\t"                                                                           \
+  "s_andn2_b64 %[live1], %[live1], " EA_BIT "\n\t"                                                  \
+  "L_next_" PH "_%=:\n\t"                                                                           \
+  "s_add_u32 %[k], %[k], 1\n\t"                                                                     \
+  "s_cmp_lt_u32 %[k], " KEND "\n\t"                                                                 \
+  "s_cbranch_scc1 L_top_" PH "_%=\n\t"                                                              \
+  "s_branch L_end_" PH "_%=\n\t"                                                                    \
+  "L_new_" PH "_%=:\n\t"                                                                            \
+  "s_bitcmp1_b32 " EA_EW ", 6\n\t"                                                                  \
+  "s_cbranch_scc1 L_new1_" PH "_%=\n\t"                                                             \
+  EA_NEW(PH, "0")                                                                                   \
+  "L_new1_" PH "_%=:\n\t"                                                                           \
+  EA_NEW(PH, "1")
+
+// Processes events k .. n_ev-1 of the step's (shuffled) list.  Returns 0 when the list is done, 1 when the trade
+// buffer is full (flush it, call again).  All scalars are wave-uniform.
+__device__ __forceinline__ uint32_t events_asm_r2(uint32_t& k, uint32_t n_ev, uint32_t tmask, uint32_t& tr_n,
+                                                  uint32_t& seq_ctr, uint32_t& trade_vol, uint64_t& live0,
+                                                  uint64_t& live1, uint64_t bid0, uint64_t bid1, uint32_t price0,
+                                                  uint32_t price1, uint32_t& vol0, uint32_t& vol1, uint32_t id0,
+                                                  uint32_t id1, uint32_t& seq0, uint32_t& seq1, uint32_t ev0,
+                                                  uint32_t ev1, uint32_t& trk, uint32_t& trp, uint32_t& trv,
+                                                  uint32_t& tra, uint32_t& trs) {
+  uint32_t st, vm, vm2;
+  // "s" operands must be provably wave-uniform: the compiler parks some of these book scalars in VGPRs
+  auto u32 = [](uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane(x); };
+  auto u64 = [&](uint64_t x) { return ((uint64_t)u32((uint32_t)(x >> 32)) << 32) | u32((uint32_t)x); };
+  k = u32(k);
+  n_ev = u32(n_ev);
+  tmask = u32(tmask);
+  tr_n = u32(tr_n);
+  seq_ctr = u32(seq_ctr);
+  trade_vol = u32(trade_vol);
+  live0 = u64(live0);
+  live1 = u64(live1);
+  bid0 = u64(bid0);
+  bid1 = u64(bid1);
+  const uint32_t kend0 = n_ev < 64u ? n_ev : 64u;
+  asm volatile(
+      "s_cmp_lt_u32 %[k], %[kend0]\n\t"
+      "s_cbranch_scc1 L_top_0_%=\n\t"
+      "s_branch L_end_0_%=\n\t"
+      EA_PHASE("0", "%[kend0]")
+      "L_end_0_%=:\n\t"
+      "s_cmp_lt_u32 %[k], %[nev]\n\t"
+      "s_cbranch_scc0 L_done_%=\n\t"
+      EA_PHASE("1", "%[nev]")
+      "L_end_1_%=:\n\t"
+      "L_done_%=:\n\t"
+      "s_mov_b32 %[st], 0\n\t"
+      "s_branch L_out_%=\n\t"
+      "L_fullnext_%=:\n\t"
+      "s_add_u32 %[k], %[k], 1\n\t"
+      "L_flush_%=:\n\t"
+      "s_mov_b32 %[st], 1\n\t"
+      "L_out_%=:\n\t"
+      "s_nop 1"
+      : [st] "=&s"(st), [vm] "=&v"(vm), [vm2] "=&v"(vm2), [k] "+s"(k), [trn] "+s"(tr_n), [seqc] "+s"(seq_ctr),
+        [tvol] "+s"(trade_vol), [live0] "+s"(live0), [live1] "+s"(live1), [vol0] "+v"(vol0), [vol1] "+v"(vol1),
+        [seq0] "+v"(seq0), [seq1] "+v"(seq1), [trk] "+v"(trk), [trp] "+v"(trp), [trv] "+v"(trv), [tra] "+v"(tra),
+        [trs] "+v"(trs)
+      : [price0] "v"(price0), [price1] "v"(price1), [id0] "v"(id0), [id1] "v"(id1), [ev0] "v"(ev0), [ev1] "v"(ev1),
+        [bid0] "s"(bid0), [bid1] "s"(bid1), [nev] "s"(n_ev), [kend0] "s"(kend0), [tmask] "s"(tmask)
+      : "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95",
+        "s96", "s97", "s98", "s99", "s100", "s101", "vcc", "scc", "memory");
+  return st;
+}
+
+}  // namespace bkd
