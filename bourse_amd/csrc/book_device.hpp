@@ -655,6 +655,12 @@ __device__ __forceinline__ uint32_t step_from_list(Book<R>& B, const DevArgs& a,
                          B.price[0], B.price[1], B.vol[0], B.vol[1], B.id[0], B.id[1], B.seq[0], B.seq[1], ev[0], ev[1],
                          B.tr_k, B.tr_price, B.tr_vol, B.tr_act, B.tr_pas))
       flush_trades<R>(B, a, book, t0, lane);
+  } else if constexpr (R == 1 && !MKT && CLS && BOURSE_AMD_ASM_EVENTS) {
+    uint32_t k = 0;
+    const uint32_t nev = rfl(n_ev), tmask = B.trading ? 0xFFFFFFFFu : 0u;
+    while (events_asm_r1(k, nev, tmask, B.tr_n, B.seq_ctr, B.trade_vol, B.live[0], B.bid[0], B.price[0], B.vol[0], B.id[0],
+                         B.seq[0], ev[0], B.tr_k, B.tr_price, B.tr_vol, B.tr_act, B.tr_pas))
+      flush_trades<R>(B, a, book, t0, lane);
   } else
 #pragma unroll
   for (int re = 0; re < R; ++re) {  // events at t0 + k (env.rs:123-127); entry k lives in lane k & 63 of ev[k >> 6]

@@ -50,6 +50,12 @@ namespace bkd {
 #define EA_X "s100"
 #define EA_X2 "s101"
 
+// text that only exists for a pool of NR = 2 registers
+#define EA_IF2_1(x) ""
+#define EA_IF2_2(x) x
+#define EA_IF1_1(x) x
+#define EA_IF1_2(x) ""
+
 // full-wave DPP reduction of %[vm] (same network as BK_DPP_REDUCE)
 #define EA_DPP(OP)                                                                                \
   "s_nop 1\n\t" OP " %[vm], %[vm], %[vm] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"      \
@@ -73,55 +79,67 @@ namespace bkd {
   "s_cbranch_scc1 L_trade_" L "\n\t"                                   \
   "s_andn2_b64 %[live" Q "], %[live" Q "], " EQ "\n\t"
 
+// "exactly one order at the touch?" - then the second reduction is skipped.  BOURSE_AMD_ASM_ALWAYS_TIE=1 drops the test
+// (4 scalar instructions + a branch per fill) and always runs the 13-instruction vector reduction instead.
+#ifndef BOURSE_AMD_ASM_ALWAYS_TIE
+#define BOURSE_AMD_ASM_ALWAYS_TIE 0
+#endif
+#if BOURSE_AMD_ASM_ALWAYS_TIE
+#define EA_TIE_TEST(L, NR) ""
+#else
+#define EA_TIE_TEST(L, NR)                                                                 \
+  "s_bcnt1_i32_b64 " EA_X ", " EA_E0 "\n\t"                                                \
+  EA_IF2_##NR("s_bcnt1_i32_b64 " EA_X2 ", " EA_E1 "\n\t"                                   \
+              "s_add_u32 " EA_X ", " EA_X ", " EA_X2 "\n\t")                               \
+  "s_cmp_eq_u32 " EA_X ", 1\n\t"                                                           \
+  "s_cbranch_scc1 L_pick_" L "\n\t"
+#endif
+
 // A New event whose slot is in pool register RG, aggressor side given by the five side-specific pieces:
 //   CAND  "s_andn2_b64" (bid: opposite = asks = live & ~bid) / "s_and_b64" (ask: opposite = bids)
 //   SENT  "-1" / "0"      neutral element of the touch reduction = price sentinel of a market order of this side
 //   VOP, DOP  v_min_u32 / v_max_u32 and the _dpp form
 //   NOX   "s_cmp_lt_u32" (bid: p < best ask) / "s_cmp_gt_u32" (ask: p > best bid): no cross
 //   KKI   instruction that forms the trade's k word: passive side bit 31
-#define EA_SIDE(L, PH, RG, CAND, SENT, VOP, DOP, NOX, KKI)                                         \
+#define EA_SIDE(L, PH, RG, NR, CAND, SENT, VOP, DOP, NOX, KKI)                                     \
   KKI "\n\t"                                                                                        \
   "s_and_b32 " EA_X ", " EA_V ", %[tmask]\n\t"          /* no volume or trading disabled: no match */ \
   "s_cbranch_scc0 L_rest_" L "\n\t"                                                                 \
   "L_match_" L ":\n\t"                                                                              \
-  CAND " " EA_C0 ", %[live0], %[bid0]\n\t"                                                          \
-  CAND " " EA_C1 ", %[live1], %[bid1]\n\t"                                                          \
-  "s_or_b64 " EA_E0 ", " EA_C0 ", " EA_C1 "\n\t"                                                    \
+  CAND " " EA_C0 ", %[live0], %[bid0]\n\t"               /* SCC = candidates exist (NR = 1) */       \
+  EA_IF2_##NR(CAND " " EA_C1 ", %[live1], %[bid1]\n\t"                                              \
+              "s_or_b64 " EA_E0 ", " EA_C0 ", " EA_C1 "\n\t")                                       \
   "s_cbranch_scc0 L_rest_" L "\n\t"                     /* best_order_idx() == None */              \
   "v_cndmask_b32_e64 %[vm], " SENT ", %[price0], " EA_C0 "\n\t"                                     \
-  "v_cndmask_b32_e64 %[vm2], " SENT ", %[price1], " EA_C1 "\n\t"                                    \
-  VOP " %[vm], %[vm], %[vm2]\n\t"                                                                   \
+  EA_IF2_##NR("v_cndmask_b32_e64 %[vm2], " SENT ", %[price1], " EA_C1 "\n\t"                        \
+              VOP " %[vm], %[vm], %[vm2]\n\t")                                                      \
   EA_DPP(DOP)                                                                                       \
   "v_readlane_b32 " EA_BEST ", %[vm], 63\n\t"                                                       \
   NOX " " EA_P ", " EA_BEST "\n\t"                                                                  \
   "s_cbranch_scc1 L_rest_" L "\n\t"                                                                 \
   "v_cmp_eq_u32_e64 " EA_E0 ", " EA_BEST ", %[price0]\n\t"                                          \
-  "v_cmp_eq_u32_e64 " EA_E1 ", " EA_BEST ", %[price1]\n\t"                                          \
+  EA_IF2_##NR("v_cmp_eq_u32_e64 " EA_E1 ", " EA_BEST ", %[price1]\n\t")                             \
   "s_and_b64 " EA_E0 ", " EA_E0 ", " EA_C0 "\n\t"                                                   \
-  "s_and_b64 " EA_E1 ", " EA_E1 ", " EA_C1 "\n\t"                                                   \
-  "s_bcnt1_i32_b64 " EA_X ", " EA_E0 "\n\t"                                                         \
-  "s_bcnt1_i32_b64 " EA_X2 ", " EA_E1 "\n\t"                                                        \
-  "s_add_u32 " EA_X ", " EA_X ", " EA_X2 "\n\t"                                                     \
-  "s_cmp_eq_u32 " EA_X ", 1\n\t"                                                                    \
-  "s_cbranch_scc1 L_pick_" L "\n\t"                                                                 \
+  EA_IF2_##NR("s_and_b64 " EA_E1 ", " EA_E1 ", " EA_C1 "\n\t")                                      \
+  EA_TIE_TEST(L, NR)                                                                                \
   /* several orders rest at the touch: the oldest (min seq stamp, unique per book) is next in the queue */ \
   "v_cndmask_b32_e64 %[vm], -1, %[seq0], " EA_E0 "\n\t"                                             \
-  "v_cndmask_b32_e64 %[vm2], -1, %[seq1], " EA_E1 "\n\t"                                            \
-  "v_min_u32 %[vm], %[vm], %[vm2]\n\t"                                                              \
+  EA_IF2_##NR("v_cndmask_b32_e64 %[vm2], -1, %[seq1], " EA_E1 "\n\t"                                \
+              "v_min_u32 %[vm], %[vm], %[vm2]\n\t")                                                 \
   EA_DPP("v_min_u32_dpp")                                                                           \
   "v_readlane_b32 " EA_X ", %[vm], 63\n\t"                                                          \
   "s_nop 1\n\t"                                                                                     \
   "v_cmp_eq_u32_e64 " EA_C0 ", " EA_X ", %[seq0]\n\t"                                               \
-  "v_cmp_eq_u32_e64 " EA_C1 ", " EA_X ", %[seq1]\n\t"                                               \
+  EA_IF2_##NR("v_cmp_eq_u32_e64 " EA_C1 ", " EA_X ", %[seq1]\n\t")                                  \
   "s_and_b64 " EA_E0 ", " EA_E0 ", " EA_C0 "\n\t"                                                   \
-  "s_and_b64 " EA_E1 ", " EA_E1 ", " EA_C1 "\n\t"                                                   \
+  EA_IF2_##NR("s_and_b64 " EA_E1 ", " EA_E1 ", " EA_C1 "\n\t")                                      \
   "L_pick_" L ":\n\t"                                                                               \
-  "s_cmp_lg_u64 " EA_E0 ", 0\n\t"                                                                   \
-  "s_cbranch_scc0 L_pick1_" L "\n\t"                                                                \
+  EA_IF2_##NR("s_cmp_lg_u64 " EA_E0 ", 0\n\t"                                                       \
+              "s_cbranch_scc0 L_pick1_" L "\n\t")                                                   \
   EA_PICK("0", EA_E0, L)                                                                            \
-  "s_branch L_trade_" L "\n\t"                                                                      \
-  "L_pick1_" L ":\n\t"                                                                              \
-  EA_PICK("1", EA_E1, L)                                                                            \
+  EA_IF2_##NR("s_branch L_trade_" L "\n\t"                                                          \
+              "L_pick1_" L ":\n\t"                                                                  \
+              EA_PICK("1", EA_E1, L))                                                               \
   "L_trade_" L ":\n\t"                                  /* Trade record, lane tr_n of the buffer */ \
   "s_sub_u32 " EA_V ", " EA_V ", " EA_TV "\n\t"                                                     \
   "s_add_u32 %[tvol], %[tvol], " EA_TV "\n\t"                                                       \
@@ -155,42 +173,43 @@ namespace bkd {
   "s_branch L_next_" PH "_%=\n\t"
 
 // a New event in pool register RG of list phase PH: read the order, dispatch on its side
-#define EA_NEW(PH, RG)                                                                              \
+#define EA_NEW(PH, RG, NR)                                                                          \
   "v_readlane_b32 " EA_P ", %[price" RG "], " EA_EW "\n\t"                                          \
   "v_readlane_b32 " EA_V ", %[vol" RG "], " EA_EW "\n\t"                                            \
   "v_readlane_b32 " EA_ID ", %[id" RG "], " EA_EW "\n\t"                                            \
   "s_bitcmp1_b32 " EA_EW ", 14\n\t"                                                                 \
   "s_cbranch_scc1 L_bid_" PH RG "_%=\n\t"                                                           \
-  EA_SIDE("a" PH RG "_%=", PH, RG, "s_and_b64", "0", "v_max_u32", "v_max_u32_dpp", "s_cmp_gt_u32",  \
+  EA_SIDE("a" PH RG "_%=", PH, RG, NR, "s_and_b64", "0", "v_max_u32", "v_max_u32_dpp", "s_cmp_gt_u32", \
           "s_or_b32 " EA_KK ", %[k], 0x80000000")                                                   \
   "L_bid_" PH RG "_%=:\n\t"                                                                         \
-  EA_SIDE("b" PH RG "_%=", PH, RG, "s_andn2_b64", "-1", "v_min_u32", "v_min_u32_dpp", "s_cmp_lt_u32", \
+  EA_SIDE("b" PH RG "_%=", PH, RG, NR, "s_andn2_b64", "-1", "v_min_u32", "v_min_u32_dpp", "s_cmp_lt_u32", \
           "s_mov_b32 " EA_KK ", %[k]")
 
 // the events of one list register (PH = "0": k < kend0 from ev0, "1": k < nev from ev1)
-#define EA_PHASE(PH, KEND)                                                                          \
+#define EA_PHASE(PH, KEND, NR)                                                                      \
   "L_top_" PH "_%=:\n\t"                                                                            \
   "v_readlane_b32 " EA_EW ", %[ev" PH "], %[k]\n\t"                                                 \
   "s_bitcmp1_b32 " EA_EW ", 15\n\t"                                                                 \
   "s_cbranch_scc1 L_new_" PH "_%=\n\t"                                                              \
   "s_lshl_b64 " EA_BIT ", 1, " EA_EW "\n\t"             /* Cancellation */                          \
-  "s_bitcmp1_b32 " EA_EW ", 6\n\t"                                                                  \
-  "s_cbranch_scc1 L_can1_" PH "_%=\n\t"                                                             \
+  EA_IF2_##NR("s_bitcmp1_b32 " EA_EW ", 6\n\t"                                                      \
+              "s_cbranch_scc1 L_can1_" PH "_%=\n\t")                                                \
   "s_andn2_b64 %[live0], %[live0], " EA_BIT "\n\t"                                                  \
-  "s_branch L_next_" PH "_%=\n\t"                                                                   \
-  "L_can1_" PH "_%=:\n\t"                                                                           \
-  "s_andn2_b64 %[live1], %[live1], " EA_BIT "\n\t"                                                  \
+  EA_IF2_##NR("s_branch L_next_" PH "_%=\n\t"                                                       \
+              "L_can1_" PH "_%=:\n\t"                                                               \
+              "s_andn2_b64 %[live1], %[live1], " EA_BIT "\n\t")                                     \
   "L_next_" PH "_%=:\n\t"                                                                           \
   "s_add_u32 %[k], %[k], 1\n\t"                                                                     \
   "s_cmp_lt_u32 %[k], " KEND "\n\t"                                                                 \
   "s_cbranch_scc1 L_top_" PH "_%=\n\t"                                                              \
   "s_branch L_end_" PH "_%=\n\t"                                                                    \
   "L_new_" PH "_%=:\n\t"                                                                            \
-  "s_bitcmp1_b32 " EA_EW ", 6\n\t"                                                                  \
-  "s_cbranch_scc1 L_new1_" PH "_%=\n\t"                                                             \
-  EA_NEW(PH, "0")                                                                                   \
-  "L_new1_" PH "_%=:\n\t"                                                                           \
-  EA_NEW(PH, "1")
+  EA_IF2_##NR("s_bitcmp1_b32 " EA_EW ", 6\n\t"                                                      \
+              "s_cbranch_scc1 L_new1_" PH "_%=\n\t")                                                \
+  EA_IF1_##NR("s_nop 1\n\t")                            /* ew as a lane select: 4 wait states */    \
+  EA_NEW(PH, "0", NR)                                                                               \
+  EA_IF2_##NR("L_new1_" PH "_%=:\n\t"                                                               \
+              EA_NEW(PH, "1", NR))
 
 // Processes events k .. n_ev-1 of the step's (shuffled) list.  Returns 0 when the list is done, 1 when the trade
 // buffer is full (flush it, call again).  All scalars are wave-uniform.
@@ -220,11 +239,11 @@ __device__ __forceinline__ uint32_t events_asm_r2(uint32_t& k, uint32_t n_ev, ui
       "s_cmp_lt_u32 %[k], %[kend0]\n\t"
       "s_cbranch_scc1 L_top_0_%=\n\t"
       "s_branch L_end_0_%=\n\t"
-      EA_PHASE("0", "%[kend0]")
+      EA_PHASE("0", "%[kend0]", 2)
       "L_end_0_%=:\n\t"
       "s_cmp_lt_u32 %[k], %[nev]\n\t"
       "s_cbranch_scc0 L_done_%=\n\t"
-      EA_PHASE("1", "%[nev]")
+      EA_PHASE("1", "%[nev]", 2)
       "L_end_1_%=:\n\t"
       "L_done_%=:\n\t"
       "s_mov_b32 %[st], 0\n\t"
@@ -241,6 +260,46 @@ __device__ __forceinline__ uint32_t events_asm_r2(uint32_t& k, uint32_t n_ev, ui
         [trs] "+v"(trs)
       : [price0] "v"(price0), [price1] "v"(price1), [id0] "v"(id0), [id1] "v"(id1), [ev0] "v"(ev0), [ev1] "v"(ev1),
         [bid0] "s"(bid0), [bid1] "s"(bid1), [nev] "s"(n_ev), [kend0] "s"(kend0), [tmask] "s"(tmask)
+      : "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95",
+        "s96", "s97", "s98", "s99", "s100", "s101", "vcc", "scc", "memory");
+  return st;
+}
+
+// The same for a 64-slot pool (R = 1): one list register, one pool register.
+__device__ __forceinline__ uint32_t events_asm_r1(uint32_t& k, uint32_t n_ev, uint32_t tmask, uint32_t& tr_n,
+                                                  uint32_t& seq_ctr, uint32_t& trade_vol, uint64_t& live0, uint64_t bid0,
+                                                  uint32_t price0, uint32_t& vol0, uint32_t id0, uint32_t& seq0,
+                                                  uint32_t ev0, uint32_t& trk, uint32_t& trp, uint32_t& trv,
+                                                  uint32_t& tra, uint32_t& trs) {
+  uint32_t st, vm;
+  auto u32 = [](uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane(x); };
+  auto u64 = [&](uint64_t x) { return ((uint64_t)u32((uint32_t)(x >> 32)) << 32) | u32((uint32_t)x); };
+  k = u32(k);
+  n_ev = u32(n_ev);
+  tmask = u32(tmask);
+  tr_n = u32(tr_n);
+  seq_ctr = u32(seq_ctr);
+  trade_vol = u32(trade_vol);
+  live0 = u64(live0);
+  bid0 = u64(bid0);
+  asm volatile(
+      "s_cmp_lt_u32 %[k], %[nev]\n\t"
+      "s_cbranch_scc0 L_done_%=\n\t"
+      EA_PHASE("0", "%[nev]", 1)
+      "L_end_0_%=:\n\t"
+      "L_done_%=:\n\t"
+      "s_mov_b32 %[st], 0\n\t"
+      "s_branch L_out_%=\n\t"
+      "L_fullnext_%=:\n\t"
+      "s_add_u32 %[k], %[k], 1\n\t"
+      "L_flush_%=:\n\t"
+      "s_mov_b32 %[st], 1\n\t"
+      "L_out_%=:\n\t"
+      "s_nop 1"
+      : [st] "=&s"(st), [vm] "=&v"(vm), [k] "+s"(k), [trn] "+s"(tr_n), [seqc] "+s"(seq_ctr), [tvol] "+s"(trade_vol),
+        [live0] "+s"(live0), [vol0] "+v"(vol0), [seq0] "+v"(seq0), [trk] "+v"(trk), [trp] "+v"(trp), [trv] "+v"(trv),
+        [tra] "+v"(tra), [trs] "+v"(trs)
+      : [price0] "v"(price0), [id0] "v"(id0), [ev0] "v"(ev0), [bid0] "s"(bid0), [nev] "s"(n_ev), [tmask] "s"(tmask)
       : "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95",
         "s96", "s97", "s98", "s99", "s100", "s101", "vcc", "scc", "memory");
   return st;
