@@ -32,23 +32,23 @@
 namespace bkd {
 
 // fixed scratch SGPRs of the statement (declared as clobbers): 64-bit pairs first
-#define EA_BIT "s[80:81]"
-#define EA_C0 "s[82:83]"
-#define EA_C1 "s[84:85]"
-#define EA_E0 "s[86:87]"
-#define EA_E1 "s[88:89]"
-#define EA_EW "s90"
-#define EA_P "s91"
-#define EA_V "s92"
-#define EA_ID "s93"
-#define EA_KK "s94"
-#define EA_BEST "s95"
-#define EA_PV "s96"
-#define EA_PID "s97"
-#define EA_TV "s98"
-#define EA_LS "s99"
-#define EA_X "s100"
-#define EA_X2 "s101"
+#define EA_BIT "s[40:41]"
+#define EA_C0 "s[42:43]"
+#define EA_C1 "s[44:45]"
+#define EA_E0 "s[46:47]"
+#define EA_E1 "s[48:49]"
+#define EA_EW "s50"
+#define EA_P "s51"
+#define EA_V "s52"
+#define EA_ID "s53"
+#define EA_KK "s54"
+#define EA_BEST "s55"
+#define EA_PV "s56"
+#define EA_PID "s57"
+#define EA_TV "s58"
+#define EA_LS "s59"
+#define EA_X "s60"
+#define EA_X2 "s61"
 
 // text that only exists for a pool of NR = 2 registers
 #define EA_IF2_1(x) ""
@@ -260,8 +260,8 @@ __device__ __forceinline__ uint32_t events_asm_r2(uint32_t& k, uint32_t n_ev, ui
         [trs] "+v"(trs)
       : [price0] "v"(price0), [price1] "v"(price1), [id0] "v"(id0), [id1] "v"(id1), [ev0] "v"(ev0), [ev1] "v"(ev1),
         [bid0] "s"(bid0), [bid1] "s"(bid1), [nev] "s"(n_ev), [kend0] "s"(kend0), [tmask] "s"(tmask)
-      : "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95",
-        "s96", "s97", "s98", "s99", "s100", "s101", "vcc", "scc", "memory");
+      : "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55",
+        "s56", "s57", "s58", "s59", "s60", "s61", "vcc", "scc", "memory");
   return st;
 }
 
@@ -300,8 +300,8 @@ __device__ __forceinline__ uint32_t events_asm_r1(uint32_t& k, uint32_t n_ev, ui
         [live0] "+s"(live0), [vol0] "+v"(vol0), [seq0] "+v"(seq0), [trk] "+v"(trk), [trp] "+v"(trp), [trv] "+v"(trv),
         [tra] "+v"(tra), [trs] "+v"(trs)
       : [price0] "v"(price0), [id0] "v"(id0), [ev0] "v"(ev0), [bid0] "s"(bid0), [nev] "s"(n_ev), [tmask] "s"(tmask)
-      : "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95",
-        "s96", "s97", "s98", "s99", "s100", "s101", "vcc", "scc", "memory");
+      : "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55",
+        "s56", "s57", "s58", "s59", "s60", "s61", "vcc", "scc", "memory");
   return st;
 }
 
