@@ -69,15 +69,30 @@ __device__ __forceinline__ uint4 wv_jump(const uint4* __restrict__ tab, uint4 s)
   return acc;
 }
 
-// index of the first set bit ABOVE position i in the 128-bit mask hi:lo (i per lane); >= 128 if there is none
+// index of the first set bit ABOVE position i in the 128-bit mask hi:lo (i per lane); >= 128 if there is none.
+// Branch-free on purpose (selects on 32-bit halves): the compiler turned 64-bit ternaries into divergent branches,
+// i.e. exec-mask juggling on the scalar unit - the scarce resource of this kernel.
 __device__ __forceinline__ uint32_t first_above(uint64_t lo, uint64_t hi, uint32_t i) {
   const uint32_t n = i + 1u;
-  const uint64_t l = n < 64u ? (lo >> n) : 0ull;
-  const uint64_t h = n < 64u ? hi : (n < 128u ? (hi >> (n - 64u)) : 0ull);
-  const uint32_t hb = n < 64u ? 64u : n;
-  const uint32_t ql = n + (uint32_t)__builtin_ctzll(l | (1ull << 63));
-  const uint32_t qh = hb + (uint32_t)__builtin_ctzll(h | (1ull << 63));
-  return l ? ql : (h ? qh : 256u);
+  const uint32_t sh = n & 63u;
+  const bool in_lo = n < 64u, in_hi = n < 128u;
+  // bits >= n of `lo` (zero once n >= 64), bits >= n of `hi` (all of it while n < 64)
+  uint64_t l = lo >> sh, h = hi >> sh;
+  uint32_t l0 = (uint32_t)l, l1 = (uint32_t)(l >> 32), h0 = (uint32_t)h, h1 = (uint32_t)(h >> 32);
+  l0 = in_lo ? l0 : 0u;
+  l1 = in_lo ? l1 : 0u;
+  h0 = in_lo ? (uint32_t)hi : (in_hi ? h0 : 0u);
+  h1 = in_lo ? (uint32_t)(hi >> 32) : (in_hi ? h1 : 0u);
+  // count of trailing zeros of each 64-bit remainder from its halves (__ffs: 1-based, 0 when no bit is set)
+  const uint32_t fl0 = (uint32_t)__ffs(l0), fl1 = (uint32_t)__ffs(l1), fh0 = (uint32_t)__ffs(h0), fh1 = (uint32_t)__ffs(h1);
+  const uint32_t cl = fl0 ? fl0 - 1u : fl1 + 31u;
+  const uint32_t ch = fh0 ? fh0 - 1u : fh1 + 31u;
+  // arithmetic selection (an absent half becomes 0xFFFFFFFF, the lower position wins): no ternary for the compiler to
+  // turn back into a branch
+  const uint32_t none_l = (l0 | l1) == 0u ? 0xFFFFFFFFu : 0u, none_h = (h0 | h1) == 0u ? 0xFFFFFFFFu : 0u;
+  const uint32_t ql = (n + cl) | none_l;                       // position of the first set bit of lo's remainder
+  const uint32_t qh = ((in_lo ? 64u : n) + ch) | none_h;       // ... of hi's
+  return min(min(ql, qh), 256u);
 }
 
 // The decoder state of one wave (= one book).  All pointers are wave-uniform; `pv` (new orders {price, vol} by pool
@@ -207,33 +222,75 @@ struct WaveDecoder {
           } else {
             p += d;
             ag += d;
-            for (;;) {  // p: a hit inside the window, ag < gend: its agent
-              const uint32_t w = rdl(pack, p);
-              uint32_t np, na;
-              const bool holds = (rdl(livev, live_base + (ag >> 5)) >> (ag & 31u)) & 1u;
-              if (holds) {  // an Active order: queue its cancellation (random_agent.rs:95-97)
-                agw = wrl(ag | WV_ACTED, p, agw);
-                np = w & 0x7Fu;
-                na = ag + (np - p);
-              } else {
-                if (w >> 31) {
-                  slow = true;
-                  break;
-                }
-                agw = wrl(ag | (EV_NEW | WV_ACTED), p, agw);
-                np = (w >> 7) & 0xFFu;
-                na = ag + ((w >> 23) & 0x7Fu);
-              }
-              if (na >= gend) {  // the group ends before the next hit: agent `gend`'s activity draw is where the run
-                const uint32_t rs = holds ? p + 1u : ((w >> 15) & 0xFFu);  // of one-draw agents that starts at rs gets to
-                p = rs + (gend - ag - 1u);
-                ag = gend;
-                break;
-              }
-              p = np;
-              ag = na;
-              if (p >= 64u) break;
-            }
+            // The walk itself, hand-written (this loop is ~half of the kernel's scalar instructions; the compiled form
+            // spends 24-26 per hit on loop-exit flags and re-materialised booleans, this one 19-21).  One iteration:
+            //   w = pack[p]; live bit of agent ag; cancellation -> event word ag | ACTED into lane p, next = w[6:0];
+            //   placement -> (w[31]: not resolvable -> slow) event word ag | NEW | ACTED, next = w[14:7], agents += w[29:23];
+            //   the group ends before the next hit -> position of agent `gend`'s draw from the run start (p + 1 or f).
+            uint32_t st, w, t0, t1, np, na;
+            asm volatile(
+                "s_nop 0\n\t"
+                "1:\n\t"
+                "s_lshr_b32 %[t0], %[ag], 5\n\t"
+                "s_add_u32 %[t0], %[t0], %[lb]\n\t"
+                "v_readlane_b32 %[w], %[pack], %[p]\n\t"
+                "v_readlane_b32 %[t1], %[livev], %[t0]\n\t"
+                "s_mov_b32 m0, %[p]\n\t"
+                "s_lshr_b32 %[t1], %[t1], %[ag]\n\t"
+                "s_bitcmp1_b32 %[t1], 0\n\t"
+                "s_cbranch_scc0 2f\n\t"
+                "s_or_b32 %[t0], %[ag], 0x10000\n\t"          /* holds an Active order: its cancellation */
+                "v_writelane_b32 %[agw], %[t0], m0\n\t"
+                "s_and_b32 %[np], %[w], 0x7f\n\t"
+                "s_sub_u32 %[t0], %[np], %[p]\n\t"
+                "s_add_u32 %[na], %[ag], %[t0]\n\t"
+                "s_cmp_ge_u32 %[na], %[gend]\n\t"
+                "s_cbranch_scc1 5f\n\t"
+                "s_mov_b32 %[p], %[np]\n\t"
+                "s_mov_b32 %[ag], %[na]\n\t"
+                "s_cmp_lt_u32 %[np], 64\n\t"
+                "s_cbranch_scc1 1b\n\t"
+                "s_mov_b32 %[st], 0\n\t"
+                "s_branch 9f\n\t"
+                "2:\n\t"
+                "s_cmp_lt_i32 %[w], 0\n\t"                    /* placement not resolvable in the look-ahead */
+                "s_cbranch_scc1 8f\n\t"
+                "s_or_b32 %[t0], %[ag], 0x18000\n\t"
+                "v_writelane_b32 %[agw], %[t0], m0\n\t"
+                "s_bfe_u32 %[np], %[w], 0x80007\n\t"
+                "s_bfe_u32 %[t0], %[w], 0x70017\n\t"
+                "s_add_u32 %[na], %[ag], %[t0]\n\t"
+                "s_cmp_ge_u32 %[na], %[gend]\n\t"
+                "s_cbranch_scc1 6f\n\t"
+                "s_mov_b32 %[p], %[np]\n\t"
+                "s_mov_b32 %[ag], %[na]\n\t"
+                "s_cmp_lt_u32 %[np], 64\n\t"
+                "s_cbranch_scc1 1b\n\t"
+                "s_mov_b32 %[st], 0\n\t"
+                "s_branch 9f\n\t"
+                "5:\n\t"                                       /* group end behind a cancellation */
+                "s_sub_u32 %[t0], %[gend], %[ag]\n\t"
+                "s_add_u32 %[p], %[p], %[t0]\n\t"
+                "s_mov_b32 %[ag], %[gend]\n\t"
+                "s_mov_b32 %[st], 1\n\t"
+                "s_branch 9f\n\t"
+                "6:\n\t"                                       /* group end behind a placement: from f */
+                "s_bfe_u32 %[t1], %[w], 0x8000f\n\t"
+                "s_sub_u32 %[t0], %[gend], %[ag]\n\t"
+                "s_add_u32 %[t0], %[t0], %[t1]\n\t"
+                "s_sub_u32 %[p], %[t0], 1\n\t"
+                "s_mov_b32 %[ag], %[gend]\n\t"
+                "s_mov_b32 %[st], 1\n\t"
+                "s_branch 9f\n\t"
+                "8:\n\t"
+                "s_mov_b32 %[st], 2\n\t"
+                "9:\n\t"
+                "s_nop 0"
+                : [st] "=&s"(st), [w] "=&s"(w), [t0] "=&s"(t0), [t1] "=&s"(t1), [np] "=&s"(np), [na] "=&s"(na), [p] "+s"(p),
+                  [ag] "+s"(ag), [agw] "+v"(agw)
+                : [pack] "v"(pack), [livev] "v"(livev), [lb] "s"(live_base), [gend] "s"(gend)
+                : "scc", "memory");
+            slow = st == 2u;
           }
         }
         // ---- the window's events, one lane each: list entry and the new order's fields
