@@ -374,12 +374,15 @@ def main():
     if all(ins.values()) and ins:
         salu = sum(v["salu"] for v in ins.values())
         valu = sum(v["valu"] for v in ins.values())
+        branch = sum(v.get("branch", 0.0) for v in ins.values())
         peak = N_CU * CLOCK_GHZ * 1e9  # instructions/s of one type, whole GPU
         per_gpu = value / world
-        issue = {"bound": "scalar/vector issue (1 SALU + 1 VALU per CU per clock)", "salu_per_book_step": salu,
-                 "valu_per_book_step": valu, "peak_insts_per_s": peak, "salu_frac": salu * per_gpu / peak,
-                 "valu_frac": valu * per_gpu / peak, "events_per_s_per_cu": ev_per_bs * per_gpu / N_CU,
-                 "assumed_clock_ghz": CLOCK_GHZ, "n_cu": N_CU}
+        # the scalar unit issues SALU instructions AND branches: one port per CU, 0.95 per clock measured
+        issue = {"bound": "scalar/vector issue (1 scalar-or-branch + 1 vector instruction per CU per clock)",
+                 "salu_per_book_step": salu, "branch_per_book_step": branch, "valu_per_book_step": valu,
+                 "peak_insts_per_s": peak, "salu_frac": salu * per_gpu / peak,
+                 "scalar_port_frac": (salu + branch) * per_gpu / peak, "valu_frac": valu * per_gpu / peak,
+                 "events_per_s_per_cu": ev_per_bs * per_gpu / N_CU, "assumed_clock_ghz": CLOCK_GHZ, "n_cu": N_CU}
         occ = pmc.get(dominant, {}).get("occupancy")
         if occ:  # achieved occupancy of the dominant kernel (PMC, committed under profiles/)
             issue["occupancy"] = occ
