@@ -167,7 +167,12 @@ def load() -> C.CDLL:
     if _lib is not None:
         return _lib
     path = _build.LIB
-    if _build.is_stale():
+    override = os.environ.get("BOURSE_AMD_LIBRARY")  # a variant build (scripts/asm_ab.sh); never rebuilt implicitly
+    if override:
+        if not os.path.exists(override):
+            raise ImportError(f"bourse_amd: BOURSE_AMD_LIBRARY={override} does not exist")
+        path = override
+    elif _build.is_stale():
         try:
             _build.build()
         except Exception as e:  # no toolchain on this machine

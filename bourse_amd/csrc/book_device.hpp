@@ -1182,6 +1182,12 @@ __global__ void k_book_service(uint32_t* state, uint32_t stride, uint32_t n_book
   }
 }
 
+// holds a stream for `ticks` x 10 ns (s_memrealtime runs at 100 MHz): the timed stagger of the split pipelines' parts
+__global__ void k_delay(uint32_t ticks) {
+  const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+  while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(16);
+}
+
 // books whose sticky flags gained a bit of `mask` relative to the snapshot taken before a guarded launch
 __global__ void k_count_new_flags(const uint32_t* state, const uint32_t* snap, uint32_t stride, uint32_t n_books,
                                   uint32_t mask, uint32_t* count) {

@@ -125,6 +125,7 @@ struct bk_env {
   DevBuf<uint4> jump_tabs;      // k_agents_wave: T^256 (block jump) then T^(4 << b), b = 0..5 (lane offsets): 7 x 8 KB
   DevBuf<uint32_t> wcache;      // k_agents_wave: per-book lane states of the RNG block in progress
   uint32_t wave_lookahead = 64;
+  uint32_t stagger_us = ~0u;    // parts of a split launch start i x stagger_us apart; ~0 = default rule, 0 = by events
   int wave_parts = 0;           // 0 = as the lane split (n_parts / min_part)
   bool wave_ok() const { return !n_mixed && M == 1 && !groups.empty(); }  // RandomAgents on independent books
   bool use_wave() const {        // split form: k_agents_wave + k_step_batch
@@ -387,7 +388,17 @@ int launch_split(bk_env* env, const DevArgs& a0, uint64_t first_step, uint32_t n
       a.hist_slot0 = a.hist_cap ? static_cast<uint32_t>((first_step + s) % a.hist_cap) : 0u;
       const uint32_t nb = a.book_end - a.book_begin;
       hipStream_t st = (P > 1 && i > 0) ? env->part_stream[i] : env->stream;
-      if (P > 1 && s == 0 && i > 0) HIPCHK(hipStreamWaitEvent(st, env->ev_first[i - 1], 0));  // stagger the parts
+      if (P > 1 && s == 0 && i > 0) {  // stagger the parts
+        // by time: i x stagger_us.  The lane split's parts cycle through a ~180 us agents kernel and a ~140 us event
+        // kernel; one agents kernel apart (the round-1 rule) puts part 2 at 360 us = almost in phase with part 0 again.
+        // Measured at C3 (driver's 20-step regions): 60 us apart 186-189 M first region / 199-201 M later ones against
+        // 182 / 192-195 M (BOURSE_AMD_STAGGER_US overrides; other pipelines keep the event-based stagger)
+        const uint32_t stagger = env->stagger_us != ~0u ? env->stagger_us : ((MIXED == 0 && !wave && P == 3) ? 60u : 0u);
+        if (stagger > 0)
+          hipLaunchKernelGGL(k_delay, dim3(1), dim3(64), 0, st, static_cast<uint32_t>(i) * stagger * 100u);
+        else                           // by one agents kernel each
+          HIPCHK(hipStreamWaitEvent(st, env->ev_first[i - 1], 0));
+      }
       {
         ProfScope ps(env, 1, st);
         if (MIXED == 2 && M > 1)
@@ -578,6 +589,7 @@ int bk_env_create(const bk_config* cfg, bk_env** out) {
     const int v = std::atoi(np);
     if (v >= 1 && v <= bk_env::MAX_PARTS) env->n_parts = v;
   }
+  if (const char* su = std::getenv("BOURSE_AMD_STAGGER_US")) env->stagger_us = static_cast<uint32_t>(std::max(0, std::atoi(su)));
   if (const char* mp = std::getenv("BOURSE_AMD_MIN_PART")) {
     const int v = std::atoi(mp);
     if (v >= 64) env->min_part = static_cast<uint32_t>(v);
