@@ -724,7 +724,7 @@ def test_c5_as_written_momentum_plus_noise_512_agents(bk, oracle):
     _compare_members(bk, oracle, 6, members, levels=64, n_steps=40, pool=512, pipeline="split_wave")
 
 
-@pytest.mark.parametrize("seed", range(8))
+@pytest.mark.parametrize("seed", range(10))
 def test_fuzz_random_agent_configs_vs_oracle(bk, oracle, seed):
     """Randomly drawn RandomAgents sets (group counts/sizes, windows, volumes incl. tiny ranges, rates incl. 0/1, ticks,
     level depth, batch size) on a randomly chosen pipeline, against the oracle."""
@@ -749,11 +749,16 @@ def test_fuzz_random_agent_configs_vs_oracle(bk, oracle, seed):
         total = 7
     n_books = int(rng.integers(1, 150)) * int(os.environ.get("BOURSE_FUZZ_BOOKS_SCALE", "1"))
     levels = int(rng.integers(1, 65))
-    _compare_random(bk, oracle, n_books=n_books, groups=groups, levels=levels, n_steps=int(rng.integers(5, 40)),
-                    tick=tick, step_size=max(int(rng.choice([300, 100_000])), total + 1),  # events per step < step_size (App. A.9)
-                    seed=int(rng.integers(0, 2**40)),
-                    pipeline=str(rng.choice(["fused", "split", "mixed"])), chunks=None if rng.random() < 0.5 else [3, 1, 1],
-                    max_live=max(64, total))
+    n_steps = int(rng.integers(5, 40))
+    step_size = max(int(rng.choice([300, 100_000])), total + 1)  # events per step < step_size (App. A.9)
+    book_seed = int(rng.integers(0, 2**40))
+    rng.choice(["fused", "split", "mixed"])  # (round 1 drew the pipeline here; kept so that the seeds keep their configurations)
+    chunks = None if rng.random() < 0.5 else [3, 1, 1]
+    # the pipeline and the wave decode's look-ahead rotate with the seed: every configuration family meets every pipeline
+    pipeline = ("fused", "split", "mixed", "wave_split", "wave")[seed % 5]
+    _compare_random(bk, oracle, n_books=n_books, groups=groups, levels=levels, n_steps=n_steps, tick=tick, step_size=step_size,
+                    seed=book_seed, pipeline=pipeline, chunks=chunks, max_live=max(64, total),
+                    lookahead=(64, 64, 3, 64, 17, 64, 1)[seed % 7])
 
 
 def test_history_ring_and_streaming_egress(bk, oracle):
