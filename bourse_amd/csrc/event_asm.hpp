@@ -66,6 +66,14 @@ namespace bkd {
   "s_nop 1\n\t" OP " %[vm], %[vm], %[vm] row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"             \
   "s_nop 1\n\t"
 
+// next event of list phase PH (inlined at the end of every path instead of a branch to one shared copy: one taken
+// branch - an instruction-buffer refill - fewer per event)
+#define EA_LOOP(PH, KEND)                       \
+  "s_add_u32 %[k], %[k], 1\n\t"                 \
+  "s_cmp_lt_u32 %[k], " KEND "\n\t"             \
+  "s_cbranch_scc1 L_top_" PH "_%=\n\t"          \
+  "s_branch L_end_" PH "_%=\n\t"
+
 // the passive order sits in pool register Q (lane = first set bit of its mask EQ): match_orders on it
 #define EA_PICK(Q, EQ, L)                                              \
   "s_ff1_i32_b64 " EA_LS ", " EQ "\n\t"                                \
@@ -101,7 +109,7 @@ namespace bkd {
 //   VOP, DOP  v_min_u32 / v_max_u32 and the _dpp form
 //   NOX   "s_cmp_lt_u32" (bid: p < best ask) / "s_cmp_gt_u32" (ask: p > best bid): no cross
 //   KKI   instruction that forms the trade's k word: passive side bit 31
-#define EA_SIDE(L, PH, RG, NR, CAND, SENT, VOP, DOP, NOX, KKI)                                     \
+#define EA_SIDE(L, PH, KEND, RG, NR, CAND, SENT, VOP, DOP, NOX, KKI)                                     \
   KKI "\n\t"                                                                                        \
   "s_and_b32 " EA_X ", " EA_V ", %[tmask]\n\t"          /* no volume or trading disabled: no match */ \
   "s_cbranch_scc0 L_rest_" L "\n\t"                                                                 \
@@ -154,7 +162,7 @@ namespace bkd {
   "s_cbranch_scc1 L_full_" L "\n\t"                                                                 \
   "s_cmp_lg_u32 " EA_V ", 0\n\t"                                                                    \
   "s_cbranch_scc1 L_match_" L "\n\t"                                                                \
-  "s_branch L_next_" PH "_%=\n\t"                       /* Filled: nothing rests */                 \
+  EA_LOOP(PH, KEND)                                     /* Filled: nothing rests */                 \
   "L_full_" L ":\n\t"                                   /* buffer full: flush outside */            \
   "s_cmp_eq_u32 " EA_V ", 0\n\t"                                                                    \
   "s_cbranch_scc1 L_fullnext_%=\n\t"                                                                \
@@ -170,19 +178,19 @@ namespace bkd {
   "s_lshl_b64 " EA_BIT ", 1, " EA_EW "\n\t"                                                         \
   "s_or_b64 %[live" RG "], %[live" RG "], " EA_BIT "\n\t"                                           \
   "s_add_u32 %[seqc], %[seqc], 1\n\t"                                                               \
-  "s_branch L_next_" PH "_%=\n\t"
+  EA_LOOP(PH, KEND)
 
 // a New event in pool register RG of list phase PH: read the order, dispatch on its side
-#define EA_NEW(PH, RG, NR)                                                                          \
+#define EA_NEW(PH, KEND, RG, NR)                                                                          \
   "v_readlane_b32 " EA_P ", %[price" RG "], " EA_EW "\n\t"                                          \
   "v_readlane_b32 " EA_V ", %[vol" RG "], " EA_EW "\n\t"                                            \
   "v_readlane_b32 " EA_ID ", %[id" RG "], " EA_EW "\n\t"                                            \
   "s_bitcmp1_b32 " EA_EW ", 14\n\t"                                                                 \
   "s_cbranch_scc1 L_bid_" PH RG "_%=\n\t"                                                           \
-  EA_SIDE("a" PH RG "_%=", PH, RG, NR, "s_and_b64", "0", "v_max_u32", "v_max_u32_dpp", "s_cmp_gt_u32", \
+  EA_SIDE("a" PH RG "_%=", PH, KEND, RG, NR, "s_and_b64", "0", "v_max_u32", "v_max_u32_dpp", "s_cmp_gt_u32", \
           "s_or_b32 " EA_KK ", %[k], 0x80000000")                                                   \
   "L_bid_" PH RG "_%=:\n\t"                                                                         \
-  EA_SIDE("b" PH RG "_%=", PH, RG, NR, "s_andn2_b64", "-1", "v_min_u32", "v_min_u32_dpp", "s_cmp_lt_u32", \
+  EA_SIDE("b" PH RG "_%=", PH, KEND, RG, NR, "s_andn2_b64", "-1", "v_min_u32", "v_min_u32_dpp", "s_cmp_lt_u32", \
           "s_mov_b32 " EA_KK ", %[k]")
 
 // the events of one list register (PH = "0": k < kend0 from ev0, "1": k < nev from ev1)
@@ -195,21 +203,18 @@ namespace bkd {
   EA_IF2_##NR("s_bitcmp1_b32 " EA_EW ", 6\n\t"                                                      \
               "s_cbranch_scc1 L_can1_" PH "_%=\n\t")                                                \
   "s_andn2_b64 %[live0], %[live0], " EA_BIT "\n\t"                                                  \
-  EA_IF2_##NR("s_branch L_next_" PH "_%=\n\t"                                                       \
+  EA_IF2_##NR(EA_LOOP(PH, KEND)                                                                     \
               "L_can1_" PH "_%=:\n\t"                                                               \
               "s_andn2_b64 %[live1], %[live1], " EA_BIT "\n\t")                                     \
   "L_next_" PH "_%=:\n\t"                                                                           \
-  "s_add_u32 %[k], %[k], 1\n\t"                                                                     \
-  "s_cmp_lt_u32 %[k], " KEND "\n\t"                                                                 \
-  "s_cbranch_scc1 L_top_" PH "_%=\n\t"                                                              \
-  "s_branch L_end_" PH "_%=\n\t"                                                                    \
+  EA_LOOP(PH, KEND)                                                                                 \
   "L_new_" PH "_%=:\n\t"                                                                            \
   EA_IF2_##NR("s_bitcmp1_b32 " EA_EW ", 6\n\t"                                                      \
               "s_cbranch_scc1 L_new1_" PH "_%=\n\t")                                                \
   EA_IF1_##NR("s_nop 1\n\t")                            /* ew as a lane select: 4 wait states */    \
-  EA_NEW(PH, "0", NR)                                                                               \
+  EA_NEW(PH, KEND, "0", NR)                                                                               \
   EA_IF2_##NR("L_new1_" PH "_%=:\n\t"                                                               \
-              EA_NEW(PH, "1", NR))
+              EA_NEW(PH, KEND, "1", NR))
 
 // Processes events k .. n_ev-1 of the step's (shuffled) list.  Returns 0 when the list is done, 1 when the trade
 // buffer is full (flush it, call again).  All scalars are wave-uniform.

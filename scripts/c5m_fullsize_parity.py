@@ -8,7 +8,7 @@ MOM_P = dict(tick_size=2, p_cancel=0.1, trade_vol=100, decay=1.0, demand=20.0, s
 NOISE_P = dict(tick_size=2, p_limit=0.3, p_market=0.2, p_cancel=0.2, trade_vol=100, price_dist_mu=0.0, price_dist_sigma=1.0)
 members = [("momentum", 0, 256, MOM_P), ("noise", 256, 256, NOISE_P)]
 B, T = 8192, 24
-env = bk.ManyBookEnv(B, 101, 0, 2, 100_000, levels=64, max_live_orders=512, trade_capacity=96 * T, history_capacity=T)
+env = bk.ManyBookEnv(B, 101, 0, 2, 100_000, levels=64, max_live_orders=512, trade_capacity=96 * T, history_capacity=T, strict=False)
 env.set_agents(members)
 for c, pipe in ((10, "split"), (4, "split_wave"), (10, "split")):
     env.set_pipeline(pipe); env.run(c)
