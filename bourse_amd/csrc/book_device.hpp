@@ -786,17 +786,38 @@ __global__ __launch_bounds__(256) void k_run_random(DevArgs a, uint64_t first_st
 // ==================================================================================
 enum Phase : uint32_t { PH_ACT = 0, PH_SIDE = 1, PH_TICK = 2, PH_VOL = 3, PH_SHUF = 4, PH_DONE = 5 };
 
+#ifndef BOURSE_AMD_FSM_TOP_VGPR
+#define BOURSE_AMD_FSM_TOP_VGPR 231  // highest VGPR k_agents_fsm claims (0 = only what it uses); see the kernel's prologue
+#endif
+#define BK_STR2(x) #x
+#define BK_STR(x) BK_STR2(x)
+
+constexpr uint32_t fsm_lds_bytes(int R) { return (64u * R * 32u + 4u * R * 64u) * 4u; }
+
 template <int R>
 __global__ __launch_bounds__(64) void k_agents_fsm(DevArgs a) {
-  __shared__ uint16_t list[64 * R * 64];  // event list of lane l: list[k * 64 + l]
+  // LDS is DYNAMIC (fsm_lds_bytes(R) at launch) so that the kernel's register footprint is the one chosen below: with a
+  // static size the compiler derives "at most 2 waves per SIMD" from it and pads the kernel descriptor's register request
+  // up to that occupancy's budget (R = 2: 169 VGPRs + 102 SGPRs for a kernel using 34 + 46; 257 VGPRs for R = 4, 8).
+  extern __shared__ uint32_t fsm_lds[];
+  uint16_t* list = reinterpret_cast<uint16_t*>(fsm_lds);  // event list of lane l: list[k * 64 + l], 64 * R * 64 entries
   // placing-agents / bid-side bit masks of lane l, 32-bit word w: pmask[w * 64 + l], smask[w * 64 + l]
   // (one ds_or per new order instead of ~20 VALU of per-lane 64-bit mask arithmetic in the hot loop)
-  __shared__ uint32_t pmask[2 * R * 64], smask[2 * R * 64];
+  uint32_t* pmask = fsm_lds + 64 * R * 32;
+  uint32_t* smask = pmask + 2 * R * 64;
   const int lane = threadIdx.x;
   // This kernel is a dependent chain of ~600 iterations on ONE wave per SIMD, co-resident with up to 7 waves of the
   // issue-bound event kernel of another part: top issue priority lets the chain run at its lone-wave pace (the part's
   // next k_step_batch cannot start before it ends) at no cost to the event kernel's throughput
   __builtin_amdgcn_s_setprio(3);
+  // ... and it CLAIMS far more VGPRs than it uses (34): the chain is VALU-latency bound, and every k_step_batch wave
+  // sharing its SIMD's VALU stretches it (151 us alone, 185-194 us under 8 event waves).  A 232-VGPR footprint leaves
+  // room for 7 event waves beside one of these waves and 1 beside two of them, instead of 8 and 8; measured on C3
+  // (profiles/r02/fsm_vgpr_sweep.txt): no pad 184 M, 104: 198, 168: 214, 200-264: 215-220 (plateau), 296: 169 M
+  // book-steps/s (from 296 up the dispatcher cannot place these waves until a whole SIMD drains).
+#if BOURSE_AMD_FSM_TOP_VGPR > 0
+  asm volatile("" ::: "v" BK_STR(BOURSE_AMD_FSM_TOP_VGPR));
+#endif
   // MarketEnv mode (assets = M > 1): the lane owns a MARKET = books [b*M, b*M + M) with one RNG stream and one event
   // queue (market_env.rs:110-121, runner.rs:108-131); RandomMarketAgents::update is RandomAgents::update addressed to
   // the group's asset (random_agent.rs:204-247), so the state machine below is unchanged.

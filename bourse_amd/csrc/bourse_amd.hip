@@ -159,6 +159,7 @@ struct bk_env {
   DevBuf<uint16_t> ml_list;
   DevBuf<uint32_t> ml_len, ml_inl;
   bool lds_attr_set = false;  // hipFuncAttributeMaxDynamicSharedMemorySize applied on this env's device
+  bool fsm_attr_set = false;  // same for k_agents_fsm (its LDS is dynamic: book_device.hpp)
   bool ml_valid = false;  // the lists describe the pool as of steps_done (false after a wave-per-book launch / restore)
   uint32_t member_asset[MAX_MEMBERS] = {0, 0, 0, 0};
   uint32_t n_fixed_a[MAX_ASSETS] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -332,6 +333,12 @@ int launch_wave_fused(bk_env* env, const DevArgs& a, uint64_t first_step, uint32
 template <int R, int MIXED = 0>
 int launch_split(bk_env* env, const DevArgs& a0, uint64_t first_step, uint32_t n_steps) {
   const MixedArgs ma = env->margs();
+  const uint32_t fsm_lds = fsm_lds_bytes(R);
+  if (MIXED == 0 && !env->fsm_attr_set) {
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_agents_fsm<R>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               static_cast<int>(fsm_lds)));
+    env->fsm_attr_set = true;
+  }
   if (MIXED == 2) {
     const size_t NB = env->cfg.n_books, cap = static_cast<size_t>(R) * 64, NU = NB / env->M;
     if (!env->ml_list.p) {
@@ -412,7 +419,7 @@ int launch_split(bk_env* env, const DevArgs& a0, uint64_t first_step, uint32_t n
         else if (wave)
           hipLaunchKernelGGL(k_agents_wave<R>, dim3((nb + 3) / 4), dim3(256), 0, st, a, wva);
         else
-          hipLaunchKernelGGL(k_agents_fsm<R>, dim3((nb + 63) / 64), dim3(64), 0, st, a);
+          hipLaunchKernelGGL(k_agents_fsm<R>, dim3((nb + 63) / 64), dim3(64), fsm_lds, st, a);
       }
       if (P > 1 && s == 0) HIPCHK(hipEventRecord(env->ev_first[i], st));
       {
