@@ -160,6 +160,19 @@ __device__ __forceinline__ void wave_reduce4(uint32_t& mx, uint32_t& mn, uint32_
   s2 = rdl(s2, 63);
 }
 
+// max / min / max interleaved the same way (key_window below)
+#define BK_DPP3(CTRL) \
+  "v_max_u32_dpp %0, %0, %0 " CTRL "\n\tv_min_u32_dpp %1, %1, %1 " CTRL "\n\tv_max_u32_dpp %2, %2, %2 " CTRL "\n\t"
+__device__ __forceinline__ void wave_reduce3(uint32_t& mx, uint32_t& mn, uint32_t& m2) {
+  asm("s_nop 1\n\t" BK_DPP3("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf") BK_DPP3("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")
+          BK_DPP3("row_half_mirror row_mask:0xf bank_mask:0xf") BK_DPP3("row_mirror row_mask:0xf bank_mask:0xf")
+              BK_DPP3("row_bcast:15 row_mask:0xa bank_mask:0xf") BK_DPP3("row_bcast:31 row_mask:0xc bank_mask:0xf") "s_nop 1"
+      : "+v"(mx), "+v"(mn), "+v"(m2));
+  mx = rdl(mx, 63);
+  mn = rdl(mn, 63);
+  m2 = rdl(m2, 63);
+}
+
 __device__ __forceinline__ uint64_t mk64(uint32_t lo, uint32_t hi) { return ((uint64_t)hi << 32) | lo; }
 
 // ----------------------------------------------------------------------------------
@@ -628,6 +641,33 @@ __device__ __forceinline__ void store_book(const Book<R>& B, const Rng& rng, uin
   }
 }
 
+// Can this step run on the keyed event loop (event_asm.hpp)?  Yes iff the prices of the live and the new orders span
+// <= 32 764 (and none is 0 or u32::MAX) and the live arrival stamps plus this step's (at most n_ev) new ones span < 65 534.
+// pbase / sbase: the key fields are price - pbase (>= 1) and seq - sbase (>= 1).  Three interleaved wave reductions.
+#ifndef BOURSE_AMD_KEYED_EVENTS
+#define BOURSE_AMD_KEYED_EVENTS 1
+#endif
+#ifndef BOURSE_AMD_KEY_SEQ_BITS  // arrival field of the key; test builds shrink it so that ordinary runs leave the window
+#define BOURSE_AMD_KEY_SEQ_BITS 16
+#endif
+constexpr uint32_t KEY_SB = BOURSE_AMD_KEY_SEQ_BITS, KEY_SMASK = (1u << KEY_SB) - 1u, KEY_PSPAN = (1u << (31 - KEY_SB)) - 4u;
+template <int R>
+__device__ __forceinline__ bool key_window(const Book<R>& B, const uint64_t (&newm)[R], uint32_t n_ev, uint32_t& pbase,
+                                           uint32_t& sbase) {
+  uint32_t pmax = 0, pmin = 0xFFFFFFFFu, age = 0;  // age = seq_ctr - seq of the oldest live order (wrapping)
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const bool lv = lane_bit(B.live[r]), in = lv | lane_bit(newm[r]);
+    pmax = max(pmax, in ? B.price[r] : 0u);
+    pmin = min(pmin, in ? B.price[r] : 0xFFFFFFFFu);
+    age = max(age, lv ? B.seq_ctr - B.seq[r] : 0u);
+  }
+  wave_reduce3(pmax, pmin, age);
+  pbase = pmin - 1u;
+  sbase = B.seq_ctr - age - 1u;
+  return pmin != 0u && pmax != 0xFFFFFFFFu && pmax - pmin <= KEY_PSPAN && age + n_ev < KEY_SMASK - 1u;
+}
+
 // ----------------------------------------------------------------------------------
 // Env::step body after the shuffle (env.rs:117-134): process the (already shuffled) event list of
 // agent/slot indices, advance the clock, snapshot, flush trades.  Returns this step's trade count.
@@ -647,20 +687,57 @@ __device__ __forceinline__ uint32_t step_from_list(Book<R>& B, const DevArgs& a,
   const uint64_t trades_before = B.n_trades;
   // step_size 0 = immediate mode (the clock is the caller's, OrderBook::set_time): no step window to overflow
   if (step_size != 0 && (uint64_t)n_ev >= step_size) B.flags |= FLAG_STEP_SIZE;
-  if constexpr (R == 2 && !MKT && CLS && BOURSE_AMD_ASM_EVENTS) {
-    // hand-written event loop (event_asm.hpp); it returns whenever the 64-record trade buffer is full
+  // CLS callers hand over this step's new-order lanes in B.pend (the event words classify themselves, so the mask is
+  // not carried through the event loop - only the keyed loop's set-up wants it)
+  uint64_t newm[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    newm[r] = CLS ? B.pend[r] : 0ull;
+    if (CLS) B.pend[r] = 0;
+  }
+  if constexpr ((R == 2 || R == 1) && !MKT && CLS && BOURSE_AMD_ASM_EVENTS) {
+    // hand-written event loops (event_asm.hpp); they return whenever the 64-record trade buffer is full
     uint32_t k = 0;
     const uint32_t nev = rfl(n_ev), tmask = B.trading ? 0xFFFFFFFFu : 0u;
-    while (events_asm_r2(k, nev, tmask, B.tr_n, B.seq_ctr, B.trade_vol, B.live[0], B.live[1], B.bid[0], B.bid[1],
-                         B.price[0], B.price[1], B.vol[0], B.vol[1], B.id[0], B.id[1], B.seq[0], B.seq[1], ev[0], ev[1],
-                         B.tr_k, B.tr_price, B.tr_vol, B.tr_act, B.tr_pas))
-      flush_trades<R>(B, a, book, t0, lane);
-  } else if constexpr (R == 1 && !MKT && CLS && BOURSE_AMD_ASM_EVENTS) {
-    uint32_t k = 0;
-    const uint32_t nev = rfl(n_ev), tmask = B.trading ? 0xFFFFFFFFu : 0u;
-    while (events_asm_r1(k, nev, tmask, B.tr_n, B.seq_ctr, B.trade_vol, B.live[0], B.bid[0], B.price[0], B.vol[0], B.id[0],
-                         B.seq[0], ev[0], B.tr_k, B.tr_price, B.tr_vol, B.tr_act, B.tr_pas))
-      flush_trades<R>(B, a, book, t0, lane);
+    uint32_t pbase, sbase;
+    if (BOURSE_AMD_KEYED_EVENTS && key_window<R>(B, newm, nev, pbase, sbase)) {
+      // keyed loop: one sort key per order (price field << 16 | arrival field), rebuilt from {price, seq} every step
+      uint32_t key[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const bool bidl = lane_bit(B.bid[r]);
+        const uint32_t kp = ((((B.price[r] - pbase) << KEY_SB) | (bidl ? KEY_SMASK : 0u)) << 1) | (bidl ? 1u : 0u);
+        key[r] = lane_bit(B.live[r]) ? (kp ^ ((B.seq[r] - sbase) << 1)) : lane_bit(newm[r]) ? kp : 0xFFFFFFFFu;
+      }
+      uint32_t sq = (B.seq_ctr - sbase) << 1;  // the loop keeps the running arrival field in key position (bit 1 up)
+      for (;;) {
+        uint32_t full;
+        if constexpr (R == 2)
+          full = events_key_r2(k, nev, tmask, B.tr_n, sq, B.live[0], B.live[1], B.bid[0], B.bid[1], B.price[0], B.price[1],
+                               B.vol[0], B.vol[1], B.id[0], B.id[1], key[0], key[1], ev[0], ev[1], B.tr_k, B.tr_price,
+                               B.tr_vol, B.tr_act, B.tr_pas);
+        else
+          full = events_key_r1(k, nev, tmask, B.tr_n, sq, B.live[0], B.bid[0], B.price[0], B.vol[0], B.id[0], key[0], ev[0],
+                               B.tr_k, B.tr_price, B.tr_vol, B.tr_act, B.tr_pas);
+        // Env::get_trade_vol: the loop leaves the sum to the vector unit (one reduction per flush, not an add per trade)
+        if (B.tr_n) B.trade_vol += wave_add((uint32_t)lane < B.tr_n ? B.tr_vol : 0u);
+        if (!full) break;
+        flush_trades<R>(B, a, book, t0, lane);
+      }
+      B.seq_ctr = sbase + (sq >> 1);
+#pragma unroll
+      for (int r = 0; r < R; ++r)  // arrival stamps of the orders resting now (the others' are never read again)
+        B.seq[r] = lane_bit(B.live[r]) ? sbase + (((key[r] >> 1) ^ (lane_bit(B.bid[r]) ? KEY_SMASK : 0u)) & KEY_SMASK) : B.seq[r];
+    } else if constexpr (R == 2) {
+      while (events_asm_r2(k, nev, tmask, B.tr_n, B.seq_ctr, B.trade_vol, B.live[0], B.live[1], B.bid[0], B.bid[1],
+                           B.price[0], B.price[1], B.vol[0], B.vol[1], B.id[0], B.id[1], B.seq[0], B.seq[1], ev[0], ev[1],
+                           B.tr_k, B.tr_price, B.tr_vol, B.tr_act, B.tr_pas))
+        flush_trades<R>(B, a, book, t0, lane);
+    } else {
+      while (events_asm_r1(k, nev, tmask, B.tr_n, B.seq_ctr, B.trade_vol, B.live[0], B.bid[0], B.price[0], B.vol[0], B.id[0],
+                           B.seq[0], ev[0], B.tr_k, B.tr_price, B.tr_vol, B.tr_act, B.tr_pas))
+        flush_trades<R>(B, a, book, t0, lane);
+    }
   } else
 #pragma unroll
   for (int re = 0; re < R; ++re) {  // events at t0 + k (env.rs:123-127); entry k lives in lane k & 63 of ev[k >> 6]
@@ -1005,7 +1082,7 @@ __global__ __launch_bounds__(64) void k_step_batch(DevArgs a, uint64_t step_inde
     B.id[r] = sel(pend, base + rank, B.id[r]);
     base += __builtin_popcountll(pend);
     B.bid[r] = (B.bid[r] & ~pend) | (side & pend);
-    B.pend[r] = 0;  // the event words classify themselves (EV_NEW): no pend mask is carried through the event loop
+    B.pend[r] = pend;  // handed to step_from_list, which clears it (the event words classify themselves: EV_NEW)
   }
   B.next_id = base;
   uint32_t n_own = 0;

@@ -310,4 +310,223 @@ __device__ __forceinline__ uint32_t events_asm_r1(uint32_t& k, uint32_t n_ev, ui
   return st;
 }
 
+// ==================================================================================
+// KEYED event loop: price-time priority as ONE 32-bit sort key per resting order, so a match step is a single DPP
+// reduction - no "how many orders at the touch" test, no second reduction over the arrival stamps, no candidate-mask
+// algebra after it (the key is unique, so `key == best` selects exactly one lane).
+//
+//   key = (price - pbase) << 17 | s << 1 | side     asks (side 0):  s = seq - sbase       best = MIN key
+//                                                   bids (side 1):  s = ~(seq - sbase)    best = MAX key (max price, oldest)
+//   pbase = (lowest price among the live and the new orders) - 1, sbase = (oldest live stamp) - 1: every live key has a
+//   price field in 1..32765 and 1 <= seq - sbase <= 65533.  book_device.hpp (key_window) checks that the step's prices
+//   and stamps fit - if not, the step runs on the loop above - and rebuilds the keys from {price, seq} at the start of
+//   every step, so nothing about them is persistent state.
+//   A NEW order's lane holds the key PREFIX kp = (price - pbase) << 17 | (bid ? 0x1FFFF : 0) until it is processed:
+//     * as an aggressor it crosses iff best ask key <= kp (bid) / best bid key >= kp (ask) - with no candidates the
+//       reduction returns its neutral element (-1 / 0) and the same compare says "no cross";
+//     * when it rests its key is kp ^ (seq_ctr - sbase) << 1 (`sq` below is kept pre-shifted and advances by 2).
+//   `key == best` needs no live / side mask: keys of one side differ in the arrival field (every order that ever rested
+//   in the window has its own), the side bit separates the two sides (WITHOUT it a dead bid and a live ask at one price
+//   collide when their arrival fields are complements), a prefix never equals a live key (those have seq - sbase >= 1)
+//   and lanes that were dead at the start of the step hold -1.
+//   Prices 0 and u32::MAX (a market order's sentinels) fail the window test, so the "market remainder is dropped" exit
+//   is not needed here.
+//
+// The fill itself is specialised three ways on one scalar subtract (SCC = borrow of passive - aggressor volume):
+//   aggressor wants more  -> passive order gone, trade = its volume, match again (unconditional branch)
+//   aggressor exhausted   -> trade = aggressor's volume, next event (the passive order dies too iff nothing is left)
+// and the trade-buffer index is kept biased by -64: `s_add_u32 trn, trn, 1` carries out exactly when the buffer is full
+// (lane selects read the low 6 bits).  The step's traded volume is summed from the buffer at every flush (book_device.hpp)
+// instead of one scalar add per trade.  Per trade: 16 scalar + branch instructions (loop above: 32).
+// ==================================================================================
+#define EK_KP EA_P  // the aggressor's key prefix lives where the loop above keeps its price
+
+#define EK_TRADE_REC(TV)                                                                              \
+  "s_mov_b32 m0, %[trn]\n\t"                                                                          \
+  "v_writelane_b32 %[trk], " EA_KK ", m0\n\t"                                                         \
+  "v_writelane_b32 %[trp], " EA_BEST ", m0\n\t"                                                       \
+  "v_writelane_b32 %[trv], " TV ", m0\n\t"                                                            \
+  "v_writelane_b32 %[tra], " EA_ID ", m0\n\t"                                                         \
+  "v_writelane_b32 %[trs], " EA_PID ", m0\n\t"                                                        \
+  "s_add_u32 %[trn], %[trn], 1\n\t"                     /* SCC = carry = buffer full */
+
+// the passive order is the single lane of mask EQ in pool register Q
+#define EK_PICK(Q, EQ, L, PH, KEND)                                                                   \
+  "s_ff1_i32_b64 " EA_LS ", " EQ "\n\t"                                                               \
+  "v_readlane_b32 " EA_PV ", %[vol" Q "], " EA_LS "\n\t"                                              \
+  "v_readlane_b32 " EA_PID ", %[id" Q "], " EA_LS "\n\t"                                              \
+  "v_readlane_b32 " EA_BEST ", %[price" Q "], " EA_LS "\n\t"  /* the trade's price */                 \
+  "s_mov_b32 m0, " EA_LS "\n\t"                                                                       \
+  "s_sub_u32 " EA_X ", " EA_PV ", " EA_V "\n\t"                                                       \
+  "s_cbranch_scc1 L_A" Q "_" L "\n\t"                                                                 \
+  "v_writelane_b32 %[vol" Q "], " EA_X ", m0\n\t"       /* aggressor exhausted; X = passive remainder */ \
+  "s_cmp_eq_u32 " EA_X ", 0\n\t"                                                                      \
+  "s_cbranch_scc0 L_B" Q "_" L "\n\t"                                                                 \
+  "s_andn2_b64 %[live" Q "], %[live" Q "], " EQ "\n\t"                                                \
+  "L_B" Q "_" L ":\n\t"                                                                               \
+  EK_TRADE_REC(EA_V)                                                                                  \
+  "s_cbranch_scc1 L_fullnext_%=\n\t"                                                                  \
+  EA_LOOP(PH, KEND)                                                                                   \
+  "L_A" Q "_" L ":\n\t"                                 /* passive order exhausted, aggressor goes on */ \
+  "v_writelane_b32 %[vol" Q "], 0, m0\n\t"                                                            \
+  "s_andn2_b64 %[live" Q "], %[live" Q "], " EQ "\n\t"                                                \
+  "s_sub_u32 " EA_V ", " EA_V ", " EA_PV "\n\t"                                                       \
+  EK_TRADE_REC(EA_PV)                                                                                 \
+  "s_cbranch_scc1 L_fullA_" L "\n\t"                                                                  \
+  "s_branch L_match_" L "\n\t"
+
+//   NOX  "s_cmp_gt_u32" (bid: best ask key > kp) / "s_cmp_lt_u32" (ask: best bid key < kp): no cross
+#define EK_SIDE(L, PH, KEND, RG, NR, CAND, SENT, VOP, DOP, NOX, KKI)                                  \
+  KKI "\n\t"                                                                                          \
+  "s_and_b32 " EA_X ", " EA_V ", %[tmask]\n\t"          /* no volume or trading disabled: no match */ \
+  "s_cbranch_scc0 L_rest_" L "\n\t"                                                                   \
+  "L_match_" L ":\n\t"                                                                                \
+  CAND " " EA_C0 ", %[live0], %[bid0]\n\t"                                                            \
+  EA_IF2_##NR(CAND " " EA_C1 ", %[live1], %[bid1]\n\t")                                               \
+  "v_cndmask_b32_e64 %[vm], " SENT ", %[key0], " EA_C0 "\n\t"                                         \
+  EA_IF2_##NR("v_cndmask_b32_e64 %[vm2], " SENT ", %[key1], " EA_C1 "\n\t"                            \
+              VOP " %[vm], %[vm], %[vm2]\n\t")                                                        \
+  EA_DPP(DOP)                                                                                         \
+  "v_readlane_b32 " EA_BEST ", %[vm], 63\n\t"                                                         \
+  NOX " " EA_BEST ", " EK_KP "\n\t"                                                                   \
+  "s_cbranch_scc1 L_rest_" L "\n\t"                                                                   \
+  "v_cmp_eq_u32_e64 " EA_E0 ", " EA_BEST ", %[key0]\n\t"                                              \
+  EA_IF2_##NR("v_cmp_eq_u32_e64 " EA_E1 ", " EA_BEST ", %[key1]\n\t"                                  \
+              "s_cmp_lg_u64 " EA_E0 ", 0\n\t"                                                         \
+              "s_cbranch_scc0 L_pick1_" L "\n\t")                                                     \
+  EK_PICK("0", EA_E0, L, PH, KEND)                                                                    \
+  EA_IF2_##NR("L_pick1_" L ":\n\t"                                                                    \
+              EK_PICK("1", EA_E1, L, PH, KEND))                                                       \
+  "L_fullA_" L ":\n\t"                                  /* buffer full, volume left: the event restarts */ \
+  "s_mov_b32 m0, " EA_EW "\n\t"                                                                       \
+  "v_writelane_b32 %[vol" RG "], " EA_V ", m0\n\t"                                                    \
+  "s_branch L_flush_%=\n\t"                                                                           \
+  "L_rest_" L ":\n\t"                                                                                 \
+  "s_mov_b32 m0, " EA_EW "\n\t"                                                                       \
+  "v_writelane_b32 %[vol" RG "], " EA_V ", m0\n\t"                                                    \
+  "s_xor_b32 " EA_X ", " EK_KP ", %[sq]\n\t"                                                          \
+  "v_writelane_b32 %[key" RG "], " EA_X ", m0\n\t"                                                    \
+  "s_lshl_b64 " EA_BIT ", 1, " EA_EW "\n\t"                                                           \
+  "s_or_b64 %[live" RG "], %[live" RG "], " EA_BIT "\n\t"                                             \
+  "s_add_u32 %[sq], %[sq], 2\n\t"                                                                     \
+  EA_LOOP(PH, KEND)
+
+#define EK_NEW(PH, KEND, RG, NR)                                                                      \
+  "v_readlane_b32 " EK_KP ", %[key" RG "], " EA_EW "\n\t"                                             \
+  "v_readlane_b32 " EA_V ", %[vol" RG "], " EA_EW "\n\t"                                              \
+  "v_readlane_b32 " EA_ID ", %[id" RG "], " EA_EW "\n\t"                                              \
+  "s_bitcmp1_b32 " EA_EW ", 14\n\t"                                                                   \
+  "s_cbranch_scc1 L_bid_" PH RG "_%=\n\t"                                                             \
+  EK_SIDE("a" PH RG "_%=", PH, KEND, RG, NR, "s_and_b64", "0", "v_max_u32", "v_max_u32_dpp", "s_cmp_lt_u32", \
+          "s_or_b32 " EA_KK ", %[k], 0x80000000")                                                     \
+  "L_bid_" PH RG "_%=:\n\t"                                                                           \
+  EK_SIDE("b" PH RG "_%=", PH, KEND, RG, NR, "s_andn2_b64", "-1", "v_min_u32", "v_min_u32_dpp", "s_cmp_gt_u32", \
+          "s_mov_b32 " EA_KK ", %[k]")
+
+#define EK_PHASE(PH, KEND, NR)                                                                        \
+  "L_top_" PH "_%=:\n\t"                                                                              \
+  "v_readlane_b32 " EA_EW ", %[ev" PH "], %[k]\n\t"                                                   \
+  "s_bitcmp1_b32 " EA_EW ", 15\n\t"                                                                   \
+  "s_cbranch_scc1 L_new_" PH "_%=\n\t"                                                                \
+  "s_lshl_b64 " EA_BIT ", 1, " EA_EW "\n\t"             /* Cancellation */                            \
+  EA_IF2_##NR("s_bitcmp1_b32 " EA_EW ", 6\n\t"                                                        \
+              "s_cbranch_scc1 L_can1_" PH "_%=\n\t")                                                  \
+  "s_andn2_b64 %[live0], %[live0], " EA_BIT "\n\t"                                                    \
+  EA_IF2_##NR(EA_LOOP(PH, KEND)                                                                       \
+              "L_can1_" PH "_%=:\n\t"                                                                 \
+              "s_andn2_b64 %[live1], %[live1], " EA_BIT "\n\t")                                       \
+  EA_LOOP(PH, KEND)                                                                                   \
+  "L_new_" PH "_%=:\n\t"                                                                              \
+  EA_IF2_##NR("s_bitcmp1_b32 " EA_EW ", 6\n\t"                                                        \
+              "s_cbranch_scc1 L_new1_" PH "_%=\n\t")                                                  \
+  EA_IF1_##NR("s_nop 1\n\t")                            /* ew as a lane select: 4 wait states */      \
+  EK_NEW(PH, KEND, "0", NR)                                                                           \
+  EA_IF2_##NR("L_new1_" PH "_%=:\n\t"                                                                 \
+              EK_NEW(PH, KEND, "1", NR))
+
+#define EK_TAIL                     \
+  "L_done_%=:\n\t"                  \
+  "s_mov_b32 %[st], 0\n\t"          \
+  "s_branch L_out_%=\n\t"           \
+  "L_fullnext_%=:\n\t"              \
+  "s_add_u32 %[k], %[k], 1\n\t"     \
+  "L_flush_%=:\n\t"                 \
+  "s_mov_b32 %[st], 1\n\t"          \
+  "L_out_%=:\n\t"                   \
+  "s_nop 1"
+
+#define EK_CLOBBERS                                                                                                 \
+  "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55",  \
+      "s56", "s57", "s58", "s59", "s60", "s61", "vcc", "scc", "memory"
+
+// Keyed form of events_asm_r2: `sq` = (seq_ctr - sbase) << 1 (the caller converts back), key0/key1 as described above.
+__device__ __forceinline__ uint32_t events_key_r2(uint32_t& k, uint32_t n_ev, uint32_t tmask, uint32_t& tr_n, uint32_t& sq,
+                                                  uint64_t& live0, uint64_t& live1, uint64_t bid0, uint64_t bid1,
+                                                  uint32_t price0, uint32_t price1, uint32_t& vol0, uint32_t& vol1,
+                                                  uint32_t id0, uint32_t id1, uint32_t& key0, uint32_t& key1, uint32_t ev0,
+                                                  uint32_t ev1, uint32_t& trk, uint32_t& trp, uint32_t& trv, uint32_t& tra,
+                                                  uint32_t& trs) {
+  uint32_t st, vm, vm2;
+  auto u32 = [](uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane(x); };
+  auto u64 = [&](uint64_t x) { return ((uint64_t)u32((uint32_t)(x >> 32)) << 32) | u32((uint32_t)x); };
+  k = u32(k);
+  n_ev = u32(n_ev);
+  tmask = u32(tmask);
+  uint32_t trn = u32(tr_n) - 64u;  // biased: see above
+  sq = u32(sq);
+  live0 = u64(live0);
+  live1 = u64(live1);
+  bid0 = u64(bid0);
+  bid1 = u64(bid1);
+  const uint32_t kend0 = n_ev < 64u ? n_ev : 64u;
+  asm volatile(
+      "s_cmp_lt_u32 %[k], %[kend0]\n\t"
+      "s_cbranch_scc1 L_top_0_%=\n\t"
+      "s_branch L_end_0_%=\n\t"
+      EK_PHASE("0", "%[kend0]", 2)
+      "L_end_0_%=:\n\t"
+      "s_cmp_lt_u32 %[k], %[nev]\n\t"
+      "s_cbranch_scc0 L_done_%=\n\t"
+      EK_PHASE("1", "%[nev]", 2)
+      "L_end_1_%=:\n\t"
+      EK_TAIL
+      : [st] "=&s"(st), [vm] "=&v"(vm), [vm2] "=&v"(vm2), [k] "+s"(k), [trn] "+s"(trn), [sq] "+s"(sq),
+        [live0] "+s"(live0), [live1] "+s"(live1), [vol0] "+v"(vol0), [vol1] "+v"(vol1), [key0] "+v"(key0),
+        [key1] "+v"(key1), [trk] "+v"(trk), [trp] "+v"(trp), [trv] "+v"(trv), [tra] "+v"(tra), [trs] "+v"(trs)
+      : [price0] "v"(price0), [price1] "v"(price1), [id0] "v"(id0), [id1] "v"(id1), [ev0] "v"(ev0), [ev1] "v"(ev1),
+        [bid0] "s"(bid0), [bid1] "s"(bid1), [nev] "s"(n_ev), [kend0] "s"(kend0), [tmask] "s"(tmask)
+      : EK_CLOBBERS);
+  tr_n = trn + 64u;
+  return st;
+}
+
+__device__ __forceinline__ uint32_t events_key_r1(uint32_t& k, uint32_t n_ev, uint32_t tmask, uint32_t& tr_n, uint32_t& sq,
+                                                  uint64_t& live0, uint64_t bid0, uint32_t price0, uint32_t& vol0,
+                                                  uint32_t id0, uint32_t& key0, uint32_t ev0, uint32_t& trk, uint32_t& trp,
+                                                  uint32_t& trv, uint32_t& tra, uint32_t& trs) {
+  uint32_t st, vm;
+  auto u32 = [](uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane(x); };
+  auto u64 = [&](uint64_t x) { return ((uint64_t)u32((uint32_t)(x >> 32)) << 32) | u32((uint32_t)x); };
+  k = u32(k);
+  n_ev = u32(n_ev);
+  tmask = u32(tmask);
+  uint32_t trn = u32(tr_n) - 64u;
+  sq = u32(sq);
+  live0 = u64(live0);
+  bid0 = u64(bid0);
+  asm volatile(
+      "s_cmp_lt_u32 %[k], %[nev]\n\t"
+      "s_cbranch_scc0 L_done_%=\n\t"
+      EK_PHASE("0", "%[nev]", 1)
+      "L_end_0_%=:\n\t"
+      EK_TAIL
+      : [st] "=&s"(st), [vm] "=&v"(vm), [k] "+s"(k), [trn] "+s"(trn), [sq] "+s"(sq), [live0] "+s"(live0),
+        [vol0] "+v"(vol0), [key0] "+v"(key0), [trk] "+v"(trk), [trp] "+v"(trp), [trv] "+v"(trv), [tra] "+v"(tra),
+        [trs] "+v"(trs)
+      : [price0] "v"(price0), [id0] "v"(id0), [ev0] "v"(ev0), [bid0] "s"(bid0), [nev] "s"(n_ev), [tmask] "s"(tmask)
+      : EK_CLOBBERS);
+  tr_n = trn + 64u;
+  return st;
+}
+
 }  // namespace bkd

@@ -605,7 +605,7 @@ __global__ __launch_bounds__(512, 6) void k_run_wave(DevArgs a, WaveArgs wa, uin
       B.id[r] = sel(pend, base + rank, B.id[r]);
       base += __builtin_popcountll(pend);
       B.bid[r] = (B.bid[r] & ~pend) | (side & pend);
-      B.pend[r] = 0;  // the event words classify themselves (EV_NEW)
+      B.pend[r] = pend;  // handed to step_from_list, which clears it (the event words classify themselves: EV_NEW)
     }
     B.next_id = base;
     wave_sync();  // the staging area becomes the snapshot's level bins

@@ -4,7 +4,7 @@ import bourse_amd
 T, L = 50, 32
 groups = [(64, (32, 64), (10, 20), 2, 0.8), (64, (32, 64), (50, 70), 2, 0.2)]
 B = 65536
-for P in (3, 4, 6, 8):
+for P in (2, 3, 4, 5, 6):
     env = bourse_amd.ManyBookEnv(B, 101, 0, 2, 100_000, levels=L, max_live_orders=128, trade_capacity=64 * T, history_capacity=T)
     env.set_random_agents(groups); env.set_pipeline("split"); env.set_split_parts(P, 2048)
     env.run(T); env.clear_trades()

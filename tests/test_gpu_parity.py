@@ -761,6 +761,36 @@ def test_fuzz_random_agent_configs_vs_oracle(bk, oracle, seed):
                     lookahead=(64, 64, 3, 64, 17, 64, 1)[seed % 7])
 
 
+# The keyed event loop (event_asm.hpp) packs price-time priority into one 32-bit key per order and falls back to the
+# two-reduction loop whenever a step's prices or arrival stamps do not fit the key's fields.  Steps on either side of
+# that test, and runs that cross it back and forth:
+KEYED_CASES = {
+    # two price windows farther apart than the 15-bit price field: every step with orders from both takes the fallback
+    "wide": dict(groups=[(40, (1, 30), (1, 20), 1, 0.6), (40, (70000, 70030), (1, 20), 1, 0.6)], n_steps=40, n_books=9),
+    # the span sits right at the field's limit (32 764): steps flip between the two loops as orders come and go
+    "edge": dict(groups=[(30, (1, 4), (1, 20), 1, 0.5), (30, (32763, 32769), (1, 20), 1, 0.5),
+                         (20, (15000, 15010), (5, 9), 1, 0.9)], n_steps=60, n_books=9),
+    # prices at the top of u32 (the window test must not wrap)
+    "top": dict(groups=[(40, (2**32 - 40, 2**32 - 1), (1, 20), 1, 0.7), (30, (2**32 - 30, 2**32 - 2), (1, 9), 1, 0.9)],
+                n_steps=40, n_books=9),
+    # arrival stamps: ten sleepers (one action per ~2 000 steps) hold their deep bids while 124 busy agents rest ~25 orders
+    # per step, so the span of the live stamps passes the 16-bit field after ~2 600 steps and comes back when they cancel
+    "age": dict(groups=[(10, (1, 3), (1, 5), 1, 0.0005), (62, (40, 60), (1, 30), 1, 1.0), (62, (50, 70), (1, 30), 1, 1.0)],
+                n_steps=8000, n_books=3),
+}
+
+
+@pytest.mark.parametrize("pipeline", ["split", "wave"])
+@pytest.mark.parametrize("case", sorted(KEYED_CASES))
+def test_keyed_event_loop_window_and_fallback(bk, oracle, case, pipeline):
+    c = KEYED_CASES[case]
+    if case == "age" and pipeline == "wave":
+        pytest.skip("one pipeline is enough for the long run")
+    n_agents = sum(g[0] for g in c["groups"])
+    _compare_random(bk, oracle, n_books=c["n_books"], groups=c["groups"], levels=16, n_steps=c["n_steps"], tick=1,
+                    seed=4242, pipeline=pipeline, max_live=max(64, n_agents), trade_cap=n_agents * c["n_steps"])
+
+
 def test_history_ring_and_streaming_egress(bk, oracle):
     """History ring: the last N steps are retained across launches and pipelines; streamed chunks equal the oracle."""
     B, T, chunk = 40, 36, 6
