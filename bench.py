@@ -206,6 +206,9 @@ def main():
     ap.add_argument("--pipeline", default="auto", choices=["auto", "fused", "split", "wave_split", "wave"])
     ap.add_argument("--wave-parts", type=int, default=0, help="parts the wave pipeline cuts the batch in (0 = library default)")
     ap.add_argument("--profile-every", type=int, default=8, help="HIP-event-time every Nth step's kernels (0 = none)")
+    ap.add_argument("--preheat-steps", type=int, default=100,
+                    help="steps of a second env of the same shape run right before the warm-up, so that the timed region "
+                         "starts at steady clocks (0 = none)")
     ap.add_argument("--repeats", type=int, default=4, help="extra timed regions of --steps after the reported one (median in `runs`)")
     args = ap.parse_args()
 
@@ -279,6 +282,20 @@ def main():
                 l1.all_gather()       # optional tier: 36 B per book, queued behind the launch on the same stream
             done += c
 
+    # Pre-heat: the GPU's clocks fall within milliseconds of idling and take ~15 ms of load to come back (k_agents_fsm, a pure
+    # latency chain, runs 170 us per launch cold and 155 us warm: scripts/region_trace.sh), and the driver's command line
+    # (--warmup 5 = 1.7 ms of work after seconds of host-side set-up) would time the ramp.  A SECOND env of the same shape is
+    # stepped right before the warm-up; the timed env sees its W warm-up steps and K timed steps and nothing else.
+    if args.preheat_steps > 0:
+        penv = bourse_amd.ManyBookEnv(B, SEED + 1, 0, TICK, STEP_SIZE, True, levels=levels, max_live_orders=min(n_agents, 512),
+                                      trade_capacity=64, history_capacity=0, book_offset=first_book, device=local_rank,
+                                      stream=stream, strict=False)
+        penv.set_agents(groups) if mixed else penv.set_random_agents(groups)
+        penv.set_pipeline(args.pipeline)
+        if args.wave_parts:
+            penv.set_wave_options(64, args.wave_parts)
+        env.trade_counts(), env.order_counts()  # first calls allocate their staging buffers: not between warm-up and t0
+        penv.run(args.preheat_steps, sync=False)
     run_steps(args.warmup)
     torch.cuda.synchronize()
     tc0 = int(env.trade_counts().sum())
@@ -396,6 +413,8 @@ def main():
                         f"seed {SEED}+book",
             "books_total": books_total, "books_per_gpu": B, "ranks": world, "agents_per_book": n_agents, "levels": levels,
             "steps_per_launch": spl,
+            "preheat": (f"{args.preheat_steps} steps of a second env of the same shape right before the warm-up (clock ramp); "
+                        f"the timed env: {args.warmup} warm-up + {args.steps} timed steps") if args.preheat_steps > 0 else "none",
             "parallelism": f"{books_total} books in {world} contiguous shards ({args.scaling} scaling), no data-path "
                            f"collective, 64 B stats all-gather per launch" if world > 1 else "single GPU",
             "trades_per_book_step": tr_per_bs, "events_per_book_step": ev_per_bs,

@@ -1281,6 +1281,16 @@ __global__ void k_book_service(uint32_t* state, uint32_t stride, uint32_t n_book
 }
 
 // holds a stream for `ticks` x 10 ns (s_memrealtime runs at 100 MHz): the timed stagger of the split pipelines' parts
+// header word(s) `word` (.. word + n_words - 1, n_words = 1 or 2) of every book, gathered into a contiguous array of u64:
+// a strided 2-D copy of 65 536 eight-byte rows takes milliseconds, this kernel + one contiguous copy ~0.1 ms
+__global__ void k_gather_header(const uint32_t* state, uint32_t stride, uint32_t word, uint32_t n_words, uint32_t n_books,
+                                unsigned long long* out) {
+  const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= n_books) return;
+  const uint32_t* h = state + (size_t)b * stride + word;
+  out[b] = n_words == 2 ? mk64(h[0], h[1]) : (unsigned long long)h[0];
+}
+
 __global__ void k_delay(uint32_t ticks) {
   const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
   while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(16);

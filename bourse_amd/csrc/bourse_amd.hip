@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -14,6 +15,7 @@
 #include <condition_variable>
 #include <cstring>
 #include <functional>
+#include <map>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -159,6 +161,7 @@ struct bk_env {
   DevBuf<uint16_t> ml_list;
   DevBuf<uint32_t> ml_len, ml_inl;
   bool lds_attr_set = false;  // hipFuncAttributeMaxDynamicSharedMemorySize applied on this env's device
+  DevBuf<uint64_t> gather_buf;  // n_books u64: gather_header()
   bool fsm_attr_set = false;  // same for k_agents_fsm (its LDS is dynamic: book_device.hpp)
   bool ml_valid = false;  // the lists describe the pool as of steps_done (false after a wave-per-book launch / restore)
   uint32_t member_asset[MAX_MEMBERS] = {0, 0, 0, 0};
@@ -327,6 +330,25 @@ int launch_wave_fused(bk_env* env, const DevArgs& a, uint64_t first_step, uint32
   return BK_OK;
 }
 
+// The parts' streams are shared by every env on a device.  HIP multiplexes streams onto 4 hardware queues in the order
+// they are first used; with a set of streams per env, a second env in the process (or any other stream user) shifts that
+// mapping and two parts of one env land on ONE queue - they then run back to back and the pipeline loses its overlap
+// (measured: C3 220 -> 124 M book-steps/s with an idle second env).  One process-wide set per device, created in order
+// on first use and never destroyed, keeps part i of every env on the same queue; envs sharing them just interleave.
+hipStream_t shared_part_stream(int device, int i) {
+  static std::mutex mu;
+  static std::map<int, std::array<hipStream_t, bk_env::MAX_PARTS>> pool;
+  std::lock_guard<std::mutex> lk(mu);
+  auto it = pool.find(device);
+  if (it == pool.end()) {
+    std::array<hipStream_t, bk_env::MAX_PARTS> st{};
+    for (int k = 1; k < bk_env::MAX_PARTS; ++k)  // part 0 runs on the caller's stream
+      if (hipStreamCreateWithFlags(&st[k], hipStreamNonBlocking) != hipSuccess) st[k] = nullptr;
+    it = pool.emplace(device, st).first;
+  }
+  return it->second[i];
+}
+
 // split pipeline: per step and per part one lane-per-book launch (RNG-serial phases) + one wave-per-book launch
 // MIXED: 0 RandomAgents groups (k_agents_fsm), 1 AgentSet members one wave per book (k_agents_mixed), 2 members one lane
 // per book (k_agents_mixed_lanes)
@@ -375,7 +397,8 @@ int launch_split(bk_env* env, const DevArgs& a0, uint64_t first_step, uint32_t n
   if (P > 1 && !env->ev_fork) {
     HIPCHK(hipEventCreateWithFlags(&env->ev_fork, hipEventDisableTiming));
     for (int i = 0; i < bk_env::MAX_PARTS; ++i) {
-      HIPCHK(hipStreamCreateWithFlags(&env->part_stream[i], hipStreamNonBlocking));
+      if (i > 0 && !(env->part_stream[i] = shared_part_stream(env->cfg.device, i)))
+        return fail(BK_HIP_ERROR, "could not create the parts' streams");
       HIPCHK(hipEventCreateWithFlags(&env->ev_first[i], hipEventDisableTiming));
       HIPCHK(hipEventCreateWithFlags(&env->ev_join[i], hipEventDisableTiming));
     }
@@ -641,8 +664,7 @@ void bk_env_destroy(bk_env* env) {
   if (env->ev_fork) {
     (void)hipEventDestroy(env->ev_fork);
     for (int i = 0; i < bk_env::MAX_PARTS; ++i) {
-      (void)hipStreamSynchronize(env->part_stream[i]);
-      (void)hipStreamDestroy(env->part_stream[i]);
+      if (env->part_stream[i]) (void)hipStreamSynchronize(env->part_stream[i]);  // shared (shared_part_stream): not destroyed
       (void)hipEventDestroy(env->ev_first[i]);
       (void)hipEventDestroy(env->ev_join[i]);
     }
@@ -1307,13 +1329,22 @@ int bk_trade_count(bk_env* env, uint32_t book, uint64_t* total, uint64_t* first_
   return BK_OK;
 }
 
+// one header counter of every book -> host (stream-ordered gather into a contiguous device array, one copy)
+int gather_header(bk_env* env, uint32_t word, uint32_t n_words, uint64_t* totals) {
+  const uint32_t NB = env->cfg.n_books;
+  if (!env->gather_buf.p) HIPCHK(env->gather_buf.alloc(NB));
+  hipLaunchKernelGGL(k_gather_header, dim3((NB + 255) / 256), dim3(256), 0, env->stream, env->state.p, env->stride, word, n_words,
+                     NB, reinterpret_cast<unsigned long long*>(env->gather_buf.p));
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(totals, env->gather_buf.p, static_cast<size_t>(NB) * 8, hipMemcpyDeviceToHost, env->stream));
+  HIPCHK(hipStreamSynchronize(env->stream));
+  return BK_OK;
+}
+
 int bk_trade_counts(bk_env* env, uint64_t* totals) {
   if (!env || !totals) return fail(BK_INVALID_ARGUMENT, "null argument");
   if (int rc = use_device(env)) return rc;
-  HIPCHK(hipStreamSynchronize(env->stream));
-  HIPCHK(hipMemcpy2D(totals, 8, env->state.p + H_TRADES_LO, static_cast<size_t>(env->stride) * 4, 8,
-                     env->cfg.n_books, hipMemcpyDeviceToHost));
-  return BK_OK;
+  return gather_header(env, H_TRADES_LO, 2, totals);
 }
 
 int bk_get_trades(bk_env* env, uint32_t book, uint64_t first, uint64_t n, bk_trade* out) {
@@ -1567,9 +1598,9 @@ int bk_steps_done(bk_env* env, uint64_t* out) {
 int bk_book_flags(bk_env* env, uint32_t* out) {
   if (!env || !out) return fail(BK_INVALID_ARGUMENT, "null argument");
   if (int rc = use_device(env)) return rc;
-  HIPCHK(hipStreamSynchronize(env->stream));
-  HIPCHK(hipMemcpy2D(out, 4, env->state.p + H_FLAGS, static_cast<size_t>(env->stride) * 4, 4, env->cfg.n_books,
-                     hipMemcpyDeviceToHost));
+  std::vector<uint64_t> v(env->cfg.n_books);
+  if (int rc = gather_header(env, H_FLAGS, 1, v.data())) return rc;
+  for (size_t b = 0; b < v.size(); ++b) out[b] = static_cast<uint32_t>(v[b]);
   return BK_OK;
 }
 
@@ -1742,12 +1773,7 @@ int bk_set_split_parts(bk_env* env, int n_parts, uint32_t min_part) {
 int bk_order_counts(bk_env* env, uint64_t* totals) {
   if (!env || !totals) return fail(BK_INVALID_ARGUMENT, "null argument");
   if (int rc = use_device(env)) return rc;
-  HIPCHK(hipStreamSynchronize(env->stream));
-  std::vector<uint32_t> v(env->cfg.n_books);
-  HIPCHK(hipMemcpy2D(v.data(), 4, env->state.p + H_NEXT_ID, static_cast<size_t>(env->stride) * 4, 4, env->cfg.n_books,
-                     hipMemcpyDeviceToHost));
-  for (size_t b = 0; b < v.size(); ++b) totals[b] = v[b];
-  return BK_OK;
+  return gather_header(env, H_NEXT_ID, 1, totals);
 }
 
 // ---------------------------------------------------------------- checkpoint / resume (on-device order flow)
