@@ -94,9 +94,10 @@ struct DevArgs {
   uint32_t asset_tick[MAX_ASSETS];
   Group groups[MAX_GROUPS];
 };
-// step batch layout (dwords): [0] n_ev; [8+2r, 9+2r] placing-agents mask r; [24+2r, 25+2r] bid mask of the
-// placements; [64, 64+32R) shuffled event list (u16 agent indices); then uint2 {price, vol} per agent slot.
-constexpr int BT_NEV = 0, BT_PEND = 8, BT_SIDE = 24, BT_EV = 64;
+// step batch layout (dwords): [0] n_ev; [64, 64+32R) shuffled event list (u16 event words: agent slot | EV_NEW | EV_BID);
+// then uint2 {price, vol} per agent slot.  (Dwords 8..39 held placing / bid-side masks until k_step_batch rebuilt them
+// from the event words itself.)
+constexpr int BT_NEV = 0, BT_EV = 64;
 // event words of k_agents_fsm: slot in bits 0..8, EV_BID / EV_NEW classify the event
 constexpr uint32_t EV_NEW = 0x8000u, EV_BID = 0x4000u, EV_SLOT = 0x1FFu;
 
@@ -869,7 +870,7 @@ enum Phase : uint32_t { PH_ACT = 0, PH_SIDE = 1, PH_TICK = 2, PH_VOL = 3, PH_SHU
 #define BK_STR2(x) #x
 #define BK_STR(x) BK_STR2(x)
 
-constexpr uint32_t fsm_lds_bytes(int R) { return (64u * R * 32u + 4u * R * 64u) * 4u; }
+constexpr uint32_t fsm_lds_bytes(int R) { return 64u * R * 32u * 4u; }
 
 template <int R>
 __global__ __launch_bounds__(64) void k_agents_fsm(DevArgs a) {
@@ -878,10 +879,8 @@ __global__ __launch_bounds__(64) void k_agents_fsm(DevArgs a) {
   // up to that occupancy's budget (R = 2: 169 VGPRs + 102 SGPRs for a kernel using 34 + 46; 257 VGPRs for R = 4, 8).
   extern __shared__ uint32_t fsm_lds[];
   uint16_t* list = reinterpret_cast<uint16_t*>(fsm_lds);  // event list of lane l: list[k * 64 + l], 64 * R * 64 entries
-  // placing-agents / bid-side bit masks of lane l, 32-bit word w: pmask[w * 64 + l], smask[w * 64 + l]
-  // (one ds_or per new order instead of ~20 VALU of per-lane 64-bit mask arithmetic in the hot loop)
-  uint32_t* pmask = fsm_lds + 64 * R * 32;
-  uint32_t* smask = pmask + 2 * R * 64;
+  // (which agents place, and on which side, is not tracked here: the event words say it - bit 15 New, bit 14 bid - and
+  // k_step_batch rebuilds the masks from them with four LDS atomics per book instead of two per new order in this loop)
   const int lane = threadIdx.x;
   // This kernel is a dependent chain of ~600 iterations on ONE wave per SIMD, co-resident with up to 7 waves of the
   // issue-bound event kernel of another part: top issue priority lets the chain run at its lone-wave pace (the part's
@@ -920,10 +919,6 @@ __global__ __launch_bounds__(64) void k_agents_fsm(DevArgs a) {
       x.y |= y.y;
     }
     live[r] = mk64(x.x, x.y);
-    pmask[(2 * r) * 64 + lane] = 0;
-    pmask[(2 * r + 1) * 64 + lane] = 0;
-    smask[(2 * r) * 64 + lane] = 0;
-    smask[(2 * r + 1) * 64 + lane] = 0;
   }
   uint2* pv = reinterpret_cast<uint2*>(bt + BT_EV + 32 * R);
 
@@ -967,9 +962,6 @@ __global__ __launch_bounds__(64) void k_agents_fsm(DevArgs a) {
       n_ev += queue ? 1u : 0u;
       if (acc_vol) {                                                    // vol drawn last (:101): the order is complete
         pv[n] = make_uint2(cur_price, G.vol_lo + val);
-        const uint32_t wi = (n >> 5) * 64 + lane;
-        atomicOr(&pmask[wi], 1u << (n & 31));
-        atomicOr(&smask[wi], cur_side << (n & 31));
       }
       const bool to_side = hit & !holds_live;
       phase = to_side ? PH_SIDE : acc_side ? PH_TICK : acc_tick ? PH_VOL : phase;
@@ -1009,11 +1001,6 @@ __global__ __launch_bounds__(64) void k_agents_fsm(DevArgs a) {
     *reinterpret_cast<uint2*>(st + (size_t)as * a.state_stride + H_S1_LO) = make_uint2(rng.b0, rng.b1);
   }
   bt[BT_NEV] = n_ev;
-#pragma unroll
-  for (int r = 0; r < R; ++r) {
-    *reinterpret_cast<uint2*>(bt + BT_PEND + 2 * r) = make_uint2(pmask[(2 * r) * 64 + lane], pmask[(2 * r + 1) * 64 + lane]);
-    *reinterpret_cast<uint2*>(bt + BT_SIDE + 2 * r) = make_uint2(smask[(2 * r) * 64 + lane], smask[(2 * r + 1) * 64 + lane]);
-  }
   for (uint32_t k = 0; k < n_ev; k += 2) {
     const uint32_t lo = list[k * 64 + lane];
     const uint32_t hi = (k + 1 < n_ev) ? list[(k + 1) * 64 + lane] : 0u;
@@ -1065,15 +1052,30 @@ __global__ __launch_bounds__(64) void k_step_batch(DevArgs a, uint64_t step_inde
   uint32_t owner[R];  // POOLPEND: the members' owner tags ride in meta bits 8..15 and must survive the store
   uint32_t base = B.next_id;
 #pragma unroll
+  for (int r = 0; r < R; ++r) ev[r] = reinterpret_cast<const uint16_t*>(bt + BT_EV)[r * 64 + lane];
+  // Which agent slots place an order in this step, and on which side: rebuilt from the event words (bit 15 New, bit 14
+  // bid, slot below) - two LDS atomics per list register scatter the bits, lanes 0 .. 4R-1 read the words back.
+  uint32_t mw = 0;
+  if (!POOLPEND) {
+    uint32_t* pm = lds[wv];  // 2R words placing, 2R words bid side (the level bins are not in use yet)
+    if (lane < 4 * R) pm[lane] = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const uint32_t ew = ev[r], slot = ew & EV_SLOT, bit = 1u << (slot & 31);
+      const bool is_new = (uint32_t)(r * 64 + lane) < n_ev && (ew & EV_NEW);
+      atomicOr(&pm[slot >> 5], is_new ? bit : 0u);
+      atomicOr(&pm[2 * R + (slot >> 5)], (is_new && (ew & EV_BID)) ? bit : 0u);
+    }
+    mw = pm[lane & (4 * R - 1)];
+  }
+#pragma unroll
   for (int r = 0; r < R; ++r) {
     if (POOLPEND) {
-      ev[r] = reinterpret_cast<const uint16_t*>(bt + BT_EV)[r * 64 + lane];
       owner[r] = st[HDR_DW + r * POOL_FIELDS * 64 + 4 * 64 + lane] & 0xFF00u;
       continue;
     }
-    const uint64_t pend = mk64(rdl(bh, BT_PEND + 2 * r), rdl(bh, BT_PEND + 2 * r + 1)) & mine[r];
-    const uint64_t side = mk64(rdl(bh, BT_SIDE + 2 * r), rdl(bh, BT_SIDE + 2 * r + 1));
-    ev[r] = reinterpret_cast<const uint16_t*>(bt + BT_EV)[r * 64 + lane];
+    const uint64_t pend = mk64(rdl(mw, 2 * r), rdl(mw, 2 * r + 1)) & mine[r];
+    const uint64_t side = mk64(rdl(mw, 2 * R + 2 * r), rdl(mw, 2 * R + 2 * r + 1));
     const uint2 pv = reinterpret_cast<const uint2*>(bt + BT_EV + 32 * R)[r * 64 + lane];
     B.price[r] = sel(pend, pv.x, B.price[r]);
     B.vol[r] = sel(pend, pv.y, B.vol[r]);

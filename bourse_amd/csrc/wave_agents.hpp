@@ -514,14 +514,7 @@ __global__ __launch_bounds__(256, 8) void k_agents_wave(DevArgs a, WaveArgs wa) 
   if (lane < 4) st[H_S0_LO + lane] = hv;
   uint32_t hb = 0;
   hb = lane == BT_NEV ? n_ev : hb;
-#pragma unroll
-  for (int r = 0; r < R; ++r) {
-    hb = lane == BT_PEND + 2 * r ? D.pm[2 * r] : hb;
-    hb = lane == BT_PEND + 2 * r + 1 ? D.pm[2 * r + 1] : hb;
-    hb = lane == BT_SIDE + 2 * r ? D.sm[2 * r] : hb;
-    hb = lane == BT_SIDE + 2 * r + 1 ? D.sm[2 * r + 1] : hb;
-  }
-  bt[lane] = hb;
+  bt[lane] = hb;  // (k_step_batch rebuilds the placing / side masks from the event words)
   for (uint32_t k = lane; k < 32u * R; k += 64u) {
     const uint32_t lo = 2u * k < n_ev ? D.evl[2u * k] : 0u, hi = 2u * k + 1u < n_ev ? D.evl[2u * k + 1u] : 0u;
     bt[BT_EV + k] = lo | (hi << 16);
