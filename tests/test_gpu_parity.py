@@ -761,6 +761,26 @@ def test_fuzz_random_agent_configs_vs_oracle(bk, oracle, seed):
                     lookahead=(64, 64, 3, 64, 17, 64, 1)[seed % 7])
 
 
+def test_two_envs_interleaved_on_the_shared_part_streams(bk, oracle):
+    """The parts' streams are process-wide (one set per device): two envs launching multi-part pipelines alternately,
+    without synchronising in between, queue behind each other on them and still get their own results."""
+    T, chunks = 12, [5, 4, 3]
+    a = bk.ManyBookEnv(4096, 11, 0, 2, 100_000, True, levels=32, max_live_orders=128, trade_capacity=128 * T, history_capacity=T)
+    b = bk.ManyBookEnv(6144, 12, 0, 2, 100_000, True, levels=32, max_live_orders=128, trade_capacity=128 * T, history_capacity=T)
+    a.set_random_agents(C3_GROUPS); b.set_random_agents(C3_GROUPS)
+    a.set_pipeline("wave_split"); a.set_wave_options(64, 2)
+    b.set_pipeline("split"); b.set_split_parts(3, 2048)
+    for c in chunks:
+        a.run(c, sync=False)
+        b.run(c, sync=False)
+    for env, seed, n in ((a, 11, 4096), (b, 12, 6144)):
+        ref = oracle.ManyBooks(n, seed, 0, 2, 100_000, True, 32, C3_GROUPS)
+        ref.run(T, n_threads=8)
+        assert not env.flags().any()
+        assert np.array_equal(env.history(), ref.history())
+        assert np.array_equal(env.trade_counts(), ref.trade_counts())
+
+
 # The keyed event loop (event_asm.hpp) packs price-time priority into one 32-bit key per order and falls back to the
 # two-reduction loop whenever a step's prices or arrival stamps do not fit the key's fields.  Steps on either side of
 # that test, and runs that cross it back and forth:
