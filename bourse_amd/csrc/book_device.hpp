@@ -19,6 +19,7 @@
 //   RNG (rand 0.8.5 / rand_xoshiro 0.6.0): SURVEY App. B
 #pragma once
 #include <hip/hip_runtime.h>
+#include <utility>
 #include <stdint.h>
 
 #include "event_asm.hpp"
@@ -669,6 +670,109 @@ __device__ __forceinline__ bool key_window(const Book<R>& B, const uint64_t (&ne
   return pmin != 0u && pmax != 0xFFFFFFFFu && pmax - pmin <= KEY_PSPAN && age + n_ev < KEY_SMASK - 1u;
 }
 
+// The keys of one step (event_asm.hpp "KEYED event loop"): key[r] per pool lane, sq = the running arrival field in key
+// position (advances by 2 per resting order).
+template <int R>
+struct KeyState {
+  uint32_t key[R];
+  uint32_t sq, sbase;
+};
+template <int R>
+__device__ __forceinline__ bool keys_begin(const Book<R>& B, const uint64_t (&newm)[R], uint32_t n_ev, KeyState<R>& K) {
+  uint32_t pbase;
+  if (!key_window<R>(B, newm, n_ev, pbase, K.sbase)) return false;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const bool bidl = lane_bit(B.bid[r]);
+    const uint32_t kp = ((((B.price[r] - pbase) << KEY_SB) | (bidl ? KEY_SMASK : 0u)) << 1) | (bidl ? 1u : 0u);
+    K.key[r] = lane_bit(B.live[r]) ? (kp ^ ((B.seq[r] - K.sbase) << 1)) : lane_bit(newm[r]) ? kp : 0xFFFFFFFFu;
+  }
+  K.sq = (B.seq_ctr - K.sbase) << 1;
+  return true;
+}
+template <int R>
+__device__ __forceinline__ void keys_end(Book<R>& B, const KeyState<R>& K) {
+  B.seq_ctr = K.sbase + (K.sq >> 1);
+#pragma unroll
+  for (int r = 0; r < R; ++r)  // arrival stamps of the orders resting now (the others' are never read again)
+    B.seq[r] = lane_bit(B.live[r]) ? K.sbase + (((K.key[r] >> 1) ^ (lane_bit(B.bid[r]) ? KEY_SMASK : 0u)) & KEY_SMASK) : B.seq[r];
+}
+
+// (a pack expansion, not a loop: `#pragma unroll` was not honoured here in the R = 8 instantiation, and a rolled loop indexes
+// the pool dynamically, which sends the whole Book to scratch memory - C5 15 -> 3 M book-steps/s)
+template <int R, bool agg_bid, int... I>
+__device__ __forceinline__ uint32_t key_touch(const Book<R>& B, const KeyState<R>& K, std::integer_sequence<int, I...>) {
+  uint32_t m = agg_bid ? 0xFFFFFFFFu : 0u;
+  ((m = agg_bid ? min(m, sel(B.live[I] & ~B.bid[I], K.key[I], 0xFFFFFFFFu)) : max(m, sel(B.live[I] & B.bid[I], K.key[I], 0u))), ...);
+  return m;
+}
+
+// The keyed loop in C++ (pools of more than 128 slots - the assembly covers R <= 2 - and the -DBOURSE_AMD_ASM_EVENTS=0
+// build): same semantics as match_side / slot_event_at with ONE reduction per match step and no tie handling.
+template <int R, bool agg_bid>
+__device__ __forceinline__ bool match_side_keyed(Book<R>& B, KeyState<R>& K, const DevArgs& a, uint32_t book, uint64_t t0,
+                                                 int lane, uint32_t k, uint32_t kp, uint32_t& v, uint32_t agg_id) {
+  const uint32_t v0 = v;
+  while (v > 0) {
+    // an empty side returns the neutral element: "no cross" by the same compare
+    const uint32_t m = key_touch<R, agg_bid>(B, K, std::make_integer_sequence<int, R>());
+    const uint32_t best = agg_bid ? wave_umin(m) : wave_umax(m);
+    if (agg_bid ? (best > kp) : (best < kp)) break;  // inclusive crossing test (:430 / :463) in key space
+    uint32_t pv = 0, pid = 0, tv = 0, price = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const uint64_t eq = __ballot(K.key[r] == best);  // the key is unique: exactly one lane of one register
+      if (eq) {
+        const uint32_t l = __builtin_ctzll(eq);
+        pv = rdl(B.vol[r], l);
+        pid = rdl(B.id[r], l);
+        price = rdl(B.price[r], l);
+        tv = v < pv ? v : pv;
+        pv -= tv;
+        B.vol[r] = wrl(pv, l, B.vol[r]);
+        if (pv == 0) B.live[r] &= ~eq;  // passive Filled -> remove_order
+      }
+    }
+    v -= tv;
+    emit_trade(B, a, book, t0, lane, k, !agg_bid, price, tv, agg_id, pid);
+    B.trade_vol += tv;
+  }
+  return v0 != 0 && v == 0;
+}
+template <int R, int RS>
+__device__ __forceinline__ void slot_event_keyed_at(Book<R>& B, KeyState<R>& K, const DevArgs& a, uint32_t book, uint64_t t0,
+                                                    int lane, uint32_t k, uint32_t sl, uint32_t ew) {
+  const uint64_t bit = 1ull << sl;
+  if (!(ew & EV_NEW)) {
+    B.live[RS] &= ~bit;  // Cancellation
+    return;
+  }
+  const uint32_t kp = rdl(K.key[RS], sl), id = rdl(B.id[RS], sl);
+  uint32_t v = rdl(B.vol[RS], sl);
+  bool filled = false;
+  if (B.trading)
+    filled = (ew & EV_BID) ? match_side_keyed<R, true>(B, K, a, book, t0, lane, k, kp, v, id)
+                           : match_side_keyed<R, false>(B, K, a, book, t0, lane, k, kp, v, id);
+  if (!filled) {  // rest the remainder (no market sentinels inside the key window) with a fresh arrival field
+    B.vol[RS] = wrl(v, sl, B.vol[RS]);
+    K.key[RS] = wrl(kp ^ K.sq, sl, K.key[RS]);
+    B.live[RS] |= bit;
+    K.sq += 2;
+  }
+}
+template <int R, int RS = 0>
+__device__ __forceinline__ void slot_event_keyed(Book<R>& B, KeyState<R>& K, const DevArgs& a, uint32_t book, uint64_t t0,
+                                                 int lane, uint32_t k, uint32_t n, uint32_t ew) {
+  if constexpr (RS + 1 < R) {  // ONE uniform branch per pool register, every pool access below with a compile-time index
+    if ((n >> 6) == (uint32_t)RS)
+      slot_event_keyed_at<R, RS>(B, K, a, book, t0, lane, k, n & 63, ew);
+    else
+      slot_event_keyed<R, RS + 1>(B, K, a, book, t0, lane, k, n, ew);
+  } else {
+    slot_event_keyed_at<R, RS>(B, K, a, book, t0, lane, k, n & 63, ew);
+  }
+}
+
 // ----------------------------------------------------------------------------------
 // Env::step body after the shuffle (env.rs:117-134): process the (already shuffled) event list of
 // agent/slot indices, advance the clock, snapshot, flush trades.  Returns this step's trade count.
@@ -700,35 +804,24 @@ __device__ __forceinline__ uint32_t step_from_list(Book<R>& B, const DevArgs& a,
     // hand-written event loops (event_asm.hpp); they return whenever the 64-record trade buffer is full
     uint32_t k = 0;
     const uint32_t nev = rfl(n_ev), tmask = B.trading ? 0xFFFFFFFFu : 0u;
-    uint32_t pbase, sbase;
-    if (BOURSE_AMD_KEYED_EVENTS && key_window<R>(B, newm, nev, pbase, sbase)) {
-      // keyed loop: one sort key per order (price field << 16 | arrival field), rebuilt from {price, seq} every step
-      uint32_t key[R];
-#pragma unroll
-      for (int r = 0; r < R; ++r) {
-        const bool bidl = lane_bit(B.bid[r]);
-        const uint32_t kp = ((((B.price[r] - pbase) << KEY_SB) | (bidl ? KEY_SMASK : 0u)) << 1) | (bidl ? 1u : 0u);
-        key[r] = lane_bit(B.live[r]) ? (kp ^ ((B.seq[r] - sbase) << 1)) : lane_bit(newm[r]) ? kp : 0xFFFFFFFFu;
-      }
-      uint32_t sq = (B.seq_ctr - sbase) << 1;  // the loop keeps the running arrival field in key position (bit 1 up)
+    KeyState<R> K;
+    if (BOURSE_AMD_KEYED_EVENTS && keys_begin<R>(B, newm, nev, K)) {
+      // keyed loop: one sort key per order (price field | arrival field | side), rebuilt from {price, seq} every step
       for (;;) {
         uint32_t full;
         if constexpr (R == 2)
-          full = events_key_r2(k, nev, tmask, B.tr_n, sq, B.live[0], B.live[1], B.bid[0], B.bid[1], B.price[0], B.price[1],
-                               B.vol[0], B.vol[1], B.id[0], B.id[1], key[0], key[1], ev[0], ev[1], B.tr_k, B.tr_price,
+          full = events_key_r2(k, nev, tmask, B.tr_n, K.sq, B.live[0], B.live[1], B.bid[0], B.bid[1], B.price[0], B.price[1],
+                               B.vol[0], B.vol[1], B.id[0], B.id[1], K.key[0], K.key[1], ev[0], ev[1], B.tr_k, B.tr_price,
                                B.tr_vol, B.tr_act, B.tr_pas);
         else
-          full = events_key_r1(k, nev, tmask, B.tr_n, sq, B.live[0], B.bid[0], B.price[0], B.vol[0], B.id[0], key[0], ev[0],
+          full = events_key_r1(k, nev, tmask, B.tr_n, K.sq, B.live[0], B.bid[0], B.price[0], B.vol[0], B.id[0], K.key[0], ev[0],
                                B.tr_k, B.tr_price, B.tr_vol, B.tr_act, B.tr_pas);
         // Env::get_trade_vol: the loop leaves the sum to the vector unit (one reduction per flush, not an add per trade)
         if (B.tr_n) B.trade_vol += wave_add((uint32_t)lane < B.tr_n ? B.tr_vol : 0u);
         if (!full) break;
         flush_trades<R>(B, a, book, t0, lane);
       }
-      B.seq_ctr = sbase + (sq >> 1);
-#pragma unroll
-      for (int r = 0; r < R; ++r)  // arrival stamps of the orders resting now (the others' are never read again)
-        B.seq[r] = lane_bit(B.live[r]) ? sbase + (((key[r] >> 1) ^ (lane_bit(B.bid[r]) ? KEY_SMASK : 0u)) & KEY_SMASK) : B.seq[r];
+      keys_end<R>(B, K);
     } else if constexpr (R == 2) {
       while (events_asm_r2(k, nev, tmask, B.tr_n, B.seq_ctr, B.trade_vol, B.live[0], B.live[1], B.bid[0], B.bid[1],
                            B.price[0], B.price[1], B.vol[0], B.vol[1], B.id[0], B.id[1], B.seq[0], B.seq[1], ev[0], ev[1],
@@ -739,6 +832,19 @@ __device__ __forceinline__ uint32_t step_from_list(Book<R>& B, const DevArgs& a,
                            B.seq[0], ev[0], B.tr_k, B.tr_price, B.tr_vol, B.tr_act, B.tr_pas))
         flush_trades<R>(B, a, book, t0, lane);
     }
+  } else if (KeyState<R> K; CLS && !MKT && BOURSE_AMD_KEYED_EVENTS && keys_begin<R>(B, newm, rfl(n_ev), K)) {
+#pragma unroll
+    for (int re = 0; re < R; ++re) {
+      const uint32_t kb = re * 64;
+      if (n_ev > kb) {
+        const uint32_t cnt = rfl((n_ev - kb) < 64u ? (n_ev - kb) : 64u);
+        for (uint32_t l = 0; l < cnt; ++l) {
+          const uint32_t ew = rdl(ev[re], l);
+          slot_event_keyed<R>(B, K, a, book, t0, lane, kb + l, ew & EV_SLOT, ew);
+        }
+      }
+    }
+    keys_end<R>(B, K);
   } else
 #pragma unroll
   for (int re = 0; re < R; ++re) {  // events at t0 + k (env.rs:123-127); entry k lives in lane k & 63 of ev[k >> 6]
