@@ -15,6 +15,11 @@ Books are independent, so each rank steps its own contiguous shard with NO data-
 64-byte market-stats all-gather per launch.  Default = BASELINE configs[3]: STRONG scaling, 65 536 books in
 total, 65 536 / N per GPU, seeds by global book index; `--scaling weak` keeps 65 536 books per GPU.
 
+Timing: W warm-up steps, barrier + synchronize, K timed steps, synchronize + barrier (max over ranks).  Right before the
+warm-up a SECOND env of the same shape is stepped for `--preheat-steps` steps (default 100; 0 = off): the GPU's clocks
+fall within milliseconds of idling and need ~15 ms of load to come back, which a short timed region (the driver's
+`--steps 20 --warmup 5` = 6 ms) would otherwise measure; the timed env sees its W + K steps only.
+
 Prints ONE JSON line (rank 0) incl. `roofline` (HIP-event kernel time vs. HBM peak) and, at
 N = 1, `cpu_baseline` (the CPU oracle = literal restatement of the reference algorithm, timed on
 this machine's host cores on a bounded sample of the same workload).
