@@ -300,6 +300,11 @@ def main():
         if args.wave_parts:
             penv.set_wave_options(64, args.wave_parts)
         env.trade_counts(), env.order_counts()  # first calls allocate their staging buffers: not between warm-up and t0
+        if dist is not None:  # ... and RCCL builds its communicator on the first collective (~20 ms): not there either
+            if gather is not None:
+                gather.all_gather()
+            dist.barrier()
+            torch.cuda.synchronize()
         penv.run(args.preheat_steps, sync=False)
     run_steps(args.warmup)
     torch.cuda.synchronize()

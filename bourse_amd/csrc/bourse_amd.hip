@@ -8,6 +8,7 @@
 
 #include <algorithm>
 #include <array>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -330,23 +331,52 @@ int launch_wave_fused(bk_env* env, const DevArgs& a, uint64_t first_step, uint32
   return BK_OK;
 }
 
-// The parts' streams are shared by every env on a device.  HIP multiplexes streams onto 4 hardware queues in the order
-// they are first used; with a set of streams per env, a second env in the process (or any other stream user) shifts that
-// mapping and two parts of one env land on ONE queue - they then run back to back and the pipeline loses its overlap
-// (measured: C3 220 -> 124 M book-steps/s with an idle second env).  One process-wide set per device, created in order
-// on first use and never destroyed, keeps part i of every env on the same queue; envs sharing them just interleave.
-hipStream_t shared_part_stream(int device, int i) {
+// The parts' streams: one process-wide set per device, every member PROBED to sit on a hardware queue of its own.
+// HIP multiplexes streams onto GPU_MAX_HW_QUEUES (4) hardware queues - a new stream joins the least-referenced queue
+// once four exist - and two parts that share a queue run back to back: the pipeline loses its overlap (C3 220 -> 124 M
+// book-steps/s with a second env that had created its own streams first, 216 -> 119 M under torch.distributed.run, where
+// RCCL's streams come first).  Which queue a stream got cannot be asked, but it can be measured: two 300 us spin kernels
+// on two streams take 300 us on different queues and 600 us on one.  Eight candidates are created, a mutually
+// concurrent subset of up to four is kept (greedy), the rest destroyed; every env on the device uses that set for all
+// its parts (the caller's stream only forks and joins), envs sharing it just interleave.  CU-masked streams, which do
+// get a queue each, were measured and are not an option (98 M).  ~10 ms once per process and device.
+const std::vector<hipStream_t>& part_streams(int device) {
   static std::mutex mu;
-  static std::map<int, std::array<hipStream_t, bk_env::MAX_PARTS>> pool;
+  static std::map<int, std::vector<hipStream_t>> pool;
   std::lock_guard<std::mutex> lk(mu);
   auto it = pool.find(device);
-  if (it == pool.end()) {
-    std::array<hipStream_t, bk_env::MAX_PARTS> st{};
-    for (int k = 1; k < bk_env::MAX_PARTS; ++k)  // part 0 runs on the caller's stream
-      if (hipStreamCreateWithFlags(&st[k], hipStreamNonBlocking) != hipSuccess) st[k] = nullptr;
-    it = pool.emplace(device, st).first;
+  if (it != pool.end()) return it->second;
+  std::vector<hipStream_t> cand, chosen;
+  for (int k = 0; k < 8; ++k) {
+    hipStream_t st = nullptr;
+    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) break;
+    hipLaunchKernelGGL(k_delay, dim3(1), dim3(64), 0, st, 1u);  // first use: the stream takes its hardware queue now
+    cand.push_back(st);
   }
-  return it->second[i];
+  for (hipStream_t st : cand) (void)hipStreamSynchronize(st);
+  constexpr uint32_t SPIN_US = 300;
+  auto concurrent = [&](hipStream_t x, hipStream_t y) {
+    const auto t0 = std::chrono::steady_clock::now();
+    hipLaunchKernelGGL(k_delay, dim3(1), dim3(64), 0, x, SPIN_US * 100u);
+    hipLaunchKernelGGL(k_delay, dim3(1), dim3(64), 0, y, SPIN_US * 100u);
+    (void)hipStreamSynchronize(x);
+    (void)hipStreamSynchronize(y);
+    const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+    return us < 1.6 * SPIN_US;
+  };
+  for (hipStream_t c : cand) {
+    bool ok = chosen.size() < 4;
+    for (size_t j = 0; ok && j < chosen.size(); ++j) ok = concurrent(c, chosen[j]);
+    if (ok)
+      chosen.push_back(c);
+    else
+      (void)hipStreamDestroy(c);
+  }
+  (void)hipGetLastError();
+  if (getenv("BOURSE_AMD_VERBOSE"))
+    fprintf(stderr, "bourse_amd: device %d: %zu of %zu candidate streams on hardware queues of their own\n", device,
+            chosen.size(), cand.size());
+  return pool.emplace(device, std::move(chosen)).first->second;
 }
 
 // split pipeline: per step and per part one lane-per-book launch (RNG-serial phases) + one wave-per-book launch
@@ -396,18 +426,17 @@ int launch_split(bk_env* env, const DevArgs& a0, uint64_t first_step, uint32_t n
   const int P = wave ? env->wave_split_parts() : env->parts();
   if (P > 1 && !env->ev_fork) {
     HIPCHK(hipEventCreateWithFlags(&env->ev_fork, hipEventDisableTiming));
+    const std::vector<hipStream_t>& ps = part_streams(env->cfg.device);
+    if (ps.empty()) return fail(BK_HIP_ERROR, "could not create the parts' streams");
     for (int i = 0; i < bk_env::MAX_PARTS; ++i) {
-      if (i > 0 && !(env->part_stream[i] = shared_part_stream(env->cfg.device, i)))
-        return fail(BK_HIP_ERROR, "could not create the parts' streams");
+      env->part_stream[i] = ps[static_cast<size_t>(i) % ps.size()];  // more parts than queues: they share
       HIPCHK(hipEventCreateWithFlags(&env->ev_first[i], hipEventDisableTiming));
       HIPCHK(hipEventCreateWithFlags(&env->ev_join[i], hipEventDisableTiming));
     }
   }
   if (P > 1) {
     HIPCHK(hipEventRecord(env->ev_fork, env->stream));
-    // part 0 runs on the caller's stream itself: P streams in all, so that four parts still map onto HIP's four
-    // hardware queues one to one (a fifth stream would share a queue with another part and serialise with it)
-    for (int i = 1; i < P; ++i) HIPCHK(hipStreamWaitEvent(env->part_stream[i], env->ev_fork, 0));
+    for (int i = 0; i < P; ++i) HIPCHK(hipStreamWaitEvent(env->part_stream[i], env->ev_fork, 0));
   }
   for (uint32_t s = 0; s < n_steps; ++s) {
     env->prof_now = env->profile > 0 && (env->prof_tick++ % env->profile) == 0;
@@ -417,7 +446,7 @@ int launch_split(bk_env* env, const DevArgs& a0, uint64_t first_step, uint32_t n
       a.book_end = (i + 1 == P) ? B : (static_cast<uint32_t>(static_cast<uint64_t>(B) * (i + 1) / P) & ~3u);
       a.hist_slot0 = a.hist_cap ? static_cast<uint32_t>((first_step + s) % a.hist_cap) : 0u;
       const uint32_t nb = a.book_end - a.book_begin;
-      hipStream_t st = (P > 1 && i > 0) ? env->part_stream[i] : env->stream;
+      hipStream_t st = P > 1 ? env->part_stream[i] : env->stream;
       if (P > 1 && s == 0 && i > 0) {  // stagger the parts
         // by time: i x stagger_us.  The lane split's parts cycle through a ~180 us agents kernel and a ~140 us event
         // kernel; one agents kernel apart (the round-1 rule) puts part 2 at 360 us = almost in phase with part 0 again.
@@ -463,7 +492,6 @@ int launch_split(bk_env* env, const DevArgs& a0, uint64_t first_step, uint32_t n
   HIPCHK(hipGetLastError());
   if (P > 1) {
     for (int i = 0; i < P; ++i) {
-      if (i == 0) continue;
       HIPCHK(hipEventRecord(env->ev_join[i], env->part_stream[i]));
       HIPCHK(hipStreamWaitEvent(env->stream, env->ev_join[i], 0));
     }
@@ -664,7 +692,7 @@ void bk_env_destroy(bk_env* env) {
   if (env->ev_fork) {
     (void)hipEventDestroy(env->ev_fork);
     for (int i = 0; i < bk_env::MAX_PARTS; ++i) {
-      if (env->part_stream[i]) (void)hipStreamSynchronize(env->part_stream[i]);  // shared (shared_part_stream): not destroyed
+      if (env->part_stream[i]) (void)hipStreamSynchronize(env->part_stream[i]);  // shared (part_streams): not destroyed
       (void)hipEventDestroy(env->ev_first[i]);
       (void)hipEventDestroy(env->ev_join[i]);
     }
