@@ -353,16 +353,19 @@ const std::vector<hipStream_t>& part_streams(int device) {
     hipLaunchKernelGGL(k_delay, dim3(1), dim3(64), 0, st, 1u);  // first use: the stream takes its hardware queue now
     cand.push_back(st);
   }
-  for (hipStream_t st : cand) (void)hipStreamSynchronize(st);
+  (void)hipDeviceSynchronize();  // the probe times kernels: nothing of ours may still be running
   constexpr uint32_t SPIN_US = 300;
   auto concurrent = [&](hipStream_t x, hipStream_t y) {
-    const auto t0 = std::chrono::steady_clock::now();
-    hipLaunchKernelGGL(k_delay, dim3(1), dim3(64), 0, x, SPIN_US * 100u);
-    hipLaunchKernelGGL(k_delay, dim3(1), dim3(64), 0, y, SPIN_US * 100u);
-    (void)hipStreamSynchronize(x);
-    (void)hipStreamSynchronize(y);
-    const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
-    return us < 1.6 * SPIN_US;
+    for (int attempt = 0; attempt < 2; ++attempt) {  // a slow pair is measured twice (someone else's work on the GPU)
+      const auto t0 = std::chrono::steady_clock::now();
+      hipLaunchKernelGGL(k_delay, dim3(1), dim3(64), 0, x, SPIN_US * 100u);
+      hipLaunchKernelGGL(k_delay, dim3(1), dim3(64), 0, y, SPIN_US * 100u);
+      (void)hipStreamSynchronize(x);
+      (void)hipStreamSynchronize(y);
+      const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+      if (us < 1.6 * SPIN_US) return true;
+    }
+    return false;
   };
   for (hipStream_t c : cand) {
     bool ok = chosen.size() < 4;
