@@ -75,7 +75,7 @@ struct DevArgs {
   uint32_t state_stride;        // dwords per book
   uint32_t l2_width;            // 5 + 4*levels
   uint32_t trade_cap, hist_cap;
-  uint32_t hist_slot0, hist_pad;  // history is a ring of hist_cap steps: slot of the launch's first step
+  uint32_t hist_slot0, step_prio;  // history is a ring of hist_cap steps: slot of the launch's first step; k_step_batch's wave priority (0 / 1)
   uint32_t n_agents_total, log_cap;
   uint32_t* state;
   uint32_t* l2_last;
@@ -1121,6 +1121,9 @@ __global__ __launch_bounds__(64) void k_step_batch(DevArgs a, uint64_t step_inde
   // one-wave workgroups: the dispatcher places every wave independently, so the wave slots left beside the
   // co-running k_agents_fsm waves are all usable (4-wave workgroups needed a free slot on every SIMD)
   __shared__ uint32_t lds[1][LDS_DW_PER_WAVE];
+  // behind the wave-parallel decode of a LARGE batch the event waves go first (bourse_amd.hip launch_split: +5-7 % at
+  // 16 384 - 24 576 books, -2 % at 8 192, nothing beside k_agents_fsm, which runs at priority 3 anyway)
+  if (a.step_prio) __builtin_amdgcn_s_setprio(1);
   const int lane = threadIdx.x;
   const int wv = 0;
   // MKT: book = market * assets + asset; the step batch is the market's (stored at the market's first book)

@@ -70,7 +70,7 @@ constexpr uint32_t RANDOM_SPLIT_MIN_BOOKS = 8192, MIXED_SPLIT_MIN_BOOKS = 4096;
 // whose kernels overlap) from there; above WAVE_MAX_BOOKS the lane-per-book k_agents_fsm costs far fewer issue slots per
 // book-step and its latency is hidden by the other parts (scripts/size_sweep.py: 2 048 / 4 096 / 8 192 / 16 384 / 32 768
 // books: k_run_wave 33 / 53 / 74 / 76 / 79 M, wave_split 32 / 50 / 85 / 97 / 99 M, lane split - / 22 / 41 / 69 / 121 M)
-constexpr uint32_t WAVE_FUSED_MAX_BOOKS = 6144, WAVE_MAX_BOOKS = 24576;
+constexpr uint32_t WAVE_FUSED_MAX_BOOKS = 6144, WAVE_MAX_BOOKS = 24576, WAVE_STEP_PRIO_BOOKS = 16384;
 
 struct HostOrder {  // immutable half of an order, fixed at create_order (orderbook.rs:356-396)
   uint8_t bid;
@@ -225,7 +225,7 @@ struct bk_env {
     a.trade_cap = cfg.trade_capacity;
     a.hist_cap = cfg.history_capacity;
     a.hist_slot0 = cfg.history_capacity ? static_cast<uint32_t>(steps_done % cfg.history_capacity) : 0u;
-    a.hist_pad = 0;
+    a.step_prio = 0;
     a.n_agents_total = n_agents_total;
     a.log_cap = cfg.max_orders;
     a.state = state.p;
@@ -448,6 +448,7 @@ int launch_split(bk_env* env, const DevArgs& a0, uint64_t first_step, uint32_t n
       a.book_begin = static_cast<uint32_t>(static_cast<uint64_t>(B) * i / P) & ~3u;
       a.book_end = (i + 1 == P) ? B : (static_cast<uint32_t>(static_cast<uint64_t>(B) * (i + 1) / P) & ~3u);
       a.hist_slot0 = a.hist_cap ? static_cast<uint32_t>((first_step + s) % a.hist_cap) : 0u;
+      a.step_prio = (wave && B >= WAVE_STEP_PRIO_BOOKS) ? 1u : 0u;
       const uint32_t nb = a.book_end - a.book_begin;
       hipStream_t st = P > 1 ? env->part_stream[i] : env->stream;
       if (P > 1 && s == 0 && i > 0) {  // stagger the parts
