@@ -11,6 +11,9 @@ for seed in range(100, 220):
         bad += 1; print("seed", seed, "FAIL", str(e)[:300])
     except Exception as e:
         bad += 1; print("seed", seed, "ERR", type(e).__name__, str(e)[:300])
+    except BaseException as e:  # pytest.skip: the drawn configuration overflowed the pool (flagged)
+        if type(e).__name__ != "Skipped":
+            raise
 for seed in range(2000, 2060):
     try:
         T.test_fuzz_random_agent_configs_vs_oracle(bk, oracle, seed)
@@ -18,4 +21,7 @@ for seed in range(2000, 2060):
         bad += 1; print("R seed", seed, "FAIL", str(e)[:300])
     except Exception as e:
         bad += 1; print("R seed", seed, "ERR", type(e).__name__, str(e)[:300])
+    except BaseException as e:
+        if type(e).__name__ != "Skipped":
+            raise
 print("done, failures:", bad)
