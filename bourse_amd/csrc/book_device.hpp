@@ -222,6 +222,22 @@ struct RngLane {
     b1 = __builtin_amdgcn_alignbit(t0, t1, 27);
     return (r << 3) + r;
   }
+  // the same in two halves: the output word of the current state, and the state update (which does not depend on it)
+  __device__ __forceinline__ uint32_t output() const {
+    const uint32_t lo5 = (a0 << 2) + a0;
+    const uint32_t hi5 = (a1 << 2) + a1 + (a0 >> 30) + (lo5 < a0 ? 1u : 0u);
+    const uint32_t r = __builtin_amdgcn_alignbit(lo5, hi5, 25);
+    return (r << 3) + r;
+  }
+  __device__ __forceinline__ void advance() {
+    const uint32_t t0 = b0 ^ a0, t1 = b1 ^ a1;
+    const uint32_t n0 = __builtin_amdgcn_alignbit(a0, a1, 8) ^ t0 ^ (t0 << 16);
+    const uint32_t n1 = __builtin_amdgcn_alignbit(a1, a0, 8) ^ t1 ^ __builtin_amdgcn_alignbit(t1, t0, 16);
+    a0 = n0;
+    a1 = n1;
+    b0 = __builtin_amdgcn_alignbit(t1, t0, 27);
+    b1 = __builtin_amdgcn_alignbit(t0, t1, 27);
+  }
 };
 
 // ----------------------------------------------------------------------------------
@@ -1042,38 +1058,43 @@ __global__ __launch_bounds__(64) void k_agents_fsm(DevArgs a) {
     // s_waitcnt lgkmcnt(0), which also waits for the iteration's own LDS writes (list append, ds_or) to drain
     asm volatile("" ::"s"(G.thr), "s"(G.tick_lo), "s"(G.tick_rng), "s"(G.tick_zone));
     asm volatile("" ::"s"(G.vol_lo), "s"(G.vol_rng), "s"(G.vol_zone), "s"(G.tick_size));
+    // Every predicate of a draw is taken as a WAVE MASK first (v_cmp into an SGPR pair), then the generator's state
+    // update runs (11 vector instructions that depend on none of them), and only then does the scalar unit combine the
+    // masks: an SALU instruction that reads an SGPR a vector compare has JUST written stalls the wave ~16 clocks
+    // (scripts/micro/lone_wave_latency.hip), and the straightforward form - `bool` predicates combined where they are
+    // used - had five of those per draw (k_agents_fsm 161 -> 141 us per launch under load).  Same instructions, same
+    // counts: the two fences only fix their order.
     uint32_t phase = PH_ACT, range = 0, zone = 0, cur_side = 0, cur_price = 0;
     while (phase != PH_DONE) {
-      const uint32_t x = rng.next_u32();
-      const bool is_act = phase == PH_ACT;
-      // ACT: p = gen::<f32>() < activity_rate (random_agent.rs:91-93)
-      const bool hit = is_act & ((x >> 8) < G.thr);
-      // other phases: UniformInt<u32>::sample_single step: accept iff lo(x * range) <= zone
-      const uint64_t m = (uint64_t)x * range;
-      const bool acc = (!is_act) & ((uint32_t)m <= zone);
+      const uint32_t x = rng.output();
+      const uint64_t m = (uint64_t)x * range;  // sample_single step of the current phase: accept iff lo <= zone
       const uint32_t val = (uint32_t)(m >> 32);
       uint64_t w = live[0];
 #pragma unroll
       for (int r = 1; r < R; ++r) w = ((n >> 6) == (uint32_t)r) ? live[r] : w;
-      const bool holds_live = (w >> (n & 63)) & 1ull;  // Active order held -> the event is its cancellation (:95-97)
-      const bool acc_side = acc & (phase == PH_SIDE), acc_tick = acc & (phase == PH_TICK);
-      const bool acc_vol = acc & (phase == PH_VOL);
-      cur_side = acc_side ? val : cur_side;                             // 0 = Ask, 1 = Bid ([Ask, Bid].choose, :99)
-      cur_price = acc_tick ? (G.tick_lo + val) * G.tick_size : cur_price;  // tick * tick_size (:100,:107)
-      // The agent's event is queued once its kind is known (still in agent order: a lane finishes agent n before it
-      // starts n + 1), and carries it: bit 15 = New, bit 14 = bid, so the event kernel does not consult the pend / side
-      // masks (EV_NEW / EV_BID).  A hit on a held Active order is its cancellation (:95-97).
-      const bool queue = (hit & holds_live) | acc_vol;
-      if (queue) list[n_ev * 64 + lane] = (uint16_t)(acc_vol ? (n | EV_NEW | (cur_side << 14)) : n);
-      n_ev += queue ? 1u : 0u;
-      if (acc_vol) {                                                    // vol drawn last (:101): the order is complete
-        pv[n] = make_uint2(cur_price, G.vol_lo + val);
-      }
-      const bool to_side = hit & !holds_live;
-      phase = to_side ? PH_SIDE : acc_side ? PH_TICK : acc_tick ? PH_VOL : phase;
-      range = to_side ? 2u : acc_side ? G.tick_rng : acc_tick ? G.vol_rng : range;
-      zone = to_side ? 0x7FFFFFFFu : acc_side ? G.tick_zone : acc_tick ? G.vol_zone : zone;
-      if ((is_act & !hit) | (hit & holds_live) | acc_vol) {  // next agent of the group, or done with the group
+      uint64_t P_ACT = __builtin_amdgcn_ballot_w64(phase == PH_ACT), P_SIDE = __builtin_amdgcn_ballot_w64(phase == PH_SIDE);
+      uint64_t P_TICK = __builtin_amdgcn_ballot_w64(phase == PH_TICK), P_VOL = __builtin_amdgcn_ballot_w64(phase == PH_VOL);
+      uint64_t C_HIT = __builtin_amdgcn_ballot_w64((x >> 8) < G.thr);       // gen::<f32>() < activity_rate (:91-93)
+      uint64_t C_ACC = __builtin_amdgcn_ballot_w64((uint32_t)m <= zone);
+      uint64_t C_LIVE = __builtin_amdgcn_ballot_w64(((w >> (n & 63)) & 1ull) != 0);  // Active order held (:95-97)
+      asm volatile("" : "+v"(rng.a0), "+v"(rng.a1), "+v"(rng.b0), "+v"(rng.b1)
+                   : "s"(P_ACT), "s"(P_SIDE), "s"(P_TICK), "s"(P_VOL), "s"(C_HIT), "s"(C_ACC), "s"(C_LIVE));
+      rng.advance();
+      asm volatile("" : "+v"(rng.a0), "+v"(rng.a1), "+v"(rng.b0), "+v"(rng.b1), "+s"(P_ACT), "+s"(P_SIDE), "+s"(P_TICK),
+                     "+s"(P_VOL), "+s"(C_HIT), "+s"(C_ACC), "+s"(C_LIVE));
+      const uint64_t HIT = P_ACT & C_HIT, CANCEL = HIT & C_LIVE, TO_SIDE = HIT & ~C_LIVE;
+      const uint64_t A_SIDE = C_ACC & P_SIDE, A_TICK = C_ACC & P_TICK, A_VOL = C_ACC & P_VOL;
+      const uint64_t QUEUE = CANCEL | A_VOL, ADV = (P_ACT & ~C_HIT) | QUEUE;
+      cur_side = sel(A_SIDE, val, cur_side);                                    // 0 = Ask, 1 = Bid ([Ask, Bid].choose, :99)
+      cur_price = sel(A_TICK, (G.tick_lo + val) * G.tick_size, cur_price);      // tick * tick_size (:100,:107)
+      // the agent's event, queued once its kind is known (agent order): bit 15 = New, bit 14 = bid
+      if (lane_bit(QUEUE)) list[n_ev * 64 + lane] = (uint16_t)sel(A_VOL, n | EV_NEW | (cur_side << 14), n);
+      n_ev += lane_bit(QUEUE) ? 1u : 0u;
+      if (lane_bit(A_VOL)) pv[n] = make_uint2(cur_price, G.vol_lo + val);       // vol drawn last (:101): the order is complete
+      phase = sel(TO_SIDE, PH_SIDE, sel(A_SIDE, PH_TICK, sel(A_TICK, PH_VOL, phase)));
+      range = sel(TO_SIDE, 2u, sel(A_SIDE, G.tick_rng, sel(A_TICK, G.vol_rng, range)));
+      zone = sel(TO_SIDE, 0x7FFFFFFFu, sel(A_SIDE, G.tick_zone, sel(A_TICK, G.vol_zone, zone)));
+      if (lane_bit(ADV)) {  // next agent of the group, or done with the group
         ++n;
         phase = (n >= gend) ? PH_DONE : PH_ACT;
       }
@@ -1087,9 +1108,13 @@ __global__ __launch_bounds__(64) void k_agents_fsm(DevArgs a) {
     uint32_t rg = i + 1;
     uint32_t zn = (rg << __builtin_clz(rg)) - 1u;
     while (i != 0) {
-      const uint32_t x = rng.next_u32();
+      const uint32_t x = rng.output();
       const uint64_t m = (uint64_t)x * rg;
-      if ((uint32_t)m <= zn) {
+      uint64_t ACC = __builtin_amdgcn_ballot_w64((uint32_t)m <= zn);  // (same ordering as in loop 1)
+      asm volatile("" : "+v"(rng.a0), "+v"(rng.a1), "+v"(rng.b0), "+v"(rng.b1) : "s"(ACC));
+      rng.advance();
+      asm volatile("" : "+v"(rng.a0), "+v"(rng.a1), "+v"(rng.b0), "+v"(rng.b1), "+s"(ACC));
+      if (lane_bit(ACC)) {
         const uint32_t j = (uint32_t)(m >> 32);
         const uint16_t ai = list[i * 64 + lane], aj = list[j * 64 + lane];
         list[i * 64 + lane] = aj;

@@ -145,7 +145,7 @@ struct bk_env {
   // split pipeline: the batch is cut into n_parts contiguous parts, each on its own stream and started one
   // k_agents_fsm apart, so the latency-bound lane-per-book kernel of one part runs under the issue-bound
   // wave-per-book kernel of another.
-  int n_parts = 3;
+  int n_parts = 4;  // one per hardware queue (part_streams)
   uint32_t min_part = 4096;  // books (markets) per part below which the batch is cut in fewer parts
   static constexpr int MAX_PARTS = 8;
   hipStream_t part_stream[MAX_PARTS] = {};
@@ -456,7 +456,7 @@ int launch_split(bk_env* env, const DevArgs& a0, uint64_t first_step, uint32_t n
         // kernel; one agents kernel apart (the round-1 rule) puts part 2 at 360 us = almost in phase with part 0 again.
         // Measured at C3 (driver's 20-step regions): 60 us apart 186-189 M first region / 199-201 M later ones against
         // 182 / 192-195 M (BOURSE_AMD_STAGGER_US overrides; other pipelines keep the event-based stagger)
-        const uint32_t stagger = env->stagger_us != ~0u ? env->stagger_us : ((MIXED == 0 && !wave && P == 3) ? 60u : 0u);
+        const uint32_t stagger = env->stagger_us != ~0u ? env->stagger_us : ((MIXED == 0 && !wave && P >= 3) ? 50u : 0u);
         if (stagger > 0)
           hipLaunchKernelGGL(k_delay, dim3(1), dim3(64), 0, st, static_cast<uint32_t>(i) * stagger * 100u);
         else                           // by one agents kernel each

@@ -711,7 +711,7 @@ def test_mixed_random_noise_momentum_set_on_device(bk, oracle):
 
 
 def test_mixed_members_split_pipeline_in_parts(bk, oracle):
-    # enough books for the three-part staggered launch of k_agents_mixed + k_step_batch
+    # enough books for the multi-part staggered launch of k_agents_mixed + k_step_batch
     members = [("momentum", 0, 10, MOM_P), ("noise", 10, 20, NOISE_P)]
     _compare_members(bk, oracle, 12300, members, levels=10, n_steps=8, pool=128, pipeline="split")
 
@@ -916,7 +916,7 @@ def test_random_market_agents_three_assets_mixed_ticks(bk, oracle):
 
 
 def test_random_market_agents_large_batch_parts(bk, oracle):
-    # enough books for the three-part staggered launch (>= 12 288 books)
+    # enough books for a staggered launch in at least three parts (>= 12 288 books)
     groups = [(0, 24, (40, 56), (10, 20), 2, 0.8), (1, 24, (40, 56), (10, 20), 2, 0.8), (1, 16, (40, 56), (50, 70), 2, 0.2)]
     _compare_markets(bk, oracle, 6200, [2, 2], groups, 16, 12)
 
@@ -1354,12 +1354,12 @@ def test_batched_submit_for_all_books_matches_per_book_calls(bk, oracle):
 
 
 def test_full_size_c3_exact_parity_vs_oracle(bk, oracle):
-    """The headline configuration itself (65 536 books x 128 agents x 32 levels, the shipped split pipeline in three
+    """The headline configuration itself (65 536 books x 128 agents x 32 levels, the shipped split pipeline in four
     parts): every book's level-2 history, trade count and RNG state against the oracle run on all host threads."""
     B, T = 65536, 12
     env = bk.ManyBookEnv(B, 101, 0, 2, 100_000, levels=32, max_live_orders=128, trade_capacity=64 * T, history_capacity=T)
     env.set_random_agents(C3_GROUPS)
-    assert env.pipeline() == ("split", 3)
+    assert env.pipeline() == ("split", 4)
     env.run(T)
     ref = oracle.ManyBooks(B, 101, 0, 2, 100_000, True, 32, C3_GROUPS)
     ref.run(T, os.cpu_count() or 8)
