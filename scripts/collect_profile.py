@@ -23,7 +23,7 @@ for B, key in ((65536, "C3"), (8192, "C3/8192")):
         if k not in allp.get(key, {}) or "SQ_WAVES" not in v:
             continue
         e = allp[key][k]
-        books = B / 3.0  # three-part launches: books per dispatch
+        books = summ[str(B)]['k_step_batch']['SQ_WAVES']  # books per dispatch = event waves per dispatch (one per book)
         hbm = (v["FETCH_SIZE"] * 2 + v["WRITE_SIZE"]) * 1024.0
         e.update(hbm_bytes_per_book_step=hbm / books, hbm_bytes_per_launch=hbm, fetch_size_kib_raw=v["FETCH_SIZE"],
                  write_size_kib=v["WRITE_SIZE"])
