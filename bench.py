@@ -479,7 +479,7 @@ def main():
         env.profile(False)
         ms1, n1 = env.profile_read_kind(2)
         env.profile_read()
-        env.set_split_parts(3, 4096)
+        env.set_split_parts(4, 4096)
         if pipe == "wave_split":
             env.set_wave_options(64, args.wave_parts)
         if n1:

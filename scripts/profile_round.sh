@@ -11,9 +11,9 @@ python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_C3_driv
 python3 $R/bench.py --books 8192 --steps 200 --warmup 50 --no-cpu-baseline > $OUT/bench_C4_shard_8192.json 2> $OUT/bench_C4.err
 for N in 32768 16384; do python3 $R/bench.py --books $N --steps 100 --warmup 50 --no-cpu-baseline > $OUT/bench_C4_shard_$N.json 2>> $OUT/bench_C4.err; done
 for W in C2 C5 C5M; do python3 $R/bench.py --workload $W --steps 100 --warmup 30 > $OUT/bench_$W.json 2> $OUT/bench_$W.err; done
-# kernel stats
-rocprofv3 --kernel-trace --stats -d $OUT/kt_C3 -o kt -f csv -- python3 $R/bench.py --steps 200 --warmup 50 --no-cpu-baseline > $OUT/bench_C3_under_rocprof.json 2> $OUT/kt_C3.err
-rocprofv3 --kernel-trace --stats -d $OUT/kt_C4 -o kt -f csv -- python3 $R/bench.py --books 8192 --steps 200 --warmup 50 --no-cpu-baseline > $OUT/bench_C4_under_rocprof.json 2> $OUT/kt_C4.err
+# kernel stats (no pre-heat env here: its launches would be averaged into the same kernel names)
+rocprofv3 --kernel-trace --stats -d $OUT/kt_C3 -o kt -f csv -- python3 $R/bench.py --steps 200 --warmup 50 --no-cpu-baseline --preheat-steps 0 > $OUT/bench_C3_under_rocprof.json 2> $OUT/kt_C3.err
+rocprofv3 --kernel-trace --stats -d $OUT/kt_C4 -o kt -f csv -- python3 $R/bench.py --books 8192 --steps 200 --warmup 50 --no-cpu-baseline --preheat-steps 0 > $OUT/bench_C4_under_rocprof.json 2> $OUT/kt_C4.err
 # PMC passes (counters only; FETCH_SIZE and WRITE_SIZE cannot share a pass)
 PA="--steps 50 --warmup 50 --no-cpu-baseline --profile-every 0 --repeats 0"
 for B in 65536 8192; do
