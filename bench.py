@@ -300,6 +300,7 @@ def main():
         if args.wave_parts:
             penv.set_wave_options(64, args.wave_parts)
         env.trade_counts(), env.order_counts()  # first calls allocate their staging buffers: not between warm-up and t0
+        env.profile(args.profile_every), env.profile(False)  # ... the event pool and the events' calibration neither
         if dist is not None:  # ... and RCCL builds its communicator on the first collective (~20 ms): not there either
             if gather is not None:
                 gather.all_gather()
