@@ -693,15 +693,23 @@ struct KeyState {
   uint32_t key[R];
   uint32_t sq, sbase;
 };
-template <int R>
+// MARKETS: the new orders may include market orders (price sentinel u32::MAX for a bid, 0 for an ask; the members of an
+// AgentSet place them): they stay out of the window test, never rest, and get a prefix that crosses whatever is there -
+// 0xFFFFFFFE (above every ask key, below the empty side's -1) / 1 (below every bid key, above the empty side's 0).
+template <int R, bool MARKETS = false>
 __device__ __forceinline__ bool keys_begin(const Book<R>& B, const uint64_t (&newm)[R], uint32_t n_ev, KeyState<R>& K) {
   uint32_t pbase;
-  if (!key_window<R>(B, newm, n_ev, pbase, K.sbase)) return false;
+  uint64_t lim[R];  // the new LIMIT orders
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+    lim[r] = MARKETS ? newm[r] & ~__ballot(B.price[r] == (lane_bit(B.bid[r]) ? 0xFFFFFFFFu : 0u)) : newm[r];
+  if (!key_window<R>(B, lim, n_ev, pbase, K.sbase)) return false;
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     const bool bidl = lane_bit(B.bid[r]);
     const uint32_t kp = ((((B.price[r] - pbase) << KEY_SB) | (bidl ? KEY_SMASK : 0u)) << 1) | (bidl ? 1u : 0u);
-    K.key[r] = lane_bit(B.live[r]) ? (kp ^ ((B.seq[r] - K.sbase) << 1)) : lane_bit(newm[r]) ? kp : 0xFFFFFFFFu;
+    K.key[r] = lane_bit(B.live[r]) ? (kp ^ ((B.seq[r] - K.sbase) << 1)) : lane_bit(lim[r]) ? kp : 0xFFFFFFFFu;
+    if (MARKETS) K.key[r] = lane_bit(newm[r] & ~lim[r]) ? (bidl ? 0xFFFFFFFEu : 1u) : K.key[r];
   }
   K.sq = (B.seq_ctr - K.sbase) << 1;
   return true;
@@ -755,37 +763,41 @@ __device__ __forceinline__ bool match_side_keyed(Book<R>& B, KeyState<R>& K, con
   }
   return v0 != 0 && v == 0;
 }
-template <int R, int RS>
+template <int R, int RS, bool CLS = true>
 __device__ __forceinline__ void slot_event_keyed_at(Book<R>& B, KeyState<R>& K, const DevArgs& a, uint32_t book, uint64_t t0,
                                                     int lane, uint32_t k, uint32_t sl, uint32_t ew) {
   const uint64_t bit = 1ull << sl;
-  if (!(ew & EV_NEW)) {
+  if (CLS ? !(ew & EV_NEW) : !(B.pend[RS] & bit)) {
     B.live[RS] &= ~bit;  // Cancellation
     return;
   }
+  if (!CLS) B.pend[RS] &= ~bit;
+  const bool is_bid = CLS ? (ew & EV_BID) != 0 : (B.bid[RS] & bit) != 0;
   const uint32_t kp = rdl(K.key[RS], sl), id = rdl(B.id[RS], sl);
   uint32_t v = rdl(B.vol[RS], sl);
+  // a market order's remainder is dropped (orderbook.rs:521-524); the event words' lists (CLS) carry none
+  const bool market = !CLS && kp == (is_bid ? 0xFFFFFFFEu : 1u);
   bool filled = false;
   if (B.trading)
-    filled = (ew & EV_BID) ? match_side_keyed<R, true>(B, K, a, book, t0, lane, k, kp, v, id)
-                           : match_side_keyed<R, false>(B, K, a, book, t0, lane, k, kp, v, id);
-  if (!filled) {  // rest the remainder (no market sentinels inside the key window) with a fresh arrival field
+    filled = is_bid ? match_side_keyed<R, true>(B, K, a, book, t0, lane, k, kp, v, id)
+                    : match_side_keyed<R, false>(B, K, a, book, t0, lane, k, kp, v, id);
+  if (!market && !filled) {  // rest the remainder with a fresh arrival field
     B.vol[RS] = wrl(v, sl, B.vol[RS]);
     K.key[RS] = wrl(kp ^ K.sq, sl, K.key[RS]);
     B.live[RS] |= bit;
     K.sq += 2;
   }
 }
-template <int R, int RS = 0>
+template <int R, int RS = 0, bool CLS = true>
 __device__ __forceinline__ void slot_event_keyed(Book<R>& B, KeyState<R>& K, const DevArgs& a, uint32_t book, uint64_t t0,
                                                  int lane, uint32_t k, uint32_t n, uint32_t ew) {
   if constexpr (RS + 1 < R) {  // ONE uniform branch per pool register, every pool access below with a compile-time index
     if ((n >> 6) == (uint32_t)RS)
-      slot_event_keyed_at<R, RS>(B, K, a, book, t0, lane, k, n & 63, ew);
+      slot_event_keyed_at<R, RS, CLS>(B, K, a, book, t0, lane, k, n & 63, ew);
     else
-      slot_event_keyed<R, RS + 1>(B, K, a, book, t0, lane, k, n, ew);
+      slot_event_keyed<R, RS + 1, CLS>(B, K, a, book, t0, lane, k, n, ew);
   } else {
-    slot_event_keyed_at<R, RS>(B, K, a, book, t0, lane, k, n & 63, ew);
+    slot_event_keyed_at<R, RS, CLS>(B, K, a, book, t0, lane, k, n & 63, ew);
   }
 }
 
@@ -797,7 +809,7 @@ __device__ __forceinline__ void slot_event_keyed(Book<R>& B, KeyState<R>& K, con
 // MKT: the list is the MARKET's queue (market_env.rs:110-121); this book processes the events of its own agents'
 // slots (`mine`) at their global positions t0 + k and skips the rest.  Returns trades; `n_own` = events processed.
 // TAGGED (MKT lists written by k_agents_mixed_lanes): entry = slot | asset << 12, ownership by the tag.
-template <int R, bool MKT = false, bool TAGGED = false, bool CLS = false>
+template <int R, bool MKT = false, bool TAGGED = false, bool CLS = false, bool PENDKEY = false>
 __device__ __forceinline__ uint32_t step_from_list(Book<R>& B, const DevArgs& a, uint32_t book, int lane,
                                                    const uint32_t (&ev)[R], uint32_t n_ev, uint32_t* bins,
                                                    uint32_t hist_slot, bool write_last, uint32_t tick,
@@ -810,10 +822,11 @@ __device__ __forceinline__ uint32_t step_from_list(Book<R>& B, const DevArgs& a,
   if (step_size != 0 && (uint64_t)n_ev >= step_size) B.flags |= FLAG_STEP_SIZE;
   // CLS callers hand over this step's new-order lanes in B.pend (the event words classify themselves, so the mask is
   // not carried through the event loop - only the keyed loop's set-up wants it)
+  // (PENDKEY - the members' lists of k_step_batch<POOLPEND> - keeps the pend bits: there they classify the events)
   uint64_t newm[R];
 #pragma unroll
   for (int r = 0; r < R; ++r) {
-    newm[r] = CLS ? B.pend[r] : 0ull;
+    newm[r] = (CLS || PENDKEY) ? B.pend[r] : 0ull;
     if (CLS) B.pend[r] = 0;
   }
   if constexpr ((R == 2 || R == 1) && !MKT && CLS && BOURSE_AMD_ASM_EVENTS) {
@@ -848,7 +861,7 @@ __device__ __forceinline__ uint32_t step_from_list(Book<R>& B, const DevArgs& a,
                            B.seq[0], ev[0], B.tr_k, B.tr_price, B.tr_vol, B.tr_act, B.tr_pas))
         flush_trades<R>(B, a, book, t0, lane);
     }
-  } else if (KeyState<R> K; CLS && !MKT && BOURSE_AMD_KEYED_EVENTS && keys_begin<R>(B, newm, rfl(n_ev), K)) {
+  } else if (KeyState<R> K; (CLS || PENDKEY) && !MKT && BOURSE_AMD_KEYED_EVENTS && keys_begin<R, !CLS>(B, newm, rfl(n_ev), K)) {
 #pragma unroll
     for (int re = 0; re < R; ++re) {
       const uint32_t kb = re * 64;
@@ -856,7 +869,7 @@ __device__ __forceinline__ uint32_t step_from_list(Book<R>& B, const DevArgs& a,
         const uint32_t cnt = rfl((n_ev - kb) < 64u ? (n_ev - kb) : 64u);
         for (uint32_t l = 0; l < cnt; ++l) {
           const uint32_t ew = rdl(ev[re], l);
-          slot_event_keyed<R>(B, K, a, book, t0, lane, kb + l, ew & EV_SLOT, ew);
+          slot_event_keyed<R, 0, CLS>(B, K, a, book, t0, lane, kb + l, CLS ? (ew & EV_SLOT) : ew, ew);
         }
       }
     }
@@ -1222,7 +1235,7 @@ __global__ __launch_bounds__(64) void k_step_batch(DevArgs a, uint64_t step_inde
   }
   B.next_id = base;
   uint32_t n_own = 0;
-  const uint32_t ntr = step_from_list<R, MKT, MKT && POOLPEND, !POOLPEND>(B, a, book, lane, ev, n_ev, lds[wv], a.hist_slot0,
+  const uint32_t ntr = step_from_list<R, MKT, MKT && POOLPEND, !POOLPEND, POOLPEND && !MKT>(B, a, book, lane, ev, n_ev, lds[wv], a.hist_slot0,
                                                                write_last != 0, MKT ? a.asset_tick[asset] : a.tick_size,
                                                                mine, n_own, asset);
   store_book<R>(B, rng, st, lane, step_index + 1, ntr, n_own);
