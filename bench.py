@@ -342,7 +342,7 @@ def main():
     # Roofline accounting: algorithmic HBM bytes per book-step of every step kernel, in the
     # device layout actually shipped (S = per-book state block, 32 B trade records, measured event/trade rates):
     #   k_run_random / k_run_mixed (fused, spl steps per launch): 2 S / spl + L2 record + 32 N_tr
-    #   k_agents_fsm  (one part, one step): 32 B in (RNG + live masks), 16 + 80 + 2 N_ev + 8 N_new out
+    #   k_agents_fsm  (one part, one step): 32 B in (RNG + live masks), 16 (RNG) + 4 (N_ev) + 2 N_ev + 8 N_new out
     #   k_step_batch  (one part, one step): 2 S + batch in (64 + 2 N_ev + 8 N_new) + L2 record + 32 N_tr
     S = env.state_bytes_per_book()
     W4 = env.width * 4
@@ -353,7 +353,7 @@ def main():
         # fused kernels: the book block in and out once per launch, the L2 record and the trade records every step;
         # k_run_wave adds its lane-state record (1.3 KB in / out per launch, ~2.5 KB of block-start spills per step)
         kind0: 2.0 * S / spl + W4 + 32.0 * tr_per_bs + ((2.0 * 1280.0 / spl + 2.5 * 1024.0) if pipe == "wave" else 0.0),
-        "k_agents_fsm": 32.0 + 96.0 + 2.0 * ev_per_bs + 8.0 * new_per_bs,
+        "k_agents_fsm": 32.0 + 20.0 + 2.0 * ev_per_bs + 8.0 * new_per_bs,
         # wave-per-book decode: header line + lane-state record (64 x 16 B + 256 B) in; record out, ~2.5 block-start
         # spills of 1 KB (one per 256-draw block crossed), RNG state, step batch (256 B header + list + new orders) out
         "k_agents_wave": 256.0 + 1280.0 + 1280.0 + 2.5 * 1024.0 + 16.0 + 256.0 + 2.0 * ev_per_bs + 8.0 * new_per_bs,
