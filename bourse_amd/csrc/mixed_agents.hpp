@@ -503,8 +503,11 @@ struct LaneRng {  // xoroshiro128** per lane
 // MKT: the lane owns a MARKET (books [b*M, b*M + M)): one RNG stream, one event queue; member j trades asset
 // ma.asset[j] (NoiseMarketAgent / MomentumMarketAgent / RandomMarketAgents: noise_agent.rs:281-339,
 // momentum_agent.rs:328-396, random_agent.rs:204-247); event entries carry the asset in bits 12..14.
+constexpr int MLQ_CAP = 128;  // deferred-price queue of k_agents_mixed_lanes: drained at 64, at most 64 more per agent turn
+                               // (2 x 80.9 KB of LDS still fit a CU at R = 8)
 constexpr size_t mixed_lanes_lds_bytes(int R, bool mkt) {
-  return (size_t)(32 * R * 64 + 2 * (2 * R * 64) + 2 * (mkt ? MAX_ASSETS * 64 : 64)) * 4 + 2 * 257 * sizeof(double);
+  return (size_t)(32 * R * 64 + 2 * (2 * R * 64) + 2 * (mkt ? MAX_ASSETS * 64 : 64)) * 4 + 2 * 257 * sizeof(double) +
+         MLQ_CAP * (2 * sizeof(double) + 4);
 }
 
 template <int R, bool MKT>
@@ -521,6 +524,15 @@ __global__ __launch_bounds__(64) void k_agents_mixed_lanes(DevArgs a, MixedArgs 
   uint32_t* cur_c = cur_w + (MKT ? MAX_ASSETS * 64 : 64);
   double* zx = reinterpret_cast<double*>(cur_c + (MKT ? MAX_ASSETS * 64 : 64));
   double* zf = zx + 257;
+  // Deferred limit prices (not MKT): a member's turn draws and decides for the 64 books in lockstep, but only the few
+  // lanes whose agent places an order need exp() and the tick rounding - 150 f64 instructions at 5-9 % lane
+  // utilisation, 60 % of this kernel's vector work (profiles/r02/pmc_c5m.json).  Those lanes create the order without a
+  // price and queue {exp argument, mid, book lane, slot}; whenever 64 entries are waiting, ALL lanes take one each.
+  // Same arithmetic on the same operands, so the same bits.  Orders that might reach the u32::MAX clamp (the one case
+  // whose outcome - Err, nothing created - changes what is drawn next) keep the in-line path.
+  double* q_arg = zf + 257;
+  double* q_mid = q_arg + MLQ_CAP;
+  uint32_t* q_info = reinterpret_cast<uint32_t*>(q_mid + MLQ_CAP);
   const int lane = threadIdx.x;
   for (int i = lane; i < 257; i += 64) {
     zx[i] = ZIG_NORM_X[i];
@@ -533,6 +545,9 @@ __global__ __launch_bounds__(64) void k_agents_mixed_lanes(DevArgs a, MixedArgs 
   uint32_t* st0 = a.state + (size_t)b * M * a.state_stride;
   uint32_t* bt = a.batch + (size_t)b * M * a.batch_stride;
   const size_t NB = ml.n_books, NU = ml.n_units;
+  const uint64_t act = __builtin_amdgcn_ballot_w64(true);  // the lanes with a book (all 64 but in the last workgroup)
+  const uint32_t n_act = __builtin_popcountll(act);
+  const uint32_t my_rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(act >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)act, 0u));
 
   LaneRng rng;
   {
@@ -620,10 +635,11 @@ __global__ __launch_bounds__(64) void k_agents_mixed_lanes(DevArgs a, MixedArgs 
     n_ev += 1;
   };
   // Env::place_order from a member: id + New event; returns the slot (or 0xFFFF when the pool is full: flagged)
-  auto create = [&](bool is_bid, uint32_t price, uint32_t vol, uint32_t tag) -> uint32_t {
+  auto create = [&](bool is_bid, uint32_t price, uint32_t vol, uint32_t tag, bool deferred = false) -> uint32_t {
     // create_order's tick check (orderbook.rs:367-382): the reference `.unwrap()`s the Err, i.e. panics — flagged, and
-    // like an Err nothing is created (see mixed_create).  Market orders (tag 0 here) carry no price.
-    if (tag != 0 && price % (MKT ? a.asset_tick[asset] : a.tick_size) != 0) {
+    // like an Err nothing is created (see mixed_create).  Market orders (tag 0 here) carry no price.  (A deferred price
+    // is a tick multiple below the clamp by construction.)
+    if (!deferred && tag != 0 && price % (MKT ? a.asset_tick[asset] : a.tick_size) != 0) {
       new_flags |= FLAG_PRICE_TICK;
       return 0xFFFFu;
     }
@@ -641,12 +657,74 @@ __global__ __launch_bounds__(64) void k_agents_mixed_lanes(DevArgs a, MixedArgs 
     const uint32_t bit = __builtin_ctz(~cw);
     cw |= 1u << bit;
     const uint32_t slot = wcur * 32u + bit;
-    *pool_ptr(slot, 0) = price;
+    if (!deferred) *pool_ptr(slot, 0) = price;
     *pool_ptr(slot, 1) = vol;
     *pool_ptr(slot, 2) = id;
     *pool_ptr(slot, 4) = 4u | (is_bid ? 2u : 0u) | (tag << 8);  // pending New
     push_event(slot);
     return slot;
+  };
+  // ---- deferred limit prices (see q_arg above)
+  const uint32_t wave_b0 = a.book_begin + blockIdx.x * 64;
+  // limit order at mid -/+ exp(arg): in line when a sell might reach the clamp (or in a market), otherwise created
+  // without its price and handed to `queue_turn` below
+  uint32_t qc = 0;  // entries waiting (wave-uniform)
+  bool pend_q = false;
+  double pend_arg = 0.0;
+  uint32_t pend_info = 0;
+  auto place_limit = [&](bool buy, double arg, double mid, double lnslack, const MixedDesc& D, uint32_t tag) -> uint32_t {
+    if (MKT || !(buy || arg < lnslack)) {
+      const double dist = pm::fabs_(pm::exp(arg));
+      const uint32_t price = buy ? round_price_down(mid - dist, D.tick_f) : round_price_up(mid + dist, D.tick_f);
+      return create(buy, price, D.trade_vol, tag);
+    }
+    const uint32_t slot = create(buy, 0u, D.trade_vol, tag, true);
+    if (slot != 0xFFFFu) {
+      pend_q = true;
+      pend_arg = arg;
+      pend_info = (uint32_t)lane | (slot << 6) | (buy ? 0x8000u : 0u);
+    }
+    return slot;
+  };
+  // all lanes, 64 (or, with `all`, whatever is left) queued orders: one each
+  auto drain = [&](bool all, double tick_f) {
+    if (MKT) return;
+    while (qc >= (all ? 1u : 64u)) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      const uint32_t take = qc < 64u ? qc : 64u, base = qc - take;
+      for (uint32_t e = my_rank; e < take; e += n_act) {
+        const double arg = q_arg[base + e], mid_e = q_mid[base + e];
+        const uint32_t info = q_info[base + e], slot = (info >> 6) & 0x1FFu;
+        const double dist = pm::fabs_(pm::exp(arg));
+        const uint32_t price = (info & 0x8000u) ? round_price_down(mid_e - dist, tick_f) : round_price_up(mid_e + dist, tick_f);
+        uint32_t* sb = a.state + (size_t)(wave_b0 + (info & 63u)) * a.state_stride;
+        sb[HDR_DW + (slot >> 6) * (POOL_FIELDS * 64) + (slot & 63u)] = price;
+      }
+      qc = base;
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+  };
+  // at the end of an agent's turn, where the lanes are together again: the orders placed in it join the queue
+  auto queue_turn = [&](double mid, double tick_f) {
+    if (MKT) return;
+    const uint64_t w = __builtin_amdgcn_ballot_w64(pend_q);
+    if (w == 0) return;
+    if (pend_q) {
+      const uint32_t q = qc + __builtin_amdgcn_mbcnt_hi((uint32_t)(w >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)w, 0u));
+      q_arg[q] = pend_arg;
+      q_mid[q] = mid;
+      q_info[q] = pend_info;
+    }
+    pend_q = false;
+    qc += __builtin_popcountll(w);
+    drain(false, tick_f);
+  };
+  // a sell at mid + exp(arg), rounded UP to the tick, stays below the u32::MAX clamp when arg < lnslack
+  auto clamp_bound = [&](double mid, double tick_f) -> double {
+    const double slack = 4294967295.0 - mid - 2.0 * tick_f - 1.0;
+    return slack > 1.0 ? pm::log(slack) - 1e-9 : -1e300;
   };
 
   for (uint32_t j = 0; j < ma.n_desc; ++j) {  // members in declaration order (crates/macros/src/lib.rs:57-73)
@@ -728,20 +806,21 @@ __global__ __launch_bounds__(64) void k_agents_mixed_lanes(DevArgs a, MixedArgs 
       keep += 1;
       atomicOr(&lds_inl[(slot >> 5) * 64 + lane], 1u << (slot & 31u));
     };
+    const double lnslack = MKT ? 0.0 : clamp_bound(mid, D.tick_f);
     if (D.type == 1) {
       // ---- NoiseAgent::update (noise_agent.rs:127-176)
       for (uint32_t t = 0; t < D.n; ++t) {
         if ((rng.next_u32() >> 8) < D.thr_limit) {                   // gen::<f32>() < p_limit
           const bool buy = rng.next_u64() < 0x8000000000000000ull;   // gen_bool(0.5)
-          const double dist = pm::fabs_(pm::exp(D.mu + D.sigma * rng.std_normal(zx, zf)));
-          const uint32_t price = buy ? round_price_down(mid - dist, D.tick_f) : round_price_up(mid + dist, D.tick_f);
-          remember(create(buy, price, D.trade_vol, tag));
+          remember(place_limit(buy, D.mu + D.sigma * rng.std_normal(zx, zf), mid, lnslack, D, tag));
         }
         if ((rng.next_u32() >> 8) < D.thr_market) {                  // gen::<f32>() < p_market
           const bool buy = rng.next_u64() < 0x8000000000000000ull;
           create(buy, buy ? 0xFFFFFFFFu : 0u, D.trade_vol, 0u);
         }
+        queue_turn(mid, D.tick_f);
       }
+      drain(true, D.tick_f);
     } else {
       // ---- MomentumAgent::update (momentum_agent.rs:146-208)
       double m = 0.0, p_market = 0.0;
@@ -756,17 +835,14 @@ __global__ __launch_bounds__(64) void k_agents_mixed_lanes(DevArgs a, MixedArgs 
       const int sgn = (m > 0.0) ? 1 : ((m < 0.0) ? -1 : 0);
       for (uint32_t t = 0; t < D.n; ++t) {
         if ((rng.next_u64() >> 11) < thr_l) {  // gen::<f64>() < p_limit
-          if (sgn != 0) {
-            const double dist = pm::fabs_(pm::exp(D.mu + D.sigma * rng.std_normal(zx, zf)));
-            const uint32_t price =
-                sgn > 0 ? round_price_down(mid - dist, D.tick_f) : round_price_up(mid + dist, D.tick_f);
-            remember(create(sgn > 0, price, D.trade_vol, tag));
-          }
+          if (sgn != 0) remember(place_limit(sgn > 0, D.mu + D.sigma * rng.std_normal(zx, zf), mid, lnslack, D, tag));
         }
         if ((rng.next_u64() >> 11) < thr_m) {  // gen::<f64>() < p_market
           if (sgn != 0) create(sgn > 0, sgn > 0 ? 0xFFFFFFFFu : 0u, D.trade_vol, 0u);
         }
+        queue_turn(mid, D.tick_f);
       }
+      drain(true, D.tick_f);
       const uint64_t mb = pm::to_bits(m), lb = pm::to_bits(mid);
       st[H_GST + 4 * j] = (uint32_t)mb;
       st[H_GST + 4 * j + 1] = (uint32_t)(mb >> 32);
