@@ -692,6 +692,9 @@ template <int R>
 struct KeyState {
   uint32_t key[R];
   uint32_t sq, sbase;
+  // alo <= best ask key, bhi >= best bid key: exact after a reduction of that side, still valid after any removal, pulled
+  // in when an order rests beyond them - a new order on the far side of the bound cannot cross and skips the reduction
+  uint32_t alo, bhi;
 };
 // MARKETS: the new orders may include market orders (price sentinel u32::MAX for a bid, 0 for an ask; the members of an
 // AgentSet place them): they stay out of the window test, never rest, and get a prefix that crosses whatever is there -
@@ -712,6 +715,8 @@ __device__ __forceinline__ bool keys_begin(const Book<R>& B, const uint64_t (&ne
     if (MARKETS) K.key[r] = lane_bit(newm[r] & ~lim[r]) ? (bidl ? 0xFFFFFFFEu : 1u) : K.key[r];
   }
   K.sq = (B.seq_ctr - K.sbase) << 1;
+  K.alo = 0u;
+  K.bhi = 0xFFFFFFFFu;
   return true;
 }
 template <int R>
@@ -741,6 +746,7 @@ __device__ __forceinline__ bool match_side_keyed(Book<R>& B, KeyState<R>& K, con
     // an empty side returns the neutral element: "no cross" by the same compare
     const uint32_t m = key_touch<R, agg_bid>(B, K, std::make_integer_sequence<int, R>());
     const uint32_t best = agg_bid ? wave_umin(m) : wave_umax(m);
+    (agg_bid ? K.alo : K.bhi) = best;
     if (agg_bid ? (best > kp) : (best < kp)) break;  // inclusive crossing test (:430 / :463) in key space
     uint32_t pv = 0, pid = 0, tv = 0, price = 0;
 #pragma unroll
@@ -778,11 +784,15 @@ __device__ __forceinline__ void slot_event_keyed_at(Book<R>& B, KeyState<R>& K, 
   // a market order's remainder is dropped (orderbook.rs:521-524); the event words' lists (CLS) carry none
   const bool market = !CLS && kp == (is_bid ? 0xFFFFFFFEu : 1u);
   bool filled = false;
-  if (B.trading)
+  if (B.trading && !(is_bid ? kp < K.alo : kp > K.bhi))  // (beyond the bound: cannot cross)
     filled = is_bid ? match_side_keyed<R, true>(B, K, a, book, t0, lane, k, kp, v, id)
                     : match_side_keyed<R, false>(B, K, a, book, t0, lane, k, kp, v, id);
   if (!market && !filled) {  // rest the remainder with a fresh arrival field
     B.vol[RS] = wrl(v, sl, B.vol[RS]);
+    if (is_bid)
+      K.bhi = max(K.bhi, kp ^ K.sq);
+    else
+      K.alo = min(K.alo, kp ^ K.sq);
     K.key[RS] = wrl(kp ^ K.sq, sl, K.key[RS]);
     B.live[RS] |= bit;
     K.sq += 2;

@@ -340,6 +340,11 @@ __device__ __forceinline__ uint32_t events_asm_r1(uint32_t& k, uint32_t n_ev, ui
 // instead of one scalar add per trade.  Per trade: 16 scalar + branch instructions (loop above: 32).
 // ==================================================================================
 #define EK_KP EA_P  // the aggressor's key prefix lives where the loop above keeps its price
+// Bounds that let a new order that cannot cross skip the reduction: EK_ALO <= best ask key, EK_BHI >= best bid key.
+// Exact right after a reduction of that side, still valid after any removal (the best only moves away), pulled in when
+// an order rests beyond them; the loosest values at statement entry.
+#define EK_ALO "s62"
+#define EK_BHI "s63"
 
 #define EK_TRADE_REC(TV)                                                                              \
   "s_mov_b32 m0, %[trn]\n\t"                                                                          \
@@ -376,10 +381,12 @@ __device__ __forceinline__ uint32_t events_asm_r1(uint32_t& k, uint32_t n_ev, ui
   "s_branch L_match_" L "\n\t"
 
 //   NOX  "s_cmp_gt_u32" (bid: best ask key > kp) / "s_cmp_lt_u32" (ask: best bid key < kp): no cross
-#define EK_SIDE(L, PH, KEND, RG, NR, CAND, SENT, VOP, DOP, NOX, KKI)                                  \
+#define EK_SIDE(L, PH, KEND, RG, NR, CAND, SENT, VOP, DOP, NOX, KKI, OPPB, SKIP, OWNB, PULL)          \
   KKI "\n\t"                                                                                          \
   "s_and_b32 " EA_X ", " EA_V ", %[tmask]\n\t"          /* no volume or trading disabled: no match */ \
   "s_cbranch_scc0 L_rest_" L "\n\t"                                                                   \
+  SKIP " " EK_KP ", " OPPB "\n\t"                      /* beyond the bound: cannot cross */           \
+  "s_cbranch_scc1 L_rest_" L "\n\t"                                                                   \
   "L_match_" L ":\n\t"                                                                                \
   CAND " " EA_C0 ", %[live0], %[bid0]\n\t"                                                            \
   EA_IF2_##NR(CAND " " EA_C1 ", %[live1], %[bid1]\n\t")                                               \
@@ -388,6 +395,7 @@ __device__ __forceinline__ uint32_t events_asm_r1(uint32_t& k, uint32_t n_ev, ui
               VOP " %[vm], %[vm], %[vm2]\n\t")                                                        \
   EA_DPP(DOP)                                                                                         \
   "v_readlane_b32 " EA_BEST ", %[vm], 63\n\t"                                                         \
+  "s_mov_b32 " OPPB ", " EA_BEST "\n\t"                /* the bound is exact now */                   \
   NOX " " EA_BEST ", " EK_KP "\n\t"                                                                   \
   "s_cbranch_scc1 L_rest_" L "\n\t"                                                                   \
   "v_cmp_eq_u32_e64 " EA_E0 ", " EA_BEST ", %[key0]\n\t"                                              \
@@ -405,6 +413,7 @@ __device__ __forceinline__ uint32_t events_asm_r1(uint32_t& k, uint32_t n_ev, ui
   "s_mov_b32 m0, " EA_EW "\n\t"                                                                       \
   "v_writelane_b32 %[vol" RG "], " EA_V ", m0\n\t"                                                    \
   "s_xor_b32 " EA_X ", " EK_KP ", %[sq]\n\t"                                                          \
+  PULL " " OWNB ", " OWNB ", " EA_X "\n\t"             /* this side's bound covers the new order */  \
   "v_writelane_b32 %[key" RG "], " EA_X ", m0\n\t"                                                    \
   "s_lshl_b64 " EA_BIT ", 1, " EA_EW "\n\t"                                                           \
   "s_or_b64 %[live" RG "], %[live" RG "], " EA_BIT "\n\t"                                             \
@@ -417,11 +426,12 @@ __device__ __forceinline__ uint32_t events_asm_r1(uint32_t& k, uint32_t n_ev, ui
   "v_readlane_b32 " EA_ID ", %[id" RG "], " EA_EW "\n\t"                                              \
   "s_bitcmp1_b32 " EA_EW ", 14\n\t"                                                                   \
   "s_cbranch_scc1 L_bid_" PH RG "_%=\n\t"                                                             \
+  /* an ask: searches the bids (cannot cross if kp > bid bound), rests among the asks (ask bound = min) */ \
   EK_SIDE("a" PH RG "_%=", PH, KEND, RG, NR, "s_and_b64", "0", "v_max_u32", "v_max_u32_dpp", "s_cmp_lt_u32", \
-          "s_or_b32 " EA_KK ", %[k], 0x80000000")                                                     \
+          "s_or_b32 " EA_KK ", %[k], 0x80000000", EK_BHI, "s_cmp_gt_u32", EK_ALO, "s_min_u32")          \
   "L_bid_" PH RG "_%=:\n\t"                                                                           \
   EK_SIDE("b" PH RG "_%=", PH, KEND, RG, NR, "s_andn2_b64", "-1", "v_min_u32", "v_min_u32_dpp", "s_cmp_gt_u32", \
-          "s_mov_b32 " EA_KK ", %[k]")
+          "s_mov_b32 " EA_KK ", %[k]", EK_ALO, "s_cmp_lt_u32", EK_BHI, "s_max_u32")
 
 #define EK_PHASE(PH, KEND, NR)                                                                        \
   "L_top_" PH "_%=:\n\t"                                                                              \
@@ -457,7 +467,7 @@ __device__ __forceinline__ uint32_t events_asm_r1(uint32_t& k, uint32_t n_ev, ui
 
 #define EK_CLOBBERS                                                                                                 \
   "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55",  \
-      "s56", "s57", "s58", "s59", "s60", "s61", "vcc", "scc", "memory"
+      "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "vcc", "scc", "memory"
 
 // Keyed form of events_asm_r2: `sq` = (seq_ctr - sbase) << 1 (the caller converts back), key0/key1 as described above.
 __device__ __forceinline__ uint32_t events_key_r2(uint32_t& k, uint32_t n_ev, uint32_t tmask, uint32_t& tr_n, uint32_t& sq,
@@ -480,6 +490,8 @@ __device__ __forceinline__ uint32_t events_key_r2(uint32_t& k, uint32_t n_ev, ui
   bid1 = u64(bid1);
   const uint32_t kend0 = n_ev < 64u ? n_ev : 64u;
   asm volatile(
+      "s_mov_b32 " EK_ALO ", 0\n\t"
+      "s_mov_b32 " EK_BHI ", -1\n\t"
       "s_cmp_lt_u32 %[k], %[kend0]\n\t"
       "s_cbranch_scc1 L_top_0_%=\n\t"
       "s_branch L_end_0_%=\n\t"
@@ -515,6 +527,8 @@ __device__ __forceinline__ uint32_t events_key_r1(uint32_t& k, uint32_t n_ev, ui
   live0 = u64(live0);
   bid0 = u64(bid0);
   asm volatile(
+      "s_mov_b32 " EK_ALO ", 0\n\t"
+      "s_mov_b32 " EK_BHI ", -1\n\t"
       "s_cmp_lt_u32 %[k], %[nev]\n\t"
       "s_cbranch_scc0 L_done_%=\n\t"
       EK_PHASE("0", "%[nev]", 1)
