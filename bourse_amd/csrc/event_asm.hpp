@@ -382,11 +382,12 @@ __device__ __forceinline__ uint32_t events_asm_r1(uint32_t& k, uint32_t n_ev, ui
 
 //   NOX  "s_cmp_gt_u32" (bid: best ask key > kp) / "s_cmp_lt_u32" (ask: best bid key < kp): no cross
 #define EK_SIDE(L, PH, KEND, RG, NR, CAND, SENT, VOP, DOP, NOX, KKI, OPPB, SKIP, OWNB, PULL)          \
-  KKI "\n\t"                                                                                          \
   "s_and_b32 " EA_X ", " EA_V ", %[tmask]\n\t"          /* no volume or trading disabled: no match */ \
-  "s_cbranch_scc0 L_rest_" L "\n\t"                                                                   \
+  "s_cbranch_scc0 L_restq_" L "\n\t"                                                                  \
   SKIP " " EK_KP ", " OPPB "\n\t"                      /* beyond the bound: cannot cross */           \
-  "s_cbranch_scc1 L_rest_" L "\n\t"                                                                   \
+  "s_cbranch_scc1 L_restq_" L "\n\t"                                                                  \
+  "v_readlane_b32 " EA_ID ", %[id" RG "], " EA_EW "\n\t" /* (only a trade needs the id and the k word) */ \
+  KKI "\n\t"                                                                                          \
   "L_match_" L ":\n\t"                                                                                \
   CAND " " EA_C0 ", %[live0], %[bid0]\n\t"                                                            \
   EA_IF2_##NR(CAND " " EA_C1 ", %[live1], %[bid1]\n\t")                                               \
@@ -409,9 +410,11 @@ __device__ __forceinline__ uint32_t events_asm_r1(uint32_t& k, uint32_t n_ev, ui
   "s_mov_b32 m0, " EA_EW "\n\t"                                                                       \
   "v_writelane_b32 %[vol" RG "], " EA_V ", m0\n\t"                                                    \
   "s_branch L_flush_%=\n\t"                                                                           \
-  "L_rest_" L ":\n\t"                                                                                 \
+  "L_rest_" L ":\n\t"                                  /* rests with what the trades left ... */      \
   "s_mov_b32 m0, " EA_EW "\n\t"                                                                       \
   "v_writelane_b32 %[vol" RG "], " EA_V ", m0\n\t"                                                    \
+  "L_restq_" L ":\n\t"                                 /* ... or untouched */                         \
+  "s_mov_b32 m0, " EA_EW "\n\t"                                                                       \
   "s_xor_b32 " EA_X ", " EK_KP ", %[sq]\n\t"                                                          \
   PULL " " OWNB ", " OWNB ", " EA_X "\n\t"             /* this side's bound covers the new order */  \
   "v_writelane_b32 %[key" RG "], " EA_X ", m0\n\t"                                                    \
@@ -423,7 +426,6 @@ __device__ __forceinline__ uint32_t events_asm_r1(uint32_t& k, uint32_t n_ev, ui
 #define EK_NEW(PH, KEND, RG, NR)                                                                      \
   "v_readlane_b32 " EK_KP ", %[key" RG "], " EA_EW "\n\t"                                             \
   "v_readlane_b32 " EA_V ", %[vol" RG "], " EA_EW "\n\t"                                              \
-  "v_readlane_b32 " EA_ID ", %[id" RG "], " EA_EW "\n\t"                                              \
   "s_bitcmp1_b32 " EA_EW ", 14\n\t"                                                                   \
   "s_cbranch_scc1 L_bid_" PH RG "_%=\n\t"                                                             \
   /* an ask: searches the bids (cannot cross if kp > bid bound), rests among the asks (ask bound = min) */ \
