@@ -66,3 +66,57 @@ def test_window_limits():
     assert not K.window_ok([5, 0xFFFFFFFF], [], 10, 4)             # u32::MAX the bid one
     assert K.window_ok([1, 1 + K.PSPAN], [], 10, 4) and not K.window_ok([1, 2 + K.PSPAN], [], 10, 4)
     assert K.window_ok([5], [10], 10 + K.SMASK - 2 - 5, 4) and not K.window_ok([5], [10], 10 + K.SMASK - 1 - 4, 4)
+
+
+def test_skip_bounds_stay_valid_and_never_skip_a_crossing_order():
+    """The two bounds of the keyed loops (alo <= best ask key, bhi >= best bid key; event_asm.hpp EK_ALO / EK_BHI,
+    book_device.hpp KeyState): exact after a reduction, valid after removals, pulled in at a rest.  Whatever the
+    sequence of cancels, fills and new orders, a new order is only ever skipped when it really cannot cross."""
+    rng = random.Random(11)
+    for _ in range(300):
+        pbase, sbase, seq = 99, 0, 1
+        asks, bids = {}, {}          # key -> volume
+        alo, bhi = 0, K.DEAD         # loosest
+        for _step in range(200):
+            op = rng.random()
+            if op < 0.35 and (asks or bids):          # a cancellation / a fill: removals never touch the bounds
+                side = asks if (asks and (not bids or rng.random() < 0.5)) else bids
+                side.pop(rng.choice(list(side)))
+            else:                                      # a new limit order
+                is_bid = rng.random() < 0.5
+                kp = K.prefix(100 + rng.randrange(12), is_bid, pbase)
+                opp = asks if is_bid else bids
+                truly = bool(opp) and (min(opp) <= kp if is_bid else max(opp) >= kp)
+                skipped = kp < alo if is_bid else kp > bhi
+                assert not (skipped and truly)
+                vol = 1 + rng.randrange(3)
+                if not skipped:
+                    while vol and opp:                 # match loop: every reduction makes the bound exact
+                        best = min(opp) if is_bid else max(opp)
+                        if is_bid:
+                            alo = best
+                        else:
+                            bhi = best
+                        if not K.crosses(kp, best, is_bid):
+                            break
+                        t = min(vol, opp[best])
+                        vol -= t
+                        opp[best] -= t
+                        if opp[best] == 0:
+                            del opp[best]
+                    else:
+                        if vol and not opp:            # the reduction over an empty side returns its neutral element
+                            if is_bid:
+                                alo = K.DEAD
+                            else:
+                                bhi = 0
+                if vol:                                # rests: its side's bound covers it
+                    k = kp ^ (seq << 1)
+                    seq += 1
+                    if is_bid:
+                        bids[k] = vol
+                        bhi = max(bhi, k)
+                    else:
+                        asks[k] = vol
+                        alo = min(alo, k)
+            assert alo <= (min(asks) if asks else K.DEAD) and bhi >= (max(bids) if bids else 0)
