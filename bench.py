@@ -16,9 +16,11 @@ Books are independent, so each rank steps its own contiguous shard with NO data-
 total, 65 536 / N per GPU, seeds by global book index; `--scaling weak` keeps 65 536 books per GPU.
 
 Timing: W warm-up steps, barrier + synchronize, K timed steps, synchronize + barrier (max over ranks).  Right before the
-warm-up a SECOND env of the same shape is stepped for `--preheat-steps` steps (default 100; 0 = off): the GPU's clocks
-fall within milliseconds of idling and need ~15 ms of load to come back, which a short timed region (the driver's
-`--steps 20 --warmup 5` = 6 ms) would otherwise measure; the timed env sees its W + K steps only.
+warm-up the env's public `bk_warm` entry runs `--preheat-steps` scratch steps (default 100; 0 = off; reported as the
+top-level `preheat_steps`): the GPU's clocks fall within milliseconds of idling and need ~15 ms of load to come back,
+which a short timed region (the driver's `--steps 20 --warmup 5` = 6 ms) would otherwise measure.  bk_warm steps the
+env's own books with its own kernels and puts everything back (state, level-2 records, step counter; no history slot,
+no trade record): the simulated steps are exactly the W + K ones.
 
 Prints ONE JSON line (rank 0) incl. `roofline` (HIP-event kernel time vs. HBM peak) and, at
 N = 1, `cpu_baseline` (the CPU oracle = literal restatement of the reference algorithm, timed on
@@ -212,8 +214,8 @@ def main():
     ap.add_argument("--wave-parts", type=int, default=0, help="parts the wave pipeline cuts the batch in (0 = library default)")
     ap.add_argument("--profile-every", type=int, default=8, help="HIP-event-time every Nth step's kernels (0 = none)")
     ap.add_argument("--preheat-steps", type=int, default=100,
-                    help="steps of a second env of the same shape run right before the warm-up, so that the timed region "
-                         "starts at steady clocks (0 = none)")
+                    help="scratch steps of the library's bk_warm entry right before the warm-up (state restored afterwards), "
+                         "so that the timed region starts at steady clocks (0 = none)")
     ap.add_argument("--repeats", type=int, default=4, help="extra timed regions of --steps after the reported one (median in `runs`)")
     args = ap.parse_args()
 
@@ -289,16 +291,9 @@ def main():
 
     # Pre-heat: the GPU's clocks fall within milliseconds of idling and take ~15 ms of load to come back (k_agents_fsm, a pure
     # latency chain, runs 170 us per launch cold and 155 us warm: scripts/region_trace.sh), and the driver's command line
-    # (--warmup 5 = 1.7 ms of work after seconds of host-side set-up) would time the ramp.  A SECOND env of the same shape is
-    # stepped right before the warm-up; the timed env sees its W warm-up steps and K timed steps and nothing else.
+    # (--warmup 5 = 1.7 ms of work after seconds of host-side set-up) would time the ramp.  bk_warm (a public entry of the
+    # library, include/bourse_amd.h) steps THIS env's books with its own kernels and puts the state back.
     if args.preheat_steps > 0:
-        penv = bourse_amd.ManyBookEnv(B, SEED + 1, 0, TICK, STEP_SIZE, True, levels=levels, max_live_orders=min(n_agents, 512),
-                                      trade_capacity=64, history_capacity=0, book_offset=first_book, device=local_rank,
-                                      stream=stream, strict=False)
-        penv.set_agents(groups) if mixed else penv.set_random_agents(groups)
-        penv.set_pipeline(args.pipeline)
-        if args.wave_parts:
-            penv.set_wave_options(64, args.wave_parts)
         env.trade_counts(), env.order_counts()  # first calls allocate their staging buffers: not between warm-up and t0
         env.profile(args.profile_every), env.profile(False)  # ... the event pool and the events' calibration neither
         if dist is not None:  # ... and RCCL builds its communicator on the first collective (~20 ms): not there either
@@ -306,7 +301,7 @@ def main():
                 gather.all_gather()
             dist.barrier()
             torch.cuda.synchronize()
-        penv.run(args.preheat_steps, sync=False)
+        env.warm(args.preheat_steps)
     run_steps(args.warmup)
     torch.cuda.synchronize()
     tc0 = int(env.trade_counts().sum())
@@ -417,15 +412,15 @@ def main():
     out = {
         "metric": "book-steps/sec", "value": value, "unit": "book-steps/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": dt * 1e3 / args.steps, "higher_is_better": True, "scaling": args.scaling,
-        "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+        "vs_baseline": None, "dtype": "u32", "data": "synthetic", "preheat_steps": args.preheat_steps,
         "config": {
             "workload": f"{args.workload}: {books_total} books ({B}/GPU) x {n_agents} on-device agents "
                         f"({len(groups)} {'members: ' + '+'.join(g[0] for g in groups) if mixed else 'groups'}), {levels} levels/side, tick {TICK}, step_size {STEP_SIZE}, "
                         f"seed {SEED}+book",
             "books_total": books_total, "books_per_gpu": B, "ranks": world, "agents_per_book": n_agents, "levels": levels,
             "steps_per_launch": spl,
-            "preheat": (f"{args.preheat_steps} steps of a second env of the same shape right before the warm-up (clock ramp); "
-                        f"the timed env: {args.warmup} warm-up + {args.steps} timed steps") if args.preheat_steps > 0 else "none",
+            "preheat": (f"bk_warm({args.preheat_steps}): scratch steps of this env right before the warm-up, state restored (clock ramp); "
+                        f"simulated: {args.warmup} warm-up + {args.steps} timed steps") if args.preheat_steps > 0 else "none",
             "parallelism": f"{books_total} books in {world} contiguous shards ({args.scaling} scaling), no data-path "
                            f"collective, 64 B stats all-gather per launch" if world > 1 else "single GPU",
             "trades_per_book_step": tr_per_bs, "events_per_book_step": ev_per_bs,
@@ -471,6 +466,7 @@ def main():
     R["frac_node"] = R["achieved_node"] / R["peak_node"]
     R["traffic_source"] = pmc_src if traffic is not None else None
     if pipe in ("split", "wave_split") and parts > 1:
+        parts_set = env.split_parts()  # (restored below: BOURSE_AMD_SPLIT_PARTS / BOURSE_AMD_MIN_PART may have set them)
         env.set_split_parts(1, 64)
         if pipe == "wave_split":
             env.set_wave_options(64, 1)
@@ -480,7 +476,7 @@ def main():
         env.profile(False)
         ms1, n1 = env.profile_read_kind(2)
         env.profile_read()
-        env.set_split_parts(4, 4096)
+        env.set_split_parts(*parts_set)
         if pipe == "wave_split":
             env.set_wave_options(64, args.wave_parts)
         if n1:

@@ -134,6 +134,9 @@ SIGNATURES = {
     "bk_trade_vol": (_i32, [_vp, _u32, _p32]),
     "bk_steps_done": (_i32, [_vp, _p64]),
     "bk_book_flags": (_i32, [_vp, _p32]),
+    "bk_clear_flags": (_i32, [_vp, _u32]),
+    "bk_flags_summary": (_i32, [_vp, _p32, _p64]),
+    "bk_warm": (_i32, [_vp, _u64]),
     "bk_rng_state": (_i32, [_vp, _u32, _p64]),
     "bk_live_orders": (_i32, [_vp, _u32, _u32, _vp, _p32]),
     "bk_stats_compute": (_i32, [_vp, C.POINTER(Stats)]),
@@ -146,6 +149,7 @@ SIGNATURES = {
     "bk_get_pipeline": (_i32, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "bk_state_bytes_per_book": (_u64, [_vp]),
     "bk_set_split_parts": (_i32, [_vp, _i32, _u32]),
+    "bk_get_split_parts": (_i32, [_vp, C.POINTER(C.c_int), _p32]),
     "bk_set_wave_options": (_i32, [_vp, _u32, _i32]),
     "bk_pipeline_fallbacks": (_i32, [_vp, _p64]),
     "bk_order_counts": (_i32, [_vp, _p64]),

@@ -18,12 +18,35 @@ from .env import ManyBookEnv
 LEVELS = 10
 
 
-class _EnvBase:
+class _TradeArchive:
+    """The reference keeps every trade forever (``OrderBook.trades``, orderbook.rs:107); the device retains
+    ``trade_capacity`` records per book.  The one-book wrappers drain them into a host archive once half the capacity is
+    in use (the strict check of every step already reads the retained count), so a long run never reaches
+    BK_FLAG_TRADE_OVERFLOW unless a single step makes more than trade_capacity / 2 trades."""
+
+    def _init_trades(self, trade_capacity):
+        self._tr_cap = int(trade_capacity)
+        self._tr_archive = []
+
+    def _maybe_drain_trades(self):
+        if self._tr_cap and 2 * self._env.last_retained_trades >= self._tr_cap:
+            a = self._env.trades(0)
+            if len(a):
+                self._tr_archive.append(a)
+                self._env.clear_trades()
+
+    def _all_trades(self) -> np.ndarray:
+        cur = self._env.trades(0)
+        return np.concatenate(self._tr_archive + [cur]) if self._tr_archive else cur
+
+
+class _EnvBase(_TradeArchive):
     def __init__(self, seed, start_time, tick_size, step_size, trading=True, *, max_live_orders=512,
                  max_orders=1 << 16, trade_capacity=1 << 16, history_capacity=1 << 12, device=0):
         self._env = ManyBookEnv(1, seed, start_time, tick_size, step_size, trading, levels=LEVELS,
                                 max_live_orders=max_live_orders, max_orders=max_orders,
                                 trade_capacity=trade_capacity, history_capacity=history_capacity, device=device)
+        self._init_trades(trade_capacity)
         self._l2_cache = None
         # The reference keeps every step's record forever (Level2DataRecords, data.rs:26-56); the device keeps a ring
         # of history_capacity steps, drained into this host archive before it wraps.
@@ -40,6 +63,7 @@ class _EnvBase:
 
     def step(self):
         self._env.step()
+        self._maybe_drain_trades()
         self._l2_cache = None
         self._hist_pending += 1
         if self._hist_cap and self._hist_pending >= self._hist_cap:
@@ -69,7 +93,7 @@ class _EnvBase:
         # PyTrade tuples (rust/src/types.rs:4-15)
         return [
             (int(r["t"]), bool(r["side"]), int(r["price"]), int(r["vol"]), int(r["active_id"]), int(r["passive_id"]))
-            for r in self._env.trades(0, first=0)
+            for r in self._all_trades()
         ]
 
     def _history(self) -> np.ndarray:
@@ -172,7 +196,7 @@ class StepEnv(_EnvBase):
         return self._l2()
 
 
-class OrderBook:
+class OrderBook(_TradeArchive):
     """``bourse.core.OrderBook(start_time, tick_size, trading=True)`` — immediate-mode book
     (ref rust/src/order_book.rs:30-380) on the GPU: every call is one event processed at the book's current
     time (``Env::step`` with a one-event queue and step_size 0), so ``set_time`` is the caller's job exactly as in
@@ -185,18 +209,19 @@ class OrderBook:
         self._env = ManyBookEnv(1, 0, start_time, tick_size, 0, trading, levels=LEVELS,
                                 max_live_orders=max_live_orders, max_orders=max_orders,
                                 trade_capacity=trade_capacity, history_capacity=0, device=device)
+        self._init_trades(trade_capacity)
         self._trading = bool(trading)
         self._trade_vol0 = 0  # OrderBook.trade_vol is never reset by this class: base + volume of all trades
 
     def trade_vol(self):
         """Cumulative traded volume (``OrderBook::get_trade_vol``, orderbook.rs:314-316), wrapping u32."""
-        return (self._trade_vol0 + int(self._env.trades(0, first=0)["vol"].sum(dtype=np.uint64))) & 0xFFFFFFFF
+        return (self._trade_vol0 + int(self._all_trades()["vol"].sum(dtype=np.uint64))) & 0xFFFFFFFF
 
     def save_json_snapshot(self, path, pretty=False):
         """``OrderBook::save_json`` (orderbook.rs:811-819; rust/src/order_book.rs:364-380)."""
         import json
 
-        state = self._env.book_state(0, trading=self._trading, trade_vol=self.trade_vol())
+        state = self._env.book_state(0, trading=self._trading, trade_vol=self.trade_vol(), trades=self._all_trades())
         with open(path, "w") as f:
             if pretty:
                 json.dump(state, f, indent=2)
@@ -256,6 +281,7 @@ class OrderBook:
         """``create_and_place_order`` (ref orderbook.rs:411-421)."""
         oid = self._env.place_order(0, bid, vol, trader_id, price)
         self._env.step()
+        self._maybe_drain_trades()
         return oid
 
     def cancel_order(self, order_id):
@@ -265,11 +291,12 @@ class OrderBook:
     def modify_order(self, order_id, new_price=None, new_vol=None):
         self._env.modify_order(0, order_id, new_price, new_vol)
         self._env.step()
+        self._maybe_drain_trades()
 
     def get_trades(self):
         return [
             (int(r["t"]), bool(r["side"]), int(r["price"]), int(r["vol"]), int(r["active_id"]), int(r["passive_id"]))
-            for r in self._env.trades(0, first=0)
+            for r in self._all_trades()
         ]
 
     def get_orders(self):

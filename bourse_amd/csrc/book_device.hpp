@@ -1436,6 +1436,29 @@ __global__ void k_book_service(uint32_t* state, uint32_t stride, uint32_t n_book
     h[H_TRADE_BASE_HI] = h[H_TRADES_HI];
   } else if (op == 1) {
     h[H_TRADING] = value;
+  } else if (op == 2) {
+    h[H_FLAGS] &= ~value;  // bk_clear_flags
+  }
+}
+
+// OR of every book's sticky flags and the largest number of retained trade records: what a strict caller polls after a
+// step (two words instead of n_books flag words; the per-book array is only fetched when a new bit shows up)
+__global__ void k_flags_summary(const uint32_t* state, uint32_t stride, uint32_t n_books, uint32_t* out /* [2] */) {
+  const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t f = 0, r = 0;
+  if (b < n_books) {
+    const uint32_t* h = state + (size_t)b * stride;
+    f = h[H_FLAGS];
+    const uint64_t n = mk64(h[H_TRADES_LO], h[H_TRADES_HI]) - mk64(h[H_TRADE_BASE_LO], h[H_TRADE_BASE_HI]);
+    r = n > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)n;
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    f |= (uint32_t)__shfl_xor((int)f, o);
+    r = max(r, (uint32_t)__shfl_xor((int)r, o));
+  }
+  if ((threadIdx.x & 63) == 0 && (f | r)) {
+    if (f) atomicOr(&out[0], f);
+    atomicMax(&out[1], r);
   }
 }
 
@@ -1455,13 +1478,16 @@ __global__ void k_delay(uint32_t ticks) {
   while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(16);
 }
 
-// books whose sticky flags gained a bit of `mask` relative to the snapshot taken before a guarded launch
-__global__ void k_count_new_flags(const uint32_t* state, const uint32_t* snap, uint32_t stride, uint32_t n_books,
+// Guarded launches: the bits of `mask` were cleared in every book before the launch (k_book_service op 2, after the
+// snapshot was taken), so a bit set now was raised BY this launch - also in a book whose sticky bit was already set.
+// Counts those books and puts the earlier bits back.
+__global__ void k_count_new_flags(uint32_t* state, const uint32_t* snap, uint32_t stride, uint32_t n_books,
                                   uint32_t mask, uint32_t* count) {
   const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= n_books) return;
   const uint32_t now = state[(size_t)b * stride + H_FLAGS], was = snap[(size_t)b * stride + H_FLAGS];
-  if (now & ~was & mask) atomicAdd(count, 1u);
+  if (now & mask) atomicAdd(count, 1u);
+  if (was & mask) state[(size_t)b * stride + H_FLAGS] = now | (was & mask);
 }
 
 struct DevStats {  // == bk_stats

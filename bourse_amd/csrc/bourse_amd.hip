@@ -124,6 +124,8 @@ struct bk_env {
   // 4 wave_split (k_agents_wave + k_step_batch), 5 wave (k_run_wave: wave-parallel decode + events, persistent)
   int pipeline = 0;
   DevBuf<uint32_t> snap, snap_count;  // guarded launches (auto pipeline, AgentSets): state + L2 copy, new-flag counter
+  DevBuf<uint32_t> warm_snap;         // bk_warm: state + L2 copy of the scratch steps
+  bool warming = false;               // bk_warm's scratch steps: no history slots, no trade records
   uint64_t n_fallbacks = 0;           // guarded launches that were rolled back and redone on the fused kernel
   DevBuf<uint4> jump_tabs;      // k_agents_wave: T^256 (block jump) then T^(4 << b), b = 0..5 (lane offsets): 7 x 8 KB
   DevBuf<uint32_t> wcache;      // k_agents_wave: per-book lane states of the RNG block in progress
@@ -234,9 +236,9 @@ struct bk_env {
     a.step_hi = static_cast<uint32_t>(cfg.step_size >> 32);
     a.state_stride = stride;
     a.l2_width = W;
-    a.trade_cap = cfg.trade_capacity;
-    a.hist_cap = cfg.history_capacity;
-    a.hist_slot0 = cfg.history_capacity ? static_cast<uint32_t>(steps_done % cfg.history_capacity) : 0u;
+    a.trade_cap = warming ? 0u : cfg.trade_capacity;
+    a.hist_cap = warming ? 0u : cfg.history_capacity;
+    a.hist_slot0 = a.hist_cap ? static_cast<uint32_t>(steps_done % cfg.history_capacity) : 0u;
     a.step_prio = 0;
     a.n_agents_total = n_agents_total;
     a.log_cap = cfg.max_orders;
@@ -381,6 +383,23 @@ const std::vector<hipStream_t>& part_streams(int device) {
   auto it = pool.find(device);
   if (it != pool.end()) return it->second;
   std::vector<hipStream_t> cand, chosen;
+  // BOURSE_AMD_PART_STREAMS=N (1..8): take N fresh streams WITHOUT probing.  For launchers that start many ranks at once
+  // (one process per GPU: each rank would otherwise run its 8 x 300 us probe kernels at start-up, all at the same time,
+  // next to RCCL's communicator set-up), and for boxes where the host-clock probe is unreliable.  Default: probe.
+  if (const char* e = std::getenv("BOURSE_AMD_PART_STREAMS")) {
+    const int want = std::atoi(e);
+    if (want >= 1 && want <= 8) {
+      for (int k = 0; k < want; ++k) {
+        hipStream_t st = nullptr;
+        if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) break;
+        chosen.push_back(st);
+      }
+      (void)hipGetLastError();
+      if (getenv("BOURSE_AMD_VERBOSE"))
+        fprintf(stderr, "bourse_amd: device %d: %zu part streams taken unprobed (BOURSE_AMD_PART_STREAMS)\n", device, chosen.size());
+      return pool.emplace(device, std::move(chosen)).first->second;
+    }
+  }
   for (int k = 0; k < 8; ++k) {
     hipStream_t st = nullptr;
     if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) break;
@@ -412,6 +431,12 @@ const std::vector<hipStream_t>& part_streams(int device) {
   (void)hipGetLastError();
   if (getenv("BOURSE_AMD_VERBOSE"))
     fprintf(stderr, "bourse_amd: device %d: %zu of %zu candidate streams on hardware queues of their own\n", device,
+            chosen.size(), cand.size());
+  // fewer than four: the parts of a split launch share queues and run back to back (C3 220 -> 124 M book-steps/s when
+  // every part sat on one queue).  Results are unaffected; say so once instead of being silently slow.
+  if (chosen.size() < 4 && !cand.empty())
+    fprintf(stderr, "bourse_amd: warning: device %d: only %zu of %zu candidate streams run concurrently (busy GPU or serialised "
+            "kernels?): multi-part launches will overlap less; BOURSE_AMD_PART_STREAMS=4 skips the probe\n", device,
             chosen.size(), cand.size());
   return pool.emplace(device, std::move(chosen)).first->second;
 }
@@ -462,14 +487,16 @@ int launch_split(bk_env* env, const DevArgs& a0, uint64_t first_step, uint32_t n
   // small batches: one part on the caller's stream
   const int P = wave ? env->wave_split_parts() : env->parts();
   if (P > 1 && !env->ev_fork) {
-    HIPCHK(hipEventCreateWithFlags(&env->ev_fork, hipEventDisableTiming));
     const std::vector<hipStream_t>& ps = part_streams(env->cfg.device);
     if (ps.empty()) return fail(BK_HIP_ERROR, "could not create the parts' streams");
     for (int i = 0; i < bk_env::MAX_PARTS; ++i) {
       env->part_stream[i] = ps[static_cast<size_t>(i) % ps.size()];  // more parts than queues: they share
-      HIPCHK(hipEventCreateWithFlags(&env->ev_first[i], hipEventDisableTiming));
-      HIPCHK(hipEventCreateWithFlags(&env->ev_join[i], hipEventDisableTiming));
+      if (!env->ev_first[i]) HIPCHK(hipEventCreateWithFlags(&env->ev_first[i], hipEventDisableTiming));
+      if (!env->ev_join[i]) HIPCHK(hipEventCreateWithFlags(&env->ev_join[i], hipEventDisableTiming));
     }
+    // last: ev_fork doubles as "the parts' streams and events are set up" (a failure above leaves it unset, so the
+    // next bk_run tries again instead of launching on null streams)
+    HIPCHK(hipEventCreateWithFlags(&env->ev_fork, hipEventDisableTiming));
   }
   if (P > 1) {
     HIPCHK(hipEventRecord(env->ev_fork, env->stream));
@@ -723,13 +750,11 @@ void bk_env_destroy(bk_env* env) {
   for (hipEvent_t e : env->prof_pool) (void)hipEventDestroy(e);
   if (env->ev_stage) (void)hipHostFree(env->ev_stage);
   if (env->off_stage) (void)hipHostFree(env->off_stage);
-  if (env->ev_fork) {
-    (void)hipEventDestroy(env->ev_fork);
-    for (int i = 0; i < bk_env::MAX_PARTS; ++i) {
-      if (env->part_stream[i]) (void)hipStreamSynchronize(env->part_stream[i]);  // shared (part_streams): not destroyed
-      (void)hipEventDestroy(env->ev_first[i]);
-      (void)hipEventDestroy(env->ev_join[i]);
-    }
+  if (env->ev_fork) (void)hipEventDestroy(env->ev_fork);
+  for (int i = 0; i < bk_env::MAX_PARTS; ++i) {
+    if (env->part_stream[i]) (void)hipStreamSynchronize(env->part_stream[i]);  // shared (part_streams): not destroyed
+    if (env->ev_first[i]) (void)hipEventDestroy(env->ev_first[i]);
+    if (env->ev_join[i]) (void)hipEventDestroy(env->ev_join[i]);
   }
   delete env;
 }
@@ -855,8 +880,8 @@ int bk_submit_instructions_csr(bk_env* env, const uint64_t* book_offsets, const 
   };
   if (nt == 1)
     task(0);
-  else
-    env->host_pool().run(nt, task);
+  else if (!env->host_pool().run(nt, task))
+    return fail(BK_CAPACITY, "host pool: too many tasks");
   for (unsigned t = 0; t < nt; ++t) {  // the first failing range in book order decides (books after it may be queued too)
     if (rcs[t] != BK_OK) {
       if (n_done) *n_done = dones[t];
@@ -927,8 +952,8 @@ int bk_step(bk_env* env) {
   };
   if (nt == 1)
     task(0);
-  else
-    env->host_pool().run(nt, task);
+  else if (!env->host_pool().run(nt, task))
+    return fail(BK_CAPACITY, "host pool: too many tasks");
   for (unsigned t = 0; t < nt; ++t)  // the first offender in market order; nothing has been uploaded or cleared
     if (bad_market[t] != NM) return fail(BK_UNKNOWN_ORDER_ID, "No order with id " + std::to_string(bad_id[t]) + " exists");
   std::memcpy(env->off_stage, off.data(), (NM + 1) * sizeof(uint32_t));
@@ -1176,6 +1201,11 @@ int bk_run(bk_env* env, uint64_t n_steps) {
       }
       HIPCHK(hipMemcpyAsync(env->snap.p, env->state.p, sb * 4, hipMemcpyDeviceToDevice, env->stream));
       HIPCHK(hipMemcpyAsync(env->snap.p + sb, env->l2_last.p, lb * 4, hipMemcpyDeviceToDevice, env->stream));
+      // the sticky bit is cleared for the launch (the snapshot keeps it; k_count_new_flags puts it back): a book that
+      // had overflowed in an earlier launch is re-detected like any other
+      hipLaunchKernelGGL(k_book_service, dim3((env->cfg.n_books + 255) / 256), dim3(256), 0, env->stream, env->state.p,
+                         env->stride, env->cfg.n_books, 2, FLAG_POOL_OVERFLOW);
+      HIPCHK(hipGetLastError());
     }
     if (mlanes) {
       switch (env->R) {
@@ -1261,6 +1291,35 @@ int bk_run(bk_env* env, uint64_t n_steps) {
   }
   if (rc != BK_OK) return rc;
   env->steps_done += n_steps;
+  return BK_OK;
+}
+
+// Warm-up without side effects: n_steps of THIS env's own kernels (same agents, same pipeline, same streams) on its own
+// books, then everything put back - state blocks, level-2 records, step counter; the scratch steps write no history slot
+// and no trade record.  Why it exists: an MI355X drops its clocks within milliseconds of idling and needs ~15 ms of load
+// to come back, and the first launch of a pipeline also pays one-off set-up (the parts' streams, dynamic-LDS
+// attributes, the decode's lane-state cache); a latency-sensitive caller - a short bk_run after host-side work - calls
+// this first.  Asynchronous on the env's stream like bk_run (two device-to-device copies around the steps).
+int bk_warm(bk_env* env, uint64_t n_steps) {
+  if (!env) return fail(BK_INVALID_ARGUMENT, "null env");
+  if (n_steps == 0) return BK_OK;
+  if (int rc = use_device(env)) return rc;
+  const size_t sb = static_cast<size_t>(env->cfg.n_books) * env->stride, lb = static_cast<size_t>(env->cfg.n_books) * env->W;
+  if (!env->warm_snap.p) HIPCHK(env->warm_snap.alloc(sb + lb));
+  HIPCHK(hipMemcpyAsync(env->warm_snap.p, env->state.p, sb * 4, hipMemcpyDeviceToDevice, env->stream));
+  HIPCHK(hipMemcpyAsync(env->warm_snap.p + sb, env->l2_last.p, lb * 4, hipMemcpyDeviceToDevice, env->stream));
+  const uint64_t steps0 = env->steps_done, fb0 = env->n_fallbacks;
+  const bool flow0 = env->device_flow;
+  env->warming = true;
+  const int rc = bk_run(env, n_steps);
+  env->warming = false;
+  env->steps_done = steps0;
+  env->n_fallbacks = fb0;
+  env->device_flow = flow0;
+  env->ml_valid = false;  // the members' lists described the scratch steps' pool
+  if (rc != BK_OK) return rc;  // (bk_run fails before launching anything: the state is untouched)
+  HIPCHK(hipMemcpyAsync(env->state.p, env->warm_snap.p, sb * 4, hipMemcpyDeviceToDevice, env->stream));
+  HIPCHK(hipMemcpyAsync(env->l2_last.p, env->warm_snap.p + sb, lb * 4, hipMemcpyDeviceToDevice, env->stream));
   return BK_OK;
 }
 
@@ -1666,6 +1725,36 @@ int bk_book_flags(bk_env* env, uint32_t* out) {
   return BK_OK;
 }
 
+// Clear sticky flag bits of every book (the caller has seen and handled them: e.g. after draining the trade records that
+// overflowed, or after reporting a capacity error once)
+int bk_clear_flags(bk_env* env, uint32_t mask) {
+  if (!env) return fail(BK_INVALID_ARGUMENT, "null env");
+  if (int rc = use_device(env)) return rc;
+  const uint32_t B = env->cfg.n_books;
+  hipLaunchKernelGGL(k_book_service, dim3((B + 255) / 256), dim3(256), 0, env->stream, env->state.p, env->stride, B, 2, mask);
+  HIPCHK(hipGetLastError());
+  return BK_OK;
+}
+
+// What a strict caller polls after every step: the OR of all books' sticky flags and the largest number of trade
+// records any book retains (towards trade_capacity) - one small reduction + an 8-byte copy instead of n_books words.
+int bk_flags_summary(bk_env* env, uint32_t* flags_or, uint64_t* max_retained_trades) {
+  if (!env) return fail(BK_INVALID_ARGUMENT, "null env");
+  if (int rc = use_device(env)) return rc;
+  const uint32_t B = env->cfg.n_books;
+  if (!env->gather_buf.p) HIPCHK(env->gather_buf.alloc(B));
+  uint32_t* out = reinterpret_cast<uint32_t*>(env->gather_buf.p);
+  HIPCHK(hipMemsetAsync(out, 0, 8, env->stream));
+  hipLaunchKernelGGL(k_flags_summary, dim3((B + 255) / 256), dim3(256), 0, env->stream, env->state.p, env->stride, B, out);
+  HIPCHK(hipGetLastError());
+  uint32_t res[2] = {0, 0};
+  HIPCHK(hipMemcpyAsync(res, out, 8, hipMemcpyDeviceToHost, env->stream));
+  HIPCHK(hipStreamSynchronize(env->stream));
+  if (flags_or) *flags_or = res[0];
+  if (max_retained_trades) *max_retained_trades = res[1];
+  return BK_OK;
+}
+
 int bk_rng_state(bk_env* env, uint32_t book, uint64_t out_state[2]) {
   if (int rc = check_book(env, book)) return rc;
   if (!out_state) return fail(BK_INVALID_ARGUMENT, "null argument");
@@ -1859,6 +1948,13 @@ int bk_set_split_parts(bk_env* env, int n_parts, uint32_t min_part) {
   return BK_OK;
 }
 
+int bk_get_split_parts(bk_env* env, int* n_parts, uint32_t* min_part) {
+  if (!env) return fail(BK_INVALID_ARGUMENT, "null env");
+  if (n_parts) *n_parts = env->n_parts;
+  if (min_part) *min_part = env->min_part;
+  return BK_OK;
+}
+
 // orders created so far per book by the on-device agents (OrderBook::current_order_id, orderbook.rs:327-329)
 int bk_order_counts(bk_env* env, uint64_t* totals) {
   if (!env || !totals) return fail(BK_INVALID_ARGUMENT, "null argument");
@@ -1927,6 +2023,9 @@ int bk_checkpoint_load(bk_env* env, const void* in, uint64_t nbytes) {
   env->steps_done = h[1];
   env->hist_base = h[1];  // retained history/trade records restart at the restored step
   env->trading = h[6] ? 1u : 0u;  // the host mirror of the books' trading flag (H_TRADING travels in the state blocks)
+  // an image is only ever taken from an on-device-order-flow env: the restored books hold the agents' orders and ids, so
+  // host-driven orders (whose ids would restart at 0) are refused from here on, exactly as after a bk_run
+  if (env->n_mixed || !env->groups.empty() || h[1] > 0) env->device_flow = true;
   const uint32_t B = env->cfg.n_books;
   hipLaunchKernelGGL(k_book_service, dim3((B + 255) / 256), dim3(256), 0, env->stream, env->state.p, env->stride, B, 0,
                      0u);

@@ -28,10 +28,12 @@ class HostPool {
     for (auto& t : workers_) t.join();
   }
   unsigned threads() const { return static_cast<unsigned>(workers_.size()) + 1; }  // + the calling thread
-  // fn(task) for task in [0, n_tasks), n_tasks <= 65535; returns when every task has finished.  One run() at a time.
-  void run(unsigned n_tasks, const std::function<void(unsigned)>& fn) {
-    if (n_tasks == 0) return;
-    if (n_tasks > 0xFFFFu) n_tasks = 0xFFFFu;
+  // fn(task) for task in [0, n_tasks); returns true when every task has finished, false (nothing run) when n_tasks does
+  // not fit the 16-bit task counter of the control word.  One run() at a time.
+  static constexpr unsigned MAX_TASKS = 0xFFFFu;
+  bool run(unsigned n_tasks, const std::function<void(unsigned)>& fn) {
+    if (n_tasks == 0) return true;
+    if (n_tasks > MAX_TASKS) return false;
     {
       std::lock_guard<std::mutex> lk(mu_);
       fn_.store(&fn, std::memory_order_release);
@@ -47,6 +49,7 @@ class HostPool {
     std::unique_lock<std::mutex> lk(mu_);
     done_cv_.wait(lk, [this] { return pending_ == 0; });
     fn_ = nullptr;
+    return true;
   }
 
  private:

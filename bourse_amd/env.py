@@ -112,10 +112,16 @@ class ManyBookEnv:
                  history_capacity: int = 0, book_offset: int = 0, device: int = 0, stream: Optional[int] = None,
                  assets: int = 1, tick_sizes: Optional[Sequence[int]] = None, strict: bool = True):
         self._L = _lib.load()
-        # strict: step() and synchronous run() raise when a book reports a capacity flag.  The reference's book is
+        # strict: step() and synchronous run() raise when a book NEWLY reports a capacity flag.  The reference's book is
         # unbounded (crates/order_book/src/orderbook.rs:113-115); here pool / trade-record / order-log capacities are
         # fixed, and an overflow must never pass silently.  strict=False leaves the sticky flags to flags().
+        # The device flags stay sticky (flags() is the record); the exception reports each bit of each book ONCE: a
+        # caller that catches it can keep stepping (clear_flags() re-arms it).  BK_FLAG_STEP_SIZE is a warning, not an
+        # error: the reference's Env::step never checks the event count against step_size (env.rs:116-134).
         self.strict = bool(strict)
+        self._flags_seen = None      # per-book bits already reported
+        self._flags_seen_or = 0
+        self.last_retained_trades = 0  # largest number of records a book retained at the last strict check
         cfg = Config()
         cfg.assets = int(assets)
         self.assets = max(1, int(assets))
@@ -213,21 +219,48 @@ class ManyBookEnv:
         if self.strict:
             self.raise_on_flags()
 
+    def flags_summary(self) -> Tuple[int, int]:
+        """(OR of every book's sticky flags, largest number of trade records a book retains): one small reduction on
+        the device and an 8-byte copy - what the strict checks poll instead of the per-book array."""
+        f, r = C.c_uint32(0), C.c_uint64(0)
+        check(self._L.bk_flags_summary(self._h, C.byref(f), C.byref(r)))
+        return int(f.value), int(r.value)
+
+    def clear_flags(self, mask: int = 0xFFFFFFFF):
+        """Clear sticky flag bits on the device (and re-arm the strict check for them)."""
+        check(self._L.bk_clear_flags(self._h, int(mask) & 0xFFFFFFFF))
+        if self._flags_seen is not None:
+            self._flags_seen &= np.uint32(~int(mask) & 0xFFFFFFFF)
+            self._flags_seen_or = int(np.bitwise_or.reduce(self._flags_seen)) if len(self._flags_seen) else 0
+
     def raise_on_flags(self, mask: Optional[int] = None):
-        """Raise ``CapacityError`` (capacity bits) / ``BourseError`` (step-size, price-tick) if any book carries a
-        sticky flag in ``mask`` (default: every flag except UNKNOWN_ORDER, which ``step`` reports itself)."""
+        """Raise ``CapacityError`` (capacity bits) / ``BourseError`` (price-tick) for flag bits in ``mask`` that a book
+        carries and that have not been reported yet (default mask: every flag except UNKNOWN_ORDER, which ``step``
+        reports itself).  A new STEP_SIZE bit alone only warns: the reference tolerates such a step."""
+        import warnings
+
+        m = (~_lib.FLAG_UNKNOWN_ORDER & 0xFFFFFFFF) if mask is None else (int(mask) & 0xFFFFFFFF)
+        any_or, self.last_retained_trades = self.flags_summary()
+        if not (any_or & m):
+            return  # nothing set anywhere (the common case): the per-book array is not fetched
         f = self.flags()
-        m = np.uint32(~_lib.FLAG_UNKNOWN_ORDER & 0xFFFFFFFF if mask is None else mask)
-        bad = f & m
-        if not bad.any():
+        if self._flags_seen is None:
+            self._flags_seen = np.zeros_like(f)
+        new = f & np.uint32(m) & ~self._flags_seen
+        self._flags_seen |= f & np.uint32(m)
+        self._flags_seen_or = int(np.bitwise_or.reduce(self._flags_seen)) if len(f) else 0
+        if not new.any():
             return
-        bits = int(np.bitwise_or.reduce(bad))
-        books = np.nonzero(bad)[0]
+        bits = int(np.bitwise_or.reduce(new))
+        books = np.nonzero(new)[0]
         names = "; ".join(n for b, n in _lib.FLAG_NAMES.items() if bits & b)
         msg = f"{len(books)} book(s) flagged (first: book {int(books[0])}): {names}"
         if bits & _lib.CAPACITY_FLAGS:
             raise _lib.CapacityError(_lib.BK_CAPACITY, msg)
-        raise _lib.BourseError(_lib.BK_STEP_SIZE if bits & _lib.FLAG_STEP_SIZE else _lib.BK_INVALID, msg)
+        if bits & ~_lib.FLAG_STEP_SIZE:
+            raise _lib.BourseError(_lib.BK_INVALID, msg)
+        warnings.warn(f"bourse_amd: {msg} (price-time keys of that step may collide; the reference does not check this)",
+                      RuntimeWarning, stacklevel=3)
 
     def order_status(self, book: int, order_id: int) -> int:
         out = C.c_uint8(0)
@@ -255,7 +288,7 @@ class ManyBookEnv:
         return kp, kt
 
     # ------------------------------------------------------------ JSON snapshots (serde layout of the reference)
-    def book_state(self, book: int, trading: bool = True, trade_vol: Optional[int] = None) -> dict:
+    def book_state(self, book: int, trading: bool = True, trade_vol: Optional[int] = None, trades=None) -> dict:
         """The book as ``serde_json`` serialises ``OrderBook`` (orderbook.rs:93-112: t, tick_size, trade_vol, orders
         [{order, key}], trades, trading; ask_side / bid_side are skipped and rebuilt on load, :891-918)."""
         side = {1: "Bid", 0: "Ask"}
@@ -272,7 +305,7 @@ class ManyBookEnv:
             })
         trades = [{"t": int(r["t"]), "side": side[int(r["side"])], "price": int(r["price"]), "vol": int(r["vol"]),
                    "active_order_id": int(r["active_id"]), "passive_order_id": int(r["passive_id"])}
-                  for r in self.trades(book, first=0)]
+                  for r in (self.trades(book, first=0) if trades is None else trades)]
         tick = self.tick_sizes[book % self.assets] if hasattr(self, "tick_sizes") else self.tick_size
         return {"t": self.time(book), "tick_size": int(tick),
                 "trade_vol": self.trade_vol(book) if trade_vol is None else int(trade_vol), "orders": orders,
@@ -377,6 +410,12 @@ class ManyBookEnv:
             self.sync()
             if self.strict:
                 self.raise_on_flags()
+
+    def warm(self, n_steps: int = 100):
+        """``bk_warm``: ``n_steps`` of this env's own kernels on its own books, then everything is put back (state,
+        level-2 records, step counter; no history slot or trade record is written).  Brings the GPU's clocks up and
+        pays the pipeline's one-off set-up before a short, latency-sensitive ``run``."""
+        check(self._L.bk_warm(self._h, int(n_steps)))
 
     def sync(self):
         check(self._L.bk_env_sync(self._h))
@@ -614,6 +653,12 @@ class ManyBookEnv:
     def set_split_parts(self, n_parts: int, min_part: int = 4096):
         """Split pipeline: cut the batch in ``min(n_parts, books / min_part)`` parts on separate streams."""
         check(self._L.bk_set_split_parts(self._h, int(n_parts), int(min_part)))
+
+    def split_parts(self) -> Tuple[int, int]:
+        """(n_parts, min_part) as set (``bk_get_split_parts``); ``pipeline()`` reports the effective number of parts."""
+        a, b = C.c_int(0), C.c_uint32(0)
+        check(self._L.bk_get_split_parts(self._h, C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
 
     def pipeline_fallbacks(self) -> int:
         """bk_run launches the auto pipeline rolled back and redid on the fused kernel (AgentSets, pool at capacity)."""

@@ -205,6 +205,12 @@ int bk_set_market_agents(bk_env* env, uint32_t n_members, const bk_agent_desc* m
 /* sim_runner's loop body n_steps times for every book: agents.update(env, rng); env.step(rng)
  * (crates/step_sim/src/runner.rs:53-68), sharing each book's RNG between agents and shuffle. */
 int bk_run(bk_env* env, uint64_t n_steps);
+/* Warm-up without side effects: n_steps of this env's own kernels on its own books (same agents, pipeline and streams),
+ * then state blocks, level-2 records and the step counter are put back; the scratch steps write no history slot and no
+ * trade record.  For a short bk_run after host-side work: the GPU's clocks fall within milliseconds of idling and take
+ * ~15 ms of load to come back, and a pipeline's first launch pays one-off set-up.  Asynchronous like bk_run.  (No
+ * counterpart in the reference: a CPU has no launch set-up to hide.) */
+int bk_warm(bk_env* env, uint64_t n_steps);
 /* One env runs ONE of the two order flows: once bk_run has stepped it with on-device agents, bk_place_order /
  * bk_cancel_order / bk_modify_order / bk_submit_instructions* / bk_step return BK_INVALID_ARGUMENT (host order ids would
  * restart at 0 and collide with the agents'); and bk_run refuses an env that holds host-placed orders. */
@@ -250,6 +256,11 @@ int bk_set_time(bk_env* env, uint32_t book, uint64_t t);         /* OrderBook::s
 int bk_trade_vol(bk_env* env, uint32_t book, uint32_t* out);     /* OrderBook::get_trade_vol (live) */
 int bk_steps_done(bk_env* env, uint64_t* out);
 int bk_book_flags(bk_env* env, uint32_t* out /* [n_books] */);   /* sticky BK_FLAG_* bits */
+/* clear the bits of `mask` in every book's sticky flags (the caller has seen and handled them) */
+int bk_clear_flags(bk_env* env, uint32_t mask);
+/* what a strict caller polls after a step: OR of every book's flags, and the largest number of trade records any book
+ * retains (towards trade_capacity) - two words instead of n_books */
+int bk_flags_summary(bk_env* env, uint32_t* flags_or, uint64_t* max_retained_trades);
 int bk_rng_state(bk_env* env, uint32_t book, uint64_t out_state[2]);
 /* resting (Active) orders of one book in price-time priority per side: bids first, then asks */
 int bk_live_orders(bk_env* env, uint32_t book, uint32_t cap, bk_order* out, uint32_t* n_out);
@@ -275,7 +286,7 @@ int bk_profile_read_kind(bk_env* env, int kind, double* total_ms, uint64_t* n_la
 /* bk_run kernel pipeline: 0 auto, 1 fused (one wave per book, all phases), 2 split (RNG-serial phases one lane per
  * book + event phase one wave per book).  Results are identical; only speed differs. */
 int bk_set_pipeline(bk_env* env, int mode);
-/* modes 4 ("wave_split") and 5 ("wave"; auto for 1 024..24 576 RandomAgents books): the RNG-serial phases run one WAVE per
+/* modes 4 ("wave_split") and 5 ("wave"): the RNG-serial phases run one WAVE per
  * book with the book's xoroshiro stream decoded 64 draws at a time (jump-ahead lane states + ballot/prefix resolution) -
  * as a kernel of its own in front of the event kernel (4), or fused with the event phase in one persistent kernel that
  * keeps the book in registers across all steps of a bk_run (5).  bk_set_wave_options: look-ahead of the decode's vector
@@ -292,8 +303,9 @@ int bk_pipeline_fallbacks(bk_env* env, uint64_t* out);
 int bk_get_pipeline(bk_env* env, int* split, int* n_parts);
 uint64_t bk_state_bytes_per_book(const bk_env* env);
 /* split-pipeline geometry: the batch is cut in min(n_parts, books / min_part) contiguous parts, each on its own HIP
- * stream (defaults 3 and 4096; n_parts in 1..8, min_part >= 64).  Results never depend on it. */
+ * stream (defaults 4 - one per hardware queue - and 4096; n_parts in 1..8, min_part >= 64).  Results never depend on it. */
 int bk_set_split_parts(bk_env* env, int n_parts, uint32_t min_part);
+int bk_get_split_parts(bk_env* env, int* n_parts, uint32_t* min_part); /* the two settings as stored */
 /* orders created so far in every book by the on-device agents: OrderBook::current_order_id / orders.len()
  * (crates/order_book/src/orderbook.rs:327-329), totals[n_books] */
 int bk_order_counts(bk_env* env, uint64_t* totals /* [n_books] */);

@@ -209,10 +209,17 @@ def test_trade_capacity_overflow_is_flagged_not_silent(bk, oracle):
         got, exp = env.trades(b, first=0, n=8), ref.book(b).trades_array()[:8]
         for f in got.dtype.names:
             assert np.array_equal(got[f], exp[f]), (b, f)
-    env.strict = False  # the flag is sticky: a strict env would raise again
+    # the device flag is sticky (the record), but the strict check reports a book's bit ONCE: the env stays usable
     env.run(5)  # the L2 history is a ring of the last 30 steps: stepping on is fine ...
+    assert (env.flags() & 2).all()
+    env.clear_trades()
+    env.clear_flags(2)  # handled: cleared on the device, and the strict check is armed again
+    assert not env.flags().any()
+    with pytest.raises(bk.CapacityError, match="TRADE_OVERFLOW"):
+        env.run(10)
+    env.run(1)
     first, n = env.history_len()
-    assert (first, n) == (5, 30)
+    assert (first, n) == (16, 30)
     with pytest.raises(bk.BourseError):
         env.history(first_step=0, n_steps=3)  # ... reading a step that was overwritten is an error, never stale data
 
@@ -1641,19 +1648,20 @@ def test_market_event_queue_overflow_is_flagged_not_silent(bk):
 
 # ------------------------------------------------------------------- every BASELINE config at its stated size
 def _full_size_vs_oracle(bk, oracle, B, levels, T, groups=None, members=None, pool=None, trade_cap=None, pipelines=("auto",),
-                         allow_flags=0, rng_stride=61, sample_books=None):
+                         allow_flags=0, rng_stride=61, sample_books=None, book_offset=0):
     """One BASELINE configuration at its FULL size: every book's level-2 record of every step, every book's trade count,
     sampled RNG states and sampled trade streams against the oracle (all host threads).  The steps are cut into one
     launch per entry of `pipelines` (the pipelines share the device state)."""
     n_agents = sum(g[0] for g in groups) if groups else sum(m[2] for m in members)
     env = bk.ManyBookEnv(B, 101, 0, 2, 100_000, levels=levels, max_live_orders=pool or min(n_agents, 512),
-                         trade_capacity=trade_cap or n_agents * T, history_capacity=T, strict=False)
+                         trade_capacity=trade_cap or n_agents * T, history_capacity=T, strict=False, book_offset=book_offset)
+    # (a shard's book b is the job's book book_offset + b: seeded 101 + book_offset + b, runner.rs:53)
     if groups:
         env.set_random_agents(groups)
-        ref = oracle.ManyBooks(B, 101, 0, 2, 100_000, True, levels, groups)
+        ref = oracle.ManyBooks(B, 101 + book_offset, 0, 2, 100_000, True, levels, groups)
     else:
         env.set_agents(members)
-        ref = oracle.ManyBooks(B, 101, 0, 2, 100_000, True, levels, members=members)
+        ref = oracle.ManyBooks(B, 101 + book_offset, 0, 2, 100_000, True, levels, members=members)
     cuts = [T // len(pipelines)] * len(pipelines)
     cuts[-1] += T - sum(cuts)
     used = []
@@ -1684,6 +1692,23 @@ def test_full_size_c2_exact_parity_vs_oracle(bk, oracle):
     """BASELINE configs[1]: 4 096 books x 64 RandomAgents x 16 levels, at its size, on the pipeline bk_run
     picks by itself and on the other ones."""
     _full_size_vs_oracle(bk, oracle, 4096, 16, 18, groups=C2_GROUPS, pipelines=("auto", "split", "fused"))
+
+
+@pytest.mark.parametrize("n_gpus,T", [(8, 12), (4, 2), (2, 2)])
+def test_full_size_c4_shard_as_written_exact_parity_vs_oracle(bk, oracle, n_gpus, T):
+    """BASELINE configs[3] as ONE RANK runs it: the LAST shard of 65 536 books x 128 agents x 32 levels cut
+    over 8 / 4 / 2 GPUs (a non-zero book_offset), on the pipeline bk_run picks by itself at that shard size - every
+    book's level-2 history and trade count, strided RNG states and four trade streams against the oracle seeded by
+    GLOBAL book index (independent books: ref crates/step_sim/src/runner.rs:46-69)."""
+    B = 65536 // n_gpus
+    used = _full_size_vs_oracle(bk, oracle, B, 32, T, groups=C3_GROUPS, pipelines=("auto",), book_offset=(n_gpus - 1) * B,
+                                rng_stride=53)
+    assert used[0] == C4_AUTO_PIPELINE[B], used
+
+
+# the auto rule at the C4 shard sizes (bourse_amd.hip bk_get_pipeline); the test above pins it so that a change of the
+# thresholds is a visible decision
+C4_AUTO_PIPELINE = {8192: ("wave_split", 3), 16384: ("wave_split", 3), 32768: ("split", 4)}
 
 
 def test_full_size_c5_standin_exact_parity_vs_oracle(bk, oracle):
@@ -1717,6 +1742,90 @@ def test_strict_env_raises_on_pool_overflow_in_step(bk):
         lax.place_order(0, True, 1, 0, 10 + i)
     lax.step()                                   # strict=False: the sticky flag is the report
     assert lax.flags()[0] & 1
+
+
+def test_strict_env_reports_a_flag_once_and_step_size_only_warns(bk):
+    """ADVICE r2: sticky flags must not make every later step() raise, and the reference's Env::step (env.rs:116-134)
+    never checks the event count against step_size - BK_FLAG_STEP_SIZE is a warning."""
+    env = bk.ManyBookEnv(2, 1, 0, 1, 1000, levels=10, max_live_orders=64, max_orders=256, trade_capacity=64, history_capacity=4)
+    for i in range(64):
+        env.place_order(0, True, 1, 0, 10 + i)
+    env.step()
+    env.place_order(0, True, 1, 0, 5)
+    with pytest.raises(bk.CapacityError, match="POOL_OVERFLOW"):
+        env.step()
+    env.place_order(1, True, 1, 0, 7)
+    env.step()                                   # book 0's bit was reported: stepping goes on
+    assert env.flags()[0] & 1 and not env.flags()[1]
+    assert env.flags_summary()[0] == 1
+    tiny = bk.ManyBookEnv(1, 1, 0, 1, 2, levels=10, max_live_orders=64, max_orders=64, trade_capacity=64)
+    for i in range(3):
+        tiny.place_order(0, True, 1, 0, 10 + i)
+    with pytest.warns(RuntimeWarning, match="STEP_SIZE"):
+        tiny.step()                              # 3 events >= step_size 2: flagged, warned, not raised
+    assert tiny.flags()[0] == 4
+    assert int(tiny.level2()[0][4]) == 3
+
+
+def test_step_env_trades_outlive_the_device_trade_buffer(bk, oracle):
+    """core.StepEnv drains the trade records into a host archive (like the level-2 history) before the
+    device buffer fills: a long run returns EVERY trade, as the reference's unbounded Vec<Trade> does."""
+    env = bk.core.StepEnv(7, 0, 1, 1000, trade_capacity=64, history_capacity=8)
+    ref = oracle.StepEnv(7, 0, 1, 1000)
+    n = 0
+    for s in range(40):
+        for e in (env, ref):
+            e.place_order(True, 5, 1, price=100)
+            e.place_order(False, 5, 2, price=100)
+            e.place_order(True, 3, 3, price=101)
+            e.place_order(False, 3, 4, price=99)
+        env.step()
+        ref.step()
+    got, want = env.get_trades(), ref.get_trades()
+    assert len(want) > 64 and got == want
+    assert not (env._env.flags() & 2).any()
+
+
+def test_bk_warm_leaves_no_trace(bk, oracle):
+    """bk_warm: scratch steps of the env's own kernels; state, level-2 records, history, trades and the step counter are
+    as if it had never run - before the first step and between launches, on every RandomAgents pipeline and an AgentSet."""
+    for pipeline in ("auto", "split", "wave_split", "fused"):
+        env = bk.ManyBookEnv(192, 101, 0, 2, 100_000, levels=32, max_live_orders=128, trade_capacity=128 * 12, history_capacity=12)
+        env.set_random_agents(C3_GROUPS)
+        env.set_pipeline(pipeline)
+        env.warm(7)
+        env.run(5)
+        env.warm(3)
+        env.run(7)
+        ref = oracle.ManyBooks(192, 101, 0, 2, 100_000, True, 32, C3_GROUPS)
+        ref.run(12, 4)
+        assert env.history_len() == (0, 12)
+        assert np.array_equal(env.history(), ref.history()), pipeline
+        assert np.array_equal(env.trade_counts(), ref.trade_counts())
+        assert not env.flags().any()
+        for b in (0, 191):
+            g, e = env.trades(b, first=0), ref.book(b).trades_array()
+            for f in g.dtype.names:
+                assert np.array_equal(g[f], e[f]), (pipeline, b, f)
+            assert env.rng_state(b) == tuple(int(x) for x in ref.rng_states()[b])
+        env.close()
+
+
+def test_checkpoint_restore_marks_the_env_as_on_device_flow(bk):
+    """a fresh env restored from an agents' checkpoint must refuse host-driven orders (their ids would restart
+    at 0 and collide with the agents')."""
+    a = bk.ManyBookEnv(4, 1, 0, 2, 1000, levels=8, max_live_orders=64, max_orders=64, trade_capacity=1024, history_capacity=4)
+    a.set_random_agents(C2_GROUPS)
+    a.run(3)
+    img = a.checkpoint()
+    b = bk.ManyBookEnv(4, 1, 0, 2, 1000, levels=8, max_live_orders=64, max_orders=64, trade_capacity=1024, history_capacity=4)
+    b.set_random_agents(C2_GROUPS)
+    b.restore(img)
+    with pytest.raises(bk.BourseError, match="on-device agents"):
+        b.place_order(0, True, 1, 0, 10)
+    b.run(2)
+    a.run(2)
+    assert np.array_equal(a.level2(), b.level2())
 
 
 def test_immediate_mode_order_book_flags_stay_clear(bk):
