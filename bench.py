@@ -318,7 +318,8 @@ def main():
     dt = time.perf_counter() - t0
     env.profile(False)
     kind0 = "k_run_mixed" if mixed else ("k_run_wave" if pipe == "wave" else "k_run_random")
-    kind1 = "k_agents_mixed_lanes" if mixed else ("k_agents_wave" if pipe == "wave_split" else "k_agents_fsm")
+    kind1 = ("k_agents_mixed_wave" if pipe == "wave_split" else "k_agents_mixed_lanes") if mixed else (
+        "k_agents_wave" if pipe == "wave_split" else "k_agents_fsm")
     per_kind = {k: env.profile_read_kind(i) for i, k in enumerate((kind0, kind1, "k_step_batch", "k_step_events"))}
     env.profile_read()
     if dist is not None:
@@ -355,10 +356,15 @@ def main():
         # lane-per-book members' update: RNG + live-mask line + touches in; the members' lists in and out (2-byte slots,
         # about one entry per resting order ~ events), 16 B per new order into the pool, the shuffled event list out
         "k_agents_mixed_lanes": 192.0 + 4.0 * ev_per_bs + 16.0 * new_per_bs + 2.0 * ev_per_bs,
+        # wave-per-book members' update: header line + lane-state record in and out (as k_agents_wave, ~6 block-start spills
+        # for ~1 500 draws), the members' lists in and out (2-byte slots, about one entry per resting order), 16 B per new
+        # order into the pool, the step batch out
+        "k_agents_mixed_wave": 256.0 + 1280.0 + 1280.0 + 6.0 * 1024.0 + 256.0 + 4.0 * ev_per_bs + 16.0 * new_per_bs + 256.0 + 2.0 * ev_per_bs,
         "k_step_batch": 2.0 * S + 64.0 + 2.0 * ev_per_bs + 8.0 * new_per_bs + W4 + 32.0 * tr_per_bs,
         "k_step_events": 2.0 * S + 2.0 * W4 + 20.0 * ev_per_bs + 32.0 * tr_per_bs,
     }
     bs_per_launch = {kind0: B * spl, "k_agents_fsm": B / parts, "k_agents_wave": B / parts, "k_agents_mixed_lanes": B / parts,
+                     "k_agents_mixed_wave": B / parts,
                      "k_step_batch": B / parts,
                      "k_step_events": B}
     # PMC figures (HBM traffic, instruction counts) cannot be collected inside this process: they are rocprofv3 --pmc

@@ -29,6 +29,7 @@
 #include "host_pool.hpp"
 #include "mixed_agents.hpp"
 #include "wave_agents.hpp"
+#include "wave_mixed.hpp"
 
 using namespace bkd;
 
@@ -65,6 +66,9 @@ uint64_t fnv1a(const void* p, size_t n, uint64_t h = 1469598103934665603ull) {
 // batch sizes from which bk_run's auto mode takes the split pipeline (measured crossovers: scripts/size_sweep.py,
 // scripts/parts_size_sweep.py, scripts/c5m_sweep.sh)
 constexpr uint32_t RANDOM_SPLIT_MIN_BOOKS = 8192, MIXED_SPLIT_MIN_BOOKS = 4096;
+// AgentSets of Noise / Momentum members on independent books: from this many books the members' update runs one WAVE per
+// book with the stream decoded 64 draws at a time (k_agents_mixed_wave, wave_mixed.hpp) in front of the event kernel
+constexpr uint32_t MIXED_WAVE_MIN_BOOKS = 512;
 // RandomAgents batches of up to WAVE_MAX_BOOKS books take the wave-parallel RNG decode: fused with the event phase in
 // one persistent kernel (k_run_wave) below WAVE_FUSED_MAX_BOOKS, as k_agents_wave in front of k_step_batch (three parts
 // whose kernels overlap) from there; above WAVE_MAX_BOOKS the lane-per-book k_agents_fsm costs far fewer issue slots per
@@ -133,6 +137,16 @@ struct bk_env {
   uint32_t stagger_us = ~0u;    // parts of a split launch start i x stagger_us apart; ~0 = default rule, 0 = by events
   int wave_parts = 0;           // 0 = as the lane split (n_parts / min_part)
   bool wave_ok() const { return !n_mixed && M == 1 && !groups.empty(); }  // RandomAgents on independent books
+  // AgentSets of Noise / Momentum members only, independent books: wave-parallel decode of the members' update
+  bool mixed_random_member = false;
+  bool pool_cyclic = false;    // the wave-per-book members' lists (wl_list) describe the pools as of steps_done
+  DevBuf<uint16_t> wl_list;    // [n_books][MAX_MEMBERS][pool]: k_agents_mixed_wave's lists, book-major
+  DevBuf<uint32_t> wl_len;
+  bool mw_attr_set = false;
+  bool use_mixed_wave() const {
+    return n_mixed && M == 1 && !mixed_random_member &&
+           (pipeline == 4 || (pipeline == 0 && cfg.n_books >= MIXED_WAVE_MIN_BOOKS));
+  }
   bool use_wave() const {        // split form: k_agents_wave + k_step_batch
     return wave_ok() && (pipeline == 4 || (pipeline == 0 && cfg.n_books >= WAVE_FUSED_MAX_BOOKS && cfg.n_books <= WAVE_MAX_BOOKS));
   }
@@ -331,6 +345,7 @@ int launch_mixed(bk_env* env, const DevArgs& a, uint64_t first_step, uint32_t n_
   env->prof_now = env->profile > 0;
   ProfScope ps(env, 0);
   const MixedArgs ma = env->margs();
+  env->pool_cyclic = false;  // k_run_mixed allocates the lowest free slot
   hipLaunchKernelGGL(k_run_mixed<R>, dim3(blocks), dim3(256), 0, env->stream, a, ma, first_step, n_steps);
   HIPCHK(hipGetLastError());
   return BK_OK;
@@ -477,11 +492,31 @@ int launch_split(bk_env* env, const DevArgs& a0, uint64_t first_step, uint32_t n
   } else if (MIXED == 1) {
     env->ml_valid = false;
   }
+  if (MIXED == 1 || MIXED == 2) env->pool_cyclic = false;  // these allocate the lowest free slot
   const MixedLists ml = env->lists();
-  const bool wave = MIXED == 0 && env->use_wave();
+  const bool wave = (MIXED == 0 && env->use_wave()) || MIXED == 3;
   WaveArgs wva{};
   if (wave)
     if (int rc = wave_args(env, &wva)) return rc;
+  if (MIXED == 3) {
+    if (!env->mw_attr_set) {  // > 64 KB of dynamic LDS at R = 8 (160 KB per workgroup on MI355X); per device
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_agents_mixed_wave<R>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 static_cast<int>(mixed_wave_lds_bytes(R))));
+      env->mw_attr_set = true;
+    }
+    if (!env->wl_list.p) {
+      HIPCHK(env->wl_list.alloc(static_cast<size_t>(env->cfg.n_books) * MAX_MEMBERS * R * 64));
+      HIPCHK(env->wl_len.alloc(static_cast<size_t>(env->cfg.n_books) * MAX_MEMBERS));
+      env->pool_cyclic = false;
+    }
+    if (!env->pool_cyclic) {  // another pipeline (or a restore / a fresh env) changed the pools: lists from the owner tags
+      hipLaunchKernelGGL(k_wave_lists_rebuild<R>, dim3((env->cfg.n_books + 3) / 4), dim3(256), 0, env->stream, a0, ma,
+                         WaveLists{env->wl_list.p, env->wl_len.p, static_cast<uint32_t>(R) * 64u});
+      HIPCHK(hipGetLastError());
+      env->pool_cyclic = true;
+    }
+    env->ml_valid = false;
+  }
   const uint32_t M = env->M;
   const uint32_t B = env->cfg.n_books / M;  // units the parts are cut in: books, or markets of M books
   // small batches: one part on the caller's stream
@@ -524,7 +559,11 @@ int launch_split(bk_env* env, const DevArgs& a0, uint64_t first_step, uint32_t n
           HIPCHK(hipStreamWaitEvent(st, env->ev_first[i - 1], 0));
       }
       const uint64_t step_no = first_step + s;
-      if (MIXED == 2 && M > 1)
+      if (MIXED == 3)
+        launch_timed(env, 1, &k_agents_mixed_wave<R>, dim3((nb + MW_WPB - 1) / MW_WPB), dim3(64 * MW_WPB),
+                     static_cast<uint32_t>(mixed_wave_lds_bytes(R)), st, a, ma, wva,
+                     WaveLists{env->wl_list.p, env->wl_len.p, static_cast<uint32_t>(R) * 64u});
+      else if (MIXED == 2 && M > 1)
         launch_timed(env, 1, &k_agents_mixed_lanes<R, true>, dim3((nb + 63) / 64), dim3(64), mixed_lanes_lds_bytes(R, true), st, a,
                      ma, ml);
       else if (MIXED == 2)
@@ -538,7 +577,7 @@ int launch_split(bk_env* env, const DevArgs& a0, uint64_t first_step, uint32_t n
         launch_timed(env, 1, &k_agents_fsm<R>, dim3((nb + 63) / 64), dim3(64), fsm_lds, st, a);
       if (P > 1 && s == 0) HIPCHK(hipEventRecord(env->ev_first[i], st));
       // the lane-per-book members' update reads the touches from the latest level-2 record: keep it current
-      const uint32_t write_last = (s + 1 == n_steps || a.hist_cap == 0 || MIXED == 2) ? 1u : 0u;
+      const uint32_t write_last = (s + 1 == n_steps || a.hist_cap == 0 || MIXED >= 2) ? 1u : 0u;
       if (MIXED && M > 1)
         launch_timed(env, 2, &k_step_batch<R, true, true>, dim3(nb * M), dim3(64), 0u, st, a, step_no, write_last);
       else if (MIXED)
@@ -1156,6 +1195,9 @@ static int set_agents_impl(bk_env* env, uint32_t n_members, const bk_agent_desc*
   HIPCHK(hipMemcpy(env->mixed_descs.p, ds.data(), ds.size() * sizeof(MixedDesc), hipMemcpyHostToDevice));
   env->n_mixed = n_members;
   env->n_fixed = fixed;
+  env->mixed_random_member = false;
+  for (uint32_t i = 0; i < n_members; ++i) env->mixed_random_member = env->mixed_random_member || members[i].type == BK_AGENT_RANDOM;
+  env->pool_cyclic = false;
   for (uint32_t i = 0; i < MAX_MEMBERS; ++i) env->member_asset[i] = (assets && i < n_members) ? assets[i] : 0u;
   for (uint32_t as = 0; as < MAX_ASSETS; ++as) env->n_fixed_a[as] = fixed_a[as];
   env->ml_valid = false;
@@ -1192,6 +1234,17 @@ int bk_run(bk_env* env, uint64_t n_steps) {
     // if the launch newly raised BK_FLAG_POOL_OVERFLOW on any book it is rolled back and redone on the fused kernel
     // (same history slots, same trade-record positions: nothing of the first attempt survives).  Costs one device-to-
     // device copy and one host sync per bk_run; a pipeline requested explicitly runs unguarded.
+    if (env->use_mixed_wave()) {  // wave-parallel decode of the members' update + the event kernel, in parts
+      switch (env->R) {
+        case 1: rc = launch_split<1, 3>(env, a, env->steps_done, ns); break;
+        case 2: rc = launch_split<2, 3>(env, a, env->steps_done, ns); break;
+        case 4: rc = launch_split<4, 3>(env, a, env->steps_done, ns); break;
+        default: rc = launch_split<8, 3>(env, a, env->steps_done, ns); break;
+      }
+      if (rc != BK_OK) return rc;
+      env->steps_done += n_steps;
+      return BK_OK;
+    }
     const bool guarded = mlanes && env->pipeline == 0 && env->M == 1;
     if (guarded) {
       const size_t sb = static_cast<size_t>(env->cfg.n_books) * env->stride, lb = static_cast<size_t>(env->cfg.n_books) * env->W;
@@ -1309,13 +1362,15 @@ int bk_warm(bk_env* env, uint64_t n_steps) {
   HIPCHK(hipMemcpyAsync(env->warm_snap.p, env->state.p, sb * 4, hipMemcpyDeviceToDevice, env->stream));
   HIPCHK(hipMemcpyAsync(env->warm_snap.p + sb, env->l2_last.p, lb * 4, hipMemcpyDeviceToDevice, env->stream));
   const uint64_t steps0 = env->steps_done, fb0 = env->n_fallbacks;
-  const bool flow0 = env->device_flow;
+  const bool flow0 = env->device_flow, cyc0 = env->pool_cyclic;
   env->warming = true;
   const int rc = bk_run(env, n_steps);
   env->warming = false;
   env->steps_done = steps0;
   env->n_fallbacks = fb0;
   env->device_flow = flow0;
+  (void)cyc0;
+  env->pool_cyclic = false;  // the wave-per-book lists described the scratch steps' pools
   env->ml_valid = false;  // the members' lists described the scratch steps' pool
   if (rc != BK_OK) return rc;  // (bk_run fails before launching anything: the state is untouched)
   HIPCHK(hipMemcpyAsync(env->state.p, env->warm_snap.p, sb * 4, hipMemcpyDeviceToDevice, env->stream));
@@ -1679,6 +1734,7 @@ int bk_load_book(bk_env* env, uint32_t book, uint64_t t, uint32_t trade_vol, uin
     HIPCHK(hipMemcpy(env->trades.p + static_cast<size_t>(book) * env->cfg.trade_capacity, tr.data(),
                      n_trades * sizeof(DevTrade), hipMemcpyHostToDevice));
   env->ml_valid = false;
+  env->pool_cyclic = false;
   bh.n_uploaded = n_orders;
   bh.log_fresh = false;
   bh.time_offset = t - (env->cfg.start_time + env->steps_done * env->cfg.step_size);
@@ -1902,7 +1958,7 @@ int bk_get_pipeline(bk_env* env, int* split, int* n_parts) {
     if (n_parts) *n_parts = 1;
     return BK_OK;
   }
-  const bool wv = env->use_wave();
+  const bool wv = env->use_wave() || env->use_mixed_wave();
   const bool sp = wv || (env->pipeline >= 2 && env->pipeline != 5) || env->M > 1 ||
                   (env->pipeline == 0 && (env->n_mixed ? env->cfg.n_books >= MIXED_SPLIT_MIN_BOOKS
                                                        : env->cfg.n_books >= RANDOM_SPLIT_MIN_BOOKS && !env->groups.empty()));
@@ -2020,6 +2076,7 @@ int bk_checkpoint_load(bk_env* env, const void* in, uint64_t nbytes) {
   HIPCHK(hipMemcpy(env->l2_last.p, reinterpret_cast<const char*>(h + CKPT_HDR) + sb,
                    static_cast<size_t>(env->cfg.n_books) * env->W * 4, hipMemcpyHostToDevice));
   env->ml_valid = false;
+  env->pool_cyclic = false;
   env->steps_done = h[1];
   env->hist_base = h[1];  // retained history/trade records restart at the restored step
   env->trading = h[6] ? 1u : 0u;  // the host mirror of the books' trading flag (H_TRADING travels in the state blocks)

@@ -663,7 +663,8 @@ def _compare_members(bk, oracle, n_books, members, levels, n_steps, tick=1, step
     for i, c in enumerate(chunks or [n_steps]):
         # fused = k_run_mixed; split = k_agents_mixed_lanes + k_step_batch per step; split_wave = k_agents_mixed + k_step_batch;
     # "mixed" cycles through the three between launches (they share the device state; the lane kernel's lists are rebuilt)
-        env.set_pipeline(("fused", "split", "split_wave")[i % 3] if pipeline == "mixed" else pipeline)
+        # wave_split = k_agents_mixed_wave (wave-parallel decode of the members' streams) + k_step_batch
+        env.set_pipeline(("fused", "wave_split", "split", "split_wave")[i % 4] if pipeline == "mixed" else pipeline)
         env.run(c)
     ref = oracle.ManyBooks(n_books, seed, 0, tick, step_size, True, levels, members=members)
     ref.run(n_steps, 2)
@@ -690,7 +691,7 @@ def _compare_members(bk, oracle, n_books, members, levels, n_steps, tick=1, step
     return hist
 
 
-@pytest.mark.parametrize("pipeline", ["fused", "split", "split_wave"])
+@pytest.mark.parametrize("pipeline", ["fused", "split", "split_wave", "wave_split"])
 def test_noise_agents_on_device(bk, oracle, pipeline):
     _compare_members(bk, oracle, 24, [("noise", 0, 20, NOISE_P)], levels=10, n_steps=80, pipeline=pipeline)
     _compare_members(bk, oracle, 5, [("noise", 3, 50, dict(NOISE_P, p_limit=0.6, p_market=0.1, p_cancel=0.3, price_dist_sigma=2.5,
@@ -706,7 +707,10 @@ def test_momentum_and_noise_doc_example_on_device(bk, oracle):
     c = _compare_members(bk, oracle, 16, members, levels=10, n_steps=50, pipeline="split")
     d = _compare_members(bk, oracle, 16, members, levels=10, n_steps=50, chunks=[7, 1, 20, 3, 9, 10], pipeline="mixed")
     e = _compare_members(bk, oracle, 16, members, levels=10, n_steps=50, pipeline="split_wave")
+    f = _compare_members(bk, oracle, 16, members, levels=10, n_steps=50, pipeline="wave_split")
+    g = _compare_members(bk, oracle, 16, members, levels=10, n_steps=50, chunks=[7, 1, 42], pipeline="wave_split")
     assert np.array_equal(a, b) and np.array_equal(a, c) and np.array_equal(a, d) and np.array_equal(a, e)
+    assert np.array_equal(a, f) and np.array_equal(a, g)
 
 
 def test_mixed_random_noise_momentum_set_on_device(bk, oracle):
@@ -729,6 +733,8 @@ def test_c5_as_written_momentum_plus_noise_512_agents(bk, oracle):
     _compare_members(bk, oracle, 6, members, levels=64, n_steps=40, pool=512)
     _compare_members(bk, oracle, 6, members, levels=64, n_steps=40, pool=512, pipeline="split")
     _compare_members(bk, oracle, 6, members, levels=64, n_steps=40, pool=512, pipeline="split_wave")
+    _compare_members(bk, oracle, 6, members, levels=64, n_steps=40, pool=512, pipeline="wave_split")
+    _compare_members(bk, oracle, 37, members, levels=64, n_steps=40, pool=512, chunks=[9, 1, 10, 5, 15], pipeline="mixed")
 
 
 @pytest.mark.parametrize("seed", range(10))
