@@ -156,7 +156,9 @@ struct bk_env {
   int wave_split_parts() const {
     if (wave_parts > 0)  // set explicitly (tests, sweeps): any batch of >= 64 books per part
       return static_cast<int>(std::max(1u, std::min(static_cast<uint32_t>(wave_parts), cfg.n_books / 64u)));
-    return static_cast<int>(std::max(1u, std::min(3u, cfg.n_books / 2048u)));
+    // (AgentSets of Noise / Momentum members: two parts - scripts sweep at C5 as written, 8 192 books: 1 part 21.9 M,
+    // 2: 26.1, 3: 25.2, 4: 25.2, 6: 19.2, 8: 20.4 M book-steps/s)
+    return static_cast<int>(std::max(1u, std::min(n_mixed ? 2u : 3u, cfg.n_books / 2048u)));
   }
   // split pipeline: the batch is cut into n_parts contiguous parts, each on its own stream and started one
   // k_agents_fsm apart, so the latency-bound lane-per-book kernel of one part runs under the issue-bound

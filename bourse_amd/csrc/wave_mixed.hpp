@@ -306,6 +306,7 @@ __global__ __launch_bounds__(512, 4) void k_agents_mixed_wave(DevArgs a, MixedAr
     }
     if (!noise && ((thr_l == 0 && thr_m == 0) || sgn == 0)) {
       S.pos += 2u * D.n;  // two threshold draws per trader, nobody can act (momentum_agent.rs:165,193)
+      S.ensure(S.pos);    // (the position never runs ahead of the generated blocks: finish() locates it in the last two)
       if (lane == 0) wl.len[(size_t)book * MAX_MEMBERS + j] = keep_pos;
       continue;
     }

@@ -641,8 +641,11 @@ class ManyBookEnv:
     def set_pipeline(self, mode: str):
         """'auto' | 'fused' | 'split' | 'split_wave' | 'wave_split' | 'wave' — kernel pipeline of run(); results are
         identical.  ('wave' / 'wave_split': RandomAgents books, the RNG-serial phases one wave per book with a
-        wave-parallel stream decode, fused with the event phase in one persistent kernel / as a kernel of its own.)  ('split_wave':
-        AgentSets with Noise/Momentum members keep their update one wave per book; for RandomAgents it equals 'split'.)"""
+        wave-parallel stream decode, fused with the event phase in one persistent kernel / as a kernel of its own;
+        'wave_split' on an AgentSet of Noise / Momentum members: their update one wave per book with the same kind of
+        decode - k_agents_mixed_wave - in front of the event kernel, the auto choice from 512 books.)  ('split_wave':
+        AgentSets with Noise/Momentum members keep their update one wave per book as scalar code; for RandomAgents it
+        equals 'split'.)"""
         check(self._L.bk_set_pipeline(self._h, {"auto": 0, "fused": 1, "split": 2, "split_wave": 3, "wave_split": 4, "wave": 5}[mode]))
 
     def set_wave_options(self, lookahead: int = 64, parts: int = 0):

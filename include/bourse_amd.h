@@ -286,7 +286,10 @@ int bk_profile_read_kind(bk_env* env, int kind, double* total_ms, uint64_t* n_la
 /* bk_run kernel pipeline: 0 auto, 1 fused (one wave per book, all phases), 2 split (RNG-serial phases one lane per
  * book + event phase one wave per book).  Results are identical; only speed differs. */
 int bk_set_pipeline(bk_env* env, int mode);
-/* modes 4 ("wave_split") and 5 ("wave"): the RNG-serial phases run one WAVE per
+/* Mode 4 on an AgentSet of Noise / Momentum members (independent books, no RandomAgents member): the members' update
+ * one WAVE per book with their stream decoded 64 draws at a time (k_agents_mixed_wave) + the event kernel; auto from 512
+ * books.  Other sets: as mode 1.
+ * Modes 4 ("wave_split") and 5 ("wave") on RandomAgents books: the RNG-serial phases run one WAVE per
  * book with the book's xoroshiro stream decoded 64 draws at a time (jump-ahead lane states + ballot/prefix resolution) -
  * as a kernel of its own in front of the event kernel (4), or fused with the event phase in one persistent kernel that
  * keeps the book in registers across all steps of a bk_run (5).  bk_set_wave_options: look-ahead of the decode's vector

@@ -14,6 +14,6 @@ for d in ("pmc_c5m1", "pmc_c5m2", "pmc_c5m3"):
             k = r["Kernel_Name"].split("(")[0][-44:]
             agg[k][r["Counter_Name"]] += float(r["Counter_Value"]); n[(k, r["Counter_Name"])] += 1
     for k, v in agg.items():
-        if "mixed_lanes" in k or "k_step_batch" in k:
+        if "mixed_lanes" in k or "mixed_wave" in k or "k_step_batch" in k:
             print(d, k, {c: round(x / n[(k, c)]) for c, x in v.items()})
 PY

@@ -1238,11 +1238,17 @@ def test_fuzz_agent_sets_and_markets_vs_oracle(bk, oracle, seed, checkpoint_at=3
     sizes, random launch chunking) against the oracle.  Off-tick clamped prices may be flagged (both sides drop them)."""
     rng = np.random.default_rng(7000 + seed)
     A = int(rng.integers(1, 4))
+    # scripts/fuzz_wave_members.py: only sets k_agents_mixed_wave takes (independent books, Noise / Momentum members)
+    wave_members = bool(os.environ.get("BOURSE_FUZZ_WAVE_MEMBERS"))
+    if wave_members:
+        A = 1
     ticks = [int(rng.choice([1, 1, 2, 5])) for _ in range(A)]
     members, fixed = [], [0] * A
     for j in range(int(rng.integers(1, 5))):
         a = int(rng.integers(0, A))
         kind = rng.choice(["random", "noise", "momentum"])
+        if wave_members and kind == "random":
+            kind = ("noise", "momentum")[j % 2]
         tsz = ticks[a] * int(rng.integers(1, 3))
         if kind == "random":
             n = int(rng.integers(1, 40))
@@ -1290,7 +1296,8 @@ def test_fuzz_agent_sets_and_markets_vs_oracle(bk, oracle, seed, checkpoint_at=3
         ref = oracle.ManyMarkets(NM, seed, 0, ticks, 1_000_000, True, levels, members=members)
     for i, c in enumerate(chunks):
         if A == 1:
-            env.set_pipeline(("split", "fused", "split_wave")[(i + seed) % 3])
+            # ("wave_split": sets with a RandomAgents member have no wave-parallel decode and run fused there)
+            env.set_pipeline(("split", "fused", "split_wave", "wave_split")[(i + seed) % 4])
         env.run(c)
     ref.run(T, 4)
     if (env.flags() & (1 | 128)).any():  # the drawn set needs more pool slots / queue entries than drawn: reported, not comparable
@@ -1309,14 +1316,14 @@ def test_fuzz_agent_sets_and_markets_vs_oracle(bk, oracle, seed, checkpoint_at=3
         a = mk()
         for i, c in enumerate(chunks[:j]):
             if A == 1:
-                a.set_pipeline(("split", "fused", "split_wave")[(i + seed) % 3])
+                a.set_pipeline(("split", "fused", "split_wave", "wave_split")[(i + seed) % 4])
             a.run(c)
         ck = a.checkpoint()
         b = mk()
         b.restore(ck)
         for i, c in enumerate(chunks[j:]):
             if A == 1:
-                b.set_pipeline(("fused", "split_wave", "split")[(i + seed) % 3])
+                b.set_pipeline(("fused", "wave_split", "split", "split_wave")[(i + seed) % 4])
             b.run(c)
         done = sum(chunks[:j])
         if ((a.flags() | b.flags()) & (1 | 128)).any():
@@ -1903,27 +1910,38 @@ def test_step_env_history_outlives_the_device_ring(bk, oracle):
 
 
 def test_auto_pipeline_does_not_change_results_at_the_pool_capacity_edge(bk):
-    """The lane-per-book members' update (the auto pipeline's choice from 4 096 books) keeps a filled order's pool slot
-    until its member's next update, so it overflows a nearly full pool where the wave-per-book kernels still fit (1 of
-    60 000 fuzz draws in round 1).  A pipeline chosen BY THE LIBRARY must not change results: the guarded launch is
-    rolled back and redone on the fused kernel.  Configurations found with scripts/find_capacity_edge.py."""
+    """The lane-per-book members' update keeps a filled order's pool slot until its member's next update, so it overflows
+    a nearly full pool where the wave-per-book kernels still fit (1 of 60 000 fuzz draws in round 1).  A pipeline chosen
+    BY THE LIBRARY must not change results.  Since round 3 the auto choice for Noise / Momentum sets is the wave-parallel
+    decode (k_agents_mixed_wave), which frees slots exactly like the fused kernel: identical results AND flags, nothing to
+    roll back.  Sets with a RandomAgents member still take the lane pipeline from 4 096 books, guarded: rolled back and
+    redone on the fused kernel when it newly overflows.  Configurations found with scripts/find_capacity_edge.py."""
     B, T = 4096, 30
-    worse = 0
+    worse = rolled = 0
     for n, pl, pm_, pc in ((125, 0.3, 0.2, 0.7), (120, 0.4, 0.3, 0.6)):
         P = dict(tick_size=1, p_limit=pl, p_market=pm_, p_cancel=pc, trade_vol=10, price_dist_mu=0.0, price_dist_sigma=1.0)
-        res = {}
-        for pipe in ("split", "fused", "auto"):
-            e = bk.ManyBookEnv(B, 11, 0, 1, 1_000_000, True, levels=8, max_live_orders=128, trade_capacity=128 * T,
-                               history_capacity=T, strict=False)
-            e.set_agents([("noise", 0, n, P)])
-            e.set_pipeline(pipe)
-            for c in (T // 3, T - T // 3):
-                e.run(c)
-            res[pipe] = (e.flags() & 1, e.pipeline_fallbacks(), e.history(), e.trade_counts(), [e.rng_state(b) for b in (0, 77, B - 1)])
-            e.close()
-        assert res["auto"][1] >= 1 and res["split"][1] == 0 and res["fused"][1] == 0   # only the library's own choice is guarded
-        for k in (0, 2, 3):
-            assert np.array_equal(res["auto"][k], res["fused"][k]), (n, k)
-        assert res["auto"][4] == res["fused"][4]
-        worse += int(res["split"][0].sum()) > int(res["fused"][0].sum())
+        for with_random in (False, True):
+            # (the RandomAgents member never acts - rate 0 - but owns pool slot 0 and draws once per step)
+            members = ([("random", 1, (50, 51), (1, 2), 1, 0.0)] if with_random else []) + [("noise", 0, n, P)]
+            res = {}
+            for pipe in ("split", "fused", "auto"):
+                e = bk.ManyBookEnv(B, 11, 0, 1, 1_000_000, True, levels=8, max_live_orders=128, trade_capacity=128 * T,
+                                   history_capacity=T, strict=False)
+                e.set_agents(members)
+                e.set_pipeline(pipe)
+                if pipe == "auto":
+                    assert e.pipeline()[0] == ("split" if with_random else "wave_split")
+                for c in (T // 3, T - T // 3):
+                    e.run(c)
+                res[pipe] = (e.flags() & 1, e.pipeline_fallbacks(), e.history(), e.trade_counts(), [e.rng_state(b) for b in (0, 77, B - 1)])
+                e.close()
+            assert res["split"][1] == 0 and res["fused"][1] == 0   # only the library's own choice is guarded
+            if not with_random:
+                assert res["auto"][1] == 0
+            rolled += res["auto"][1]
+            for k in (0, 2, 3):
+                assert np.array_equal(res["auto"][k], res["fused"][k]), (n, with_random, k)
+            assert res["auto"][4] == res["fused"][4]
+            worse += int(res["split"][0].sum()) > int(res["fused"][0].sum())
     assert worse >= 1  # the edge exists: unguarded, the lane pipeline flags books the fused kernel does not
+    print("guarded launches rolled back:", rolled)
