@@ -58,6 +58,17 @@ struct Group {  // RandomAgents::new, host-preprocessed
   uint32_t pad[2];
 };
 
+// n / d for a wave-uniform divisor without the 25-instruction u32 division sequence (Granlund-Montgomery round-up
+// method, exact for every u32 n): t = umulhi(m, n); q = (t + ((n - t) >> sh1)) >> sh2.  Built on the host
+// (host_math.hpp make_udiv, checked against `/` by tests/cpp/host_math_test.cpp).
+struct UDiv {
+  uint32_t m, sh1, sh2, d;
+};
+__device__ __forceinline__ uint32_t udiv(uint32_t n, const UDiv& dv) {
+  const uint32_t t = __umulhi(dv.m, n);
+  return (t + ((n - t) >> dv.sh1)) >> dv.sh2;
+}
+
 struct DevTrade {  // 32 B device trade record
   uint32_t t_lo, t_hi, price, vol, active, passive, side_is_bid, pad;
 };
@@ -93,6 +104,7 @@ struct DevArgs {
   // shuffled event queue; 1 = independent books.  asset_tick = the books' tick sizes (market.rs:74-81).
   uint32_t assets;
   uint32_t asset_tick[MAX_ASSETS];
+  UDiv tick_div, asset_div[MAX_ASSETS];  // division by tick_size / asset_tick[i] (the level-2 snapshot's level index)
   Group groups[MAX_GROUPS];
 };
 // step batch layout (dwords): [0] n_ev; [64, 64+32R) shuffled event list (u16 event words: agent slot | EV_NEW | EV_BID);
@@ -524,7 +536,7 @@ __device__ __forceinline__ void process_slot_event(Book<R>& B, const DevArgs& a,
 template <int R>
 __device__ __forceinline__ void snapshot(const Book<R>& B, const DevArgs& a, uint32_t book, int lane,
                                          uint32_t* __restrict__ bins /* LDS, >= 4*levels */, uint32_t hist_slot,
-                                         uint32_t& flags, bool write_last, uint32_t tick) {
+                                         uint32_t& flags, bool write_last, const UDiv& tick) {
   const uint32_t L = a.levels;
   uint32_t mb = 0u, ma = 0xFFFFFFFFu, sb = 0u, sa = 0u;
 #pragma unroll
@@ -550,8 +562,8 @@ __device__ __forceinline__ void snapshot(const Book<R>& B, const DevArgs& a, uin
     if (is_live) {
       // level i of a side holds the orders priced touch -/+ i*tick (wrapping arithmetic never matches)
       const uint32_t d = is_bid ? (bid_best - B.price[r]) : (B.price[r] - ask_best);
-      const uint32_t q = d / tick;
-      if (q * tick == d && q < L) {
+      const uint32_t q = udiv(d, tick);
+      if (q * tick.d == d && q < L) {
         atomicAdd(&bins[4 * q + (is_bid ? 0 : 2)], B.vol[r]);
         atomicAdd(&bins[4 * q + (is_bid ? 1 : 3)], 1u);
       }
@@ -822,7 +834,7 @@ __device__ __forceinline__ void slot_event_keyed(Book<R>& B, KeyState<R>& K, con
 template <int R, bool MKT = false, bool TAGGED = false, bool CLS = false, bool PENDKEY = false>
 __device__ __forceinline__ uint32_t step_from_list(Book<R>& B, const DevArgs& a, uint32_t book, int lane,
                                                    const uint32_t (&ev)[R], uint32_t n_ev, uint32_t* bins,
-                                                   uint32_t hist_slot, bool write_last, uint32_t tick,
+                                                   uint32_t hist_slot, bool write_last, const UDiv& tick,
                                                    const uint64_t (&mine)[R], uint32_t& n_own, uint32_t asset = 0) {
   const uint64_t step_size = mk64(a.step_lo, a.step_hi);
   const uint64_t t0 = B.t;
@@ -991,7 +1003,7 @@ __global__ __launch_bounds__(256) void k_run_random(DevArgs a, uint64_t first_st
       slot_write<R>(ev, j, ai);
     }
     last_ntr = step_from_list<R>(B, a, book, lane, ev, n_ev, bins, a.hist_cap ? (a.hist_slot0 + s) % a.hist_cap : 0u,
-                                 s + 1 == n_steps || a.hist_cap == 0, a.tick_size, B.pend, last_nev);
+                                 s + 1 == n_steps || a.hist_cap == 0, a.tick_div, B.pend, last_nev);
   }
   store_book<R>(B, rng, st, lane, first_step + n_steps, last_ntr, last_nev);
 }
@@ -1246,7 +1258,7 @@ __global__ __launch_bounds__(64) void k_step_batch(DevArgs a, uint64_t step_inde
   B.next_id = base;
   uint32_t n_own = 0;
   const uint32_t ntr = step_from_list<R, MKT, MKT && POOLPEND, !POOLPEND, POOLPEND && !MKT>(B, a, book, lane, ev, n_ev, lds[wv], a.hist_slot0,
-                                                               write_last != 0, MKT ? a.asset_tick[asset] : a.tick_size,
+                                                               write_last != 0, MKT ? a.asset_div[asset] : a.tick_div,
                                                                mine, n_own, asset);
   store_book<R>(B, rng, st, lane, step_index + 1, ntr, n_own);
   if (POOLPEND) {
@@ -1418,7 +1430,7 @@ __global__ __launch_bounds__(64) void k_step_events(DevArgs a, uint64_t step_ind
   }
   B.n_events += n_own;
   B.t = t0 + step_size;
-  snapshot<R>(B, a, book, lane, bins, a.hist_slot0, B.flags, true, a.asset_tick[asset]);
+  snapshot<R>(B, a, book, lane, bins, a.hist_slot0, B.flags, true, a.asset_div[asset]);
   flush_trades<R>(B, a, book, t0, lane);
   store_book<R>(B, rng, st, lane, step_index + 1, (uint32_t)(B.n_trades - trades_before), n_own);
 }

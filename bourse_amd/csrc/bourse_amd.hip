@@ -271,6 +271,12 @@ struct bk_env {
     a.book_end = cfg.n_books / M;
     a.assets = M;
     for (int i = 0; i < MAX_ASSETS; ++i) a.asset_tick[i] = asset_tick[i];
+    auto dv = [](uint32_t d) {
+      const HostUDiv h = make_udiv(d ? d : 1u);
+      return UDiv{h.m, h.sh1, h.sh2, h.d};
+    };
+    a.tick_div = dv(cfg.tick_size);
+    for (int i = 0; i < MAX_ASSETS; ++i) a.asset_div[i] = dv(asset_tick[i]);
     for (size_t g = 0; g < groups.size(); ++g) a.groups[g] = groups[g];
     return a;
   }

@@ -78,6 +78,24 @@ inline std::vector<uint32_t> xoroshiro_jump_table(uint64_t n_steps) {
     }
   return tab;
 }
+// Division of any u32 by the invariant d >= 1 as multiply-high + shifts (Granlund & Montgomery, "Division by invariant
+// integers using multiplication", round-up method): L = ceil(log2 d), m = floor(2^32 (2^L - d) / d) + 1,
+// q = (t + ((n - t) >> min(L, 1))) >> max(L - 1, 0) with t = umulhi(m, n).  Plain integers: the device mirror is
+// book_device.hpp udiv().
+struct HostUDiv {
+  uint32_t m, sh1, sh2, d;
+};
+inline HostUDiv make_udiv(uint32_t d) {
+  uint32_t L = 0;
+  while (L < 32 && (1ull << L) < d) ++L;
+  const uint64_t m = ((1ull << 32) * ((1ull << L) - d)) / d + 1ull;
+  return HostUDiv{static_cast<uint32_t>(m), L < 1u ? L : 1u, L > 0u ? L - 1u : 0u, d};
+}
+inline uint32_t udiv_apply(uint32_t n, const HostUDiv& dv) {
+  const uint32_t t = static_cast<uint32_t>((static_cast<uint64_t>(dv.m) * n) >> 32);
+  return (t + ((n - t) >> dv.sh1)) >> dv.sh2;
+}
+
 // the same lookup the device performs (host mirror, used by the CPU test)
 inline void xoroshiro_jump_apply(const uint32_t* tab, uint64_t& s0, uint64_t& s1) {
   const uint32_t w[4] = {static_cast<uint32_t>(s0), static_cast<uint32_t>(s0 >> 32), static_cast<uint32_t>(s1),

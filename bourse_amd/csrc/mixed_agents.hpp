@@ -396,7 +396,7 @@ __global__ __launch_bounds__(256) void k_run_mixed(DevArgs a, MixedArgs ma, uint
     mixed_update_and_shuffle<R>(B, C, rng, ma, S, lane);
     last_ntr = step_from_list<R>(B, a, book, lane, C.ev, C.n_ev, lds[wv],
                                  a.hist_cap ? (a.hist_slot0 + s) % a.hist_cap : 0u, s + 1 == n_steps || a.hist_cap == 0,
-                                 a.tick_size, B.pend, last_nev);
+                                 a.tick_div, B.pend, last_nev);
   }
   store_book<R>(B, rng, st, lane, first_step + n_steps, last_ntr, last_nev);
   mixed_store_state<R>(S, B, C, st, lane);

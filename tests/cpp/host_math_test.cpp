@@ -77,6 +77,22 @@ int main(int argc, char** argv) {
       }
     }
   }
+  // make_udiv: multiply-high division == `/` for every divisor class (1, powers of two, odd, near 2^31 / 2^32) against
+  // boundary and random numerators
+  {
+    std::vector<uint32_t> ds = {1u, 2u, 3u, 4u, 5u, 6u, 7u, 10u, 12u, 100u, 641u, 65535u, 65536u, 65537u, 0x7FFFFFFFu, 0x80000000u,
+                                0x80000001u, 0xFFFFFFFEu, 0xFFFFFFFFu};
+    for (int i = 0; i < 2000; ++i) ds.push_back(static_cast<uint32_t>(rng() >> (rng() % 32)) | 1u);
+    for (uint32_t d : ds) {
+      const bkd::HostUDiv dv = bkd::make_udiv(d);
+      std::vector<uint32_t> ns = {0u, 1u, d - 1u, d, d + 1u, 2u * d - 1u, 2u * d, 0x7FFFFFFFu, 0x80000000u, 0xFFFFFFFEu, 0xFFFFFFFFu};
+      for (uint64_t k : {1ull, 2ull, 3ull, 1000ull})
+        for (int o = -1; o <= 1; ++o) ns.push_back(static_cast<uint32_t>(k * d + o));
+      for (int i = 0; i < 200; ++i) ns.push_back(static_cast<uint32_t>(rng()));
+      for (uint32_t n : ns)
+        if (bkd::udiv_apply(n, dv) != n / d) { std::printf("udiv: %u / %u\n", n, d); return 5; }
+    }
+  }
   uint64_t s0, s1;
   bkd::seed_from_u64(101, s0, s1);
   if (argc > 1) std::printf("%llu %llu\n", (unsigned long long)s0, (unsigned long long)s1);

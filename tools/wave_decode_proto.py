@@ -151,11 +151,16 @@ class WaveRng:
 
 
 def first_above(mask128, i):
-    """index of the first set bit > i, or 128"""
-    m = mask128 >> (i + 1)
+    """index of the first set bit > i among the next 64 positions (and below 128), or 128 - the device's
+    first_above_near (wave_agents.hpp): a set bit further away is reported as none, the placement then counts as not
+    resolvable inside the look-ahead and takes the exact draw-by-draw path"""
+    n = i + 1
+    if n >= 128:
+        return 128
+    m = (mask128 >> n) & ((1 << min(64, 128 - n)) - 1)
     if m == 0:
         return 128
-    return i + 1 + ((m & -m).bit_length() - 1)
+    return n + ((m & -m).bit_length() - 1)
 
 
 def wave_step(s0, s1, groups, live, tab_block, lane_tabs, lookahead=64, stats=None):
