@@ -126,6 +126,8 @@ struct WaveDecoder {
   uint2* pv;           // new orders by slot
   uint16_t* jarr;      // LDS: shuffle targets, jarr[i] = gen_range(0..i+1) of step i (64 R entries)
   uint4* wmask;        // LDS (R <= 2): 128 x 128-bit "steps that target this position" masks of the shuffle resolution
+  uint32_t* co = nullptr;      // LDS (R > 2, optional): 64 R words {count << 16 | offset} of the bucketed resolution; without
+  uint16_t* bucket = nullptr;  // them (+ 64 R u16) the swaps of a pool of more than 128 slots run one by one
   uint4* wcs;          // global: the 64 lane states of the cache record
   int lane;
   uint4 cs;            // this lane's chunk-start state in the last generated block
@@ -387,7 +389,7 @@ struct WaveDecoder {
         acc = nacc;
       }
       const uint32_t cnt = (uint32_t)__builtin_popcountll(acc);
-      if constexpr (R <= 2) {
+      if (R <= 2 || co != nullptr) {
         if (lane_bit(acc)) jarr[ii] = (uint16_t)jj;  // resolved in one go below
       } else {
         // the swaps, in stream order (uniform addresses: every lane reads the same pair and writes the same values)
@@ -452,6 +454,70 @@ struct WaveDecoder {
         }
         wave_sync();
       }
+    } else if (co != nullptr && n_ev >= 2u) {
+      // The same rule for up to 512 positions, where a mask per position would be 32 KB: the steps are BUCKETED by their
+      // target instead (counting sort through LDS atomics: count, exclusive prefix, fill), and "the most recent earlier
+      // step that targets y" is the smallest s > t in y's bucket - buckets hold ~1 step on average.  Replaces ~n
+      // dependent LDS round trips (23 us for the 157 events of C5 as written) by a handful of wave-parallel passes.
+      wave_sync();
+#pragma unroll
+      for (int r = 0; r < R; ++r) co[r * 64 + lane] = 0u;
+      wave_sync();
+      uint32_t jx[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const uint32_t x = (uint32_t)lane + 64u * r;
+        jx[r] = (x >= 1u && x < n_ev) ? jarr[x] : x;
+        if (jx[r] != x) atomicAdd(&co[jx[r]], 0x10000u);  // a self-swap moves nothing
+      }
+      wave_sync();
+      uint32_t run = 0;
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const uint32_t c = co[r * 64 + lane] >> 16;
+        uint32_t v = c;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+          const uint32_t u = (uint32_t)__shfl_up((int)v, o);
+          v += lane >= o ? u : 0u;
+        }
+        co[r * 64 + lane] = (c << 16) | (run + v - c);  // count | start of the bucket (advanced to its end by the fill)
+        run += rdl(v, 63);
+      }
+      wave_sync();
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const uint32_t x = (uint32_t)lane + 64u * r;
+        if (jx[r] != x) bucket[atomicAdd(&co[jx[r]], 1u) & 0xFFFFu] = (uint16_t)x;
+      }
+      wave_sync();
+      uint32_t val[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const uint32_t x = (uint32_t)lane + 64u * r;
+        uint32_t y = jx[r], t = x;
+        bool go = x < n_ev;
+        while (__ballot(go)) {
+          const uint32_t c = co[y & (64u * R - 1u)], e = c & 0xFFFFu, k = go ? c >> 16 : 0u;
+          uint32_t best = 0xFFFFFFFFu;
+          for (uint32_t i = 0; __ballot(i < k); ++i) {
+            const uint32_t sx = i < k ? (uint32_t)bucket[(e - k + i) & (64u * R - 1u)] : 0u;
+            best = (i < k && sx > t && sx < best) ? sx : best;
+          }
+          const bool hop = go && best != 0xFFFFFFFFu;
+          y = hop ? best : y;
+          t = hop ? best : t;
+          go = hop;
+        }
+        val[r] = evl[y & (64u * R - 1u)];
+      }
+      wave_sync();
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const uint32_t x = (uint32_t)lane + 64u * r;
+        if (x < n_ev) evl[x] = (uint16_t)val[r];
+      }
+      wave_sync();
     }
   }
 
@@ -494,6 +560,7 @@ __global__ __launch_bounds__(256, 8) void k_agents_wave(DevArgs a, WaveArgs wa) 
   __shared__ uint16_t evl_s[4][64 * R];
   __shared__ uint32_t pm_s[4][2 * R], sm_s[4][2 * R];
   __shared__ uint16_t jarr_s[4][64 * R];
+  __shared__ uint16_t bucket_s[4][R > 2 ? 64 * R : 1];  // bucketed shuffle resolution of the large pools
   const int lane = threadIdx.x & 63;
   const int wv = (int)rfl(threadIdx.x >> 6);  // wave-uniform: the per-wave LDS regions get scalar base addresses
   for (int i = threadIdx.x; i < 512; i += 256) tab[i] = wa.jt_block[i];
@@ -513,6 +580,11 @@ __global__ __launch_bounds__(256, 8) void k_agents_wave(DevArgs a, WaveArgs wa) 
   D.pv = reinterpret_cast<uint2*>(bt + BT_EV + 32 * R);
   D.jarr = jarr_s[wv];
   D.wmask = reinterpret_cast<uint4*>(ring_s[wv]);  // the generated draws are dead once the shuffle's windows are resolved
+  if (R > 2) {  // (64 R count|offset words = 2 KB at R = 8: the ring's memory, like the masks of the small pools)
+    static_assert(R <= 8, "the bucket words alias the 2 KB ring");
+    D.co = ring_s[wv];
+    D.bucket = bucket_s[wv];
+  }
   D.wcs = reinterpret_cast<uint4*>(wc + WC_HDR);
   D.lane = lane;
   // the book's RNG state and live masks (header dwords H_LIVE0 + w hold bits [32 w, 32 w + 32) of the pool's live mask)

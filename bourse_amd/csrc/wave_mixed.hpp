@@ -34,14 +34,21 @@
 
 namespace bkd {
 
+// timing experiments only (scripts/mw_phase_times.sh): -DBOURSE_AMD_MW_SKIP=bits leaves phases out (results are then
+// wrong): 1 the shuffle, 2 the traders' windows, 4 the cancel pass, 8 the window's order placement
+#ifndef BOURSE_AMD_MW_SKIP
+#define BOURSE_AMD_MW_SKIP 0
+#endif
 constexpr uint32_t FLAG_DECODE_LOOKAHEAD = 256u;  // a ziggurat ran past the decode's look-ahead (p < 2^-90): flagged
 constexpr uint32_t MW_RING = 512;                 // generated u64 draws kept in LDS
 constexpr uint32_t MW_LOOK = 192;                 // a window's draws + look-ahead: positions [w0, w0 + MW_LOOK)
 constexpr int MW_WPB = 8;                         // books (waves) per workgroup
 
 // per wave: the u64 ring | event list, free-slot table (u16 x 64 R each; the table's memory becomes the shuffle's swap
-// targets) | orbit marks (72) + the pool's live words (16) + pad
-constexpr uint32_t mw_wave_dwords(int R) { return 2 * MW_RING + 2 * 32 * R + 96; }
+// targets) | orbit marks (72) + the pool's live words (16) + pad | deferred-price queue: 128 x f64 argument (its memory
+// becomes the shuffle's buckets) + 128 x u16 {slot, side}
+constexpr uint32_t MW_QCAP = 128;
+constexpr uint32_t mw_wave_dwords(int R) { return 2 * MW_RING + 2 * 32 * R + 96 + 2 * MW_QCAP + MW_QCAP / 2; }
 constexpr uint32_t MW_SHARED_DW = 2048 + 2 * 514 + 4;  // T^256 table, ziggurat x / f tables (257 doubles each), pad
 constexpr size_t mixed_wave_lds_bytes(int R) { return (size_t)(MW_SHARED_DW + MW_WPB * mw_wave_dwords(R)) * 4; }
 
@@ -207,6 +214,13 @@ __global__ __launch_bounds__(512, 4) void k_agents_mixed_wave(DevArgs a, MixedAr
   uint16_t* freelist = evl + SL;  // the step's free slots in allocation order (then the shuffle's swap targets)
   uint32_t* mark = wbase + 2 * MW_RING + 2 * 32 * R;  // 72 dwords: the orbit's marks (index 64: left the window)
   uint32_t* lvw = mark + 72;                          // 16 dwords: the pool's live mask, 32 slots per word
+  // Deferred limit prices: a window's orders are created at once, but exp() and the tick rounding - ~200 f64 instructions
+  // - would run for the 2-3 lanes of every window that place one.  Those lanes create the order WITHOUT its price and
+  // queue {exp argument, slot, side}; whenever 64 entries wait, all lanes price one each (same arithmetic on the same
+  // operands, so the same bits).  A sell that might reach the u32::MAX clamp - the one case whose outcome (create_order's
+  // Err: no id) changes what follows - keeps the in-line path.
+  double* q_arg = reinterpret_cast<double*>(mark + 96);
+  uint16_t* q_info = reinterpret_cast<uint16_t*>(mark + 96 + 2 * MW_QCAP);
 
   uint32_t* st = a.state + (size_t)book * a.state_stride;
   uint32_t* bt = a.batch + (size_t)book * a.batch_stride;
@@ -261,7 +275,7 @@ __global__ __launch_bounds__(512, 4) void k_agents_mixed_wave(DevArgs a, MixedAr
     uint16_t* my = wl.list + ((size_t)book * MAX_MEMBERS + j) * wl.cap;
     const uint32_t len = rfl(wl.len[(size_t)book * MAX_MEMBERS + j]);
     uint32_t keep_pos = 0;
-    for (uint32_t c = 0; c < len; c += 64u) {
+    for (uint32_t c = 0; c < ((BOURSE_AMD_MW_SKIP & 4) ? 0u : len); c += 64u) {
       const uint32_t idx = c + (uint32_t)lane;
       const uint32_t slot = idx < len ? (uint32_t)my[idx] : 0u;
       const bool alive = idx < len && ((lvw[(slot >> 5) & 15u] >> (slot & 31u)) & 1u) != 0u;  // else: filled / cancelled meanwhile
@@ -304,12 +318,34 @@ __global__ __launch_bounds__(512, 4) void k_agents_mixed_wave(DevArgs a, MixedAr
       hdr_out = lane == H_GST + 4 * (int)j + 3 ? (uint32_t)(lb >> 32) : hdr_out;
       gflags |= 1u << j;
     }
-    if (!noise && ((thr_l == 0 && thr_m == 0) || sgn == 0)) {
+    if ((BOURSE_AMD_MW_SKIP & 2) || (!noise && ((thr_l == 0 && thr_m == 0) || sgn == 0))) {
       S.pos += 2u * D.n;  // two threshold draws per trader, nobody can act (momentum_agent.rs:165,193)
       S.ensure(S.pos);    // (the position never runs ahead of the generated blocks: finish() locates it in the last two)
       if (lane == 0) wl.len[(size_t)book * MAX_MEMBERS + j] = keep_pos;
       continue;
     }
+    // a sell at mid + exp(arg), rounded UP to the tick, stays below the u32::MAX clamp when arg < lnslack
+    double lnslack;
+    {
+      const double slack = 4294967295.0 - mid - 2.0 * D.tick_f - 1.0;
+      lnslack = uni(slack > 1.0 ? pm::log(slack) - 1e-9 : -1e300);
+    }
+    uint32_t qc = 0;  // queued prices
+    auto drain = [&](uint32_t at_least) {
+      while (qc >= at_least && qc > 0u) {
+        wave_sync();
+        const uint32_t take = qc < 64u ? qc : 64u, base = qc - take;
+        if ((uint32_t)lane < take) {
+          const double arg = q_arg[base + lane];
+          const uint32_t info = q_info[base + lane], slot = info & 0x7FFFu;
+          const double dist = pm::fabs_(pm::exp(arg));
+          st[HDR_DW + (slot >> 6) * (POOL_FIELDS * 64) + (slot & 63u)] =
+              (info & 0x8000u) ? round_price_down(mid - dist, D.tick_f) : round_price_up(mid + dist, D.tick_f);
+        }
+        qc = base;
+        wave_sync();
+      }
+    };
     uint32_t t = 0;
     while (t < D.n) {
       const uint32_t w0 = S.pos & ~63u, p0 = S.pos - w0, lim = w0 + MW_LOOK;
@@ -353,19 +389,24 @@ __global__ __launch_bounds__(512, 4) void k_agents_mixed_wave(DevArgs a, MixedAr
       S.pos = rdl(f_end, last);
       if (__ballot(vis && over)) new_flags |= FLAG_DECODE_LOOKAHEAD;
       // ---- the window's orders, all at once.  Limit: place_buy/sell_limit_order (common.rs:92-141)
-      const bool do_a = vis && hit_a;
+      const bool do_a = vis && hit_a && !(BOURSE_AMD_MW_SKIP & 8);
       bool buy_a = sgn > 0, ok_a = false;
       uint32_t price_a = 0;
-      if (do_a) {
-        if (noise) buy_a = (S.at(q + 1u) >> 63) == 0ull;  // gen_bool(0.5): next_u64() < 2^63
-        const double dist = pm::fabs_(pm::exp(D.mu + D.sigma * zval));
+      const double arg_a = D.mu + D.sigma * zval;
+      if (noise) buy_a = (S.at(q + 1u) >> 63) == 0ull;  // gen_bool(0.5): next_u64() < 2^63
+      // a buy rounds DOWN from below the mid (clamped at 0), a sell below the clamp rounds to a multiple of the member's
+      // tick, itself a multiple of the book's: create_order accepts both, whatever the price turns out to be
+      const bool defer_a = do_a && (buy_a || arg_a < lnslack);
+      if (do_a && !defer_a) {
+        const double dist = pm::fabs_(pm::exp(arg_a));
         price_a = buy_a ? round_price_down(mid - dist, D.tick_f) : round_price_up(mid + dist, D.tick_f);
         // create_order's tick check (orderbook.rs:367-382): the reference `.unwrap()`s the Err (panics); flagged, and
         // like an Err nothing is created (see mixed_create)
         ok_a = price_a % a.tick_size == 0u;
       }
+      ok_a = ok_a || defer_a;
       if (__ballot(do_a && !ok_a)) new_flags |= FLAG_PRICE_TICK;
-      const bool do_b = vis && hit_b;
+      const bool do_b = vis && hit_b && !(BOURSE_AMD_MW_SKIP & 8);
       const bool buy_b = noise ? (S.at(qb + 1u) >> 63) == 0ull : sgn > 0;
       const uint64_t CA = __ballot(do_a && ok_a), CB = __ballot(do_b);
       const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(CA >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)CA, 0u)) +
@@ -388,6 +429,17 @@ __global__ __launch_bounds__(512, 4) void k_agents_mixed_wave(DevArgs a, MixedAr
         const uint32_t li = keep_pos + __builtin_amdgcn_mbcnt_hi((uint32_t)(CA >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)CA, 0u));
         if (slot != 0xFFFFu) my[li] = (uint16_t)slot;
       }
+      {  // the orders whose price is still to come
+        const bool qd = defer_a && n_created + before < n_free;
+        const uint64_t qm = __ballot(qd);
+        if (qd) {
+          const uint32_t qi = qc + __builtin_amdgcn_mbcnt_hi((uint32_t)(qm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)qm, 0u));
+          q_arg[qi] = arg_a;
+          q_info[qi] = (uint16_t)(freelist[n_created + before] | (buy_a ? 0x8000u : 0u));
+        }
+        qc += (uint32_t)__builtin_popcountll(qm);
+        drain(64u);
+      }
       if (do_b) emit(n_created + before + ((do_a && ok_a) ? 1u : 0u), buy_b, buy_b ? 0xFFFFFFFFu : 0u, 0u);
       const uint32_t cnt = (uint32_t)__builtin_popcountll(CA) + (uint32_t)__builtin_popcountll(CB);
       const uint32_t room = n_free > n_created ? n_free - n_created : 0u;
@@ -406,6 +458,7 @@ __global__ __launch_bounds__(512, 4) void k_agents_mixed_wave(DevArgs a, MixedAr
       }
       n_created += cnt;
     }
+    drain(1u);
     if (lane == 0) wl.len[(size_t)book * MAX_MEMBERS + j] = keep_pos;
   }
   wave_sync();
@@ -430,13 +483,17 @@ __global__ __launch_bounds__(512, 4) void k_agents_mixed_wave(DevArgs a, MixedAr
     Dc.pv = nullptr;
     Dc.jarr = freelist;
     Dc.wmask = reinterpret_cast<uint4*>(r32 + MW_RING);  // the upper half of the 64-bit ring's memory (2 KB), R <= 2 only
+    if (R > 2) {  // large pools: the bucketed resolution's words there instead, its buckets in the price queue's memory
+      Dc.co = r32 + MW_RING;
+      Dc.bucket = reinterpret_cast<uint16_t*>(q_arg);
+    }
     Dc.wcs = S.wcs;
     Dc.lane = lane;
     Dc.cs = S.cs;
     Dc.gen_end = S.gen_end;
     Dc.pos = S.pos;
   }
-  Dc.shuffle(n_ev);
+  if (!(BOURSE_AMD_MW_SKIP & 1)) Dc.shuffle(n_ev);
 
   // ---- publish: RNG state + lane-state cache, member state, ids, cursor, flags; the step batch
   uint32_t n0, n1, n2, n3;
