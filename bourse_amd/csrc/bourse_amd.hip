@@ -69,12 +69,21 @@ constexpr uint32_t RANDOM_SPLIT_MIN_BOOKS = 8192, MIXED_SPLIT_MIN_BOOKS = 4096;
 // AgentSets of Noise / Momentum members on independent books: from this many books the members' update runs one WAVE per
 // book with the stream decoded 64 draws at a time (k_agents_mixed_wave, wave_mixed.hpp) in front of the event kernel
 constexpr uint32_t MIXED_WAVE_MIN_BOOKS = 512;
-// RandomAgents batches of up to WAVE_MAX_BOOKS books take the wave-parallel RNG decode: fused with the event phase in
-// one persistent kernel (k_run_wave) below WAVE_FUSED_MAX_BOOKS, as k_agents_wave in front of k_step_batch (three parts
-// whose kernels overlap) from there; above WAVE_MAX_BOOKS the lane-per-book k_agents_fsm costs far fewer issue slots per
-// book-step and its latency is hidden by the other parts (scripts/size_sweep.py: 2 048 / 4 096 / 8 192 / 16 384 / 32 768
-// books: k_run_wave 33 / 53 / 74 / 76 / 79 M, wave_split 32 / 50 / 85 / 97 / 99 M, lane split - / 22 / 41 / 69 / 121 M)
-constexpr uint32_t WAVE_FUSED_MAX_BOOKS = 6144, WAVE_MAX_BOOKS = 24576, WAVE_STEP_PRIO_BOOKS = 16384;
+// The auto rule for RandomAgents books, derived from the SHAPE (pool registers R = pool / 64) instead of a book count
+// swept at one shape (scripts/shape_sweep.py, profiles/r03/shape_sweep.txt: C2 R = 1, C3 R = 2, a 256-slot pool R = 4,
+// C5 R = 8, 1 024 .. 65 536 books):
+//   * `wave` (k_run_wave: decode + events fused, book in registers across the launch) while the batch fits the chip in
+//     ONE residency round of that kernel - asked of the runtime (hipOccupancyMaxActiveBlocksPerMultiprocessor x 8 books
+//     per workgroup x CUs: 6 144 books at R <= 2, 4 096 at R = 4, 2 048 at R = 8); one book more and a second round at a
+//     fraction of the occupancy costs more than the split form's launches (C3: 103 M at 6 144, 94 M at 7 168 books).
+//     64-slot pools are the exception: their book-step is so short that the persistent kernel wins up to the lane split's
+//     take-over (C2: 195 M vs 170 M at 8 192, 216 vs 206 at 16 384);
+//   * `wave_split` (k_agents_wave + k_step_batch, three parts) from there;
+//   * `split` (lane-per-book k_agents_fsm + k_step_batch, four parts) from lane_split_min_books(R): its 140 us chain
+//     per step needs that many books to be hidden (crossovers measured at 26 k / 28 k / 21 k / 28 k books for R = 1, 2,
+//     4, 8).
+constexpr uint32_t WAVE_STEP_PRIO_BOOKS = 16384;
+constexpr uint32_t lane_split_min_books(int R) { return R == 1 ? 26624u : (R == 4 ? 21504u : 28672u); }
 
 struct HostOrder {  // immutable half of an order, fixed at create_order (orderbook.rs:356-396)
   uint8_t bid;
@@ -147,11 +156,19 @@ struct bk_env {
     return n_mixed && M == 1 && !mixed_random_member &&
            (pipeline == 4 || (pipeline == 0 && cfg.n_books >= MIXED_WAVE_MIN_BOOKS));
   }
+  uint32_t fused_resident = 0;   // books one residency round of k_run_wave<R> holds on this device (0 = not asked yet)
+  uint32_t wave_fused_max() const {
+    if (R == 1) return lane_split_min_books(1) - 1u;
+    const uint32_t res = fused_resident ? fused_resident : (R == 8 ? 2048u : 6144u);
+    // (256-slot pools: a round holds 6 144 books like the 128-slot ones, but the split form is already ahead at 5 120 -
+    // 37.7 vs 33.8 M - and level at 4 096)
+    return R >= 4 ? std::min(res, 4096u) : res;
+  }
   bool use_wave() const {        // split form: k_agents_wave + k_step_batch
-    return wave_ok() && (pipeline == 4 || (pipeline == 0 && cfg.n_books >= WAVE_FUSED_MAX_BOOKS && cfg.n_books <= WAVE_MAX_BOOKS));
+    return wave_ok() && (pipeline == 4 || (pipeline == 0 && cfg.n_books > wave_fused_max() && cfg.n_books < lane_split_min_books(R)));
   }
   bool use_wave_fused() const {  // persistent fused form: k_run_wave
-    return wave_ok() && (pipeline == 5 || (pipeline == 0 && cfg.n_books < WAVE_FUSED_MAX_BOOKS));
+    return wave_ok() && (pipeline == 5 || (pipeline == 0 && cfg.n_books <= wave_fused_max()));
   }
   int wave_split_parts() const {
     if (wave_parts > 0)  // set explicitly (tests, sweeps): any batch of >= 64 books per part
@@ -1215,9 +1232,30 @@ static int set_agents_impl(bk_env* env, uint32_t n_members, const bk_agent_desc*
   return BK_OK;
 }
 
+// books one residency round of the fused wave kernel holds (the auto rule's `wave` limit): asked of the runtime once
+static void query_fused_resident(bk_env* env) {
+  if (env->fused_resident || !env->wave_ok()) return;
+  if (hipSetDevice(env->cfg.device) != hipSuccess) return;
+  int blocks = 0, cus = 0;
+  hipError_t e = hipSuccess;
+  switch (env->R) {
+    case 1: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, k_run_wave<1>, 512, 0); break;
+    case 2: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, k_run_wave<2>, 512, 0); break;
+    case 4: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, k_run_wave<4>, 512, 0); break;
+    default: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, k_run_wave<8>, 512, 0); break;
+  }
+  if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, env->cfg.device);
+  if (e == hipSuccess && blocks > 0 && cus > 0) env->fused_resident = static_cast<uint32_t>(blocks) * 8u * static_cast<uint32_t>(cus);
+  (void)hipGetLastError();
+  if (getenv("BOURSE_AMD_VERBOSE"))
+    fprintf(stderr, "bourse_amd: k_run_wave<%d>: %d workgroups per CU x %d CUs -> one round holds %u books\n", env->R, blocks, cus,
+            env->fused_resident);
+}
+
 int bk_run(bk_env* env, uint64_t n_steps) {
   if (!env) return fail(BK_INVALID_ARGUMENT, "null env");
   if (n_steps == 0) return BK_OK;
+  query_fused_resident(env);
   if (n_steps > 0xFFFFFFFFull) return fail(BK_INVALID_ARGUMENT, "n_steps too large for one launch");
   if (int rc = use_device(env)) return rc;
   for (const BookHost& bh : env->books)
@@ -1961,6 +1999,7 @@ int bk_profile_read_kind(bk_env* env, int kind, double* total_ms, uint64_t* n_la
 
 int bk_get_pipeline(bk_env* env, int* split, int* n_parts) {
   if (!env) return fail(BK_INVALID_ARGUMENT, "null env");
+  query_fused_resident(env);
   if (env->use_wave_fused()) {
     if (split) *split = 3;
     if (n_parts) *n_parts = 1;
