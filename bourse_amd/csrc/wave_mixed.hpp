@@ -294,7 +294,7 @@ __global__ __launch_bounds__(512, 4) void k_agents_mixed_wave(DevArgs a, MixedAr
       S.pos += (uint32_t)__builtin_popcountll(am);
     }
     // ---- the member's traders
-    const bool noise = D.type == 1;
+    const bool noise_member = D.type == 1, noise = noise_member;
     double m = 0.0;
     uint64_t thr_l = 0, thr_m = 0;
     int sgn = 0;
@@ -346,6 +346,9 @@ __global__ __launch_bounds__(512, 4) void k_agents_mixed_wave(DevArgs a, MixedAr
         wave_sync();
       }
     };
+    // (the traders' loop is instantiated per member kind: no per-lane selects between the two draw patterns)
+    auto traders = [&](auto kind) {
+    constexpr bool noise = decltype(kind)::value;
     uint32_t t = 0;
     while (t < D.n) {
       const uint32_t w0 = S.pos & ~63u, p0 = S.pos - w0, lim = w0 + MW_LOOK;
@@ -458,6 +461,11 @@ __global__ __launch_bounds__(512, 4) void k_agents_mixed_wave(DevArgs a, MixedAr
       }
       n_created += cnt;
     }
+    };
+    if (noise_member)
+      traders(std::true_type{});
+    else
+      traders(std::false_type{});
     drain(1u);
     if (lane == 0) wl.len[(size_t)book * MAX_MEMBERS + j] = keep_pos;
   }
