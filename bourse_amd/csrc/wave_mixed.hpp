@@ -367,27 +367,33 @@ __global__ __launch_bounds__(512, 4) void k_agents_mixed_wave(DevArgs a, MixedAr
       const uint64_t xb = S.at(qb);
       const bool hit_b = noise ? ((uint32_t)xb >> 8) < D.thr_market : (xb >> 11) < thr_m;
       const uint32_t f_end = qb + 1u + ((noise && hit_b) ? 1u : 0u);  // Noise: the market order's gen_bool (noise_agent.rs:163)
-      // ---- the positions visited from p0: orbit under lane -> f_end - w0 (pointer doubling; a turn takes >= 2 draws)
-      uint32_t jk = min(f_end - w0, 64u);
-      bool vis = (uint32_t)lane == p0;
-#pragma unroll
-      for (int k = 0; k < 5; ++k) {
-        mark[lane] = 0;
-        wave_sync();
-        if (vis) mark[jk] = 1u;
-        wave_sync();
-        vis = vis || mark[lane] != 0u;
-        const uint32_t jn = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(jk << 2), (int)jk);
-        jk = jk < 64u ? jn : 64u;
-      }
-      uint64_t V = __ballot(vis);
+      // ---- the positions visited from p0: the orbit of p0 under lane -> f_end - w0 (a turn takes >= 2 draws: <= 32 hops)
+      const uint32_t jk0 = min(f_end - w0, 64u);
       const uint32_t rem = D.n - t;
-      if ((uint32_t)__builtin_popcountll(V) > rem) {  // the member's last trader sits inside this window
-        const uint32_t rk = __builtin_amdgcn_mbcnt_hi((uint32_t)(V >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)V, 0u));
-        vis = vis && rk < rem;
+      uint64_t V = 0;
+      uint32_t last = p0;
+      {  // pointer doubling: 5 rounds of {marks through LDS, jump table squared by ds_bpermute}.  (A scalar walk - one
+         // v_readlane per hop - was measured and is slower: 167 vs 147 us per full-batch launch at C5 as written.)
+        uint32_t jk = jk0;
+        bool vis = (uint32_t)lane == p0;
+        mark[lane] = 0;  // (marks only ever get set inside a window: cleared once, not per round)
+        wave_sync();
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+          if (vis) mark[jk] = 1u;
+          wave_sync();
+          vis = vis || mark[lane] != 0u;
+          const uint32_t jn = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(jk << 2), (int)jk);
+          jk = jk < 64u ? jn : 64u;
+        }
         V = __ballot(vis);
+        if ((uint32_t)__builtin_popcountll(V) > rem) {  // the member's last trader sits inside this window
+          const uint32_t rk = __builtin_amdgcn_mbcnt_hi((uint32_t)(V >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)V, 0u));
+          V = __ballot(vis && rk < rem);
+        }
+        last = 63u - (uint32_t)__builtin_clzll(V);
       }
-      const uint32_t last = 63u - (uint32_t)__builtin_clzll(V);  // V != 0: p0 is always visited
+      const bool vis = lane_bit(V);
       t += (uint32_t)__builtin_popcountll(V);
       S.pos = rdl(f_end, last);
       if (__ballot(vis && over)) new_flags |= FLAG_DECODE_LOOKAHEAD;
