@@ -577,7 +577,9 @@ int launch_split(bk_env* env, const DevArgs& a0, uint64_t first_step, uint32_t n
         // kernel; one agents kernel apart (the round-1 rule) puts part 2 at 360 us = almost in phase with part 0 again.
         // Measured at C3 (driver's 20-step regions): 60 us apart 186-189 M first region / 199-201 M later ones against
         // 182 / 192-195 M (BOURSE_AMD_STAGGER_US overrides; other pipelines keep the event-based stagger)
-        const uint32_t stagger = env->stagger_us != ~0u ? env->stagger_us : ((MIXED == 0 && !wave && P >= 3) ? 50u : 0u);
+        // (round 3, 20-step regions, first / median of five: 0 us 226 / 229 M, 20 us 240 / 246, 35 us 238 / 244, 50 us 241 / 242,
+        // 70 us 235 / 238; no difference over 200 steps)
+        const uint32_t stagger = env->stagger_us != ~0u ? env->stagger_us : ((MIXED == 0 && !wave && P >= 3) ? 30u : 0u);
         if (stagger > 0)
           hipLaunchKernelGGL(k_delay, dim3(1), dim3(64), 0, st, static_cast<uint32_t>(i) * stagger * 100u);
         else                           // by one agents kernel each
