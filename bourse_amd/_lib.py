@@ -15,13 +15,15 @@ BK_OK, BK_PRICE, BK_UNKNOWN_ORDER, BK_CAPACITY, BK_STEP_SIZE, BK_INVALID, BK_HIP
 
 FLAG_POOL_OVERFLOW, FLAG_TRADE_OVERFLOW, FLAG_STEP_SIZE, FLAG_ORDER_LOG_FULL = 1, 2, 4, 8
 FLAG_UNKNOWN_ORDER, FLAG_HIST_OVERFLOW, FLAG_PRICE_TICK, FLAG_EVENT_OVERFLOW = 16, 32, 64, 128
+FLAG_DECODE_LOOKAHEAD = 256
 FLAG_NAMES = {1: "POOL_OVERFLOW (live-order pool full: a resting order was dropped)",
               2: "TRADE_OVERFLOW (trade_capacity exceeded: records dropped, counts exact)",
               4: "STEP_SIZE (a step queued >= step_size events)",
               8: "ORDER_LOG_FULL (order id beyond max_orders)",
               16: "UNKNOWN_ORDER", 32: "HIST_OVERFLOW",
               64: "PRICE_TICK (a Noise/Momentum limit price clamped to u32::MAX was not a tick multiple)",
-              128: "EVENT_OVERFLOW (a market queued more events in one step than its shared list holds)"}
+              128: "EVENT_OVERFLOW (a market queued more events in one step than its shared list holds)",
+              256: "DECODE_LOOKAHEAD (a ziggurat rejection loop outran the members' decode's 128-draw look-ahead)"}
 CAPACITY_FLAGS = FLAG_POOL_OVERFLOW | FLAG_TRADE_OVERFLOW | FLAG_ORDER_LOG_FULL | FLAG_EVENT_OVERFLOW
 
 

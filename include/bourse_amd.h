@@ -40,6 +40,8 @@ enum bk_status {
 #define BK_FLAG_HIST_OVERFLOW 32u  /* (unused: the L2 history is a ring; reading a step that was overwritten is an error) */
 #define BK_FLAG_PRICE_TICK 64u     /* a Noise/Momentum agent's limit price (clamped to u32::MAX) was not a tick multiple:
                                      * the reference panics here (`.unwrap()`, common.rs:107,140); the order is not created */
+#define BK_FLAG_DECODE_LOOKAHEAD 256u /* the wave-parallel decode of a Noise/Momentum member met a ziggurat rejection loop
+                                     * longer than its 128-draw look-ahead (p < 2^-90): results of that book are suspect */
 #define BK_FLAG_EVENT_OVERFLOW 128u /* a MARKET with Noise/Momentum members queued more than max_live_orders events in one
                                      * step (its books share one queue of that size): the excess events were dropped */
 

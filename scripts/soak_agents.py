@@ -14,6 +14,22 @@ def check(env, ref, T, chunk, n_units, stride):
     want = ref.rng_states()
     assert all(env.rng_state(u * stride) == (int(want[u, 0]), int(want[u, 1])) for u in range(n_units)), "rng"
 
+# 0. Noise / Momentum sets on the wave-parallel members' decode (k_agents_mixed_wave): long runs exercise the lists'
+# compaction, slot re-use, the arrival-stamp window and thousands of ziggurat slow paths; every fourth chunk on another
+# pipeline (lists rebuilt from the owner tags on the way back)
+for B, T, chunk, pool, n_m, n_n in ((1024, 2000, 100, 512, 64, 64), (96, 600, 50, 512, 256, 256)):
+    mem = [("momentum", 0, n_m, dict(MOM, demand=20.0 if n_m > 64 else 8.0)), ("noise", n_m, n_n, NOI)]
+    env = bk.ManyBookEnv(B, 5, 0, 1, 1_000_000, levels=16, max_live_orders=pool, trade_capacity=256 * chunk, history_capacity=chunk, strict=False)
+    env.set_agents(mem)
+    ref = oracle.ManyBooks(B, 5, 0, 1, 1_000_000, True, 16, members=mem)
+    t0 = time.time()
+    for i in range(T // chunk):
+        env.set_pipeline(("wave_split", "wave_split", "wave_split", "split", "wave_split", "fused", "wave_split", "split_wave")[i % 8]); env.run(chunk); env.clear_trades()
+    t1 = time.time(); ref.run(T, NT); t2 = time.time()
+    check(env, ref, T, chunk, B, 1)
+    assert np.array_equal(env.trade_counts(), ref.trade_counts())
+    print(f"wave-members soak ok: {B} books x {T} steps x {n_m + n_n} agents, {int(ref.trade_counts().sum())} trades (gpu {t1-t0:.1f} s, oracle {t2-t1:.1f} s)")
+    del env, ref
 # 1. AgentSet (momentum + noise + random), 1024 books x 1500 steps, pipelines cycling every chunk
 members = [("momentum", 0, 64, MOM), ("noise", 64, 64, NOI), ("random", 32, (1_000_000_000, 1_000_000_032), (10, 20), 1, 0.5)]
 B, T, chunk = 1024, 1500, 100
