@@ -106,6 +106,7 @@ int main(void) {
     bk_random_agents g[2] = {{32, 40, 56, 10, 20, 2, 0.8f}, {32, 40, 56, 50, 70, 2, 0.2f}};
     CHECK(bk_set_random_agents(env, 2, g));
     CHECK(bk_set_pipeline(env, rep == 0 ? 1 : 2)); /* fused, then split: identical results */
+    if (rep == 1) CHECK(bk_warm(env, 7));          /* scratch steps: state, records and the step counter are put back */
     CHECK(bk_run(env, 20));
     CHECK(bk_env_sync(env));
     bk_stats st;
@@ -115,9 +116,19 @@ int main(void) {
     CHECK(bk_history(env, 0, 20, 0, 256, h));
     for (size_t i = 0; i < (size_t)20 * 256 * bk_l2_width(env); ++i) sum[rep] = sum[rep] * 31u + h[i];
     free(h);
-    uint32_t flags[256];
+    uint32_t flags[256], any = 1;
+    uint64_t retained = 0, steps = 0;
     CHECK(bk_book_flags(env, flags));
     for (int b = 0; b < 256; ++b) EXPECT(flags[b] == 0);
+    CHECK(bk_flags_summary(env, &any, &retained));
+    EXPECT(any == 0 && retained > 0 && retained <= 4096);
+    CHECK(bk_clear_flags(env, 0xFFFFFFFFu));
+    CHECK(bk_steps_done(env, &steps));
+    EXPECT(steps == 20);
+    int np = 0;
+    uint32_t mp = 0;
+    CHECK(bk_get_split_parts(env, &np, &mp));
+    EXPECT(np == 4 && mp == 4096);
     bk_env_destroy(env);
   }
   EXPECT(sum[0] == sum[1]);
