@@ -182,6 +182,9 @@ struct WaveDecoder {
   // livev: lane live_base + w holds bits [32 w, 32 w + 32) of the pool's live mask.  Returns the number of events.
   __device__ __forceinline__ uint32_t agents(const DevArgs& a, uint32_t lim, uint32_t livev, uint32_t live_base) {
     uint32_t n_ev = 0, ag = 0, gbase = 0;
+    // (R <= 2) the pool's live masks as two scalar pairs for the walk
+    const uint64_t lv0 = mk64(rdl(livev, live_base), rdl(livev, live_base + 1u));
+    const uint64_t lv1 = R >= 2 ? mk64(rdl(livev, live_base + 2u), rdl(livev, live_base + 3u)) : 0ull;
     for (uint32_t g = 0; g < a.n_groups; ++g) {
       const Group G = a.groups[g];
       const uint32_t gend = gbase + G.n;
@@ -248,70 +251,139 @@ struct WaveDecoder {
             //   w = pack[p]; live bit of agent ag; cancellation -> event word ag | ACTED into lane p, next = w[6:0];
             //   placement -> (w[31]: not resolvable -> slow) event word ag | NEW | ACTED, next = w[14:7], agents += w[29:23];
             //   the group ends before the next hit -> position of agent `gend`'s draw from the run start (p + 1 or f).
-            uint32_t st, w, t0, t1, np, na;
-            asm volatile(
-                "s_nop 0\n\t"
-                "1:\n\t"
-                "s_lshr_b32 %[t0], %[ag], 5\n\t"
-                "s_add_u32 %[t0], %[t0], %[lb]\n\t"
-                "v_readlane_b32 %[w], %[pack], %[p]\n\t"
-                "v_readlane_b32 %[t1], %[livev], %[t0]\n\t"
-                "s_mov_b32 m0, %[p]\n\t"
-                "s_lshr_b32 %[t1], %[t1], %[ag]\n\t"
-                "s_bitcmp1_b32 %[t1], 0\n\t"
-                "s_cbranch_scc0 2f\n\t"
-                "s_or_b32 %[t0], %[ag], 0x10000\n\t"          /* holds an Active order: its cancellation */
-                "v_writelane_b32 %[agw], %[t0], m0\n\t"
-                "s_and_b32 %[np], %[w], 0x7f\n\t"
-                "s_sub_u32 %[t0], %[np], %[p]\n\t"
-                "s_add_u32 %[na], %[ag], %[t0]\n\t"
-                "s_cmp_ge_u32 %[na], %[gend]\n\t"
-                "s_cbranch_scc1 5f\n\t"
-                "s_mov_b32 %[p], %[np]\n\t"
-                "s_mov_b32 %[ag], %[na]\n\t"
-                "s_cmp_lt_u32 %[np], 64\n\t"
-                "s_cbranch_scc1 1b\n\t"
-                "s_mov_b32 %[st], 0\n\t"
-                "s_branch 9f\n\t"
-                "2:\n\t"
-                "s_cmp_lt_i32 %[w], 0\n\t"                    /* placement not resolvable in the look-ahead */
-                "s_cbranch_scc1 8f\n\t"
-                "s_or_b32 %[t0], %[ag], 0x18000\n\t"
-                "v_writelane_b32 %[agw], %[t0], m0\n\t"
-                "s_bfe_u32 %[np], %[w], 0x80007\n\t"
-                "s_bfe_u32 %[t0], %[w], 0x70017\n\t"
-                "s_add_u32 %[na], %[ag], %[t0]\n\t"
-                "s_cmp_ge_u32 %[na], %[gend]\n\t"
-                "s_cbranch_scc1 6f\n\t"
-                "s_mov_b32 %[p], %[np]\n\t"
-                "s_mov_b32 %[ag], %[na]\n\t"
-                "s_cmp_lt_u32 %[np], 64\n\t"
-                "s_cbranch_scc1 1b\n\t"
-                "s_mov_b32 %[st], 0\n\t"
-                "s_branch 9f\n\t"
-                "5:\n\t"                                       /* group end behind a cancellation */
-                "s_sub_u32 %[t0], %[gend], %[ag]\n\t"
-                "s_add_u32 %[p], %[p], %[t0]\n\t"
-                "s_mov_b32 %[ag], %[gend]\n\t"
-                "s_mov_b32 %[st], 1\n\t"
-                "s_branch 9f\n\t"
-                "6:\n\t"                                       /* group end behind a placement: from f */
-                "s_bfe_u32 %[t1], %[w], 0x8000f\n\t"
-                "s_sub_u32 %[t0], %[gend], %[ag]\n\t"
-                "s_add_u32 %[t0], %[t0], %[t1]\n\t"
-                "s_sub_u32 %[p], %[t0], 1\n\t"
-                "s_mov_b32 %[ag], %[gend]\n\t"
-                "s_mov_b32 %[st], 1\n\t"
-                "s_branch 9f\n\t"
-                "8:\n\t"
-                "s_mov_b32 %[st], 2\n\t"
-                "9:\n\t"
-                "s_nop 0"
-                : [st] "=&s"(st), [w] "=&s"(w), [t0] "=&s"(t0), [t1] "=&s"(t1), [np] "=&s"(np), [na] "=&s"(na), [p] "+s"(p),
-                  [ag] "+s"(ag), [agw] "+v"(agw)
-                : [pack] "v"(pack), [livev] "v"(livev), [lb] "s"(live_base), [gend] "s"(gend)
-                : "scc", "memory");
-            slow = st == 2u;
+            if constexpr (R <= 2) {
+              // pools of <= 128 slots: the live masks sit in two SGPR pairs and the test is three scalar instructions (the
+              // general form below reads the mask word back from a VGPR: two more scalar instructions, one more
+              // v_readlane and a second vector-to-scalar hand-over on the walk's critical path)
+              uint32_t st, w, t0, t1, np, na;
+              uint64_t lm;
+              asm volatile(
+                  "s_nop 0\n\t"
+                  "1:\n\t"
+                  "v_readlane_b32 %[w], %[pack], %[p]\n\t"
+                  "s_bitcmp1_b32 %[ag], 6\n\t"                  /* agent 64..127: the second mask */
+                  "s_cselect_b64 %[lm], %[lv1], %[lv0]\n\t"
+                  "s_mov_b32 m0, %[p]\n\t"
+                  "s_bitcmp1_b64 %[lm], %[ag]\n\t"              /* (the bit index is ag[5:0]) */
+                  "s_cbranch_scc0 2f\n\t"
+                  "s_or_b32 %[t0], %[ag], 0x10000\n\t"          /* holds an Active order: its cancellation */
+                  "v_writelane_b32 %[agw], %[t0], m0\n\t"
+                  "s_and_b32 %[np], %[w], 0x7f\n\t"
+                  "s_sub_u32 %[t0], %[np], %[p]\n\t"
+                  "s_add_u32 %[na], %[ag], %[t0]\n\t"
+                  "s_cmp_ge_u32 %[na], %[gend]\n\t"
+                  "s_cbranch_scc1 5f\n\t"
+                  "s_mov_b32 %[p], %[np]\n\t"
+                  "s_mov_b32 %[ag], %[na]\n\t"
+                  "s_cmp_lt_u32 %[np], 64\n\t"
+                  "s_cbranch_scc1 1b\n\t"
+                  "s_mov_b32 %[st], 0\n\t"
+                  "s_branch 9f\n\t"
+                  "2:\n\t"
+                  "s_cmp_lt_i32 %[w], 0\n\t"                    /* placement not resolvable in the look-ahead */
+                  "s_cbranch_scc1 8f\n\t"
+                  "s_or_b32 %[t0], %[ag], 0x18000\n\t"
+                  "v_writelane_b32 %[agw], %[t0], m0\n\t"
+                  "s_bfe_u32 %[np], %[w], 0x80007\n\t"
+                  "s_bfe_u32 %[t0], %[w], 0x70017\n\t"
+                  "s_add_u32 %[na], %[ag], %[t0]\n\t"
+                  "s_cmp_ge_u32 %[na], %[gend]\n\t"
+                  "s_cbranch_scc1 6f\n\t"
+                  "s_mov_b32 %[p], %[np]\n\t"
+                  "s_mov_b32 %[ag], %[na]\n\t"
+                  "s_cmp_lt_u32 %[np], 64\n\t"
+                  "s_cbranch_scc1 1b\n\t"
+                  "s_mov_b32 %[st], 0\n\t"
+                  "s_branch 9f\n\t"
+                  "5:\n\t"                                       /* group end behind a cancellation */
+                  "s_sub_u32 %[t0], %[gend], %[ag]\n\t"
+                  "s_add_u32 %[p], %[p], %[t0]\n\t"
+                  "s_mov_b32 %[ag], %[gend]\n\t"
+                  "s_mov_b32 %[st], 1\n\t"
+                  "s_branch 9f\n\t"
+                  "6:\n\t"                                       /* group end behind a placement: from f */
+                  "s_bfe_u32 %[t1], %[w], 0x8000f\n\t"
+                  "s_sub_u32 %[t0], %[gend], %[ag]\n\t"
+                  "s_add_u32 %[t0], %[t0], %[t1]\n\t"
+                  "s_sub_u32 %[p], %[t0], 1\n\t"
+                  "s_mov_b32 %[ag], %[gend]\n\t"
+                  "s_mov_b32 %[st], 1\n\t"
+                  "s_branch 9f\n\t"
+                  "8:\n\t"
+                  "s_mov_b32 %[st], 2\n\t"
+                  "9:\n\t"
+                  "s_nop 0"
+                  : [st] "=&s"(st), [w] "=&s"(w), [t0] "=&s"(t0), [t1] "=&s"(t1), [np] "=&s"(np), [na] "=&s"(na), [p] "+s"(p),
+                    [ag] "+s"(ag), [agw] "+v"(agw), [lm] "=&s"(lm)
+                  : [pack] "v"(pack), [lv0] "s"(lv0), [lv1] "s"(lv1), [gend] "s"(gend)
+                  : "scc", "memory");
+              slow = st == 2u;
+            } else {
+              uint32_t st, w, t0, t1, np, na;
+              asm volatile(
+                  "s_nop 0\n\t"
+                  "1:\n\t"
+                  "s_lshr_b32 %[t0], %[ag], 5\n\t"
+                  "s_add_u32 %[t0], %[t0], %[lb]\n\t"
+                  "v_readlane_b32 %[w], %[pack], %[p]\n\t"
+                  "v_readlane_b32 %[t1], %[livev], %[t0]\n\t"
+                  "s_mov_b32 m0, %[p]\n\t"
+                  "s_lshr_b32 %[t1], %[t1], %[ag]\n\t"
+                  "s_bitcmp1_b32 %[t1], 0\n\t"
+                  "s_cbranch_scc0 2f\n\t"
+                  "s_or_b32 %[t0], %[ag], 0x10000\n\t"          /* holds an Active order: its cancellation */
+                  "v_writelane_b32 %[agw], %[t0], m0\n\t"
+                  "s_and_b32 %[np], %[w], 0x7f\n\t"
+                  "s_sub_u32 %[t0], %[np], %[p]\n\t"
+                  "s_add_u32 %[na], %[ag], %[t0]\n\t"
+                  "s_cmp_ge_u32 %[na], %[gend]\n\t"
+                  "s_cbranch_scc1 5f\n\t"
+                  "s_mov_b32 %[p], %[np]\n\t"
+                  "s_mov_b32 %[ag], %[na]\n\t"
+                  "s_cmp_lt_u32 %[np], 64\n\t"
+                  "s_cbranch_scc1 1b\n\t"
+                  "s_mov_b32 %[st], 0\n\t"
+                  "s_branch 9f\n\t"
+                  "2:\n\t"
+                  "s_cmp_lt_i32 %[w], 0\n\t"                    /* placement not resolvable in the look-ahead */
+                  "s_cbranch_scc1 8f\n\t"
+                  "s_or_b32 %[t0], %[ag], 0x18000\n\t"
+                  "v_writelane_b32 %[agw], %[t0], m0\n\t"
+                  "s_bfe_u32 %[np], %[w], 0x80007\n\t"
+                  "s_bfe_u32 %[t0], %[w], 0x70017\n\t"
+                  "s_add_u32 %[na], %[ag], %[t0]\n\t"
+                  "s_cmp_ge_u32 %[na], %[gend]\n\t"
+                  "s_cbranch_scc1 6f\n\t"
+                  "s_mov_b32 %[p], %[np]\n\t"
+                  "s_mov_b32 %[ag], %[na]\n\t"
+                  "s_cmp_lt_u32 %[np], 64\n\t"
+                  "s_cbranch_scc1 1b\n\t"
+                  "s_mov_b32 %[st], 0\n\t"
+                  "s_branch 9f\n\t"
+                  "5:\n\t"                                       /* group end behind a cancellation */
+                  "s_sub_u32 %[t0], %[gend], %[ag]\n\t"
+                  "s_add_u32 %[p], %[p], %[t0]\n\t"
+                  "s_mov_b32 %[ag], %[gend]\n\t"
+                  "s_mov_b32 %[st], 1\n\t"
+                  "s_branch 9f\n\t"
+                  "6:\n\t"                                       /* group end behind a placement: from f */
+                  "s_bfe_u32 %[t1], %[w], 0x8000f\n\t"
+                  "s_sub_u32 %[t0], %[gend], %[ag]\n\t"
+                  "s_add_u32 %[t0], %[t0], %[t1]\n\t"
+                  "s_sub_u32 %[p], %[t0], 1\n\t"
+                  "s_mov_b32 %[ag], %[gend]\n\t"
+                  "s_mov_b32 %[st], 1\n\t"
+                  "s_branch 9f\n\t"
+                  "8:\n\t"
+                  "s_mov_b32 %[st], 2\n\t"
+                  "9:\n\t"
+                  "s_nop 0"
+                  : [st] "=&s"(st), [w] "=&s"(w), [t0] "=&s"(t0), [t1] "=&s"(t1), [np] "=&s"(np), [na] "=&s"(na), [p] "+s"(p),
+                    [ag] "+s"(ag), [agw] "+v"(agw)
+                  : [pack] "v"(pack), [livev] "v"(livev), [lb] "s"(live_base), [gend] "s"(gend)
+                  : "scc", "memory");
+              slow = st == 2u;
+            }
           }
         }
         // ---- the window's events, one lane each: list entry and the new order's fields

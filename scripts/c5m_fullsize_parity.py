@@ -7,11 +7,15 @@ import numpy as np, bourse_amd as bk, pyoracle as oracle
 MOM_P = dict(tick_size=2, p_cancel=0.1, trade_vol=100, decay=1.0, demand=20.0, scale=0.5, order_ratio=1.0, price_dist_mu=0.0, price_dist_sigma=10.0)
 NOISE_P = dict(tick_size=2, p_limit=0.3, p_market=0.2, p_cancel=0.2, trade_vol=100, price_dist_mu=0.0, price_dist_sigma=1.0)
 members = [("momentum", 0, 256, MOM_P), ("noise", 256, 256, NOISE_P)]
-B, T = 8192, 24
+B, T = 8192, int(sys.argv[1]) if len(sys.argv) > 1 else 24
 env = bk.ManyBookEnv(B, 101, 0, 2, 100_000, levels=64, max_live_orders=512, trade_capacity=96 * T, history_capacity=T, strict=False)
 env.set_agents(members)
-for c, pipe in ((10, "split"), (4, "split_wave"), (10, "split")):
-    env.set_pipeline(pipe); env.run(c)
+# mostly the auto pipeline (round 3: the wave-parallel members' decode in two parts), with the other pipelines in between
+left = T
+for c, pipe in ((T // 3, "auto"), (4, "split"), (2, "split_wave"), (T, "auto")):
+    c = min(c, left); left -= c
+    if c:
+        env.set_pipeline(pipe); env.run(c)
 ref = oracle.ManyBooks(B, 101, 0, 2, 100_000, True, 64, members=members)
 t0 = time.time(); ref.run(T, os.cpu_count()); t1 = time.time()
 f = env.flags()
