@@ -1177,7 +1177,9 @@ __global__ __launch_bounds__(64) void k_agents_fsm(DevArgs a) {
 // POOLPEND (split pipeline of AgentSets with Noise/Momentum members, k_agents_mixed): the new orders already sit in the
 // pool with their pend bit and id (created by the members' update); the batch only carries the shuffled event list.
 template <int R, bool MKT, bool POOLPEND = false>
-__global__ __launch_bounds__(64) void k_step_batch(DevArgs a, uint64_t step_index, uint32_t write_last) {
+// (512-slot pools: asked to fit 5 waves per SIMD - 96 VGPRs, 44-52 B of scratch - instead of the 119 VGPRs / 4 waves the
+// compiler takes by itself: C5 stand-in 272 -> 186 us per launch, 19.0 -> 21.1 M book-steps/s; 6 waves: 201 us)
+__global__ __launch_bounds__(64, R >= 8 ? 5 : 1) void k_step_batch(DevArgs a, uint64_t step_index, uint32_t write_last) {
   // one-wave workgroups: the dispatcher places every wave independently, so the wave slots left beside the
   // co-running k_agents_fsm waves are all usable (4-wave workgroups needed a free slot on every SIMD)
   __shared__ uint32_t lds[1][LDS_DW_PER_WAVE];
