@@ -823,6 +823,40 @@ __device__ __forceinline__ void slot_event_keyed(Book<R>& B, KeyState<R>& K, con
   }
 }
 
+// Lazy cancellations of the keyed assembly loop (event_asm.hpp): from the step's (shuffled, self-classifying) event list
+//   dt[r]  per pool lane: the list position at which that slot's order is cancelled in this step, else all ones;
+//   evc[r] the NEW orders only, in list order, each word = event word | position << 16 | (passive side is bid) << 23.
+// A slot is cancelled at most once per step and never re-used in it (one event per agent).  lds: >= 128 R dwords.
+template <int R>
+__device__ __forceinline__ uint32_t lc_prepare(const uint32_t (&ev)[R], uint32_t n_ev, int lane, uint32_t* lds, uint32_t (&dt)[R],
+                                               uint32_t (&evc)[R]) {
+#pragma unroll
+  for (int r = 0; r < R; ++r) lds[r * 64 + lane] = 0xFFFFFFFFu;
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  uint32_t base = 0;
+#pragma unroll
+  for (int re = 0; re < R; ++re) {
+    const uint32_t k = (uint32_t)(re * 64 + lane), ew = ev[re];
+    const bool valid = k < n_ev, is_new = valid && (ew & EV_NEW) != 0u;
+    if (valid && !is_new) lds[ew & EV_SLOT] = k;
+    const uint64_t nm = __ballot(is_new);
+    const uint32_t idx = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(nm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)nm, 0u));
+    if (is_new) lds[64 * R + idx] = (ew & 0xFFFFu) | (k << 16) | ((ew & EV_BID) ? 0u : (1u << 23));
+    base += (uint32_t)__builtin_popcountll(nm);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    dt[r] = lds[r * 64 + lane];
+    evc[r] = lds[64 * R + r * 64 + lane];
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  return base;
+}
+
 // ----------------------------------------------------------------------------------
 // Env::step body after the shuffle (env.rs:117-134): process the (already shuffled) event list of
 // agent/slot indices, advance the clock, snapshot, flush trades.  Returns this step's trade count.
@@ -858,20 +892,45 @@ __device__ __forceinline__ uint32_t step_from_list(Book<R>& B, const DevArgs& a,
     KeyState<R> K;
     if (BOURSE_AMD_KEYED_EVENTS && keys_begin<R>(B, newm, nev, K)) {
       // keyed loop: one sort key per order (price field | arrival field | side), rebuilt from {price, seq} every step
+#if BOURSE_AMD_LAZY_CANCEL
+      // ... over the NEW orders only: cancellations become a death time per pool lane (event_asm.hpp, lc_prepare)
+      uint32_t dt[R], evl[R];
+      const uint32_t n_list = rfl(lc_prepare<R>(ev, nev, lane, bins, dt, evl));
+#else
+      const uint32_t(&evl)[R] = ev;
+      const uint32_t n_list = nev;
+#endif
       for (;;) {
         uint32_t full;
         if constexpr (R == 2)
-          full = events_key_r2(k, nev, tmask, B.tr_n, K.sq, B.live[0], B.live[1], B.bid[0], B.bid[1], B.price[0], B.price[1],
-                               B.vol[0], B.vol[1], B.id[0], B.id[1], K.key[0], K.key[1], ev[0], ev[1], B.tr_k, B.tr_price,
-                               B.tr_vol, B.tr_act, B.tr_pas);
+          full = events_key_r2(k, n_list, tmask, B.tr_n, K.sq, B.live[0], B.live[1], B.bid[0], B.bid[1], B.price[0], B.price[1],
+                               B.vol[0], B.vol[1], B.id[0], B.id[1], K.key[0], K.key[1], evl[0], evl[1], B.tr_k, B.tr_price,
+                               B.tr_vol, B.tr_act, B.tr_pas
+#if BOURSE_AMD_LAZY_CANCEL
+                               , dt[0], dt[1]
+#endif
+          );
         else
-          full = events_key_r1(k, nev, tmask, B.tr_n, K.sq, B.live[0], B.bid[0], B.price[0], B.vol[0], B.id[0], K.key[0], ev[0],
-                               B.tr_k, B.tr_price, B.tr_vol, B.tr_act, B.tr_pas);
+          full = events_key_r1(k, n_list, tmask, B.tr_n, K.sq, B.live[0], B.bid[0], B.price[0], B.vol[0], B.id[0], K.key[0], evl[0],
+                               B.tr_k, B.tr_price, B.tr_vol, B.tr_act, B.tr_pas
+#if BOURSE_AMD_LAZY_CANCEL
+                               , dt[0]
+#endif
+          );
+#if BOURSE_AMD_LAZY_CANCEL
+        // the loop wrote the records' k words as the list carries them (position | passive side << 7): into the record
+        // format (position | side << 31); only the lanes filled since the last flush are touched
+        B.tr_k = (B.tr_k & 0xFFFFFF00u) == 0u ? ((B.tr_k & 0x7Fu) | ((B.tr_k & 0x80u) << 24)) : B.tr_k;
+#endif
         // Env::get_trade_vol: the loop leaves the sum to the vector unit (one reduction per flush, not an add per trade)
         if (B.tr_n) B.trade_vol += wave_add((uint32_t)lane < B.tr_n ? B.tr_vol : 0u);
         if (!full) break;
         flush_trades<R>(B, a, book, t0, lane);
       }
+#if BOURSE_AMD_LAZY_CANCEL
+#pragma unroll
+      for (int r = 0; r < R; ++r) B.live[r] &= ~__ballot(dt[r] != 0xFFFFFFFFu);  // the step's cancellations, all at once
+#endif
       keys_end<R>(B, K);
     } else if constexpr (R == 2) {
       while (events_asm_r2(k, nev, tmask, B.tr_n, B.seq_ctr, B.trade_vol, B.live[0], B.live[1], B.bid[0], B.bid[1],

@@ -339,6 +339,29 @@ __device__ __forceinline__ uint32_t events_asm_r1(uint32_t& k, uint32_t n_ev, ui
 // (lane selects read the low 6 bits).  The step's traded volume is summed from the buffer at every flush (book_device.hpp)
 // instead of one scalar add per trade.  Per trade: 16 scalar + branch instructions (loop above: 32).
 // ==================================================================================
+// LAZY CANCELLATIONS (round 3).  A cancellation is ~10 scalar-port instructions of pure loop overhead (fetch the word, two
+// tests, a 64-bit shift, an and-not, the loop's own three) and the scalar port is what binds these kernels at small
+// batches.  With BOURSE_AMD_LAZY_CANCEL the caller (book_device.hpp lc_prepare) hands over a list of the NEW orders only
+// - each word carrying its original position k in bits 16..22 and the passive side in bit 23 - plus, per pool lane, the
+// position dt at which that slot's order is cancelled this step (else all ones).  An order is a candidate of a match at
+// position k iff it is live AND k < dt: two vector instructions per pool register and reduction (v_cmp into VCC + a
+// VCC-select of the neutral element) instead of one loop iteration per cancellation; the live bits of the cancelled
+// orders are cleared after the loop.  Exact because a slot is cancelled at most once per step and never re-used in it.
+// MEASURED AND NOT SHIPPED (parity-green on the whole suite): -0.4 k scalar-port instructions per book-step, but the
+// prologue's two LDS passes and +4 vector instructions per reduction cost as much: C3 253 -> 250 M (k_step_batch 103 ->
+// 110 us per launch), 8 192-book shard 110.5 -> 110.0 M, 32 768 books 158 -> 160 M, C2 168 -> 171 M.  -D...=1 builds it.
+#ifndef BOURSE_AMD_LAZY_CANCEL
+#define BOURSE_AMD_LAZY_CANCEL 0
+#endif
+#if BOURSE_AMD_LAZY_CANCEL
+#define EK_LC(x) x
+#define EK_NLC(x) ""
+#else
+#define EK_LC(x) ""
+#define EK_NLC(x) x
+#endif
+#define EK_KT "s61"  // position of the event being matched (lazy cancellations)
+
 #define EK_KP EA_P  // the aggressor's key prefix lives where the loop above keeps its price
 // Bounds that let a new order that cannot cross skip the reduction: EK_ALO <= best ask key, EK_BHI >= best bid key.
 // Exact right after a reduction of that side, still valid after any removal (the best only moves away), pulled in when
@@ -387,12 +410,18 @@ __device__ __forceinline__ uint32_t events_asm_r1(uint32_t& k, uint32_t n_ev, ui
   SKIP " " EK_KP ", " OPPB "\n\t"                      /* beyond the bound: cannot cross */           \
   "s_cbranch_scc1 L_restq_" L "\n\t"                                                                  \
   "v_readlane_b32 " EA_ID ", %[id" RG "], " EA_EW "\n\t" /* (only a trade needs the id and the k word) */ \
-  KKI "\n\t"                                                                                          \
+  EK_NLC(KKI "\n\t")                                                                                  \
+  EK_LC("s_lshr_b32 " EA_KK ", " EA_EW ", 16\n\t"     /* k | passive side << 7, as the list word carries them */ \
+        "s_and_b32 " EK_KT ", " EA_KK ", 0x7f\n\t")                                                   \
   "L_match_" L ":\n\t"                                                                                \
   CAND " " EA_C0 ", %[live0], %[bid0]\n\t"                                                            \
   EA_IF2_##NR(CAND " " EA_C1 ", %[live1], %[bid1]\n\t")                                               \
   "v_cndmask_b32_e64 %[vm], " SENT ", %[key0], " EA_C0 "\n\t"                                         \
+  EK_LC("v_cmp_lt_u32_e32 vcc, " EK_KT ", %[dt0]\n\t"   /* not cancelled yet at this position? */     \
+        "v_cndmask_b32_e32 %[vm], " SENT ", %[vm], vcc\n\t")                                          \
   EA_IF2_##NR("v_cndmask_b32_e64 %[vm2], " SENT ", %[key1], " EA_C1 "\n\t"                            \
+              EK_LC("v_cmp_lt_u32_e32 vcc, " EK_KT ", %[dt1]\n\t"                                     \
+                    "v_cndmask_b32_e32 %[vm2], " SENT ", %[vm2], vcc\n\t")                            \
               VOP " %[vm], %[vm], %[vm2]\n\t")                                                        \
   EA_DPP(DOP)                                                                                         \
   "v_readlane_b32 " EA_BEST ", %[vm], 63\n\t"                                                         \
@@ -438,17 +467,18 @@ __device__ __forceinline__ uint32_t events_asm_r1(uint32_t& k, uint32_t n_ev, ui
 #define EK_PHASE(PH, KEND, NR)                                                                        \
   "L_top_" PH "_%=:\n\t"                                                                              \
   "v_readlane_b32 " EA_EW ", %[ev" PH "], %[k]\n\t"                                                   \
-  "s_bitcmp1_b32 " EA_EW ", 15\n\t"                                                                   \
-  "s_cbranch_scc1 L_new_" PH "_%=\n\t"                                                                \
-  "s_lshl_b64 " EA_BIT ", 1, " EA_EW "\n\t"             /* Cancellation */                            \
-  EA_IF2_##NR("s_bitcmp1_b32 " EA_EW ", 6\n\t"                                                        \
-              "s_cbranch_scc1 L_can1_" PH "_%=\n\t")                                                  \
-  "s_andn2_b64 %[live0], %[live0], " EA_BIT "\n\t"                                                    \
-  EA_IF2_##NR(EA_LOOP(PH, KEND)                                                                       \
-              "L_can1_" PH "_%=:\n\t"                                                                 \
-              "s_andn2_b64 %[live1], %[live1], " EA_BIT "\n\t")                                       \
-  EA_LOOP(PH, KEND)                                                                                   \
-  "L_new_" PH "_%=:\n\t"                                                                              \
+  EK_LC("s_nop 1\n\t")          /* (stands in for the two instructions of the New test: ew becomes a lane select) */ \
+  EK_NLC("s_bitcmp1_b32 " EA_EW ", 15\n\t"                                                            \
+         "s_cbranch_scc1 L_new_" PH "_%=\n\t"                                                         \
+         "s_lshl_b64 " EA_BIT ", 1, " EA_EW "\n\t"      /* Cancellation */                            \
+         EA_IF2_##NR("s_bitcmp1_b32 " EA_EW ", 6\n\t"                                                 \
+                     "s_cbranch_scc1 L_can1_" PH "_%=\n\t")                                           \
+         "s_andn2_b64 %[live0], %[live0], " EA_BIT "\n\t"                                             \
+         EA_IF2_##NR(EA_LOOP(PH, KEND)                                                                \
+                     "L_can1_" PH "_%=:\n\t"                                                          \
+                     "s_andn2_b64 %[live1], %[live1], " EA_BIT "\n\t")                                \
+         EA_LOOP(PH, KEND)                                                                            \
+         "L_new_" PH "_%=:\n\t")                                                                      \
   EA_IF2_##NR("s_bitcmp1_b32 " EA_EW ", 6\n\t"                                                        \
               "s_cbranch_scc1 L_new1_" PH "_%=\n\t")                                                  \
   EA_IF1_##NR("s_nop 1\n\t")                            /* ew as a lane select: 4 wait states */      \
@@ -477,7 +507,7 @@ __device__ __forceinline__ uint32_t events_key_r2(uint32_t& k, uint32_t n_ev, ui
                                                   uint32_t price0, uint32_t price1, uint32_t& vol0, uint32_t& vol1,
                                                   uint32_t id0, uint32_t id1, uint32_t& key0, uint32_t& key1, uint32_t ev0,
                                                   uint32_t ev1, uint32_t& trk, uint32_t& trp, uint32_t& trv, uint32_t& tra,
-                                                  uint32_t& trs) {
+                                                  uint32_t& trs, uint32_t dt0 = 0xFFFFFFFFu, uint32_t dt1 = 0xFFFFFFFFu) {
   uint32_t st, vm, vm2;
   auto u32 = [](uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane(x); };
   auto u64 = [&](uint64_t x) { return ((uint64_t)u32((uint32_t)(x >> 32)) << 32) | u32((uint32_t)x); };
@@ -508,7 +538,8 @@ __device__ __forceinline__ uint32_t events_key_r2(uint32_t& k, uint32_t n_ev, ui
         [live0] "+s"(live0), [live1] "+s"(live1), [vol0] "+v"(vol0), [vol1] "+v"(vol1), [key0] "+v"(key0),
         [key1] "+v"(key1), [trk] "+v"(trk), [trp] "+v"(trp), [trv] "+v"(trv), [tra] "+v"(tra), [trs] "+v"(trs)
       : [price0] "v"(price0), [price1] "v"(price1), [id0] "v"(id0), [id1] "v"(id1), [ev0] "v"(ev0), [ev1] "v"(ev1),
-        [bid0] "s"(bid0), [bid1] "s"(bid1), [nev] "s"(n_ev), [kend0] "s"(kend0), [tmask] "s"(tmask)
+        [bid0] "s"(bid0), [bid1] "s"(bid1), [nev] "s"(n_ev), [kend0] "s"(kend0), [tmask] "s"(tmask), [dt0] "v"(dt0),
+        [dt1] "v"(dt1)
       : EK_CLOBBERS);
   tr_n = trn + 64u;
   return st;
@@ -517,7 +548,7 @@ __device__ __forceinline__ uint32_t events_key_r2(uint32_t& k, uint32_t n_ev, ui
 __device__ __forceinline__ uint32_t events_key_r1(uint32_t& k, uint32_t n_ev, uint32_t tmask, uint32_t& tr_n, uint32_t& sq,
                                                   uint64_t& live0, uint64_t bid0, uint32_t price0, uint32_t& vol0,
                                                   uint32_t id0, uint32_t& key0, uint32_t ev0, uint32_t& trk, uint32_t& trp,
-                                                  uint32_t& trv, uint32_t& tra, uint32_t& trs) {
+                                                  uint32_t& trv, uint32_t& tra, uint32_t& trs, uint32_t dt0 = 0xFFFFFFFFu) {
   uint32_t st, vm;
   auto u32 = [](uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane(x); };
   auto u64 = [&](uint64_t x) { return ((uint64_t)u32((uint32_t)(x >> 32)) << 32) | u32((uint32_t)x); };
@@ -539,7 +570,8 @@ __device__ __forceinline__ uint32_t events_key_r1(uint32_t& k, uint32_t n_ev, ui
       : [st] "=&s"(st), [vm] "=&v"(vm), [k] "+s"(k), [trn] "+s"(trn), [sq] "+s"(sq), [live0] "+s"(live0),
         [vol0] "+v"(vol0), [key0] "+v"(key0), [trk] "+v"(trk), [trp] "+v"(trp), [trv] "+v"(trv), [tra] "+v"(tra),
         [trs] "+v"(trs)
-      : [price0] "v"(price0), [id0] "v"(id0), [ev0] "v"(ev0), [bid0] "s"(bid0), [nev] "s"(n_ev), [tmask] "s"(tmask)
+      : [price0] "v"(price0), [id0] "v"(id0), [ev0] "v"(ev0), [bid0] "s"(bid0), [nev] "s"(n_ev), [tmask] "s"(tmask),
+        [dt0] "v"(dt0)
       : EK_CLOBBERS);
   tr_n = trn + 64u;
   return st;
