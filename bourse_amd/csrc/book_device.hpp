@@ -1551,18 +1551,6 @@ __global__ void k_delay(uint32_t ticks) {
   while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(16);
 }
 
-// Guarded launches: the bits of `mask` were cleared in every book before the launch (k_book_service op 2, after the
-// snapshot was taken), so a bit set now was raised BY this launch - also in a book whose sticky bit was already set.
-// Counts those books and puts the earlier bits back.
-__global__ void k_count_new_flags(uint32_t* state, const uint32_t* snap, uint32_t stride, uint32_t n_books,
-                                  uint32_t mask, uint32_t* count) {
-  const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= n_books) return;
-  const uint32_t now = state[(size_t)b * stride + H_FLAGS], was = snap[(size_t)b * stride + H_FLAGS];
-  if (now & mask) atomicAdd(count, 1u);
-  if (was & mask) state[(size_t)b * stride + H_FLAGS] = now | (was & mask);
-}
-
 struct DevStats {  // == bk_stats
   unsigned long long n_books, sum_trade_vol, sum_trades, sum_events, sum_bid_vol, sum_ask_vol;
   uint32_t min_bid, max_bid, min_ask, max_ask;

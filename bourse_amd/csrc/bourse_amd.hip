@@ -136,24 +136,23 @@ struct bk_env {
   // 0 auto, 1 fused (k_run_random), 2 split (k_agents_fsm + k_step_batch), 3 split with wave-per-book AgentSet members,
   // 4 wave_split (k_agents_wave + k_step_batch), 5 wave (k_run_wave: wave-parallel decode + events, persistent)
   int pipeline = 0;
-  DevBuf<uint32_t> snap, snap_count;  // guarded launches (auto pipeline, AgentSets): state + L2 copy, new-flag counter
   DevBuf<uint32_t> warm_snap;         // bk_warm: state + L2 copy of the scratch steps
   bool warming = false;               // bk_warm's scratch steps: no history slots, no trade records
-  uint64_t n_fallbacks = 0;           // guarded launches that were rolled back and redone on the fused kernel
+  uint64_t n_fallbacks = 0;           // (rounds 1-2: guarded launches rolled back and redone; always 0 since round 3)
   DevBuf<uint4> jump_tabs;      // k_agents_wave: T^256 (block jump) then T^(4 << b), b = 0..5 (lane offsets): 7 x 8 KB
   DevBuf<uint32_t> wcache;      // k_agents_wave: per-book lane states of the RNG block in progress
   uint32_t wave_lookahead = 64;
   uint32_t stagger_us = ~0u;    // parts of a split launch start i x stagger_us apart; ~0 = default rule, 0 = by events
   int wave_parts = 0;           // 0 = as the lane split (n_parts / min_part)
   bool wave_ok() const { return !n_mixed && M == 1 && !groups.empty(); }  // RandomAgents on independent books
-  // AgentSets of Noise / Momentum members only, independent books: wave-parallel decode of the members' update
+  // AgentSets with Noise / Momentum members on independent books: wave-parallel decode of the members' update
   bool mixed_random_member = false;
   bool pool_cyclic = false;    // the wave-per-book members' lists (wl_list) describe the pools as of steps_done
   DevBuf<uint16_t> wl_list;    // [n_books][MAX_MEMBERS][pool]: k_agents_mixed_wave's lists, book-major
   DevBuf<uint32_t> wl_len;
   bool mw_attr_set = false;
   bool use_mixed_wave() const {
-    return n_mixed && M == 1 && !mixed_random_member &&
+    return n_mixed && M == 1 &&
            (pipeline == 4 || (pipeline == 0 && cfg.n_books >= MIXED_WAVE_MIN_BOOKS));
   }
   uint32_t fused_resident = 0;   // books one residency round of k_run_wave<R> holds on this device (0 = not asked yet)
@@ -1277,11 +1276,10 @@ int bk_run(bk_env* env, uint64_t n_steps) {
     // event kernel, the batch cut in parts that overlap.  Mode 3 keeps the wave-per-book members' update selectable.
     const bool mlanes = env->pipeline == 2 || env->M > 1 || (env->pipeline == 0 && env->cfg.n_books >= MIXED_SPLIT_MIN_BOOKS);
     // The lane-per-book members' update keeps a filled order's pool slot reserved until its member's next update, so a
-    // pool the wave-per-book kernels just fit can overflow there.  A pipeline CHOSEN BY THE LIBRARY must not change
-    // results: in auto mode (independent books) the launch is guarded - state and level-2 records are copied aside, and
-    // if the launch newly raised BK_FLAG_POOL_OVERFLOW on any book it is rolled back and redone on the fused kernel
-    // (same history slots, same trade-record positions: nothing of the first attempt survives).  Costs one device-to-
-    // device copy and one host sync per bk_run; a pipeline requested explicitly runs unguarded.
+    // pool the wave-per-book kernels just fit can overflow there (flagged).  Rounds 1-2 guarded the library's own choice
+    // of it with a snapshot / roll-back; since round 3 the auto choice for independent books is the wave-parallel decode
+    // (which frees slots like the fused kernel), and the lane pipeline is only ever taken on request (mode 2) or for
+    // markets, where the fused kernel does not exist - nothing of the library's choosing is left to guard.
     if (env->use_mixed_wave()) {  // wave-parallel decode of the members' update + the event kernel, in parts
       switch (env->R) {
         case 1: rc = launch_split<1, 3>(env, a, env->steps_done, ns); break;
@@ -1293,50 +1291,12 @@ int bk_run(bk_env* env, uint64_t n_steps) {
       env->steps_done += n_steps;
       return BK_OK;
     }
-    const bool guarded = mlanes && env->pipeline == 0 && env->M == 1;
-    if (guarded) {
-      const size_t sb = static_cast<size_t>(env->cfg.n_books) * env->stride, lb = static_cast<size_t>(env->cfg.n_books) * env->W;
-      if (!env->snap.p) {
-        HIPCHK(env->snap.alloc(sb + lb));
-        HIPCHK(env->snap_count.alloc(1));
-      }
-      HIPCHK(hipMemcpyAsync(env->snap.p, env->state.p, sb * 4, hipMemcpyDeviceToDevice, env->stream));
-      HIPCHK(hipMemcpyAsync(env->snap.p + sb, env->l2_last.p, lb * 4, hipMemcpyDeviceToDevice, env->stream));
-      // the sticky bit is cleared for the launch (the snapshot keeps it; k_count_new_flags puts it back): a book that
-      // had overflowed in an earlier launch is re-detected like any other
-      hipLaunchKernelGGL(k_book_service, dim3((env->cfg.n_books + 255) / 256), dim3(256), 0, env->stream, env->state.p,
-                         env->stride, env->cfg.n_books, 2, FLAG_POOL_OVERFLOW);
-      HIPCHK(hipGetLastError());
-    }
     if (mlanes) {
       switch (env->R) {
         case 1: rc = launch_split<1, 2>(env, a, env->steps_done, ns); break;
         case 2: rc = launch_split<2, 2>(env, a, env->steps_done, ns); break;
         case 4: rc = launch_split<4, 2>(env, a, env->steps_done, ns); break;
         default: rc = launch_split<8, 2>(env, a, env->steps_done, ns); break;
-      }
-      if (rc == BK_OK && guarded) {
-        const uint32_t B = env->cfg.n_books;
-        const size_t sb = static_cast<size_t>(B) * env->stride, lb = static_cast<size_t>(B) * env->W;
-        HIPCHK(hipMemsetAsync(env->snap_count.p, 0, 4, env->stream));
-        hipLaunchKernelGGL(k_count_new_flags, dim3((B + 255) / 256), dim3(256), 0, env->stream, env->state.p, env->snap.p,
-                           env->stride, B, FLAG_POOL_OVERFLOW, env->snap_count.p);
-        HIPCHK(hipGetLastError());
-        uint32_t n_new = 0;
-        HIPCHK(hipMemcpyAsync(&n_new, env->snap_count.p, 4, hipMemcpyDeviceToHost, env->stream));
-        HIPCHK(hipStreamSynchronize(env->stream));
-        if (n_new) {  // roll back and redo this launch one wave per book
-          HIPCHK(hipMemcpyAsync(env->state.p, env->snap.p, sb * 4, hipMemcpyDeviceToDevice, env->stream));
-          HIPCHK(hipMemcpyAsync(env->l2_last.p, env->snap.p + sb, lb * 4, hipMemcpyDeviceToDevice, env->stream));
-          env->ml_valid = false;
-          env->n_fallbacks += 1;
-          switch (env->R) {
-            case 1: rc = launch_mixed<1>(env, a, env->steps_done, ns); break;
-            case 2: rc = launch_mixed<2>(env, a, env->steps_done, ns); break;
-            case 4: rc = launch_mixed<4>(env, a, env->steps_done, ns); break;
-            default: rc = launch_mixed<8>(env, a, env->steps_done, ns); break;
-          }
-        }
       }
     } else if (env->pipeline == 3) {
       switch (env->R) {

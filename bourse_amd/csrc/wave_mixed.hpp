@@ -24,8 +24,8 @@
 //
 // Semantics restated from (paths relative to the reference repo): agents/common.rs:21-141, noise_agent.rs:127-176,
 // momentum_agent.rs:146-208, rand 0.8.5 / rand_distr 0.4.3 sampling as in mixed_agents.hpp (PARITY UNPINNED against
-// Rust, bit-exact against the oracle through pm_math.hpp).  Independent books only (assets == 1), no RandomAgents member
-// in the set (those sets keep the lane-per-book update).
+// Rust, bit-exact against the oracle through pm_math.hpp).  Independent books only (assets == 1; markets keep the
+// lane-per-book update); a RandomAgents member of such a set is walked draw by draw on the scalar path.
 #pragma once
 #include "mixed_agents.hpp"
 #include "wave_agents.hpp"
@@ -264,11 +264,50 @@ __global__ __launch_bounds__(512, 4) void k_agents_mixed_wave(DevArgs a, MixedAr
     }
     n_free = rank_slots<R>(fr, freelist, lane);
   }
-  uint32_t n_ev = 0, n_created = 0;
+  uint32_t n_ev = 0, n_created = 0;  // n_created: orders of Noise / Momentum members (each takes a free slot, in this order)
+  uint32_t id_extra = 0;             // ids consumed by RandomAgents members (fixed slots): id = next_id + both counters
 
   for (uint32_t j = 0; j < ma.n_desc; ++j) {  // members in declaration order (crates/macros/src/lib.rs:57-73)
     const MixedDesc D = ma.descs[j];
-    if (D.type == 0) continue;  // (sets with RandomAgents members never get here: host check)
+    if (D.type == 0) {
+      // ---- RandomAgents::update (random_agent.rs:85-119) as a MEMBER of such a set: fixed slots [slot_base, slot_base + n),
+      // its draws taken one by one on the scalar path (uniform LDS reads of the generated stream).  Mixed sets are the
+      // rare case and their RandomAgents members small; what matters is that the set as a whole stays on this kernel
+      // instead of the lane-per-book update (a RandomAgents-only set has its own decode, wave_agents.hpp).
+      auto draw = [&]() -> uint32_t {
+        S.ensure(S.pos + 1u);
+        const uint32_t x = rfl((uint32_t)S.at(S.pos));
+        S.pos += 1u;
+        return x;
+      };
+      auto below = [&](uint32_t range, uint32_t zone) -> uint32_t {  // UniformInt<u32>::sample_single
+        for (;;) {
+          const uint64_t mm = (uint64_t)draw() * range;
+          if ((uint32_t)mm <= zone) return (uint32_t)(mm >> 32);
+        }
+      };
+      for (uint32_t i = 0; i < D.n; ++i) {
+        const uint32_t slot = D.slot_base + i;
+        if ((draw() >> 8) < D.thr) {  // gen::<f32>() < activity_rate
+          if (lane == 0) evl[n_ev] = (uint16_t)slot;
+          n_ev += 1u;
+          if (!((rfl(lvw[(slot >> 5) & 15u]) >> (slot & 31u)) & 1u)) {  // no Active order: side, tick, vol (:99-101)
+            const uint32_t side = below(2u, 0x7FFFFFFFu);
+            const uint32_t tick = D.tick_lo + below(D.tick_rng, D.tick_zone);
+            const uint32_t vol = D.vol_lo + below(D.vol_rng, D.vol_zone);
+            if (lane == 0) {
+              uint32_t* p = st + HDR_DW + (slot >> 6) * (POOL_FIELDS * 64) + (slot & 63u);
+              p[0 * 64] = tick * D.tick_size;
+              p[1 * 64] = vol;
+              p[2 * 64] = next_id + n_created + id_extra;
+              p[4 * 64] = 4u | (side ? 2u : 0u);  // pending New, owner tag 0
+            }
+            id_extra += 1u;
+          }  // else: its cancellation (the event kernel tells the two apart by the slot's pend bit)
+        }
+      }
+      continue;
+    }
     const uint32_t tag = j + 1;
     // ---- common::cancel_live_orders (common.rs:54-76): the list's Active orders in order, one f32 draw each; a draw
     // `> p_cancel` keeps the order, otherwise its cancellation is queued.  64 entries per iteration.
@@ -427,7 +466,7 @@ __global__ __launch_bounds__(512, 4) void k_agents_mixed_wave(DevArgs a, MixedAr
         uint32_t* p = st + HDR_DW + (slot >> 6) * (POOL_FIELDS * 64) + (slot & 63u);
         p[0 * 64] = price;
         p[1 * 64] = D.trade_vol;
-        p[2 * 64] = next_id + k;
+        p[2 * 64] = next_id + id_extra + k;
         p[4 * 64] = 4u | (bid ? 2u : 0u) | (tg << 8);  // pending New
         evl[n_ev + (k - n_created)] = (uint16_t)slot;
         return slot;
@@ -516,7 +555,7 @@ __global__ __launch_bounds__(512, 4) void k_agents_mixed_wave(DevArgs a, MixedAr
   hdr_out = lane == H_S0_HI ? n1 : hdr_out;
   hdr_out = lane == H_S1_LO ? n2 : hdr_out;
   hdr_out = lane == H_S1_HI ? n3 : hdr_out;
-  hdr_out = lane == H_NEXT_ID ? next_id + n_created : hdr_out;
+  hdr_out = lane == H_NEXT_ID ? next_id + n_created + id_extra : hdr_out;
   hdr_out = lane == H_FLAGS ? (hdr | new_flags) : hdr_out;
   hdr_out = lane == H_GFLAGS ? gflags : hdr_out;
   st[lane] = hdr_out;

@@ -38,7 +38,7 @@ env.set_agents(members)
 ref = oracle.ManyBooks(B, 7, 0, 1, 1_000_000, True, 16, members=members)
 t0 = time.time()
 for i in range(T // chunk):
-    env.set_pipeline(("split", "fused", "split_wave")[i % 3]); env.run(chunk); env.clear_trades()
+    env.set_pipeline(("split", "fused", "wave_split", "split_wave")[i % 4]); env.run(chunk); env.clear_trades()
 t1 = time.time(); ref.run(T, NT); t2 = time.time()
 check(env, ref, T, chunk, B, 1)
 assert np.array_equal(env.trade_counts(), ref.trade_counts())

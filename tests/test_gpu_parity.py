@@ -719,6 +719,7 @@ def test_mixed_random_noise_momentum_set_on_device(bk, oracle):
     _compare_members(bk, oracle, 12, members, levels=32, n_steps=60, tick=2, pool=512)
     _compare_members(bk, oracle, 12, members, levels=32, n_steps=60, tick=2, pool=512, chunks=[11, 20, 10, 4, 15], pipeline="mixed")
     _compare_members(bk, oracle, 70, members, levels=32, n_steps=60, tick=2, pool=512, pipeline="split")
+    _compare_members(bk, oracle, 70, members, levels=32, n_steps=60, tick=2, pool=512, pipeline="wave_split")
 
 
 def test_mixed_members_split_pipeline_in_parts(bk, oracle):
@@ -1296,7 +1297,6 @@ def test_fuzz_agent_sets_and_markets_vs_oracle(bk, oracle, seed, checkpoint_at=3
         ref = oracle.ManyMarkets(NM, seed, 0, ticks, 1_000_000, True, levels, members=members)
     for i, c in enumerate(chunks):
         if A == 1:
-            # ("wave_split": sets with a RandomAgents member have no wave-parallel decode and run fused there)
             env.set_pipeline(("split", "fused", "split_wave", "wave_split")[(i + seed) % 4])
         env.run(c)
     ref.run(T, 4)
@@ -1912,12 +1912,12 @@ def test_step_env_history_outlives_the_device_ring(bk, oracle):
 def test_auto_pipeline_does_not_change_results_at_the_pool_capacity_edge(bk):
     """The lane-per-book members' update keeps a filled order's pool slot until its member's next update, so it overflows
     a nearly full pool where the wave-per-book kernels still fit (1 of 60 000 fuzz draws in round 1).  A pipeline chosen
-    BY THE LIBRARY must not change results.  Since round 3 the auto choice for Noise / Momentum sets is the wave-parallel
-    decode (k_agents_mixed_wave), which frees slots exactly like the fused kernel: identical results AND flags, nothing to
-    roll back.  Sets with a RandomAgents member still take the lane pipeline from 4 096 books, guarded: rolled back and
-    redone on the fused kernel when it newly overflows.  Configurations found with scripts/find_capacity_edge.py."""
+    BY THE LIBRARY must not change results.  Rounds 1-2 guarded the auto-selected lane pipeline with a snapshot and a
+    roll-back; since round 3 the auto choice for every AgentSet on independent books is the wave-parallel decode
+    (k_agents_mixed_wave), which frees slots exactly like the fused kernel: identical results AND flags, nothing to roll
+    back - with and without a RandomAgents member in the set.  Configurations found with scripts/find_capacity_edge.py."""
     B, T = 4096, 30
-    worse = rolled = 0
+    worse = 0
     for n, pl, pm_, pc in ((125, 0.3, 0.2, 0.7), (120, 0.4, 0.3, 0.6)):
         P = dict(tick_size=1, p_limit=pl, p_market=pm_, p_cancel=pc, trade_vol=10, price_dist_mu=0.0, price_dist_sigma=1.0)
         for with_random in (False, True):
@@ -1930,18 +1930,14 @@ def test_auto_pipeline_does_not_change_results_at_the_pool_capacity_edge(bk):
                 e.set_agents(members)
                 e.set_pipeline(pipe)
                 if pipe == "auto":
-                    assert e.pipeline()[0] == ("split" if with_random else "wave_split")
+                    assert e.pipeline()[0] == "wave_split"
                 for c in (T // 3, T - T // 3):
                     e.run(c)
                 res[pipe] = (e.flags() & 1, e.pipeline_fallbacks(), e.history(), e.trade_counts(), [e.rng_state(b) for b in (0, 77, B - 1)])
                 e.close()
-            assert res["split"][1] == 0 and res["fused"][1] == 0   # only the library's own choice is guarded
-            if not with_random:
-                assert res["auto"][1] == 0
-            rolled += res["auto"][1]
+            assert res["split"][1] == 0 and res["fused"][1] == 0 and res["auto"][1] == 0
             for k in (0, 2, 3):
                 assert np.array_equal(res["auto"][k], res["fused"][k]), (n, with_random, k)
             assert res["auto"][4] == res["fused"][4]
             worse += int(res["split"][0].sum()) > int(res["fused"][0].sum())
-    assert worse >= 1  # the edge exists: unguarded, the lane pipeline flags books the fused kernel does not
-    print("guarded launches rolled back:", rolled)
+    assert worse >= 1  # the edge exists: the (explicitly requested) lane pipeline flags books the other kernels do not
