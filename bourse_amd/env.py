@@ -664,7 +664,8 @@ class ManyBookEnv:
         return int(a.value), int(b.value)
 
     def pipeline_fallbacks(self) -> int:
-        """bk_run launches the auto pipeline rolled back and redid on the fused kernel (AgentSets, pool at capacity)."""
+        """Rounds 1-2: bk_run launches the auto pipeline rolled back and redid on the fused kernel.  Always 0 since round
+        3 (the auto choice frees pool slots like the fused kernel; nothing is left to roll back)."""
         out = C.c_uint64(0)
         check(self._L.bk_pipeline_fallbacks(self._h, C.byref(out)))
         return int(out.value)

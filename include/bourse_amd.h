@@ -298,10 +298,9 @@ int bk_set_pipeline(bk_env* env, int mode);
  * path (1..64 draws, default 64; smaller values push placements onto its scalar slow path - a test knob) and the number
  * of parts mode 4 cuts the batch in (0 = default). */
 int bk_set_wave_options(bk_env* env, uint32_t lookahead, int parts);
-/* AgentSets with Noise/Momentum members, auto pipeline: the lane-per-book members' update keeps a filled order's pool slot
- * until its member's next update, so it can raise BK_FLAG_POOL_OVERFLOW where the wave-per-book kernels still fit.  The
- * library's own choice must not change results: such a bk_run is rolled back and redone on the fused kernel (one state
- * copy + one host sync per bk_run in that mode).  *out = number of launches redone so far. */
+/* Rounds 1-2 rolled an auto-selected launch of the lane-per-book members' update back when it overflowed a pool the
+ * other kernels still fit, and counted those here.  Since round 3 the auto rule never picks that pipeline for independent
+ * books (the wave-parallel members' decode frees slots like the fused kernel): *out is always 0.  Kept for ABI stability. */
 int bk_pipeline_fallbacks(bk_env* env, uint64_t* out);
 /* the pipeline bk_run will use: *split = 0 fused / 1 split (lane-per-book agents) / 2 wave_split / 3 wave; *n_parts =
  * contiguous book parts launched on separate streams */
