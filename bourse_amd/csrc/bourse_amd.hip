@@ -147,7 +147,7 @@ struct bk_env {
   bool wave_ok() const { return !n_mixed && M == 1 && !groups.empty(); }  // RandomAgents on independent books
   // AgentSets with Noise / Momentum members on independent books: wave-parallel decode of the members' update
   bool mixed_random_member = false;
-  bool pool_cyclic = false;    // the wave-per-book members' lists (wl_list) describe the pools as of steps_done
+  bool wl_valid = false;    // the wave-per-book members' lists (wl_list) describe the pools as of steps_done
   DevBuf<uint16_t> wl_list;    // [n_books][MAX_MEMBERS][pool]: k_agents_mixed_wave's lists, book-major
   DevBuf<uint32_t> wl_len;
   bool mw_attr_set = false;
@@ -369,7 +369,7 @@ int launch_mixed(bk_env* env, const DevArgs& a, uint64_t first_step, uint32_t n_
   env->prof_now = env->profile > 0;
   ProfScope ps(env, 0);
   const MixedArgs ma = env->margs();
-  env->pool_cyclic = false;  // k_run_mixed allocates the lowest free slot
+  env->wl_valid = false;  // (the wave-per-book lists no longer describe the pools)
   hipLaunchKernelGGL(k_run_mixed<R>, dim3(blocks), dim3(256), 0, env->stream, a, ma, first_step, n_steps);
   HIPCHK(hipGetLastError());
   return BK_OK;
@@ -516,7 +516,7 @@ int launch_split(bk_env* env, const DevArgs& a0, uint64_t first_step, uint32_t n
   } else if (MIXED == 1) {
     env->ml_valid = false;
   }
-  if (MIXED == 1 || MIXED == 2) env->pool_cyclic = false;  // these allocate the lowest free slot
+  if (MIXED == 1 || MIXED == 2) env->wl_valid = false;  // (the wave-per-book lists no longer describe the pools)
   const MixedLists ml = env->lists();
   const bool wave = (MIXED == 0 && env->use_wave()) || MIXED == 3;
   WaveArgs wva{};
@@ -531,13 +531,13 @@ int launch_split(bk_env* env, const DevArgs& a0, uint64_t first_step, uint32_t n
     if (!env->wl_list.p) {
       HIPCHK(env->wl_list.alloc(static_cast<size_t>(env->cfg.n_books) * MAX_MEMBERS * R * 64));
       HIPCHK(env->wl_len.alloc(static_cast<size_t>(env->cfg.n_books) * MAX_MEMBERS));
-      env->pool_cyclic = false;
+      env->wl_valid = false;
     }
-    if (!env->pool_cyclic) {  // another pipeline (or a restore / a fresh env) changed the pools: lists from the owner tags
+    if (!env->wl_valid) {  // another pipeline (or a restore / a fresh env) changed the pools: lists from the owner tags
       hipLaunchKernelGGL(k_wave_lists_rebuild<R>, dim3((env->cfg.n_books + 3) / 4), dim3(256), 0, env->stream, a0, ma,
                          WaveLists{env->wl_list.p, env->wl_len.p, static_cast<uint32_t>(R) * 64u});
       HIPCHK(hipGetLastError());
-      env->pool_cyclic = true;
+      env->wl_valid = true;
     }
     env->ml_valid = false;
   }
@@ -1223,7 +1223,7 @@ static int set_agents_impl(bk_env* env, uint32_t n_members, const bk_agent_desc*
   env->n_fixed = fixed;
   env->mixed_random_member = false;
   for (uint32_t i = 0; i < n_members; ++i) env->mixed_random_member = env->mixed_random_member || members[i].type == BK_AGENT_RANDOM;
-  env->pool_cyclic = false;
+  env->wl_valid = false;
   for (uint32_t i = 0; i < MAX_MEMBERS; ++i) env->member_asset[i] = (assets && i < n_members) ? assets[i] : 0u;
   for (uint32_t as = 0; as < MAX_ASSETS; ++as) env->n_fixed_a[as] = fixed_a[as];
   env->ml_valid = false;
@@ -1370,15 +1370,14 @@ int bk_warm(bk_env* env, uint64_t n_steps) {
   HIPCHK(hipMemcpyAsync(env->warm_snap.p, env->state.p, sb * 4, hipMemcpyDeviceToDevice, env->stream));
   HIPCHK(hipMemcpyAsync(env->warm_snap.p + sb, env->l2_last.p, lb * 4, hipMemcpyDeviceToDevice, env->stream));
   const uint64_t steps0 = env->steps_done, fb0 = env->n_fallbacks;
-  const bool flow0 = env->device_flow, cyc0 = env->pool_cyclic;
+  const bool flow0 = env->device_flow;
   env->warming = true;
   const int rc = bk_run(env, n_steps);
   env->warming = false;
   env->steps_done = steps0;
   env->n_fallbacks = fb0;
   env->device_flow = flow0;
-  (void)cyc0;
-  env->pool_cyclic = false;  // the wave-per-book lists described the scratch steps' pools
+  env->wl_valid = false;  // the wave-per-book lists described the scratch steps' pools
   env->ml_valid = false;  // the members' lists described the scratch steps' pool
   if (rc != BK_OK) return rc;  // (bk_run fails before launching anything: the state is untouched)
   HIPCHK(hipMemcpyAsync(env->state.p, env->warm_snap.p, sb * 4, hipMemcpyDeviceToDevice, env->stream));
@@ -1742,7 +1741,7 @@ int bk_load_book(bk_env* env, uint32_t book, uint64_t t, uint32_t trade_vol, uin
     HIPCHK(hipMemcpy(env->trades.p + static_cast<size_t>(book) * env->cfg.trade_capacity, tr.data(),
                      n_trades * sizeof(DevTrade), hipMemcpyHostToDevice));
   env->ml_valid = false;
-  env->pool_cyclic = false;
+  env->wl_valid = false;
   bh.n_uploaded = n_orders;
   bh.log_fresh = false;
   bh.time_offset = t - (env->cfg.start_time + env->steps_done * env->cfg.step_size);
@@ -2085,7 +2084,7 @@ int bk_checkpoint_load(bk_env* env, const void* in, uint64_t nbytes) {
   HIPCHK(hipMemcpy(env->l2_last.p, reinterpret_cast<const char*>(h + CKPT_HDR) + sb,
                    static_cast<size_t>(env->cfg.n_books) * env->W * 4, hipMemcpyHostToDevice));
   env->ml_valid = false;
-  env->pool_cyclic = false;
+  env->wl_valid = false;
   env->steps_done = h[1];
   env->hist_base = h[1];  // retained history/trade records restart at the restored step
   env->trading = h[6] ? 1u : 0u;  // the host mirror of the books' trading flag (H_TRADING travels in the state blocks)
