@@ -635,7 +635,8 @@ template <int R>
 __device__ __forceinline__ void store_book(const Book<R>& B, const Rng& rng, uint32_t* __restrict__ st, int lane,
                                            uint64_t steps_done, uint32_t last_ntrades, uint32_t last_nevents) {
   uint32_t hdr = st[lane];  // keep reserved words
-  auto put = [&](int idx, uint32_t v) { hdr = (lane == idx) ? v : hdr; };
+  // (wave-uniform values into their lanes with one v_writelane each - a compare + select per field before)
+  auto put = [&](int idx, uint32_t v) { hdr = wrl(rfl(v), (uint32_t)idx, hdr); };
   put(H_T_LO, (uint32_t)B.t);
   put(H_T_HI, (uint32_t)(B.t >> 32));
   put(H_S0_LO, (uint32_t)rng.s0);
