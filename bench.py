@@ -302,11 +302,12 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
         env.warm(args.preheat_steps)
-    run_steps(args.warmup)
-    torch.cuda.synchronize()
+    # (the device counters are read BEFORE the warm-up and the rates below are per warm-up + timed step: two device-to-host
+    # reads between the warm-up and t0 idle the GPU for long enough to cost the first region 1-2 % of clock)
     tc0 = int(env.trade_counts().sum())
     oc0 = int(env.order_counts().sum())
-    env.profile(args.profile_every)
+    run_steps(args.warmup)
+    env.profile(args.profile_every)  # (host-side switch: its event pool exists since the pre-heat)
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -331,8 +332,20 @@ def main():
     if flags.any():
         raise SystemExit(f"device flags set during the timed region: {np.unique(flags)} (trade/history capacity?)")
     n_trades = int(env.trade_counts().sum()) - tc0
-    n_new = int(env.order_counts().sum()) - oc0  # orders created = New events of the timed region (device counters)
+    n_new = int(env.order_counts().sum()) - oc0  # orders created = New events of warm-up + timed region (device counters)
     st = env.stats()
+    sampled_in = "the timed region"
+    if not any(nl for _, nl in per_kind.values()):
+        # --profile-every 0 (an unperturbed timed region, e.g. under rocprofv3 --pmc): the launch durations of the roofline
+        # come from a few sampled steps AFTER it
+        torch.cuda.synchronize()
+        env.profile(1)
+        run_steps(min(8, args.steps))
+        torch.cuda.synchronize()
+        env.profile(False)
+        per_kind = {k: env.profile_read_kind(i) for i, k in enumerate((kind0, kind1, "k_step_batch", "k_step_events"))}
+        env.profile_read()
+        sampled_in = "%d steps after the timed region (--profile-every 0)" % min(8, args.steps)
 
     value = books_total * args.steps / dt  # whole job: every rank's books (shards differ by at most one book)
     # Roofline accounting: algorithmic HBM bytes per book-step of every step kernel, in the
@@ -342,9 +355,9 @@ def main():
     #   k_step_batch  (one part, one step): 2 S + batch in (64 + 2 N_ev + 8 N_new) + L2 record + 32 N_tr
     S = env.state_bytes_per_book()
     W4 = env.width * 4
-    tr_per_bs = n_trades / (B * args.steps)
+    tr_per_bs = n_trades / (B * (args.steps + args.warmup))
     ev_per_bs = st["sum_events"] / (B * (args.steps + args.warmup))
-    new_per_bs = n_new / (B * args.steps)
+    new_per_bs = n_new / (B * (args.steps + args.warmup))
     per_bs = {
         # fused kernels: the book block in and out once per launch, the L2 record and the trade records every step;
         # k_run_wave adds its lane-state record (1.3 KB in / out per launch, ~2.5 KB of block-start spills per step)
@@ -441,6 +454,7 @@ def main():
             "book_steps_per_launch": book_steps_per_launch,
             "kernels": kernels,
             "issue": issue,
+            "launches_sampled_in": sampled_in,
         },
     }
     # median of >= 5 runs.  `value` above is the contract's single timed region; the same region is repeated
