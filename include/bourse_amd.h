@@ -8,6 +8,10 @@
  * Each entry point cites the reference interface it replaces (paths relative to the
  * reference repository).  INTEGRATION.md shows the Rust `extern "C"` / ctypes bindings.
  *
+ * Threads: a `bk_env` is used by ONE host thread at a time (like `&mut Env`); DISTINCT envs may be driven from distinct
+ * threads concurrently (every call selects the env's device; bk_last_error() is per thread; the process-wide part streams
+ * are created under a lock) - tests/test_gpu_parity.py test_envs_driven_from_concurrent_host_threads.
+ *
  * Status codes: every function returns one of these.
  */
 #ifndef BOURSE_AMD_H

@@ -1941,3 +1941,83 @@ def test_auto_pipeline_does_not_change_results_at_the_pool_capacity_edge(bk):
             assert res["auto"][4] == res["fused"][4]
             worse += int(res["split"][0].sum()) > int(res["fused"][0].sum())
     assert worse >= 1  # the edge exists: the (explicitly requested) lane pipeline flags books the other kernels do not
+
+
+def test_env_lifecycle_returns_its_device_memory(bk):
+    """bk_env_destroy frees everything bk_env_create and the first launches allocated: 40 envs of every flow created, run and
+    destroyed leave the device's free memory where it was (the parts' streams are process-wide and stay)."""
+    import ctypes
+
+    hip = ctypes.CDLL("libamdhip64.so")
+
+    def free_bytes():
+        assert hip.hipDeviceSynchronize() == 0
+        free, total = ctypes.c_size_t(0), ctypes.c_size_t(0)
+        assert hip.hipMemGetInfo(ctypes.byref(free), ctypes.byref(total)) == 0
+        return free.value
+
+    def cycle(i):
+        env = bk.ManyBookEnv(2048 + 64 * (i % 3), 5 + i, 0, 2, 100_000, levels=16, max_live_orders=128 if i % 2 else 512,
+                             trade_capacity=4096, history_capacity=4, strict=False)
+        if i % 4 == 3:
+            env.set_agents([("momentum", 0, 32, dict(tick_size=2, p_cancel=0.1, trade_vol=100, decay=1.0, demand=8.0, scale=0.5,
+                                                      order_ratio=1.0, price_dist_mu=0.0, price_dist_sigma=3.0)),
+                            ("noise", 32, 32, dict(tick_size=2, p_limit=0.3, p_market=0.2, p_cancel=0.2, trade_vol=100,
+                                                   price_dist_mu=0.0, price_dist_sigma=1.0))])
+        else:
+            env.set_random_agents(C3_GROUPS if i % 2 else C5_GROUPS)
+        env.set_pipeline(("split", "wave_split", "fused", "wave_split")[i % 4])
+        env.run(3)
+        env.trade_counts(), env.level2(), env.stats(), env.checkpoint()
+        env.warm(2)
+        env.close()
+
+    for i in range(4):  # first use of every pipeline: streams, event pools, lazily created staging buffers
+        cycle(i)
+    free0 = free_bytes()
+    for i in range(40):
+        cycle(i)
+    free1 = free_bytes()
+    assert free0 - free1 < 32 << 20, f"device memory shrank by {(free0 - free1) >> 20} MiB over 40 env lifecycles"
+
+
+def test_envs_driven_from_concurrent_host_threads(bk, oracle):
+    """Distinct envs may be driven from distinct host threads at the same time (include/bourse_amd.h "Threads"): four threads,
+    each with its own env and pipeline, run chunked launches, read results and poll flags concurrently (ctypes releases the
+    GIL inside every call) - every env must still match its oracle run."""
+    import threading
+
+    T, chunks = 15, [4, 6, 5]
+    jobs = [(3072, 31, "split", C3_GROUPS, 128), (2048, 32, "wave_split", C3_GROUPS, 128), (1024, 33, "fused", C2_GROUPS, 64),
+            (1536, 34, "wave_split", C5_GROUPS, 512)]
+    out, errs = {}, []
+
+    def work(n, seed, pipe, groups, pool):
+        try:
+            env = bk.ManyBookEnv(n, seed, 0, 2, 100_000, True, levels=32, max_live_orders=pool, trade_capacity=512 * T,
+                                 history_capacity=T, strict=False)
+            env.set_random_agents(groups)
+            env.set_pipeline(pipe)
+            if pipe == "split":
+                env.set_split_parts(3, 512)
+            for c in chunks:
+                env.run(c)
+                env.flags_summary(); env.trade_counts()
+            out[seed] = (env.flags().copy(), env.history().copy(), env.trade_counts().copy(), env.rng_state(n - 1))
+            env.close()
+        except Exception as e:  # noqa: BLE001
+            errs.append((seed, repr(e)))
+
+    th = [threading.Thread(target=work, args=j) for j in jobs]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errs, errs
+    for n, seed, pipe, groups, pool in jobs:
+        ref = oracle.ManyBooks(n, seed, 0, 2, 100_000, True, 32, groups)
+        ref.run(T, n_threads=8)
+        flags, hist, tc, rs = out[seed]
+        assert not flags.any(), (seed, np.unique(flags))
+        assert np.array_equal(hist, ref.history()), (seed, pipe)
+        assert np.array_equal(tc, ref.trade_counts()), (seed, pipe)
+        want = ref.rng_states()[n - 1]
+        assert rs == (int(want[0]), int(want[1])), (seed, pipe)
