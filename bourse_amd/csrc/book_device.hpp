@@ -221,10 +221,17 @@ struct Rng {
 // (v_alignbit / v_lshl_add / v_xor3) instead of 64-bit shifts and quarter-rate 32x32 multiplies.
 struct RngLane {
   uint32_t a0, a1, b0, b1;
+  // s0 * 5 as ONE v_mad_u64_u32 (low word + carry) + two adds for the high word: the compiler's shift-and-add form of
+  // the constant multiply needs five instructions for the 64-bit product (the 5 is hidden in an SGPR to keep it from it)
+  static __device__ __forceinline__ uint32_t mul5_rotl7_lo(uint32_t a0, uint32_t a1) {
+    uint32_t five = 5u;
+    asm("" : "+s"(five));
+    const uint64_t p = (uint64_t)a0 * five;
+    const uint32_t hi5 = (a1 << 2) + (uint32_t)(p >> 32) + a1;             // (s0 * 5) bits 32..63
+    return __builtin_amdgcn_alignbit((uint32_t)p, hi5, 25);                // low word of rotl(s0 * 5, 7)
+  }
   __device__ __forceinline__ uint32_t next_u32() {
-    const uint32_t lo5 = (a0 << 2) + a0;                                   // (s0 * 5) bits 0..31
-    const uint32_t hi5 = (a1 << 2) + a1 + (a0 >> 30) + (lo5 < a0 ? 1u : 0u);  // bits 32..63
-    const uint32_t r = __builtin_amdgcn_alignbit(lo5, hi5, 25);            // low word of rotl(s0 * 5, 7)
+    const uint32_t r = mul5_rotl7_lo(a0, a1);
     const uint32_t t0 = b0 ^ a0, t1 = b1 ^ a1;
     const uint32_t n0 = __builtin_amdgcn_alignbit(a0, a1, 8) ^ t0 ^ (t0 << 16);  // rotl(s0, 24) ^ t ^ (t << 16)
     const uint32_t n1 = __builtin_amdgcn_alignbit(a1, a0, 8) ^ t1 ^ __builtin_amdgcn_alignbit(t1, t0, 16);
@@ -236,9 +243,7 @@ struct RngLane {
   }
   // the same in two halves: the output word of the current state, and the state update (which does not depend on it)
   __device__ __forceinline__ uint32_t output() const {
-    const uint32_t lo5 = (a0 << 2) + a0;
-    const uint32_t hi5 = (a1 << 2) + a1 + (a0 >> 30) + (lo5 < a0 ? 1u : 0u);
-    const uint32_t r = __builtin_amdgcn_alignbit(lo5, hi5, 25);
+    const uint32_t r = mul5_rotl7_lo(a0, a1);
     return (r << 3) + r;
   }
   __device__ __forceinline__ void advance() {
@@ -1159,40 +1164,50 @@ __global__ __launch_bounds__(64) void k_agents_fsm(DevArgs a) {
     // (scripts/micro/lone_wave_latency.hip), and the straightforward form - `bool` predicates combined where they are
     // used - had five of those per draw (k_agents_fsm 161 -> 141 us per launch under load).  Same instructions, same
     // counts: the two fences only fix their order.
-    uint32_t phase = PH_ACT, range = 0, zone = 0, cur_side = 0, cur_price = 0;
-    while (phase != PH_DONE) {
-      const uint32_t x = rng.output();
-      const uint64_t m = (uint64_t)x * range;  // sample_single step of the current phase: accept iff lo <= zone
-      const uint32_t val = (uint32_t)(m >> 32);
+    // the group's ranges and zones as VECTOR registers for the loop: a select under an SGPR mask cannot also read an
+    // SGPR source (one scalar operand per VOP3), so the compiler copied each of the four into a VGPR on every draw
+    uint32_t v_trng = G.tick_rng, v_vrng = G.vol_rng, v_tzone = G.tick_zone, v_vzone = G.vol_zone;
+    asm volatile("" : "+v"(v_trng), "+v"(v_vrng), "+v"(v_tzone), "+v"(v_vzone));
+    // The group is walked in SEGMENTS that stay inside one 64-slot pool register, so that the live word of the agent
+    // at hand is one register pair per segment, not a per-draw select over the pool's registers (lanes re-converge at
+    // a segment's end as they do at a group's; the benchmark groups are 64-aligned: no extra boundary there).
+    for (uint32_t sbeg = gend - G.n; sbeg < gend;) {
+      const uint32_t send = gend < (sbeg | 63u) + 1u ? gend : (sbeg | 63u) + 1u;
       uint64_t w = live[0];
 #pragma unroll
-      for (int r = 1; r < R; ++r) w = ((n >> 6) == (uint32_t)r) ? live[r] : w;
-      uint64_t P_ACT = __builtin_amdgcn_ballot_w64(phase == PH_ACT), P_SIDE = __builtin_amdgcn_ballot_w64(phase == PH_SIDE);
-      uint64_t P_TICK = __builtin_amdgcn_ballot_w64(phase == PH_TICK), P_VOL = __builtin_amdgcn_ballot_w64(phase == PH_VOL);
-      uint64_t C_HIT = __builtin_amdgcn_ballot_w64((x >> 8) < G.thr);       // gen::<f32>() < activity_rate (:91-93)
-      uint64_t C_ACC = __builtin_amdgcn_ballot_w64((uint32_t)m <= zone);
-      uint64_t C_LIVE = __builtin_amdgcn_ballot_w64(((w >> (n & 63)) & 1ull) != 0);  // Active order held (:95-97)
-      asm volatile("" : "+v"(rng.a0), "+v"(rng.a1), "+v"(rng.b0), "+v"(rng.b1)
-                   : "s"(P_ACT), "s"(P_SIDE), "s"(P_TICK), "s"(P_VOL), "s"(C_HIT), "s"(C_ACC), "s"(C_LIVE));
-      rng.advance();
-      asm volatile("" : "+v"(rng.a0), "+v"(rng.a1), "+v"(rng.b0), "+v"(rng.b1), "+s"(P_ACT), "+s"(P_SIDE), "+s"(P_TICK),
-                     "+s"(P_VOL), "+s"(C_HIT), "+s"(C_ACC), "+s"(C_LIVE));
-      const uint64_t HIT = P_ACT & C_HIT, CANCEL = HIT & C_LIVE, TO_SIDE = HIT & ~C_LIVE;
-      const uint64_t A_SIDE = C_ACC & P_SIDE, A_TICK = C_ACC & P_TICK, A_VOL = C_ACC & P_VOL;
-      const uint64_t QUEUE = CANCEL | A_VOL, ADV = (P_ACT & ~C_HIT) | QUEUE;
-      cur_side = sel(A_SIDE, val, cur_side);                                    // 0 = Ask, 1 = Bid ([Ask, Bid].choose, :99)
-      cur_price = sel(A_TICK, (G.tick_lo + val) * G.tick_size, cur_price);      // tick * tick_size (:100,:107)
-      // the agent's event, queued once its kind is known (agent order): bit 15 = New, bit 14 = bid
-      if (lane_bit(QUEUE)) list[n_ev * 64 + lane] = (uint16_t)sel(A_VOL, n | EV_NEW | (cur_side << 14), n);
-      n_ev += lane_bit(QUEUE) ? 1u : 0u;
-      if (lane_bit(A_VOL)) pv[n] = make_uint2(cur_price, G.vol_lo + val);       // vol drawn last (:101): the order is complete
-      phase = sel(TO_SIDE, PH_SIDE, sel(A_SIDE, PH_TICK, sel(A_TICK, PH_VOL, phase)));
-      range = sel(TO_SIDE, 2u, sel(A_SIDE, G.tick_rng, sel(A_TICK, G.vol_rng, range)));
-      zone = sel(TO_SIDE, 0x7FFFFFFFu, sel(A_SIDE, G.tick_zone, sel(A_TICK, G.vol_zone, zone)));
-      if (lane_bit(ADV)) {  // next agent of the group, or done with the group
-        ++n;
-        phase = (n >= gend) ? PH_DONE : PH_ACT;
+      for (int r = 1; r < R; ++r) w = ((sbeg >> 6) == (uint32_t)r) ? live[r] : w;
+      uint32_t phase = PH_ACT, cur_side = 0, cur_price = 0;
+      while (n < send) {
+        const uint32_t x = rng.output();
+        uint64_t P_ACT = __builtin_amdgcn_ballot_w64(phase == PH_ACT), P_SIDE = __builtin_amdgcn_ballot_w64(phase == PH_SIDE);
+        uint64_t P_TICK = __builtin_amdgcn_ballot_w64(phase == PH_TICK), P_VOL = __builtin_amdgcn_ballot_w64(phase == PH_VOL);
+        // range and zone of the phase at hand, from its masks (two selects each; no loop-carried copies)
+        const uint32_t range = sel(P_SIDE, 2u, sel(P_TICK, v_trng, v_vrng));
+        const uint32_t zone = sel(P_SIDE, 0x7FFFFFFFu, sel(P_TICK, v_tzone, v_vzone));
+        const uint64_t m = (uint64_t)x * range;  // sample_single step of the current phase: accept iff lo <= zone
+        const uint32_t val = (uint32_t)(m >> 32);
+        uint64_t C_HIT = __builtin_amdgcn_ballot_w64((x >> 8) < G.thr);       // gen::<f32>() < activity_rate (:91-93)
+        uint64_t C_ACC = __builtin_amdgcn_ballot_w64((uint32_t)m <= zone);
+        uint64_t C_LIVE = __builtin_amdgcn_ballot_w64(((w >> (n & 63)) & 1ull) != 0);  // Active order held (:95-97)
+        asm volatile("" : "+v"(rng.a0), "+v"(rng.a1), "+v"(rng.b0), "+v"(rng.b1)
+                     : "s"(P_ACT), "s"(P_SIDE), "s"(P_TICK), "s"(P_VOL), "s"(C_HIT), "s"(C_ACC), "s"(C_LIVE));
+        rng.advance();
+        asm volatile("" : "+v"(rng.a0), "+v"(rng.a1), "+v"(rng.b0), "+v"(rng.b1), "+s"(P_ACT), "+s"(P_SIDE), "+s"(P_TICK),
+                       "+s"(P_VOL), "+s"(C_HIT), "+s"(C_ACC), "+s"(C_LIVE));
+        const uint64_t HIT = P_ACT & C_HIT, CANCEL = HIT & C_LIVE, TO_SIDE = HIT & ~C_LIVE;
+        const uint64_t A_SIDE = C_ACC & P_SIDE, A_TICK = C_ACC & P_TICK, A_VOL = C_ACC & P_VOL;
+        const uint64_t QUEUE = CANCEL | A_VOL, ADV = (P_ACT & ~C_HIT) | QUEUE;
+        cur_side = sel(A_SIDE, val, cur_side);                                    // 0 = Ask, 1 = Bid ([Ask, Bid].choose, :99)
+        cur_price = sel(A_TICK, (G.tick_lo + val) * G.tick_size, cur_price);      // tick * tick_size (:100,:107)
+        // the agent's event, queued once its kind is known (agent order): bit 15 = New, bit 14 = bid
+        if (lane_bit(QUEUE)) list[n_ev * 64 + lane] = (uint16_t)sel(A_VOL, n | EV_NEW | (cur_side << 14), n);
+        asm("v_addc_co_u32_e64 %0, vcc, 0, %0, %1" : "+v"(n_ev) : "s"(QUEUE) : "vcc");  // n_ev += lane_bit(QUEUE)
+        if (lane_bit(A_VOL)) pv[n] = make_uint2(cur_price, G.vol_lo + val);       // vol drawn last (:101): the order is complete
+        // next phase; an agent that is done (inactive, cancelled or placed) hands over to the next one
+        phase = sel(ADV, PH_ACT, sel(TO_SIDE, PH_SIDE, sel(A_SIDE, PH_TICK, sel(A_TICK, PH_VOL, phase))));
+        asm("v_addc_co_u32_e64 %0, vcc, 0, %0, %1" : "+v"(n) : "s"(ADV) : "vcc");  // n += lane_bit(ADV)
       }
+      sbeg = send;
     }
   }
 
