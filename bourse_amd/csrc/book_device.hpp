@@ -219,22 +219,28 @@ struct Rng {
 
 // The same generator for the lane-per-book kernel, on 32-bit halves (s0 = a1:a0, s1 = b1:b0): full-rate VALU only
 // (v_alignbit / v_lshl_add / v_xor3) instead of 64-bit shifts and quarter-rate 32x32 multiplies.
+__device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) {
+  return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96);  // gfx950 v_bitop3_b32: any 3-input boolean; 0x96 = a ^ b ^ c
+}
 struct RngLane {
   uint32_t a0, a1, b0, b1;
   // s0 * 5 as ONE v_mad_u64_u32 (low word + carry) + two adds for the high word: the compiler's shift-and-add form of
   // the constant multiply needs five instructions for the 64-bit product (the 5 is hidden in an SGPR to keep it from it)
-  static __device__ __forceinline__ uint32_t mul5_rotl7_lo(uint32_t a0, uint32_t a1) {
+  static __device__ __forceinline__ uint32_t opaque5() {
     uint32_t five = 5u;
     asm("" : "+s"(five));
+    return five;
+  }
+  static __device__ __forceinline__ uint32_t mul5_rotl7_lo(uint32_t a0, uint32_t a1, uint32_t five) {
     const uint64_t p = (uint64_t)a0 * five;
     const uint32_t hi5 = (a1 << 2) + (uint32_t)(p >> 32) + a1;             // (s0 * 5) bits 32..63
     return __builtin_amdgcn_alignbit((uint32_t)p, hi5, 25);                // low word of rotl(s0 * 5, 7)
   }
   __device__ __forceinline__ uint32_t next_u32() {
-    const uint32_t r = mul5_rotl7_lo(a0, a1);
+    const uint32_t r = mul5_rotl7_lo(a0, a1, opaque5());
     const uint32_t t0 = b0 ^ a0, t1 = b1 ^ a1;
-    const uint32_t n0 = __builtin_amdgcn_alignbit(a0, a1, 8) ^ t0 ^ (t0 << 16);  // rotl(s0, 24) ^ t ^ (t << 16)
-    const uint32_t n1 = __builtin_amdgcn_alignbit(a1, a0, 8) ^ t1 ^ __builtin_amdgcn_alignbit(t1, t0, 16);
+    const uint32_t n0 = xor3(__builtin_amdgcn_alignbit(a0, a1, 8), t0, t0 << 16);  // rotl(s0, 24) ^ t ^ (t << 16)
+    const uint32_t n1 = xor3(__builtin_amdgcn_alignbit(a1, a0, 8), t1, __builtin_amdgcn_alignbit(t1, t0, 16));
     a0 = n0;
     a1 = n1;
     b0 = __builtin_amdgcn_alignbit(t1, t0, 27);  // rotl(t, 37)
@@ -242,14 +248,15 @@ struct RngLane {
     return (r << 3) + r;
   }
   // the same in two halves: the output word of the current state, and the state update (which does not depend on it)
-  __device__ __forceinline__ uint32_t output() const {
-    const uint32_t r = mul5_rotl7_lo(a0, a1);
+  // (five = opaque5(), taken once outside the caller's loop)
+  __device__ __forceinline__ uint32_t output(uint32_t five) const {
+    const uint32_t r = mul5_rotl7_lo(a0, a1, five);
     return (r << 3) + r;
   }
   __device__ __forceinline__ void advance() {
     const uint32_t t0 = b0 ^ a0, t1 = b1 ^ a1;
-    const uint32_t n0 = __builtin_amdgcn_alignbit(a0, a1, 8) ^ t0 ^ (t0 << 16);
-    const uint32_t n1 = __builtin_amdgcn_alignbit(a1, a0, 8) ^ t1 ^ __builtin_amdgcn_alignbit(t1, t0, 16);
+    const uint32_t n0 = xor3(__builtin_amdgcn_alignbit(a0, a1, 8), t0, t0 << 16);
+    const uint32_t n1 = xor3(__builtin_amdgcn_alignbit(a1, a0, 8), t1, __builtin_amdgcn_alignbit(t1, t0, 16));
     a0 = n0;
     a1 = n1;
     b0 = __builtin_amdgcn_alignbit(t1, t0, 27);
@@ -1148,6 +1155,7 @@ __global__ __launch_bounds__(64) void k_agents_fsm(DevArgs a) {
   // machine that performs exactly ONE next_u32() draw per iteration (a lane never waits for another lane's rejection
   // loop); the group's parameters are wave-uniform (SGPRs).  Lanes re-converge at each group boundary.
   // Select-style body (v_cndmask) with three short predicated blocks: list append, new-order store, next agent.
+  const uint32_t five = RngLane::opaque5();
   uint32_t n = 0, n_ev = 0, gbase = 0;
   for (uint32_t g = 0; g < a.n_groups; ++g) {
     const Group G = a.groups[g];
@@ -1168,6 +1176,10 @@ __global__ __launch_bounds__(64) void k_agents_fsm(DevArgs a) {
     // SGPR source (one scalar operand per VOP3), so the compiler copied each of the four into a VGPR on every draw
     uint32_t v_trng = G.tick_rng, v_vrng = G.vol_rng, v_tzone = G.tick_zone, v_vzone = G.vol_zone;
     asm volatile("" : "+v"(v_trng), "+v"(v_vrng), "+v"(v_tzone), "+v"(v_vzone));
+    const uint64_t thr8 = (uint64_t)G.thr << 8;
+    // price = (tick_lo + val) * tick_size as one multiply-add: val * tick_size + tick_lo * tick_size (mod 2^32)
+    uint64_t price0 = (uint64_t)(G.tick_lo * G.tick_size);
+    asm volatile("" : "+v"(price0));  // (kept in a VGPR pair: the addend of the multiply-add below)
     // The group is walked in SEGMENTS that stay inside one 64-slot pool register, so that the live word of the agent
     // at hand is one register pair per segment, not a per-draw select over the pool's registers (lanes re-converge at
     // a segment's end as they do at a group's; the benchmark groups are 64-aligned: no extra boundary there).
@@ -1178,7 +1190,7 @@ __global__ __launch_bounds__(64) void k_agents_fsm(DevArgs a) {
       for (int r = 1; r < R; ++r) w = ((sbeg >> 6) == (uint32_t)r) ? live[r] : w;
       uint32_t phase = PH_ACT, cur_side = 0, cur_price = 0;
       while (n < send) {
-        const uint32_t x = rng.output();
+        const uint32_t x = rng.output(five);
         uint64_t P_ACT = __builtin_amdgcn_ballot_w64(phase == PH_ACT), P_SIDE = __builtin_amdgcn_ballot_w64(phase == PH_SIDE);
         uint64_t P_TICK = __builtin_amdgcn_ballot_w64(phase == PH_TICK), P_VOL = __builtin_amdgcn_ballot_w64(phase == PH_VOL);
         // range and zone of the phase at hand, from its masks (two selects each; no loop-carried copies)
@@ -1186,7 +1198,8 @@ __global__ __launch_bounds__(64) void k_agents_fsm(DevArgs a) {
         const uint32_t zone = sel(P_SIDE, 0x7FFFFFFFu, sel(P_TICK, v_tzone, v_vzone));
         const uint64_t m = (uint64_t)x * range;  // sample_single step of the current phase: accept iff lo <= zone
         const uint32_t val = (uint32_t)(m >> 32);
-        uint64_t C_HIT = __builtin_amdgcn_ballot_w64((x >> 8) < G.thr);       // gen::<f32>() < activity_rate (:91-93)
+        // gen::<f32>() < activity_rate (:91-93): (x >> 8) < thr as ONE 64-bit compare x < thr << 8 (thr <= 2^24)
+        uint64_t C_HIT = __builtin_amdgcn_ballot_w64((uint64_t)x < thr8);
         uint64_t C_ACC = __builtin_amdgcn_ballot_w64((uint32_t)m <= zone);
         uint64_t C_LIVE = __builtin_amdgcn_ballot_w64(((w >> (n & 63)) & 1ull) != 0);  // Active order held (:95-97)
         asm volatile("" : "+v"(rng.a0), "+v"(rng.a1), "+v"(rng.b0), "+v"(rng.b1)
@@ -1198,7 +1211,11 @@ __global__ __launch_bounds__(64) void k_agents_fsm(DevArgs a) {
         const uint64_t A_SIDE = C_ACC & P_SIDE, A_TICK = C_ACC & P_TICK, A_VOL = C_ACC & P_VOL;
         const uint64_t QUEUE = CANCEL | A_VOL, ADV = (P_ACT & ~C_HIT) | QUEUE;
         cur_side = sel(A_SIDE, val, cur_side);                                    // 0 = Ask, 1 = Bid ([Ask, Bid].choose, :99)
-        cur_price = sel(A_TICK, (G.tick_lo + val) * G.tick_size, cur_price);      // tick * tick_size (:100,:107)
+        {  // tick * tick_size (:100,:107)
+          uint64_t pr, cy;
+          asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(pr), "=s"(cy) : "v"(val), "s"(G.tick_size), "v"(price0));
+          cur_price = sel(A_TICK, (uint32_t)pr, cur_price);
+        }
         // the agent's event, queued once its kind is known (agent order): bit 15 = New, bit 14 = bid
         if (lane_bit(QUEUE)) list[n_ev * 64 + lane] = (uint16_t)sel(A_VOL, n | EV_NEW | (cur_side << 14), n);
         asm("v_addc_co_u32_e64 %0, vcc, 0, %0, %1" : "+v"(n_ev) : "s"(QUEUE) : "vcc");  // n_ev += lane_bit(QUEUE)
@@ -1218,7 +1235,7 @@ __global__ __launch_bounds__(64) void k_agents_fsm(DevArgs a) {
     uint32_t rg = i + 1;
     uint32_t zn = (rg << __builtin_clz(rg)) - 1u;
     while (i != 0) {
-      const uint32_t x = rng.output();
+      const uint32_t x = rng.output(five);
       const uint64_t m = (uint64_t)x * rg;
       uint64_t ACC = __builtin_amdgcn_ballot_w64((uint32_t)m <= zn);  // (same ordering as in loop 1)
       asm volatile("" : "+v"(rng.a0), "+v"(rng.a1), "+v"(rng.b0), "+v"(rng.b1) : "s"(ACC));
