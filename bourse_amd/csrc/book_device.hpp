@@ -254,9 +254,13 @@ struct RngLane {
     return (r << 3) + r;
   }
   __device__ __forceinline__ void advance() {
-    const uint32_t t0 = b0 ^ a0, t1 = b1 ^ a1;
-    const uint32_t n0 = xor3(__builtin_amdgcn_alignbit(a0, a1, 8), t0, t0 << 16);
-    const uint32_t n1 = xor3(__builtin_amdgcn_alignbit(a1, a0, 8), t1, __builtin_amdgcn_alignbit(t1, t0, 16));
+    uint32_t t0 = b0 ^ a0, t1 = b1 ^ a1;
+    uint32_t r0 = __builtin_amdgcn_alignbit(a0, a1, 8), r1 = __builtin_amdgcn_alignbit(a1, a0, 8);  // rotl(s0, 24)
+    // every read of the old s0 before the new one is formed: the new state then takes the old one's registers (the
+    // scheduler had left one rotate behind the new low word, which cost a register copy per draw in k_agents_fsm)
+    asm volatile("" : "+v"(t0), "+v"(t1), "+v"(r0), "+v"(r1));
+    const uint32_t n0 = xor3(r0, t0, t0 << 16);
+    const uint32_t n1 = xor3(r1, t1, __builtin_amdgcn_alignbit(t1, t0, 16));
     a0 = n0;
     a1 = n1;
     b0 = __builtin_amdgcn_alignbit(t1, t0, 27);
