@@ -1534,8 +1534,9 @@ __global__ __launch_bounds__(64) void k_step_events(DevArgs a, uint64_t step_ind
 }
 
 // ==================================================================================
-// small service kernels
+// small service kernels (not templates: defined in ONE translation unit - fsm_unit.hip leaves them out)
 // ==================================================================================
+#ifndef BOURSE_AMD_FSM_UNIT
 // set trade_base = n_trades for every book (bk_clear_trades) / set trading flag
 __global__ void k_book_service(uint32_t* state, uint32_t stride, uint32_t n_books, int op, uint32_t value) {
   const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1723,5 +1724,6 @@ __global__ void k_selftest_reduce(const uint32_t* in, uint32_t* out) {
   const uint32_t ssum = wave_add(s);
   if (lane == 0) out[blockIdx.x * 4 + 3] = ssum;
 }
+#endif  // BOURSE_AMD_FSM_UNIT
 
 }  // namespace bkd

@@ -25,6 +25,13 @@
 
 #include "../../include/bourse_amd.h"
 #include "book_device.hpp"
+// k_agents_fsm is compiled in its own unit (fsm_unit.hip: another machine-scheduler strategy); only declared here
+namespace bkd {
+extern template __global__ void k_agents_fsm<1>(DevArgs);
+extern template __global__ void k_agents_fsm<2>(DevArgs);
+extern template __global__ void k_agents_fsm<4>(DevArgs);
+extern template __global__ void k_agents_fsm<8>(DevArgs);
+}  // namespace bkd
 #include "host_math.hpp"
 #include "host_pool.hpp"
 #include "mixed_agents.hpp"
