@@ -5,7 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np, bourse_amd as bk
 B, N, T = int(sys.argv[1]) if len(sys.argv) > 1 else 8192, 48, 30
-env = bk.ManyBookEnv(B, 1, 0, 1, 100_000, levels=16, max_live_orders=256, max_orders=N * (T + 5), trade_capacity=64 * (T + 5),
+env = bk.ManyBookEnv(B, 1, 0, 1, 100_000, levels=16, max_live_orders=256, max_orders=N * (T + 5), trade_capacity=64 * (T + 5), strict=False,
                      history_capacity=0)
 rng = np.random.default_rng(0)
 off = (np.arange(B + 1, dtype=np.uint64) * N)

@@ -4,7 +4,7 @@ sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import numpy as np, bourse_amd as bk
 from bourse_amd import _lib
 B, N, T = 8192, 48, 20
-env = bk.ManyBookEnv(B, 1, 0, 1, 100_000, levels=16, max_live_orders=256, max_orders=N * (T + 5), trade_capacity=64 * (T + 5), history_capacity=0)
+env = bk.ManyBookEnv(B, 1, 0, 1, 100_000, levels=16, max_live_orders=256, max_orders=N * (T + 5), trade_capacity=64 * (T + 5), history_capacity=0, strict=False)
 rng = np.random.default_rng(0)
 off = (np.arange(B + 1, dtype=np.uint64) * N); n = B * N
 tw = tc = 0.0
