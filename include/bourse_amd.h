@@ -62,7 +62,7 @@ typedef struct bk_config {
   uint64_t step_size;
   uint64_t seed;            /* book b is seeded seed + book_offset + b (identity for B = 1) */
   uint64_t book_offset;     /* global index of this GPU's first book (multi-GPU sharding) */
-  uint32_t max_live_orders; /* live-order pool per book, rounded up to a multiple of 64 (<= 1024) */
+  uint32_t max_live_orders; /* live-order pool per book, rounded up to 64, 128, 256 or 512 (0 = 128; more is refused) */
   uint32_t max_orders;      /* order-log capacity per book for the host-driven path (0 = no log) */
   uint32_t trade_capacity;  /* trade records retained per book between bk_clear_trades() calls */
   uint32_t history_capacity;/* L2 history ring: the last N steps are retained (0 = keep only the latest record) */
