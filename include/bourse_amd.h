@@ -287,10 +287,12 @@ int bk_level2_device_ptr(bk_env* env, void** out);
 /* accumulate HIP-event timings of the step kernels: on = 0 off, N >= 1 time the kernels of every Nth step */
 int bk_profile_enable(bk_env* env, int on);
 int bk_profile_read(bk_env* env, double* total_ms, uint64_t* n_launches, int reset);
-/* per kernel: kind 0 k_run_random (fused), 1 k_agents_fsm, 2 k_step_batch (split pipeline), 3 k_step_events */
+/* per kernel: kind 0 the fused kernels (k_run_random / k_run_wave / k_run_mixed), 1 the agents kernel of a split pipeline
+ * (k_agents_fsm / k_agents_wave / k_agents_mixed_*), 2 k_step_batch, 3 k_step_events (host-driven flow) */
 int bk_profile_read_kind(bk_env* env, int kind, double* total_ms, uint64_t* n_launches);
-/* bk_run kernel pipeline: 0 auto, 1 fused (one wave per book, all phases), 2 split (RNG-serial phases one lane per
- * book + event phase one wave per book).  Results are identical; only speed differs. */
+/* bk_run kernel pipeline: 0 auto (by shape and batch size), 1 fused (one wave per book, all phases),
+ * 2 split (RNG-serial phases one lane per book + event phase one wave per book), 3 split with the members of an AgentSet
+ * decoded one wave per book (older form of 4), 4 / 5 below.  Results are identical; only speed differs. */
 int bk_set_pipeline(bk_env* env, int mode);
 /* Mode 4 on an AgentSet of Noise / Momentum members (independent books, no RandomAgents member): the members' update
  * one WAVE per book with their stream decoded 64 draws at a time (k_agents_mixed_wave) + the event kernel; auto from 512
