@@ -917,19 +917,25 @@ __device__ __forceinline__ uint32_t step_from_list(Book<R>& B, const DevArgs& a,
       const uint32_t(&evl)[R] = ev;
       const uint32_t n_list = nev;
 #endif
+      // the loop tests "no volume or trading disabled" on every new order (two scalar instructions) unless this step is
+      // known not to need it: trading enabled and no new order with volume 0 (one ballot per pool register here)
+      uint64_t zero_vol = 0;
+#pragma unroll
+      for (int r = 0; r < R; ++r) zero_vol |= __ballot(lane_bit(newm[r]) && B.vol[r] == 0u);
+      const uint32_t checked = (!B.trading || zero_vol != 0) ? 1u : 0u;
       for (;;) {
         uint32_t full;
         if constexpr (R == 2)
-          full = events_key_r2(k, n_list, tmask, B.tr_n, K.sq, B.live[0], B.live[1], B.bid[0], B.bid[1], B.price[0], B.price[1],
-                               B.vol[0], B.vol[1], B.id[0], B.id[1], K.key[0], K.key[1], evl[0], evl[1], B.tr_k, B.tr_price,
-                               B.tr_vol, B.tr_act, B.tr_pas
+          full = events_key_r2(checked, k, n_list, tmask, B.tr_n, K.sq, B.live[0], B.live[1], B.bid[0], B.bid[1], B.price[0],
+                               B.price[1], B.vol[0], B.vol[1], B.id[0], B.id[1], K.key[0], K.key[1], evl[0], evl[1], B.tr_k,
+                               B.tr_price, B.tr_vol, B.tr_act, B.tr_pas
 #if BOURSE_AMD_LAZY_CANCEL
                                , dt[0], dt[1]
 #endif
           );
         else
-          full = events_key_r1(k, n_list, tmask, B.tr_n, K.sq, B.live[0], B.bid[0], B.price[0], B.vol[0], B.id[0], K.key[0], evl[0],
-                               B.tr_k, B.tr_price, B.tr_vol, B.tr_act, B.tr_pas
+          full = events_key_r1(checked, k, n_list, tmask, B.tr_n, K.sq, B.live[0], B.bid[0], B.price[0], B.vol[0], B.id[0],
+                               K.key[0], evl[0], B.tr_k, B.tr_price, B.tr_vol, B.tr_act, B.tr_pas
 #if BOURSE_AMD_LAZY_CANCEL
                                , dt[0]
 #endif

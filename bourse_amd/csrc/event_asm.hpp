@@ -404,9 +404,13 @@ __device__ __forceinline__ uint32_t events_asm_r1(uint32_t& k, uint32_t n_ev, ui
   "s_branch L_match_" L "\n\t"
 
 //   NOX  "s_cmp_gt_u32" (bid: best ask key > kp) / "s_cmp_lt_u32" (ask: best bid key < kp): no cross
-#define EK_SIDE(L, PH, KEND, RG, NR, CAND, SENT, VOP, DOP, NOX, KKI, OPPB, SKIP, OWNB, PULL)          \
-  "s_and_b32 " EA_X ", " EA_V ", %[tmask]\n\t"          /* no volume or trading disabled: no match */ \
-  "s_cbranch_scc0 L_restq_" L "\n\t"                                                                  \
+// VCHK: EK_VCHK(L) - "no volume or trading disabled: no match" - or "" when the caller has established that trading is
+// enabled and no new order of this step has volume 0 (two scalar instructions per new order; book_device.hpp)
+#define EK_VCHK(L)                                   \
+  "s_and_b32 " EA_X ", " EA_V ", %[tmask]\n\t"       \
+  "s_cbranch_scc0 L_restq_" L "\n\t"
+#define EK_SIDE(L, PH, KEND, RG, NR, CAND, SENT, VOP, DOP, NOX, KKI, OPPB, SKIP, OWNB, PULL, VCHK)    \
+  VCHK                                                                                                \
   SKIP " " EK_KP ", " OPPB "\n\t"                      /* beyond the bound: cannot cross */           \
   "s_cbranch_scc1 L_restq_" L "\n\t"                                                                  \
   "v_readlane_b32 " EA_ID ", %[id" RG "], " EA_EW "\n\t" /* (only a trade needs the id and the k word) */ \
@@ -447,44 +451,45 @@ __device__ __forceinline__ uint32_t events_asm_r1(uint32_t& k, uint32_t n_ev, ui
   "s_xor_b32 " EA_X ", " EK_KP ", %[sq]\n\t"                                                          \
   PULL " " OWNB ", " OWNB ", " EA_X "\n\t"             /* this side's bound covers the new order */  \
   "v_writelane_b32 %[key" RG "], " EA_X ", m0\n\t"                                                    \
-  "s_lshl_b64 " EA_BIT ", 1, " EA_EW "\n\t"                                                           \
-  "s_or_b64 %[live" RG "], %[live" RG "], " EA_BIT "\n\t"                                             \
+  "s_bitset1_b64 %[live" RG "], " EA_EW "\n\t"         /* (bit ew[5:0]) */                             \
   "s_add_u32 %[sq], %[sq], 2\n\t"                                                                     \
   EA_LOOP(PH, KEND)
 
-#define EK_NEW(PH, KEND, RG, NR)                                                                      \
+#define EK_NEW(PH, KEND, RG, NR, CHK)                                                                 \
   "v_readlane_b32 " EK_KP ", %[key" RG "], " EA_EW "\n\t"                                             \
   "v_readlane_b32 " EA_V ", %[vol" RG "], " EA_EW "\n\t"                                              \
   "s_bitcmp1_b32 " EA_EW ", 14\n\t"                                                                   \
   "s_cbranch_scc1 L_bid_" PH RG "_%=\n\t"                                                             \
   /* an ask: searches the bids (cannot cross if kp > bid bound), rests among the asks (ask bound = min) */ \
   EK_SIDE("a" PH RG "_%=", PH, KEND, RG, NR, "s_and_b64", "0", "v_max_u32", "v_max_u32_dpp", "s_cmp_lt_u32", \
-          "s_or_b32 " EA_KK ", %[k], 0x80000000", EK_BHI, "s_cmp_gt_u32", EK_ALO, "s_min_u32")          \
+          "s_or_b32 " EA_KK ", %[k], 0x80000000", EK_BHI, "s_cmp_gt_u32", EK_ALO, "s_min_u32",          \
+          CHK("a" PH RG "_%="))                                                                        \
   "L_bid_" PH RG "_%=:\n\t"                                                                           \
   EK_SIDE("b" PH RG "_%=", PH, KEND, RG, NR, "s_andn2_b64", "-1", "v_min_u32", "v_min_u32_dpp", "s_cmp_gt_u32", \
-          "s_mov_b32 " EA_KK ", %[k]", EK_ALO, "s_cmp_lt_u32", EK_BHI, "s_max_u32")
+          "s_mov_b32 " EA_KK ", %[k]", EK_ALO, "s_cmp_lt_u32", EK_BHI, "s_max_u32", CHK("b" PH RG "_%="))
 
-#define EK_PHASE(PH, KEND, NR)                                                                        \
+#define EK_NOCHK(L) ""
+#define EK_PHASE(PH, EVN, KEND, NR, CHK)                                                              \
   "L_top_" PH "_%=:\n\t"                                                                              \
-  "v_readlane_b32 " EA_EW ", %[ev" PH "], %[k]\n\t"                                                   \
+  "v_readlane_b32 " EA_EW ", %[ev" EVN "], %[k]\n\t"                                                  \
   EK_LC("s_nop 1\n\t")          /* (stands in for the two instructions of the New test: ew becomes a lane select) */ \
   EK_NLC("s_bitcmp1_b32 " EA_EW ", 15\n\t"                                                            \
          "s_cbranch_scc1 L_new_" PH "_%=\n\t"                                                         \
-         "s_lshl_b64 " EA_BIT ", 1, " EA_EW "\n\t"      /* Cancellation */                            \
+         /* Cancellation: s_bitset0_b64 clears bit ew[5:0] of the slot's live mask (one instruction for shift + and-not) */ \
          EA_IF2_##NR("s_bitcmp1_b32 " EA_EW ", 6\n\t"                                                 \
                      "s_cbranch_scc1 L_can1_" PH "_%=\n\t")                                           \
-         "s_andn2_b64 %[live0], %[live0], " EA_BIT "\n\t"                                             \
+         "s_bitset0_b64 %[live0], " EA_EW "\n\t"                                                      \
          EA_IF2_##NR(EA_LOOP(PH, KEND)                                                                \
                      "L_can1_" PH "_%=:\n\t"                                                          \
-                     "s_andn2_b64 %[live1], %[live1], " EA_BIT "\n\t")                                \
+                     "s_bitset0_b64 %[live1], " EA_EW "\n\t")                                         \
          EA_LOOP(PH, KEND)                                                                            \
          "L_new_" PH "_%=:\n\t")                                                                      \
   EA_IF2_##NR("s_bitcmp1_b32 " EA_EW ", 6\n\t"                                                        \
               "s_cbranch_scc1 L_new1_" PH "_%=\n\t")                                                  \
   EA_IF1_##NR("s_nop 1\n\t")                            /* ew as a lane select: 4 wait states */      \
-  EK_NEW(PH, KEND, "0", NR)                                                                           \
+  EK_NEW(PH, KEND, "0", NR, CHK)                                                                      \
   EA_IF2_##NR("L_new1_" PH "_%=:\n\t"                                                                 \
-              EK_NEW(PH, KEND, "1", NR))
+              EK_NEW(PH, KEND, "1", NR, CHK))
 
 #define EK_TAIL                     \
   "L_done_%=:\n\t"                  \
@@ -501,8 +506,69 @@ __device__ __forceinline__ uint32_t events_asm_r1(uint32_t& k, uint32_t n_ev, ui
   "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55",  \
       "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "vcc", "scc", "memory"
 
+// ONE statement holds the loop twice: with the "no volume or trading disabled" test on every new order (phases 0 / 1) and
+// without it (phases 2 / 3; %[chk] = 0: the caller has established that trading is on and no new order of the step has
+// volume 0).  Two statements - one per variant - cost the kernel 10 VGPRs (46 instead of 36), and with them two of the
+// seven event waves that fit beside a k_agents_fsm wave on a SIMD: C3 277 -> 210 M.
+#define EK_R2_STMT \
+  asm volatile( \
+      "s_mov_b32 " EK_ALO ", 0\n\t" \
+      "s_mov_b32 " EK_BHI ", -1\n\t" \
+      "s_cmp_eq_u32 %[chk], 0\n\t" \
+      "s_cbranch_scc1 L_fast_%=\n\t" \
+      "s_cmp_lt_u32 %[k], %[kend0]\n\t" \
+      "s_cbranch_scc1 L_top_0_%=\n\t" \
+      "s_branch L_end_0_%=\n\t" \
+      EK_PHASE("0", "0", "%[kend0]", 2, EK_VCHK) \
+      "L_end_0_%=:\n\t" \
+      "s_cmp_lt_u32 %[k], %[nev]\n\t" \
+      "s_cbranch_scc0 L_done_%=\n\t" \
+      EK_PHASE("1", "1", "%[nev]", 2, EK_VCHK) \
+      "L_end_1_%=:\n\t" \
+      "s_branch L_done_%=\n\t" \
+      "L_fast_%=:\n\t" \
+      "s_cmp_lt_u32 %[k], %[kend0]\n\t" \
+      "s_cbranch_scc1 L_top_2_%=\n\t" \
+      "s_branch L_end_2_%=\n\t" \
+      EK_PHASE("2", "0", "%[kend0]", 2, EK_NOCHK) \
+      "L_end_2_%=:\n\t" \
+      "s_cmp_lt_u32 %[k], %[nev]\n\t" \
+      "s_cbranch_scc0 L_done_%=\n\t" \
+      EK_PHASE("3", "1", "%[nev]", 2, EK_NOCHK) \
+      "L_end_3_%=:\n\t" \
+      EK_TAIL \
+      : [st] "=&s"(st), [vm] "=&v"(vm), [vm2] "=&v"(vm2), [k] "+s"(k), [trn] "+s"(trn), [sq] "+s"(sq), \
+        [live0] "+s"(live0), [live1] "+s"(live1), [vol0] "+v"(vol0), [vol1] "+v"(vol1), [key0] "+v"(key0), \
+        [key1] "+v"(key1), [trk] "+v"(trk), [trp] "+v"(trp), [trv] "+v"(trv), [tra] "+v"(tra), [trs] "+v"(trs) \
+      : [price0] "v"(price0), [price1] "v"(price1), [id0] "v"(id0), [id1] "v"(id1), [ev0] "v"(ev0), [ev1] "v"(ev1), \
+        [bid0] "s"(bid0), [bid1] "s"(bid1), [nev] "s"(n_ev), [kend0] "s"(kend0), [tmask] "s"(tmask), [dt0] "v"(dt0), \
+        [dt1] "v"(dt1), [chk] "s"(checked) \
+      : EK_CLOBBERS);
+
+#define EK_R1_STMT \
+  asm volatile( \
+      "s_mov_b32 " EK_ALO ", 0\n\t" \
+      "s_mov_b32 " EK_BHI ", -1\n\t" \
+      "s_cmp_lt_u32 %[k], %[nev]\n\t" \
+      "s_cbranch_scc0 L_done_%=\n\t" \
+      "s_cmp_eq_u32 %[chk], 0\n\t" \
+      "s_cbranch_scc1 L_top_2_%=\n\t" \
+      EK_PHASE("0", "0", "%[nev]", 1, EK_VCHK) \
+      "L_end_0_%=:\n\t" \
+      "s_branch L_done_%=\n\t" \
+      EK_PHASE("2", "0", "%[nev]", 1, EK_NOCHK) \
+      "L_end_2_%=:\n\t" \
+      EK_TAIL \
+      : [st] "=&s"(st), [vm] "=&v"(vm), [k] "+s"(k), [trn] "+s"(trn), [sq] "+s"(sq), [live0] "+s"(live0), \
+        [vol0] "+v"(vol0), [key0] "+v"(key0), [trk] "+v"(trk), [trp] "+v"(trp), [trv] "+v"(trv), [tra] "+v"(tra), \
+        [trs] "+v"(trs) \
+      : [price0] "v"(price0), [id0] "v"(id0), [ev0] "v"(ev0), [bid0] "s"(bid0), [nev] "s"(n_ev), [tmask] "s"(tmask), \
+        [dt0] "v"(dt0), [chk] "s"(checked) \
+      : EK_CLOBBERS);
+
 // Keyed form of events_asm_r2: `sq` = (seq_ctr - sbase) << 1 (the caller converts back), key0/key1 as described above.
-__device__ __forceinline__ uint32_t events_key_r2(uint32_t& k, uint32_t n_ev, uint32_t tmask, uint32_t& tr_n, uint32_t& sq,
+// checked = 0: the caller guarantees trading is enabled and every new order of the step has volume > 0
+__device__ __forceinline__ uint32_t events_key_r2(uint32_t checked, uint32_t& k, uint32_t n_ev, uint32_t tmask, uint32_t& tr_n, uint32_t& sq,
                                                   uint64_t& live0, uint64_t& live1, uint64_t bid0, uint64_t bid1,
                                                   uint32_t price0, uint32_t price1, uint32_t& vol0, uint32_t& vol1,
                                                   uint32_t id0, uint32_t id1, uint32_t& key0, uint32_t& key1, uint32_t ev0,
@@ -511,6 +577,7 @@ __device__ __forceinline__ uint32_t events_key_r2(uint32_t& k, uint32_t n_ev, ui
   uint32_t st, vm, vm2;
   auto u32 = [](uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane(x); };
   auto u64 = [&](uint64_t x) { return ((uint64_t)u32((uint32_t)(x >> 32)) << 32) | u32((uint32_t)x); };
+  checked = u32(checked);
   k = u32(k);
   n_ev = u32(n_ev);
   tmask = u32(tmask);
@@ -521,37 +588,19 @@ __device__ __forceinline__ uint32_t events_key_r2(uint32_t& k, uint32_t n_ev, ui
   bid0 = u64(bid0);
   bid1 = u64(bid1);
   const uint32_t kend0 = n_ev < 64u ? n_ev : 64u;
-  asm volatile(
-      "s_mov_b32 " EK_ALO ", 0\n\t"
-      "s_mov_b32 " EK_BHI ", -1\n\t"
-      "s_cmp_lt_u32 %[k], %[kend0]\n\t"
-      "s_cbranch_scc1 L_top_0_%=\n\t"
-      "s_branch L_end_0_%=\n\t"
-      EK_PHASE("0", "%[kend0]", 2)
-      "L_end_0_%=:\n\t"
-      "s_cmp_lt_u32 %[k], %[nev]\n\t"
-      "s_cbranch_scc0 L_done_%=\n\t"
-      EK_PHASE("1", "%[nev]", 2)
-      "L_end_1_%=:\n\t"
-      EK_TAIL
-      : [st] "=&s"(st), [vm] "=&v"(vm), [vm2] "=&v"(vm2), [k] "+s"(k), [trn] "+s"(trn), [sq] "+s"(sq),
-        [live0] "+s"(live0), [live1] "+s"(live1), [vol0] "+v"(vol0), [vol1] "+v"(vol1), [key0] "+v"(key0),
-        [key1] "+v"(key1), [trk] "+v"(trk), [trp] "+v"(trp), [trv] "+v"(trv), [tra] "+v"(tra), [trs] "+v"(trs)
-      : [price0] "v"(price0), [price1] "v"(price1), [id0] "v"(id0), [id1] "v"(id1), [ev0] "v"(ev0), [ev1] "v"(ev1),
-        [bid0] "s"(bid0), [bid1] "s"(bid1), [nev] "s"(n_ev), [kend0] "s"(kend0), [tmask] "s"(tmask), [dt0] "v"(dt0),
-        [dt1] "v"(dt1)
-      : EK_CLOBBERS);
+  EK_R2_STMT
   tr_n = trn + 64u;
   return st;
 }
 
-__device__ __forceinline__ uint32_t events_key_r1(uint32_t& k, uint32_t n_ev, uint32_t tmask, uint32_t& tr_n, uint32_t& sq,
+__device__ __forceinline__ uint32_t events_key_r1(uint32_t checked, uint32_t& k, uint32_t n_ev, uint32_t tmask, uint32_t& tr_n, uint32_t& sq,
                                                   uint64_t& live0, uint64_t bid0, uint32_t price0, uint32_t& vol0,
                                                   uint32_t id0, uint32_t& key0, uint32_t ev0, uint32_t& trk, uint32_t& trp,
                                                   uint32_t& trv, uint32_t& tra, uint32_t& trs, uint32_t dt0 = 0xFFFFFFFFu) {
   uint32_t st, vm;
   auto u32 = [](uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane(x); };
   auto u64 = [&](uint64_t x) { return ((uint64_t)u32((uint32_t)(x >> 32)) << 32) | u32((uint32_t)x); };
+  checked = u32(checked);
   k = u32(k);
   n_ev = u32(n_ev);
   tmask = u32(tmask);
@@ -559,20 +608,7 @@ __device__ __forceinline__ uint32_t events_key_r1(uint32_t& k, uint32_t n_ev, ui
   sq = u32(sq);
   live0 = u64(live0);
   bid0 = u64(bid0);
-  asm volatile(
-      "s_mov_b32 " EK_ALO ", 0\n\t"
-      "s_mov_b32 " EK_BHI ", -1\n\t"
-      "s_cmp_lt_u32 %[k], %[nev]\n\t"
-      "s_cbranch_scc0 L_done_%=\n\t"
-      EK_PHASE("0", "%[nev]", 1)
-      "L_end_0_%=:\n\t"
-      EK_TAIL
-      : [st] "=&s"(st), [vm] "=&v"(vm), [k] "+s"(k), [trn] "+s"(trn), [sq] "+s"(sq), [live0] "+s"(live0),
-        [vol0] "+v"(vol0), [key0] "+v"(key0), [trk] "+v"(trk), [trp] "+v"(trp), [trv] "+v"(trv), [tra] "+v"(tra),
-        [trs] "+v"(trs)
-      : [price0] "v"(price0), [id0] "v"(id0), [ev0] "v"(ev0), [bid0] "s"(bid0), [nev] "s"(n_ev), [tmask] "s"(tmask),
-        [dt0] "v"(dt0)
-      : EK_CLOBBERS);
+  EK_R1_STMT
   tr_n = trn + 64u;
   return st;
 }

@@ -141,6 +141,20 @@ def test_random_agents_edge_shapes(bk, oracle, pipeline):
                     step_size=10, pipeline=pipeline)
 
 
+@pytest.mark.parametrize("pipeline", PIPELINES)
+def test_zero_volume_orders_rest_without_trading(bk, oracle, pipeline):
+    """Volume ranges that start at 0: a new order of volume 0 matches nothing and rests (place_order's `while order.vol > 0`,
+    orderbook.rs:429 / :462), a resting one is "filled" by the first aggressor with a zero-volume trade.  The keyed event loop
+    only tests for it in steps that hold such an order (event_asm.hpp EK_VCHK): both of its variants run here, on 64-, 128-
+    and 256-slot pools."""
+    _compare_random(bk, oracle, n_books=9, groups=[(40, (10, 16), (0, 3), 1, 0.9), (24, (12, 18), (0, 2), 1, 0.7)], levels=8,
+                    n_steps=60, tick=1, pipeline=pipeline)
+    _compare_random(bk, oracle, n_books=5, groups=[(70, (10, 16), (0, 2), 1, 0.9), (50, (12, 18), (3, 9), 1, 0.7)], levels=8,
+                    n_steps=50, tick=1, pipeline=pipeline)
+    _compare_random(bk, oracle, n_books=3, groups=[(200, (10, 30), (0, 4), 2, 0.8)], levels=16, n_steps=30, tick=2,
+                    pipeline=pipeline)
+
+
 @pytest.mark.parametrize("pipeline", PIPELINES + ["mixed"])
 def test_chunked_launches_equal_one_launch(bk, oracle, pipeline):
     a = _compare_random(bk, oracle, n_books=16, groups=C2_GROUPS, levels=16, n_steps=30, chunks=[1, 2, 3, 24],
