@@ -31,7 +31,7 @@ def is_stale() -> bool:
 FSM_SCHED = ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]  # fsm_unit.hip only (see its header)
 
 
-def build(force: bool = False, verbose: bool = False, out: str = None, defines=()) -> str:
+def build(force: bool = False, verbose: bool = False, out: str = None, defines=(), remarks: list = None) -> str:
     """Build libbourse_amd.so in-tree; `out` + `defines` build a VARIANT somewhere else (e.g. -DBOURSE_AMD_ASM_EVENTS=0:
     the compiled C++ event loop instead of the hand-written one) that BOURSE_AMD_LIBRARY=<path> makes _lib load.
     Two translation units: bourse_amd.hip (everything) and fsm_unit.hip (k_agents_fsm under the max-ilp scheduler)."""
@@ -44,7 +44,7 @@ def build(force: bool = False, verbose: bool = False, out: str = None, defines=(
     fsm_extra = os.environ.get("BOURSE_AMD_FSM_HIPCC_FLAGS", " ".join(FSM_SCHED)).split()
     target = out or LIB
     base = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"] + extra + ["-D" + d for d in defines]
-    if verbose:
+    if verbose or remarks is not None:  # (`remarks`: a list that receives the compiler's kernel-resource-usage report)
         base.insert(1, "-Rpass-analysis=kernel-resource-usage")
     objs = []
     log = ""
@@ -65,6 +65,8 @@ def build(force: bool = False, verbose: bool = False, out: str = None, defines=(
                              cwd=CSRC, capture_output=True, text=True)
         if res.returncode != 0:
             raise RuntimeError("hipcc link failed:\n" + res.stdout + res.stderr)
+    if remarks is not None:
+        remarks.append(log)
     if verbose:
         print(log)
     return target

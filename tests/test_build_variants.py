@@ -34,5 +34,19 @@ def test_keyed_loop_test_variant_builds(tmp_path):
     from bourse_amd import _build
 
     out = str(tmp_path / "libbourse_amd_sb8.so")
-    assert _build.build(out=out, defines=["BOURSE_AMD_KEY_SEQ_BITS=8"]) == out and os.path.getsize(out) > 100_000
+    remarks = []
+    assert _build.build(out=out, defines=["BOURSE_AMD_KEY_SEQ_BITS=8"], remarks=remarks) == out and os.path.getsize(out) > 100_000
     assert open(out, "rb").read() != open(_build.LIB, "rb").read()
+    # The register budget the split pipeline's throughput rests on (docs/EXPERIMENTS.md): the lane-per-book
+    # agents kernel claims 232 VGPRs so that SEVEN event waves of <= 40 VGPRs fit beside one of its waves on a SIMD
+    # (232 + 7 x 40 = 512).  An event kernel of 46 VGPRs (five waves) once cost C3 a quarter of its rate.
+    def vgprs(mangled):
+        import re
+
+        m = re.search(r"Function Name: " + re.escape(mangled) + r"\b.*?VGPRs: (\d+)", remarks[0], re.S)
+        assert m, mangled
+        return int(m.group(1))
+
+    assert vgprs("_ZN3bkd12k_agents_fsmILi2EEEvNS_7DevArgsE") == 232
+    for r in (1, 2):
+        assert vgprs(f"_ZN3bkd12k_step_batchILi{r}ELb0ELb0EEEvNS_7DevArgsEmj") <= 40, r
