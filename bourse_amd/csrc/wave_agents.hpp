@@ -625,8 +625,15 @@ struct WaveDecoder {
 // ==================================================================================
 // Split form: k_agents_wave writes the step batch, k_step_batch (book_device.hpp) consumes it.
 // ==================================================================================
+// Compiled for SIX waves per SIMD at R <= 2 (80 VGPRs, no scratch): asked to fit eight the kernel takes 64 VGPRs + 32 B
+// of scratch per lane and is slower wherever it runs (same box: 8 192 books 111.6 -> 114.6 M, 12 288: 126.5 -> 132.6 M,
+// 16 384: 133.8 -> 134.8 M; seven waves 113.4 / 130.8 / 133.4, five 113.4 / 130.5 / 132.2, four 113.6 / 130.6 / 131.4).
+// The larger pools never reached eight (R = 4: seven, R = 8: five) and keep the request.
+#ifndef BOURSE_AMD_AW_OCC
+#define BOURSE_AMD_AW_OCC(R) ((R) <= 2 ? 6 : 8)
+#endif
 template <int R>
-__global__ __launch_bounds__(256, 8) void k_agents_wave(DevArgs a, WaveArgs wa) {
+__global__ __launch_bounds__(256, BOURSE_AMD_AW_OCC(R)) void k_agents_wave(DevArgs a, WaveArgs wa) {
   __shared__ uint4 tab[512];
   __shared__ uint32_t ring_s[4][WV_RING];
   __shared__ uint16_t evl_s[4][64 * R];
