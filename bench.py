@@ -206,6 +206,11 @@ def main():
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
                     help="N > 1: strong = the workload's books sharded over the GPUs (BASELINE configs[3]); weak = that many per GPU")
     ap.add_argument("--selftest-gloo", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--dry-ranks", action="store_true",
+                    help="N > 1 on a box with ONE GPU: every rank steps its shard on GPU 0 and the collectives run over gloo. "
+                         "Executes the whole multi-rank code path except RCCL-over-xGMI (rendezvous, N concurrent stream probes, "
+                         "sharding, region / barrier logic, stats all-gather, consistency checks); the rate it prints is that of "
+                         "N processes sharing one GPU, NOT a measurement of N GPUs (the line says `dry_ranks: true`)")
     ap.add_argument("--steps-per-launch", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--l1-gather", action="store_true", help="also all-gather every book's L1 record per launch (SURVEY 8e ii)")
@@ -233,13 +238,28 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no GPU visible (bourse_amd has no CPU path)")
+    if args.dry_ranks:
+        local_rank = 0  # every rank on the one GPU there is
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1 or "RANK" in os.environ:  # launched by torch.distributed.run (also with one rank: exercises RCCL path)
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.dry_ranks:  # RCCL refuses two ranks on one device: the 64-byte records travel over gloo instead
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    coll_dev = "cpu" if args.dry_ranks else "cuda"  # where the small bookkeeping tensors of the collectives live
+
+    def all_ranks(x):
+        """Every rank's value of a python float (one all-gather); [x] without a process group."""
+        if dist is None:
+            return [float(x)]
+        t = torch.tensor([x], dtype=torch.float64, device=coll_dev)
+        out = torch.empty(world, dtype=torch.float64, device=coll_dev)
+        dist.all_gather_into_tensor(out, t)
+        return [float(v) for v in out.cpu()]
 
     import bourse_amd
     from bourse_amd import parallel
@@ -272,6 +292,8 @@ def main():
         env.set_wave_options(64, args.wave_parts)
     pipe, parts = env.pipeline()
     gather = parallel.StatsGather(env, dist) if dist is not None else None
+    if args.l1_gather and args.dry_ranks:
+        raise SystemExit("--l1-gather is a device-to-device RCCL all-gather: not part of a --dry-ranks run")
     if args.l1_gather and books_total != world * B:
         raise SystemExit("--l1-gather needs equal shards (all_gather_into_tensor)")
     l1 = parallel.L1Gather(env, dist) if (dist is not None and args.l1_gather) else None
@@ -323,10 +345,8 @@ def main():
         "k_agents_wave" if pipe == "wave_split" else "k_agents_fsm")
     per_kind = {k: env.profile_read_kind(i) for i, k in enumerate((kind0, kind1, "k_step_batch", "k_step_events"))}
     env.profile_read()
-    if dist is not None:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+    dt_ranks = all_ranks(dt)  # every rank's wall time of the region: a straggler is visible in the line
+    dt = max(dt_ranks)
 
     flags = env.flags()
     if flags.any():
@@ -386,11 +406,10 @@ def main():
     pmc, pmc_src = {}, None
     try:
         allp = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-        # keyed by workload and books per GPU: per-book-step PMC figures of one batch size do not carry over to another
-        key = args.workload if B == books_default else f"{args.workload}/{B}"
+        # keyed by workload AND books per GPU: per-book-step PMC figures of one batch size do not carry over to another
+        key = f"{args.workload}/{B}"
         pmc = allp.get(key, {})
-        pmc_src = "profiles/pmc_traffic.json[%s] (rocprofv3 --pmc passes of `bench.py --workload %s --books %d`, scripts/profile_round.sh; replayed, not measured in this run)" % (
-            key, args.workload, B) if pmc else None
+        pmc_src = ("profiles/pmc_traffic.json[%s]: %s; replayed, not measured in this run" % (key, allp.get("_source", "")) if pmc else None)
     except Exception:
         pass
     kernels = {}
@@ -409,29 +428,38 @@ def main():
     K = kernels[dominant]
     achieved, avg_ms, n_launch, traffic = K["achieved"], K["avg_launch_ms"], K["launches"], K["traffic"]
     bytes_per_bookstep, book_steps_per_launch = K["bytes_per_book_step"], K["book_steps_per_launch"]
-    # What actually bounds the path: instruction ISSUE, not bytes.  Per CU and clock the sequencer issues
-    # at most one scalar and one vector instruction; the counts per book-step are PMC figures committed under profiles/.
+    # What actually bounds the path: instruction ISSUE, not bytes.  The ports' peaks are MEASURED ones
+    # (scripts/micro/mixed_issue_bench.hip, 8 waves per SIMD, independent instructions): s_add_u32 alone 0.95 per CU and
+    # clock, v_add_u32 alone 1.65, a 1:1 mix of both 1.70 in total (0.85 + 0.85: the scalar port binds a balanced mix).
+    # The counts per book-step are PMC figures committed under profiles/ (scalar = SALU + branches: one port).
     issue = None
+    SCALAR_PEAK, VECTOR_PEAK, MIX_1TO1_PEAK = 0.95, 1.65, 1.70
     ins = {k: pmc.get(k, {}).get("insts_per_book_step") for k in kernels}
     if all(ins.values()) and ins:
         salu = sum(v["salu"] for v in ins.values())
         valu = sum(v["valu"] for v in ins.values())
         branch = sum(v.get("branch", 0.0) for v in ins.values())
-        peak = N_CU * CLOCK_GHZ * 1e9  # instructions/s of one type, whole GPU
+        cu_clk = N_CU * CLOCK_GHZ * 1e9  # CU-clocks per second, whole GPU
         per_gpu = value / world
-        # the scalar unit issues SALU instructions AND branches: one port per CU, 0.95 per clock measured
-        issue = {"bound": "scalar/vector issue (1 scalar-or-branch + 1 vector instruction per CU per clock)",
+        s_rate, v_rate = (salu + branch) * per_gpu / cu_clk, valu * per_gpu / cu_clk  # instructions per CU and clock
+        issue = {"bound": "instruction issue: one scalar port (SALU + branches) and one vector port per CU",
                  "salu_per_book_step": salu, "branch_per_book_step": branch, "valu_per_book_step": valu,
-                 "peak_insts_per_s": peak, "salu_frac": salu * per_gpu / peak,
-                 "scalar_port_frac": (salu + branch) * per_gpu / peak, "valu_frac": valu * per_gpu / peak,
+                 "scalar_per_cu_clk": s_rate, "vector_per_cu_clk": v_rate,
+                 "scalar_peak_per_clk": SCALAR_PEAK, "vector_peak_per_clk": VECTOR_PEAK, "mixed_1to1_total_peak_per_clk": MIX_1TO1_PEAK,
+                 "peaks_source": "scripts/micro/mixed_issue_bench.hip on this GPU model (profiles/r04/mixed_issue_bench.txt): "
+                                 "s_add_u32 0.95, v_add_u32 1.65, 1:1 mix 1.70 instructions per CU and clock at 8 waves per SIMD",
+                 "scalar_port_frac": s_rate / SCALAR_PEAK, "vector_port_frac": v_rate / VECTOR_PEAK,
+                 "total_per_cu_clk": s_rate + v_rate,
                  "events_per_s_per_cu": ev_per_bs * per_gpu / N_CU, "assumed_clock_ghz": CLOCK_GHZ, "n_cu": N_CU}
         occ = pmc.get(dominant, {}).get("occupancy")
-        if occ:  # achieved occupancy of the dominant kernel (PMC, committed under profiles/)
+        if occ:  # wave-cycle split of the dominant kernel (PMC, committed under profiles/)
             issue["occupancy"] = occ
     out = {
         "metric": "book-steps/sec", "value": value, "unit": "book-steps/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": dt * 1e3 / args.steps, "higher_is_better": True, "scaling": args.scaling,
         "vs_baseline": None, "dtype": "u32", "data": "synthetic", "preheat_steps": args.preheat_steps,
+        "rank_region_ms": {"min": min(dt_ranks) * 1e3, "median": float(np.median(dt_ranks)) * 1e3, "max": max(dt_ranks) * 1e3,
+                           "all": [d * 1e3 for d in dt_ranks]},
         "config": {
             "workload": f"{args.workload}: {books_total} books ({B}/GPU) x {n_agents} on-device agents "
                         f"({len(groups)} {'members: ' + '+'.join(g[0] for g in groups) if mixed else 'groups'}), {levels} levels/side, tick {TICK}, step_size {STEP_SIZE}, "
@@ -469,11 +497,7 @@ def main():
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
-        d = time.perf_counter() - t0
-        if dist is not None:
-            tm = torch.tensor([d], dtype=torch.float64, device="cuda")
-            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
-            d = float(tm.item())
+        d = max(all_ranks(time.perf_counter() - t0))
         vals.append(books_total * args.steps / d)
     out["runs"] = {"n": len(vals), "values": vals, "median": float(np.median(vals))}
     # The per-launch roofline above is measured while the parts' kernels overlap each other on separate streams, which
@@ -525,6 +549,9 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if args.dry_ranks:
+        out["dry_ranks"] = True
+        out["config"]["parallelism"] += " - DRY RUN: all ranks on ONE GPU, collectives over gloo; the rate is not an N-GPU measurement"
     if rank == 0:
         print(json.dumps(out))
 

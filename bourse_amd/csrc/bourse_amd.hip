@@ -70,9 +70,6 @@ uint64_t fnv1a(const void* p, size_t n, uint64_t h = 1469598103934665603ull) {
       return fail(BK_HIP_ERROR, std::string(#expr) + ": " + hipGetErrorString(_e));               \
   } while (0)
 
-// batch sizes from which bk_run's auto mode takes the split pipeline (measured crossovers: scripts/size_sweep.py,
-// scripts/parts_size_sweep.py, scripts/c5m_sweep.sh)
-constexpr uint32_t RANDOM_SPLIT_MIN_BOOKS = 8192, MIXED_SPLIT_MIN_BOOKS = 4096;
 // AgentSets of Noise / Momentum members on independent books: from this many books the members' update runs one WAVE per
 // book with the stream decoded 64 draws at a time (k_agents_mixed_wave, wave_mixed.hpp) in front of the event kernel
 constexpr uint32_t MIXED_WAVE_MIN_BOOKS = 512;
@@ -146,7 +143,6 @@ struct bk_env {
   int pipeline = 0;
   DevBuf<uint32_t> warm_snap;         // bk_warm: state + L2 copy of the scratch steps
   bool warming = false;               // bk_warm's scratch steps: no history slots, no trade records
-  uint64_t n_fallbacks = 0;           // (rounds 1-2: guarded launches rolled back and redone; always 0 since round 3)
   DevBuf<uint4> jump_tabs;      // k_agents_wave: T^256 (block jump) then T^(4 << b), b = 0..5 (lane offsets): 7 x 8 KB
   DevBuf<uint32_t> wcache;      // k_agents_wave: per-book lane states of the RNG block in progress
   uint32_t wave_lookahead = 64;
@@ -154,7 +150,6 @@ struct bk_env {
   int wave_parts = 0;           // 0 = as the lane split (n_parts / min_part)
   bool wave_ok() const { return !n_mixed && M == 1 && !groups.empty(); }  // RandomAgents on independent books
   // AgentSets with Noise / Momentum members on independent books: wave-parallel decode of the members' update
-  bool mixed_random_member = false;
   bool wl_valid = false;    // the wave-per-book members' lists (wl_list) describe the pools as of steps_done
   DevBuf<uint16_t> wl_list;    // [n_books][MAX_MEMBERS][pool]: k_agents_mixed_wave's lists, book-major
   DevBuf<uint32_t> wl_len;
@@ -183,6 +178,36 @@ struct bk_env {
     // (AgentSets of Noise / Momentum members: two parts - scripts sweep at C5 as written, 8 192 books: 1 part 21.9 M,
     // 2: 26.1, 3: 25.2, 4: 25.2, 6: 19.2, 8: 20.4 M book-steps/s)
     return static_cast<int>(std::max(1u, std::min(n_mixed ? 2u : 3u, cfg.n_books / 2048u)));
+  }
+  // THE pipeline choice: the one function bk_run launches from and bk_get_pipeline reports from (they duplicated the rule
+  // until round 4).  `pipeline` is the caller's request (0 auto); a request the env's agents cannot take (e.g. "wave" for
+  // a market) falls back as the comments say.
+  enum PlanKind {
+    PL_FUSED_RANDOM,  // k_run_random: one wave per book, all phases, n_steps per launch (also: no agents = plain steps)
+    PL_FUSED_WAVE,    // k_run_wave: wave-parallel decode + events, persistent
+    PL_SPLIT_LANES,   // k_agents_fsm (one lane per book / market) + k_step_batch
+    PL_SPLIT_WAVE,    // k_agents_wave (one wave per book, stream decoded 64 draws at a time) + k_step_batch
+    PL_MIXED_FUSED,   // k_run_mixed: AgentSet members, fused
+    PL_MIXED_WAVE,    // k_agents_mixed_wave + k_step_batch<POOLPEND>
+    PL_MIXED_LANES,   // k_agents_mixed_lanes + k_step_batch<POOLPEND> (markets' only pipeline; on request otherwise)
+    PL_MIXED_WPB,     // k_agents_mixed (one wave per book, scalar) + k_step_batch<POOLPEND> (mode 3, on request)
+  };
+  struct Plan {
+    PlanKind kind;
+    int parts;
+  };
+  Plan plan() const {
+    if (n_mixed) {
+      if (use_mixed_wave()) return {PL_MIXED_WAVE, wave_split_parts()};
+      if (pipeline == 2 || M > 1) return {PL_MIXED_LANES, parts()};
+      if (pipeline == 3) return {PL_MIXED_WPB, parts()};
+      return {PL_MIXED_FUSED, 1};
+    }
+    if (use_wave_fused()) return {PL_FUSED_WAVE, 1};
+    if (use_wave()) return {PL_SPLIT_WAVE, wave_split_parts()};
+    // (auto with RandomAgents on independent books never gets here below lane_split_min_books: the wave forms take it)
+    if ((pipeline >= 2 && pipeline != 5) || M > 1 || (pipeline == 0 && wave_ok())) return {PL_SPLIT_LANES, parts()};
+    return {PL_FUSED_RANDOM, 1};
   }
   // split pipeline: the batch is cut into n_parts contiguous parts, each on its own stream and started one
   // k_agents_fsm apart, so the latency-bound lane-per-book kernel of one part runs under the issue-bound
@@ -1229,8 +1254,6 @@ static int set_agents_impl(bk_env* env, uint32_t n_members, const bk_agent_desc*
   HIPCHK(hipMemcpy(env->mixed_descs.p, ds.data(), ds.size() * sizeof(MixedDesc), hipMemcpyHostToDevice));
   env->n_mixed = n_members;
   env->n_fixed = fixed;
-  env->mixed_random_member = false;
-  for (uint32_t i = 0; i < n_members; ++i) env->mixed_random_member = env->mixed_random_member || members[i].type == BK_AGENT_RANDOM;
   env->wl_valid = false;
   for (uint32_t i = 0; i < MAX_MEMBERS; ++i) env->member_asset[i] = (assets && i < n_members) ? assets[i] : 0u;
   for (uint32_t as = 0; as < MAX_ASSETS; ++as) env->n_fixed_a[as] = fixed_a[as];
@@ -1278,86 +1301,46 @@ int bk_run(bk_env* env, uint64_t n_steps) {
   int rc = BK_OK;
   const uint32_t ns = static_cast<uint32_t>(n_steps);
   if (env->n_mixed || a.n_groups) env->device_flow = true;
-  if (env->n_mixed) {
-    // fused for small batches (the book stays in registers across steps); from MIXED_SPLIT_MIN_BOOKS books (where it
-    // overtakes the fused kernel, scripts/c5m_sweep.sh) the members' update runs one LANE per book in front of the lean
-    // event kernel, the batch cut in parts that overlap.  Mode 3 keeps the wave-per-book members' update selectable.
-    const bool mlanes = env->pipeline == 2 || env->M > 1 || (env->pipeline == 0 && env->cfg.n_books >= MIXED_SPLIT_MIN_BOOKS);
-    // The lane-per-book members' update keeps a filled order's pool slot reserved until its member's next update, so a
-    // pool the wave-per-book kernels just fit can overflow there (flagged).  Rounds 1-2 guarded the library's own choice
-    // of it with a snapshot / roll-back; since round 3 the auto choice for independent books is the wave-parallel decode
-    // (which frees slots like the fused kernel), and the lane pipeline is only ever taken on request (mode 2) or for
-    // markets, where the fused kernel does not exist - nothing of the library's choosing is left to guard.
-    if (env->use_mixed_wave()) {  // wave-parallel decode of the members' update + the event kernel, in parts
-      switch (env->R) {
-        case 1: rc = launch_split<1, 3>(env, a, env->steps_done, ns); break;
-        case 2: rc = launch_split<2, 3>(env, a, env->steps_done, ns); break;
-        case 4: rc = launch_split<4, 3>(env, a, env->steps_done, ns); break;
-        default: rc = launch_split<8, 3>(env, a, env->steps_done, ns); break;
-      }
-      if (rc != BK_OK) return rc;
-      env->steps_done += n_steps;
-      return BK_OK;
-    }
-    if (mlanes) {
-      switch (env->R) {
-        case 1: rc = launch_split<1, 2>(env, a, env->steps_done, ns); break;
-        case 2: rc = launch_split<2, 2>(env, a, env->steps_done, ns); break;
-        case 4: rc = launch_split<4, 2>(env, a, env->steps_done, ns); break;
-        default: rc = launch_split<8, 2>(env, a, env->steps_done, ns); break;
-      }
-    } else if (env->pipeline == 3) {
-      switch (env->R) {
-        case 1: rc = launch_split<1, 1>(env, a, env->steps_done, ns); break;
-        case 2: rc = launch_split<2, 1>(env, a, env->steps_done, ns); break;
-        case 4: rc = launch_split<4, 1>(env, a, env->steps_done, ns); break;
-        default: rc = launch_split<8, 1>(env, a, env->steps_done, ns); break;
-      }
-    } else {
+  // Which kernels (bk_env::plan - the rule itself is documented there and in DESIGN.md 2.1):
+  //  * the fused kernels keep a book in registers across all steps of the launch but run the RNG-serial phases on the
+  //    scalar unit of ONE wave per book; the split forms move them to one lane per book (>= 64 books per wave to pay off)
+  //    or decode the stream wave-parallel, in front of the lean event kernel, the batch cut in parts that overlap;
+  //  * markets always take a split form: the market's RNG-serial phase is one lane, its books are M waves;
+  //  * the lane-per-book members' update keeps a filled order's pool slot reserved until its member's next update, so a
+  //    pool the wave-per-book kernels just fit can overflow there (flagged): it is only ever taken on request (mode 2) or
+  //    for markets, where the other kernels do not exist - nothing of the library's choosing is left to guard.
+#define BK_BY_R(CALL_1, CALL_2, CALL_4, CALL_8) \
+  switch (env->R) {                             \
+    case 1: rc = CALL_1; break;                 \
+    case 2: rc = CALL_2; break;                 \
+    case 4: rc = CALL_4; break;                 \
+    default: rc = CALL_8; break;                \
+  }
+#define BK_SPLIT(MODE) \
+  BK_BY_R((launch_split<1, MODE>(env, a, env->steps_done, ns)), (launch_split<2, MODE>(env, a, env->steps_done, ns)), \
+          (launch_split<4, MODE>(env, a, env->steps_done, ns)), (launch_split<8, MODE>(env, a, env->steps_done, ns)))
+  switch (env->plan().kind) {
+    case bk_env::PL_MIXED_WAVE: BK_SPLIT(3) break;
+    case bk_env::PL_MIXED_LANES: BK_SPLIT(2) break;
+    case bk_env::PL_MIXED_WPB: BK_SPLIT(1) break;
+    case bk_env::PL_MIXED_FUSED:
       env->ml_valid = false;
-      switch (env->R) {
-        case 1: rc = launch_mixed<1>(env, a, env->steps_done, ns); break;
-        case 2: rc = launch_mixed<2>(env, a, env->steps_done, ns); break;
-        case 4: rc = launch_mixed<4>(env, a, env->steps_done, ns); break;
-        default: rc = launch_mixed<8>(env, a, env->steps_done, ns); break;
-      }
-    }
-    if (rc != BK_OK) return rc;
-    env->steps_done += n_steps;
-    return BK_OK;
+      BK_BY_R(launch_mixed<1>(env, a, env->steps_done, ns), launch_mixed<2>(env, a, env->steps_done, ns),
+              launch_mixed<4>(env, a, env->steps_done, ns), launch_mixed<8>(env, a, env->steps_done, ns))
+      break;
+    case bk_env::PL_FUSED_WAVE:
+      BK_BY_R(launch_wave_fused<1>(env, a, env->steps_done, ns), launch_wave_fused<2>(env, a, env->steps_done, ns),
+              launch_wave_fused<4>(env, a, env->steps_done, ns), launch_wave_fused<8>(env, a, env->steps_done, ns))
+      break;
+    case bk_env::PL_SPLIT_WAVE:
+    case bk_env::PL_SPLIT_LANES: BK_SPLIT(0) break;  // (launch_split<R, 0> takes k_agents_wave when env->use_wave())
+    case bk_env::PL_FUSED_RANDOM:
+      BK_BY_R(launch_run<1>(env, a, env->steps_done, ns), launch_run<2>(env, a, env->steps_done, ns),
+              launch_run<4>(env, a, env->steps_done, ns), launch_run<8>(env, a, env->steps_done, ns))
+      break;
   }
-  // The fused kernel keeps a book in registers across all steps of the launch but runs the RNG-serial
-  // phases on the scalar unit of ONE wave per book; the split pipeline runs them one lane per book and needs
-  // >= 64 books per wave to pay off.  auto: split once the batch fills the chip several times over.
-  // Markets always take the split pipeline: the market's RNG-serial phase is one lane, its books are M waves.
-  if (env->use_wave_fused()) {
-    switch (env->R) {
-      case 1: rc = launch_wave_fused<1>(env, a, env->steps_done, ns); break;
-      case 2: rc = launch_wave_fused<2>(env, a, env->steps_done, ns); break;
-      case 4: rc = launch_wave_fused<4>(env, a, env->steps_done, ns); break;
-      default: rc = launch_wave_fused<8>(env, a, env->steps_done, ns); break;
-    }
-    if (rc != BK_OK) return rc;
-    env->steps_done += n_steps;
-    return BK_OK;
-  }
-  const bool split = (env->pipeline >= 2 && env->pipeline != 5) || env->M > 1 || env->use_wave() ||
-                     (env->pipeline == 0 && env->cfg.n_books >= RANDOM_SPLIT_MIN_BOOKS && a.n_groups > 0);
-  if (split) {
-    switch (env->R) {
-      case 1: rc = launch_split<1>(env, a, env->steps_done, ns); break;
-      case 2: rc = launch_split<2>(env, a, env->steps_done, ns); break;
-      case 4: rc = launch_split<4>(env, a, env->steps_done, ns); break;
-      default: rc = launch_split<8>(env, a, env->steps_done, ns); break;
-    }
-  } else {
-    switch (env->R) {
-      case 1: rc = launch_run<1>(env, a, env->steps_done, ns); break;
-      case 2: rc = launch_run<2>(env, a, env->steps_done, ns); break;
-      case 4: rc = launch_run<4>(env, a, env->steps_done, ns); break;
-      default: rc = launch_run<8>(env, a, env->steps_done, ns); break;
-    }
-  }
+#undef BK_SPLIT
+#undef BK_BY_R
   if (rc != BK_OK) return rc;
   env->steps_done += n_steps;
   return BK_OK;
@@ -1377,19 +1360,27 @@ int bk_warm(bk_env* env, uint64_t n_steps) {
   if (!env->warm_snap.p) HIPCHK(env->warm_snap.alloc(sb + lb));
   HIPCHK(hipMemcpyAsync(env->warm_snap.p, env->state.p, sb * 4, hipMemcpyDeviceToDevice, env->stream));
   HIPCHK(hipMemcpyAsync(env->warm_snap.p + sb, env->l2_last.p, lb * 4, hipMemcpyDeviceToDevice, env->stream));
-  const uint64_t steps0 = env->steps_done, fb0 = env->n_fallbacks;
+  const uint64_t steps0 = env->steps_done;
   const bool flow0 = env->device_flow;
   env->warming = true;
   const int rc = bk_run(env, n_steps);
   env->warming = false;
   env->steps_done = steps0;
-  env->n_fallbacks = fb0;
   env->device_flow = flow0;
   env->wl_valid = false;  // the wave-per-book lists described the scratch steps' pools
   env->ml_valid = false;  // the members' lists described the scratch steps' pool
-  if (rc != BK_OK) return rc;  // (bk_run fails before launching anything: the state is untouched)
-  HIPCHK(hipMemcpyAsync(env->state.p, env->warm_snap.p, sb * 4, hipMemcpyDeviceToDevice, env->stream));
-  HIPCHK(hipMemcpyAsync(env->l2_last.p, env->warm_snap.p + sb, lb * 4, hipMemcpyDeviceToDevice, env->stream));
+  // put the books back WHATEVER bk_run returned: a launch that failed half-way (an event record / wait between two kernel
+  // launches) has already stepped some parts, and the step counter above is rolled back either way.  bk_run's own error
+  // (and its message) wins over one of the restore copies.
+  std::string run_err = rc != BK_OK ? g_err : std::string();
+  if (rc != BK_OK)  // (a failed multi-part launch never reached its join: the parts' streams may still be stepping)
+    for (int i = 0; i < bk_env::MAX_PARTS; ++i)
+      if (env->part_stream[i]) (void)hipStreamSynchronize(env->part_stream[i]);
+  const hipError_t e1 = hipMemcpyAsync(env->state.p, env->warm_snap.p, sb * 4, hipMemcpyDeviceToDevice, env->stream);
+  const hipError_t e2 = hipMemcpyAsync(env->l2_last.p, env->warm_snap.p + sb, lb * 4, hipMemcpyDeviceToDevice, env->stream);
+  if (rc != BK_OK) return fail(rc, run_err);
+  HIPCHK(e1);
+  HIPCHK(e2);
   return BK_OK;
 }
 
@@ -1969,18 +1960,20 @@ int bk_profile_read_kind(bk_env* env, int kind, double* total_ms, uint64_t* n_la
 int bk_get_pipeline(bk_env* env, int* split, int* n_parts) {
   if (!env) return fail(BK_INVALID_ARGUMENT, "null env");
   query_fused_resident(env);
-  if (env->use_wave_fused()) {
-    if (split) *split = 3;
-    if (n_parts) *n_parts = 1;
-    return BK_OK;
+  const bk_env::Plan pl = env->plan();  // the same function bk_run launches from
+  int code = 0;
+  switch (pl.kind) {
+    case bk_env::PL_FUSED_RANDOM:
+    case bk_env::PL_MIXED_FUSED: code = 0; break;
+    case bk_env::PL_SPLIT_LANES:
+    case bk_env::PL_MIXED_LANES:
+    case bk_env::PL_MIXED_WPB: code = 1; break;
+    case bk_env::PL_SPLIT_WAVE:
+    case bk_env::PL_MIXED_WAVE: code = 2; break;
+    case bk_env::PL_FUSED_WAVE: code = 3; break;
   }
-  const bool wv = env->use_wave() || env->use_mixed_wave();
-  const bool sp = wv || (env->pipeline >= 2 && env->pipeline != 5) || env->M > 1 ||
-                  (env->pipeline == 0 && (env->n_mixed ? env->cfg.n_books >= MIXED_SPLIT_MIN_BOOKS
-                                                       : env->cfg.n_books >= RANDOM_SPLIT_MIN_BOOKS && !env->groups.empty()));
-  const int P = wv ? env->wave_split_parts() : env->parts();
-  if (split) *split = wv ? 2 : (sp ? 1 : 0);
-  if (n_parts) *n_parts = sp ? P : 1;
+  if (split) *split = code;
+  if (n_parts) *n_parts = pl.parts;
   return BK_OK;
 }
 
@@ -1993,11 +1986,11 @@ int bk_set_pipeline(bk_env* env, int mode) {
   return BK_OK;
 }
 
-// number of bk_run launches the auto pipeline rolled back and redid on the fused kernel (pool overflow on the lane-per-book
-// members' update that the wave-per-book kernels avoid)
+// DEPRECATED (kept so that clients built against rounds 1-3 still link): those rounds rolled a launch of the library's
+// own pipeline choice back when it overflowed a pool the other kernels fit; no such launch exists any more.  Always 0.
 int bk_pipeline_fallbacks(bk_env* env, uint64_t* out) {
   if (!env || !out) return fail(BK_INVALID_ARGUMENT, "null argument");
-  *out = env->n_fallbacks;
+  *out = 0;
   return BK_OK;
 }
 

@@ -119,8 +119,7 @@ class ManyBookEnv:
         # caller that catches it can keep stepping (clear_flags() re-arms it).  BK_FLAG_STEP_SIZE is a warning, not an
         # error: the reference's Env::step never checks the event count against step_size (env.rs:116-134).
         self.strict = bool(strict)
-        self._flags_seen = None      # per-book bits already reported
-        self._flags_seen_or = 0
+        self._flags_sticky = None    # per-book bits a strict check has reported and moved off the device (see raise_on_flags)
         self.last_retained_trades = 0  # largest number of records a book retained at the last strict check
         cfg = Config()
         cfg.assets = int(assets)
@@ -227,31 +226,33 @@ class ManyBookEnv:
         return int(f.value), int(r.value)
 
     def clear_flags(self, mask: int = 0xFFFFFFFF):
-        """Clear sticky flag bits on the device (and re-arm the strict check for them)."""
+        """Clear sticky flag bits (on the device and in the host-side record of the bits already reported)."""
         check(self._L.bk_clear_flags(self._h, int(mask) & 0xFFFFFFFF))
-        if self._flags_seen is not None:
-            self._flags_seen &= np.uint32(~int(mask) & 0xFFFFFFFF)
-            self._flags_seen_or = int(np.bitwise_or.reduce(self._flags_seen)) if len(self._flags_seen) else 0
+        if self._flags_sticky is not None:
+            self._flags_sticky &= np.uint32(~int(mask) & 0xFFFFFFFF)
 
     def raise_on_flags(self, mask: Optional[int] = None):
         """Raise ``CapacityError`` (capacity bits) / ``BourseError`` (price-tick) for flag bits in ``mask`` that a book
-        carries and that have not been reported yet (default mask: every flag except UNKNOWN_ORDER, which ``step``
-        reports itself).  A new STEP_SIZE bit alone only warns: the reference tolerates such a step."""
+        carries (default mask: every flag except UNKNOWN_ORDER, which ``step`` reports itself).  A STEP_SIZE bit alone
+        only warns: the reference tolerates such a step.  Reported bits MOVE from the device to a host-side sticky record
+        (``flags()`` returns both): the two-word summary reads 0 again, so the next check stays cheap, and a book that
+        overflows AGAIN after the caller caught the error is reported again instead of passing silently."""
         import warnings
 
         m = (~_lib.FLAG_UNKNOWN_ORDER & 0xFFFFFFFF) if mask is None else (int(mask) & 0xFFFFFFFF)
         any_or, self.last_retained_trades = self.flags_summary()
         if not (any_or & m):
             return  # nothing set anywhere (the common case): the per-book array is not fetched
-        f = self.flags()
-        if self._flags_seen is None:
-            self._flags_seen = np.zeros_like(f)
-        new = f & np.uint32(m) & ~self._flags_seen
-        self._flags_seen |= f & np.uint32(m)
-        self._flags_seen_or = int(np.bitwise_or.reduce(self._flags_seen)) if len(f) else 0
+        f = np.zeros(self.n_books, dtype=np.uint32)
+        check(self._L.bk_book_flags(self._h, _lib.p32(f)))
+        new = f & np.uint32(m)
         if not new.any():
             return
         bits = int(np.bitwise_or.reduce(new))
+        if self._flags_sticky is None:
+            self._flags_sticky = np.zeros_like(f)
+        self._flags_sticky |= new
+        check(self._L.bk_clear_flags(self._h, bits))
         books = np.nonzero(new)[0]
         names = "; ".join(n for b, n in _lib.FLAG_NAMES.items() if bits & b)
         msg = f"{len(books)} book(s) flagged (first: book {int(books[0])}): {names}"
@@ -587,8 +588,11 @@ class ManyBookEnv:
         return int(out.value)
 
     def flags(self) -> np.ndarray:
+        """Every book's sticky flag word: the device's bits OR the ones a strict check has already reported."""
         out = np.zeros(self.n_books, dtype=np.uint32)
         check(self._L.bk_book_flags(self._h, _lib.p32(out)))
+        if self._flags_sticky is not None:
+            out |= self._flags_sticky
         return out
 
     def rng_state(self, book: int) -> Tuple[int, int]:

@@ -83,6 +83,11 @@ class StatsGather:
 
         self.env, self.dist, self.torch = env, dist, torch
         self.out = None
+        # gloo (CPU collectives: several ranks sharing one GPU in a dry run, or tests): the record travels as a host tensor
+        self.host = dist.get_backend() == "gloo"
+        if self.host:
+            self.record, self.zero_copy = None, False
+            return
         try:
             self.record = torch.as_tensor(_DevicePtr(env.stats_device_ptr(), 64), device="cuda")
             self.zero_copy = True
@@ -91,6 +96,9 @@ class StatsGather:
             self.zero_copy = False
 
     def all_gather(self):
+        if self.host:
+            self.out = all_gather_records(self.torch.from_numpy(pack_stats(self.env.stats()).copy()), self.dist)
+            return self.out
         if self.zero_copy:
             self.env.stats_compute_async()
         else:

@@ -41,7 +41,8 @@ enum bk_status {
 #define BK_FLAG_STEP_SIZE 4u       /* a step queued >= step_size events */
 #define BK_FLAG_ORDER_LOG_FULL 8u  /* order id beyond the order-log capacity */
 #define BK_FLAG_UNKNOWN_ORDER 16u  /* cancel/modify of an id that was never created */
-#define BK_FLAG_HIST_OVERFLOW 32u  /* (unused: the L2 history is a ring; reading a step that was overwritten is an error) */
+#define BK_FLAG_HIST_OVERFLOW 32u  /* RESERVED, never set (the L2 history is a ring; reading an overwritten step is an
+                                     * error of the reader): the bit keeps its place so that the others keep theirs */
 #define BK_FLAG_PRICE_TICK 64u     /* a Noise/Momentum agent's limit price (clamped to u32::MAX) was not a tick multiple:
                                      * the reference panics here (`.unwrap()`, common.rs:107,140); the order is not created */
 #define BK_FLAG_DECODE_LOOKAHEAD 256u /* the wave-parallel decode of a Noise/Momentum member met a ziggurat rejection loop
@@ -294,9 +295,9 @@ int bk_profile_read_kind(bk_env* env, int kind, double* total_ms, uint64_t* n_la
  * 2 split (RNG-serial phases one lane per book + event phase one wave per book), 3 split with the members of an AgentSet
  * decoded one wave per book (older form of 4), 4 / 5 below.  Results are identical; only speed differs. */
 int bk_set_pipeline(bk_env* env, int mode);
-/* Mode 4 on an AgentSet of Noise / Momentum members (independent books, no RandomAgents member): the members' update
- * one WAVE per book with their stream decoded 64 draws at a time (k_agents_mixed_wave) + the event kernel; auto from 512
- * books.  Other sets: as mode 1.
+/* Mode 4 on an AgentSet with Noise / Momentum members (independent books): the members' update one WAVE per book with
+ * their stream decoded 64 draws at a time (k_agents_mixed_wave) + the event kernel; auto from 512 books.  A RandomAgents
+ * member of such a set is walked on that kernel's scalar path (same results).  Markets (assets > 1): as mode 2.
  * Modes 4 ("wave_split") and 5 ("wave") on RandomAgents books: the RNG-serial phases run one WAVE per
  * book with the book's xoroshiro stream decoded 64 draws at a time (jump-ahead lane states + ballot/prefix resolution) -
  * as a kernel of its own in front of the event kernel (4), or fused with the event phase in one persistent kernel that
@@ -304,9 +305,9 @@ int bk_set_pipeline(bk_env* env, int mode);
  * path (1..64 draws, default 64; smaller values push placements onto its scalar slow path - a test knob) and the number
  * of parts mode 4 cuts the batch in (0 = default). */
 int bk_set_wave_options(bk_env* env, uint32_t lookahead, int parts);
-/* Rounds 1-2 rolled an auto-selected launch of the lane-per-book members' update back when it overflowed a pool the
- * other kernels still fit, and counted those here.  Since round 3 the auto rule never picks that pipeline for independent
- * books (the wave-parallel members' decode frees slots like the fused kernel): *out is always 0.  Kept for ABI stability. */
+/* DEPRECATED, always *out = 0; kept only so that clients built against rounds 1-3 still link.  (Those rounds rolled an
+ * auto-selected launch of the lane-per-book members' update back when it overflowed a pool the other kernels still fit,
+ * and counted the roll-backs here; the auto rule has not picked that pipeline since round 3.) */
 int bk_pipeline_fallbacks(bk_env* env, uint64_t* out);
 /* the pipeline bk_run will use: *split = 0 fused / 1 split (lane-per-book agents) / 2 wave_split / 3 wave; *n_parts =
  * contiguous book parts launched on separate streams */

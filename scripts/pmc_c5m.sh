@@ -1,6 +1,6 @@
 # Where does k_agents_mixed_lanes (the C5-as-written members' update) spend its time?  SQ counters, GPU box.
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:-/root/repo}
 run() { d=$1; shift; rocprofv3 --pmc "$@" -d $R/gpurun_out/$d -o p -f csv -- python3 $R/bench.py --workload C5M --steps 20 --warmup 10 --no-cpu-baseline --profile-every 0 --preheat-steps 0 --repeats 0 > /dev/null 2> $R/gpurun_out/$d.err; }
 run pmc_c5m1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_WAVES
 run pmc_c5m2 SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_BRANCH SQ_INSTS_SMEM SQ_WAVES

@@ -1,7 +1,7 @@
 # Scalar / vector instructions of k_step_batch per book-step as a function of the activity rate (0 = no events: the
 # fixed load + snapshot + store part).  GPU box.
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:-/root/repo}
 export BOURSE_AMD_SPLIT_PARTS=1
 cat > /tmp/rate_run.py <<PY
 import sys

@@ -1,6 +1,6 @@
 # Where do k_step_batch's cycles go?  SQ activity / wait / instruction-cache counters, one part per launch (GPU box).
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:-/root/repo}
 export BOURSE_AMD_SPLIT_PARTS=1
 run() { d=$1; shift; rocprofv3 --pmc "$@" -d $R/gpurun_out/$d -o p -f csv -- python3 $R/bench.py --steps 20 --warmup 20 --steps-per-launch 20 --no-cpu-baseline --profile-every 0 > /dev/null 2> $R/gpurun_out/$d.err; }
 run pmc_stall1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VALU SQ_IFETCH

@@ -1,7 +1,7 @@
 # k_agents_wave / k_step_batch at B books (default 8192): kernel times (rocprofv3 --kernel-trace --stats) and SQ counters.
 # GPU box:  bash scripts/pmc_wave.sh [books] [tag]
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:-/root/repo}
 B=${1:-8192}
 TAG=${2:-wave}
 PIPE=${3:-wave}

@@ -1,7 +1,8 @@
 # SQ instruction counters per kernel of one bench workload (default C5): bash scripts/pmc_workload.sh [workload].  GPU box.
 W=${1:-C5}
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
+set -u
+R=${GRAFT_REPO_ROOT:-/root/repo}
 mkdir -p $R/gpurun_out
 run() { d=$1; shift; rocprofv3 --pmc "$@" -d $R/gpurun_out/$d -o p -f csv -- python3 $R/bench.py --workload $W --steps 20 --warmup 10 --no-cpu-baseline --profile-every 0 --preheat-steps 0 --repeats 0 > /dev/null 2> $R/gpurun_out/$d.err; }
 run pmc_w1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_WAVES

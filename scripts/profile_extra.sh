@@ -1,5 +1,5 @@
 # rocprofv3 kernel stats for the other workloads (GPU box): bash scripts/profile_extra.sh
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/prof_extra
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp

@@ -1,6 +1,6 @@
 # Round profile: rocprofv3 kernel stats of the bench commands + HBM traffic / instruction counters (separate passes).
 # GPU box:  bash scripts/profile_round.sh r02     -> gpurun_out/prof_r02/ (copy the summaries to profiles/r02/)
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:-/root/repo}
 TAG=${1:-r02}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT

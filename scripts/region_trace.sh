@@ -2,7 +2,7 @@
 # idle gaps between launches - where does the first timed region lose its 5-8 %?  GPU box.
 # usage: region_trace.sh <bench args...>
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:-/root/repo}
 rm -rf $R/gpurun_out/region_trace
 rocprofv3 --kernel-trace -d $R/gpurun_out/region_trace -o kt -f csv -- python3 $R/bench.py --no-cpu-baseline "$@" > /dev/null 2> $R/gpurun_out/region_trace.err
 python3 - <<PY

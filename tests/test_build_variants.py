@@ -47,6 +47,12 @@ def test_keyed_loop_test_variant_builds(tmp_path):
         assert m, mangled
         return int(m.group(1))
 
-    assert vgprs("_ZN3bkd12k_agents_fsmILi2EEEvNS_7DevArgsE") == 232
+    # (an inequality, not the compiler's exact allocation: VGPRs are handed out in blocks of 8)
+    def alloc(n):
+        return (n + 7) // 8 * 8
+
+    fsm = vgprs("_ZN3bkd12k_agents_fsmILi2EEEvNS_7DevArgsE")
+    assert 200 <= fsm <= 264  # the measured plateau of its deliberate footprint (profiles/r02/fsm_vgpr_sweep.txt)
     for r in (1, 2):
-        assert vgprs(f"_ZN3bkd12k_step_batchILi{r}ELb0ELb0EEEvNS_7DevArgsEmj") <= 40, r
+        ev = vgprs(f"_ZN3bkd12k_step_batchILi{r}ELb0ELb0EEEvNS_7DevArgsEmj")
+        assert alloc(fsm) + 7 * alloc(ev) <= 512, (r, fsm, ev)
