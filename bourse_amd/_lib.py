@@ -103,6 +103,9 @@ SIGNATURES = {
     "bk_submit_instructions_csr": (_i32, [_vp, _p64, _p32, _p8, _p32, _p32, _p32, _p64, _p64, C.POINTER(_sz)]),
     "bk_enable_trading": (_i32, [_vp, _i32]),
     "bk_step": (_i32, [_vp]),
+    "bk_device_ingress_enable": (_i32, [_vp, _u32]),
+    "bk_submit_instructions_device": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "bk_step_async": (_i32, [_vp]),
     "bk_order_status": (_i32, [_vp, _u32, _u64, _p8]),
     "bk_order_count": (_i32, [_vp, _u32, _p64]),
     "bk_get_orders": (_i32, [_vp, _u32, _u64, _u64, _vp]),

@@ -96,6 +96,10 @@ struct DevArgs {
   // host-driven event batch (k_step_events only); CSR per book
   const uint32_t* ev_off;    // [n_books + 1]
   const uint4* ev;           // {word = kind | bid<<8 | has_price<<9 | has_vol<<10 | asset<<16, id, price, vol}
+  // device-resident ingress (k_ingest): the queues are fixed-capacity rows filled ON the device - market m's events are
+  // ev[m * ev_stride ..] and their number is ev_len[m] (null: the CSR form above, uploaded by the host)
+  const uint32_t* ev_len;
+  uint32_t ev_stride;
   // split pipeline: per-book step batch written by k_agents_fsm, consumed by k_step_batch
   uint32_t* batch;
   uint32_t batch_stride;  // dwords per book: 64 + 160 * R
@@ -1417,8 +1421,8 @@ __global__ __launch_bounds__(64) void k_step_events(DevArgs a, uint64_t step_ind
   Rng rng;
   load_book<R>(B, rng, st, lane);
   const uint64_t step_size = mk64(a.step_lo, a.step_hi);
-  const uint32_t e0 = a.ev_off[mkt];
-  const uint32_t n_ev = a.ev_off[mkt + 1] - e0;
+  const uint32_t e0 = a.ev_len ? mkt * a.ev_stride : a.ev_off[mkt];
+  const uint32_t n_ev = a.ev_len ? a.ev_len[mkt] : a.ev_off[mkt + 1] - e0;
   uint32_t n_own = 0;
   LogCtx lg{a.order_log ? a.order_log + (size_t)book * a.log_cap : nullptr, a.log_cap};
 
@@ -1452,6 +1456,12 @@ __global__ __launch_bounds__(64) void k_step_events(DevArgs a, uint64_t step_ind
     const uint32_t evv = rdl(evr.w, k & 63u);
     const uint32_t kind = w & 0xFFu;
     const uint64_t tk = t0 + k;
+    // an id that was never created: the reference panics while processing (orderbook.rs:642); the host-driven path refuses
+    // the step before uploading anything, the device-resident ingress (no host in the loop) flags the book and drops it
+    if (a.ev_len && kind != 0 && id >= B.next_id) {
+      B.flags |= FLAG_UNKNOWN_ORDER;
+      continue;
+    }
     if (kind == 0) {
       // ---- New: place_order (orderbook.rs:583-611); a fresh id is New by construction
       const bool is_bid = (w >> 8) & 1u;
@@ -1556,6 +1566,122 @@ __global__ void k_book_service(uint32_t* state, uint32_t stride, uint32_t n_book
   } else if (op == 2) {
     h[H_FLAGS] &= ~value;  // bk_clear_flags
   }
+}
+
+// ==================================================================================
+// Device-resident instruction ingress (rust/src/step_sim_numpy.rs:233-275 `submit_instructions` + the host half of
+// Env::place_order / cancel_order / modify_order, env.rs:166-219, for EVERY book in one launch, no host in the loop).
+// The six SoA arrays live in device memory (an agent layer running on the GPU wrote them); the instructions of book b are
+// elements [off[b], off[b + 1]).  One wave per MARKET (per book when assets == 1) walks its books' batches 64 elements at
+// a time:
+//   * create_order's tick check (orderbook.rs:367-382): the first new order whose price is not a multiple of the book's
+//     tick size stops THAT BOOK's batch - earlier elements stay created and queued, later ones are not looked at
+//     (`.collect::<Result<Vec<_>, _>>()` short-circuits, step_sim_numpy.rs:255-268); status = {code, elements applied};
+//   * ids: dense per book, in element order - base + exclusive prefix count of the new orders (a ballot + mbcnt);
+//   * the events are appended to the market's queue in element (then asset) order, the position = queue length +
+//     exclusive prefix count of the event-producing elements; action 0 / unknown actions produce nothing (:266);
+//   * the immutable half of every new order and its initial order-log entry (status New, arr_time = now) are written
+//     for the readers (bk_get_orders ...).
+// action 3 = Env::modify_order (env.rs:208-219; not part of the numpy API): side bit 1 = has price, bit 2 = has volume.
+// ==================================================================================
+struct IngestArgs {
+  const unsigned long long* off;  // [n_books + 1]
+  const uint32_t* action;
+  const uint8_t* side;
+  const uint32_t* vol;
+  const uint32_t* trader;
+  const uint32_t* price;
+  const unsigned long long* order_id;
+  unsigned long long* out_ids;    // nullable: id of the order an element created, else u64::MAX
+  uint32_t* status;               // nullable: [2 * n_books] {code (bk_status), elements of the book's batch applied}
+  uint4* q;                       // [n_markets][qcap] event records (HostEvent layout)
+  uint32_t* qlen;                 // [n_markets]
+  uint32_t qcap;
+  uint4* dorders;                 // [n_books][log_cap][2]: {start_vol, trader, price, bid} {create_lo, create_hi, 0, 0}
+};
+constexpr uint32_t ING_OK = 0u, ING_PRICE = 1u, ING_CAPACITY = 3u;  // == BK_OK / BK_PRICE_NOT_TICK_MULTIPLE / BK_CAPACITY
+
+__global__ __launch_bounds__(64) void k_ingest(DevArgs a, IngestArgs g) {
+  const int lane = threadIdx.x;
+  const uint32_t mkt = blockIdx.x, M = a.assets;
+  uint32_t qn = g.qlen[mkt];
+  uint4* q = g.q + (size_t)mkt * g.qcap;
+  for (uint32_t asset = 0; asset < M; ++asset) {
+    const uint32_t book = mkt * M + asset;
+    uint32_t* hdr = a.state + (size_t)book * a.state_stride;
+    const uint32_t tick = a.asset_tick[asset];
+    uint32_t next_id = rfl(hdr[H_NEXT_ID]);
+    const uint32_t t_lo = rfl(hdr[H_T_LO]), t_hi = rfl(hdr[H_T_HI]);  // now: the book's clock (Env::place_order stamps it)
+    const unsigned long long lo = g.off[book], hi = g.off[book + 1];
+    uint32_t code = ING_OK;
+    unsigned long long applied = 0;
+    for (unsigned long long base = lo; base < hi && code == ING_OK; base += 64) {
+      const unsigned long long i = base + (uint32_t)lane;
+      const bool in = i < hi;
+      const uint32_t act = in ? g.action[i] : 0u, sd = in ? g.side[i] : 0u, vol = in ? g.vol[i] : 0u;
+      const uint32_t price = in ? g.price[i] : 0u, trader = in ? g.trader[i] : 0u;
+      const unsigned long long oid = in ? g.order_id[i] : 0ull;
+      const bool is_new = act == 1u, is_ev = act >= 1u && act <= 3u;
+      // the first bad price of the chunk stops the book's batch (earlier elements are applied)
+      const uint64_t badm = __ballot(is_new && price % tick != 0u);
+      uint32_t cut = badm ? (uint32_t)__builtin_ctzll(badm) : 64u;
+      if (badm) code = ING_PRICE;
+      // ... so does a full queue / an exhausted id space (cannot occur in the reference: BK_CAPACITY)
+      uint64_t evm = __ballot(in && is_ev && (uint32_t)lane < cut);
+      const uint32_t room = g.qcap - qn;
+      if ((uint32_t)__builtin_popcountll(evm) > room) {
+        uint64_t m = evm;  // the events that do not fit: all but the first `room`
+        for (uint32_t r = 0; r < room; ++r) m &= m - 1ull;
+        cut = (uint32_t)__builtin_ctzll(m);  // (before the bad price, if there is one: the earlier failure is reported)
+        code = ING_CAPACITY;
+        evm = __ballot(in && is_ev && (uint32_t)lane < cut);
+      }
+      if ((uint64_t)next_id + 64u >= 0xFFFFFFFFull) {  // ids are u32 on the device: refuse the chunk
+        cut = 0;
+        code = ING_CAPACITY;
+        evm = 0;
+      }
+      const bool valid = in && (uint32_t)lane < cut;
+      const uint64_t newm = __ballot(valid && is_new);
+      const uint32_t rank_ev = __builtin_amdgcn_mbcnt_hi((uint32_t)(evm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)evm, 0u));
+      const uint32_t rank_new = __builtin_amdgcn_mbcnt_hi((uint32_t)(newm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)newm, 0u));
+      const uint32_t id = next_id + rank_new;
+      if (valid && is_ev) {
+        uint4 e;
+        const uint32_t idc = oid > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)oid;
+        if (is_new) {
+          e = make_uint4(0u | ((sd & 1u) << 8) | (asset << 16), id, price, vol);
+        } else if (act == 2u) {
+          e = make_uint4(1u | (asset << 16), idc, 0u, 0u);
+        } else {
+          e = make_uint4(2u | ((sd & 2u) ? 1u << 9 : 0u) | ((sd & 4u) ? 1u << 10 : 0u) | (asset << 16), idc, price, vol);
+        }
+        q[qn + rank_ev] = e;
+      }
+      if (valid && is_new && id < a.log_cap) {
+        uint4* d = g.dorders + ((size_t)book * a.log_cap + id) * 2;
+        d[0] = make_uint4(vol, trader, price, sd & 1u);
+        d[1] = make_uint4(t_lo, t_hi, 0u, 0u);
+        // initial order-log entry: status New, nothing traded, provisional key (price, 0) (orderbook.rs:388-391)
+        uint4* l = reinterpret_cast<uint4*>(a.order_log + (size_t)book * a.log_cap + id);
+        l[0] = make_uint4(0u, vol, price, price);
+        l[1] = make_uint4(t_lo, t_hi, 0xFFFFFFFFu, 0xFFFFFFFFu);
+        l[2] = make_uint4(0u, 0u, 0u, 0u);
+      }
+      if (valid && g.out_ids) g.out_ids[i] = is_new ? (unsigned long long)id : ~0ull;
+      next_id += (uint32_t)__builtin_popcountll(newm);
+      qn += (uint32_t)__builtin_popcountll(evm);
+      applied += cut < 64u ? cut : (hi - base < 64ull ? hi - base : 64ull);
+    }
+    if (lane == 0) {
+      hdr[H_NEXT_ID] = next_id;
+      if (g.status) {
+        g.status[2 * book] = code;
+        g.status[2 * book + 1] = applied > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)applied;
+      }
+    }
+  }
+  if (lane == 0) g.qlen[mkt] = qn;
 }
 
 // OR of every book's sticky flags and the largest number of retained trade records: what a strict caller polls after a

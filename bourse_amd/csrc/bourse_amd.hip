@@ -106,6 +106,7 @@ struct BookHost {
   uint64_t n_uploaded = 0;  // orders whose New event has reached the device
   uint64_t time_offset = 0;  // set by bk_set_time: book time = start_time + steps_done * step_size + time_offset (wrapping)
   bool log_fresh = false;
+  uint64_t mirror_epoch = ~0ull;  // device-resident ingress: `orders` mirrors the device's records as of this ingest epoch
 };
 
 template <class T>
@@ -263,6 +264,13 @@ struct bk_env {
   std::vector<Group> groups;
   uint32_t n_agents_total = 0;
   uint64_t agents_hash = 0;   // FNV-1a of the installed agent set (checkpoint compatibility)
+  // device-resident instruction ingress (bk_device_ingress_enable): the queues, the id counters and the immutable halves of
+  // the orders live on the device; the per-order host entries are refused, the readers mirror on demand
+  bool device_ingress = false;
+  uint32_t qcap = 0;               // events per book (market) and step
+  DevBuf<uint4> dq, dorders;       // [n_markets][qcap] event records; [n_books][max_orders][2] immutable halves
+  DevBuf<uint32_t> dqlen;          // [n_markets] queue lengths
+  uint64_t ingest_epoch = 0;       // bumped by every submit / step: invalidates the readers' mirrors
   bool device_flow = false;   // bk_run has stepped this env with on-device agents: host-driven orders are refused
   uint64_t steps_done = 0, hist_base = 0;
   uint32_t trading = 1;
@@ -313,7 +321,9 @@ struct bk_env {
     a.trades = trades.p;
     a.order_log = order_log.p;
     a.ev_off = ev_off.p;
-    a.ev = ev.p;
+    a.ev = device_ingress ? dq.p : ev.p;
+    a.ev_len = device_ingress ? dqlen.p : nullptr;
+    a.ev_stride = qcap;
     a.batch = batch.p;
     a.batch_stride = batch_stride;
     a.book_begin = 0;
@@ -671,6 +681,9 @@ int order_after(hipStream_t later, hipStream_t earlier) {
 // Host-driven orders on an env whose books are populated by on-device agents would restart the order ids at 0 (colliding
 // with the agents' ids) and could take an agent's pool slot: one env runs ONE of the two flows.
 int host_flow_ok(bk_env* env) {
+  if (env->device_ingress)
+    return fail(BK_INVALID_ARGUMENT, "this env takes its instructions from device memory (bk_device_ingress_enable): "
+                                     "per-order host calls would collide with the ids assigned on the device");
   if (env->device_flow)
     return fail(BK_INVALID_ARGUMENT, "host-driven orders cannot be mixed with bk_run's on-device agents on the same env");
   return BK_OK;
@@ -693,6 +706,33 @@ int refresh_log(bk_env* env, uint32_t book) {
                      n * sizeof(DevOrderLog), hipMemcpyDeviceToHost));
   }
   bh.log_fresh = true;
+  return BK_OK;
+}
+
+// Device-resident ingress: the readers' view of one book's orders.  The immutable halves written by k_ingest and the
+// book's id counter are fetched into the same BookHost fields the host-driven path fills at bk_place_order, so every
+// reader below works unchanged; valid until the next submit / step (ingest_epoch).
+int mirror_orders(bk_env* env, uint32_t book) {
+  if (!env->device_ingress) return BK_OK;
+  BookHost& bh = env->books[book];
+  if (bh.mirror_epoch == env->ingest_epoch) return BK_OK;
+  HIPCHK(hipSetDevice(env->cfg.device));
+  HIPCHK(hipStreamSynchronize(env->stream));
+  uint32_t count = 0;
+  HIPCHK(hipMemcpy(&count, env->state.p + static_cast<size_t>(book) * env->stride + H_NEXT_ID, 4, hipMemcpyDeviceToHost));
+  const uint64_t logged = std::min<uint64_t>(count, env->cfg.max_orders);
+  std::vector<uint4> rows(logged * 2);
+  if (logged)
+    HIPCHK(hipMemcpy(rows.data(), env->dorders.p + static_cast<size_t>(book) * env->cfg.max_orders * 2, logged * 32,
+                     hipMemcpyDeviceToHost));
+  bh.orders.assign(count, HostOrder{0, 0, 0, 0, 0});
+  for (uint64_t id = 0; id < logged; ++id) {
+    const uint4 a = rows[2 * id], b = rows[2 * id + 1];
+    bh.orders[id] = HostOrder{static_cast<uint8_t>(a.w & 1u), a.x, a.z, a.y, (static_cast<uint64_t>(b.y) << 32) | b.x};
+  }
+  bh.n_uploaded = count;  // every order has had a log entry since k_ingest created it
+  bh.log_fresh = false;
+  bh.mirror_epoch = env->ingest_epoch;
   return BK_OK;
 }
 
@@ -1003,6 +1043,11 @@ int bk_enable_trading(bk_env* env, int enabled) {
 
 int bk_step(bk_env* env) {
   if (!env) return fail(BK_INVALID_ARGUMENT, "null env");
+  if (env->device_ingress) {  // the queues are on the device already: launch, then wait as this entry always has
+    if (int rc = bk_step_async(env)) return rc;
+    HIPCHK(hipStreamSynchronize(env->stream));
+    return BK_OK;
+  }
   if (int rc = host_flow_ok(env)) return rc;
   if (int rc = use_device(env)) return rc;
   const size_t B = env->cfg.n_books, M = env->M, NM = B / M;
@@ -1078,8 +1123,86 @@ int bk_step(bk_env* env) {
   return BK_OK;
 }
 
+// ------------------------------------------------------------------ device-resident instruction ingress
+// (rust/src/step_sim_numpy.rs:233-275 submit_instructions + env.rs:166-219, for every book, with no host in the loop)
+int bk_device_ingress_enable(bk_env* env, uint32_t queue_capacity) {
+  if (!env) return fail(BK_INVALID_ARGUMENT, "null env");
+  if (env->device_ingress) {
+    if (queue_capacity != env->qcap) return fail(BK_INVALID_ARGUMENT, "device ingress is already enabled with another queue capacity");
+    return BK_OK;
+  }
+  if (queue_capacity == 0 || queue_capacity > EV_LDS_CAP)
+    return fail(BK_INVALID_ARGUMENT, "queue_capacity must be in 1..8192 events per book (market) and step");
+  if (env->device_flow || env->n_mixed || !env->groups.empty())
+    return fail(BK_INVALID_ARGUMENT, "an env runs ONE order flow: on-device agents (bk_run) or submitted instructions");
+  for (const BookHost& bh : env->books)
+    if (!bh.queue.empty() || !bh.orders.empty())
+      return fail(BK_INVALID_ARGUMENT, "enable the device ingress before any order is placed through the host entries");
+  if (int rc = use_device(env)) return rc;
+  const size_t NM = env->cfg.n_books / env->M;
+  HIPCHK(env->dq.alloc(NM * queue_capacity));
+  HIPCHK(env->dqlen.alloc(NM));
+  HIPCHK(hipMemsetAsync(env->dqlen.p, 0, NM * 4, env->stream));
+  HIPCHK(env->dorders.alloc(static_cast<size_t>(env->cfg.n_books) * env->cfg.max_orders * 2));
+  env->qcap = queue_capacity;
+  env->device_ingress = true;
+  return BK_OK;
+}
+
+int bk_submit_instructions_device(bk_env* env, const uint64_t* book_offsets_dev, const uint32_t* action_dev, const uint8_t* side_dev,
+                                  const uint32_t* vol_dev, const uint32_t* trader_dev, const uint32_t* price_dev,
+                                  const uint64_t* order_id_dev, uint64_t* out_ids_dev, uint32_t* status_dev) {
+  if (!env) return fail(BK_INVALID_ARGUMENT, "null env");
+  if (!env->device_ingress) return fail(BK_INVALID_ARGUMENT, "call bk_device_ingress_enable first");
+  if (!book_offsets_dev || !action_dev || !side_dev || !vol_dev || !trader_dev || !price_dev || !order_id_dev)
+    return fail(BK_INVALID_ARGUMENT, "null instruction array");
+  if (int rc = use_device(env)) return rc;
+  IngestArgs g{};
+  g.off = reinterpret_cast<const unsigned long long*>(book_offsets_dev);
+  g.action = action_dev;
+  g.side = side_dev;
+  g.vol = vol_dev;
+  g.trader = trader_dev;
+  g.price = price_dev;
+  g.order_id = reinterpret_cast<const unsigned long long*>(order_id_dev);
+  g.out_ids = reinterpret_cast<unsigned long long*>(out_ids_dev);
+  g.status = status_dev;
+  g.q = env->dq.p;
+  g.qlen = env->dqlen.p;
+  g.qcap = env->qcap;
+  g.dorders = env->dorders.p;
+  const DevArgs a = env->args();
+  hipLaunchKernelGGL(k_ingest, dim3(env->cfg.n_books / env->M), dim3(64), 0, env->stream, a, g);
+  HIPCHK(hipGetLastError());
+  env->ingest_epoch += 1;
+  return BK_OK;
+}
+
+// Env::step over the device-resident queues, asynchronous on the env's stream (bk_step = this + a wait)
+int bk_step_async(bk_env* env) {
+  if (!env) return fail(BK_INVALID_ARGUMENT, "null env");
+  if (!env->device_ingress) return fail(BK_INVALID_ARGUMENT, "bk_step_async steps the device-resident queues: call bk_device_ingress_enable first");
+  if (int rc = use_device(env)) return rc;
+  const DevArgs a = env->args();
+  int rc = BK_OK;
+  // (the shuffle permutation's LDS is sized for a full queue: the host does not know the queues' lengths - nothing of this
+  // step has been on the host)
+  switch (env->R) {
+    case 1: rc = launch_events<1>(env, a, env->steps_done, env->qcap); break;
+    case 2: rc = launch_events<2>(env, a, env->steps_done, env->qcap); break;
+    case 4: rc = launch_events<4>(env, a, env->steps_done, env->qcap); break;
+    default: rc = launch_events<8>(env, a, env->steps_done, env->qcap); break;
+  }
+  if (rc != BK_OK) return rc;
+  HIPCHK(hipMemsetAsync(env->dqlen.p, 0, static_cast<size_t>(env->cfg.n_books / env->M) * 4, env->stream));
+  env->steps_done += 1;
+  env->ingest_epoch += 1;
+  return BK_OK;
+}
+
 int bk_order_status(bk_env* env, uint32_t book, uint64_t order_id, uint8_t* out_status) {
   if (int rc = check_book(env, book)) return rc;
+  if (int rc = mirror_orders(env, book)) return rc;
   BookHost& bh = env->books[book];
   if (order_id >= bh.orders.size())
     return fail(BK_UNKNOWN_ORDER_ID, "No order with id " + std::to_string(order_id) + " exists");
@@ -1095,12 +1218,14 @@ int bk_order_status(bk_env* env, uint32_t book, uint64_t order_id, uint8_t* out_
 
 int bk_order_count(bk_env* env, uint32_t book, uint64_t* out) {
   if (int rc = check_book(env, book)) return rc;
+  if (int rc = mirror_orders(env, book)) return rc;
   if (out) *out = env->books[book].orders.size();
   return BK_OK;
 }
 
 int bk_get_orders(bk_env* env, uint32_t book, uint64_t first, uint64_t n, bk_order* out) {
   if (int rc = check_book(env, book)) return rc;
+  if (int rc = mirror_orders(env, book)) return rc;
   BookHost& bh = env->books[book];
   if (first > bh.orders.size() || n > bh.orders.size() - first) return fail(BK_INVALID_ARGUMENT, "order range out of bounds");
   if (n && !out) return fail(BK_INVALID_ARGUMENT, "null argument");
@@ -1290,6 +1415,7 @@ int bk_run(bk_env* env, uint64_t n_steps) {
   query_fused_resident(env);
   if (n_steps > 0xFFFFFFFFull) return fail(BK_INVALID_ARGUMENT, "n_steps too large for one launch");
   if (int rc = use_device(env)) return rc;
+  if (env->device_ingress) return fail(BK_INVALID_ARGUMENT, "bk_run cannot be mixed with submitted instructions on the same env");
   for (const BookHost& bh : env->books)
     if (!bh.queue.empty() || !bh.orders.empty())
       return fail(BK_INVALID_ARGUMENT, "bk_run cannot be mixed with host-driven orders on the same env");
@@ -1610,6 +1736,7 @@ int bk_clear_trades(bk_env* env) {
 int bk_get_order_keys(bk_env* env, uint32_t book, uint64_t first, uint64_t n, uint32_t* key_price,
                       uint64_t* key_time) {
   if (int rc = check_book(env, book)) return rc;
+  if (int rc = mirror_orders(env, book)) return rc;
   BookHost& bh = env->books[book];
   if (first > bh.orders.size() || n > bh.orders.size() - first) return fail(BK_INVALID_ARGUMENT, "order range out of bounds");
   if (env->cfg.max_orders == 0) return fail(BK_INVALID_ARGUMENT, "order log disabled (max_orders == 0)");
@@ -2054,6 +2181,7 @@ uint64_t bk_checkpoint_bytes(const bk_env* env) {
 int bk_checkpoint_save(bk_env* env, void* out, uint64_t nbytes) {
   if (!env || !out) return fail(BK_INVALID_ARGUMENT, "null argument");
   if (nbytes < bk_checkpoint_bytes(env)) return fail(BK_INVALID_ARGUMENT, "checkpoint buffer too small");
+  if (env->device_ingress) return fail(BK_INVALID_ARGUMENT, "checkpointing a host-driven env is not supported");
   for (const BookHost& bh : env->books)
     if (!bh.orders.empty()) return fail(BK_INVALID_ARGUMENT, "checkpointing a host-driven env is not supported");
   if (int rc = use_device(env)) return rc;

@@ -212,11 +212,66 @@ class ManyBookEnv:
     def disable_trading(self):
         check(self._L.bk_enable_trading(self._h, 0))
 
-    def step(self):
-        """``Env::step`` (env.rs:116-135) for every book over the queued events."""
+    def step(self, sync: bool = True):
+        """``Env::step`` (env.rs:116-135) for every book over the queued events.  ``sync=False`` (device-resident
+        ingress only): queue the step on the env's stream and return (no flag check)."""
+        if not sync:
+            check(self._L.bk_step_async(self._h))
+            return
         check(self._L.bk_step(self._h))
         if self.strict:
             self.raise_on_flags()
+
+    # ------------------------------------------------------------ device-resident instruction ingress
+    def enable_device_ingress(self, queue_capacity: int = 256):
+        """Switch this (fresh) env to instructions submitted FROM DEVICE MEMORY (``bk_device_ingress_enable``): at most
+        ``queue_capacity`` events per book (market) and step."""
+        check(self._L.bk_device_ingress_enable(self._h, int(queue_capacity)))
+        self._device_ingress = True
+
+    @staticmethod
+    def _dev_ptr(x, itemsize, name):
+        """Device pointer of a torch CUDA tensor / anything with ``__cuda_array_interface__`` (contiguous, right width)."""
+        if x is None:
+            return None
+        if hasattr(x, "data_ptr"):  # torch
+            if not x.is_cuda or not x.is_contiguous() or x.element_size() != itemsize:
+                raise ValueError(f"{name}: a contiguous CUDA tensor of {itemsize}-byte elements is needed")
+            return C.c_void_p(x.data_ptr())
+        cai = getattr(x, "__cuda_array_interface__", None)
+        if cai is None or cai.get("strides") or np.dtype(cai["typestr"]).itemsize != itemsize:
+            raise ValueError(f"{name}: a contiguous device array of {itemsize}-byte elements is needed")
+        return C.c_void_p(cai["data"][0])
+
+    def submit_instructions_device(self, book_offsets, action, side, vol, trader_id, price, order_id, out_ids=None,
+                                   status=None, check_status: bool = False):
+        """``submit_instructions`` (rust/src/step_sim_numpy.rs:233-275) for every book from DEVICE arrays, nothing passing
+        through the host: book ``b``'s instructions are elements ``[book_offsets[b], book_offsets[b+1])``.  Arguments are
+        torch CUDA tensors (or any ``__cuda_array_interface__`` object): ``book_offsets`` 8-byte ints (n_books + 1),
+        ``action`` / ``vol`` / ``trader_id`` / ``price`` 4-byte ints, ``side`` 1-byte (bool / uint8), ``order_id`` 8-byte.
+        ``out_ids`` (8-byte, one per element) receives the created ids (2**64 - 1 elsewhere), ``status`` (4-byte,
+        2 per book) ``{code, elements applied}``.  Queued on the env's stream - which must be the stream the arrays were
+        written on (``ManyBookEnv(stream=torch.cuda.current_stream().cuda_stream)``).  ``check_status=True`` waits and
+        raises the reference's ``ValueError`` for the first book whose batch stopped at a bad price."""
+        P = self._dev_ptr
+        check(self._L.bk_submit_instructions_device(self._h, P(book_offsets, 8, "book_offsets"), P(action, 4, "action"),
+                                                    P(side, 1, "side"), P(vol, 4, "vol"), P(trader_id, 4, "trader_id"),
+                                                    P(price, 4, "price"), P(order_id, 8, "order_id"), P(out_ids, 8, "out_ids"),
+                                                    P(status, 4, "status")))
+        if check_status:
+            if status is None:
+                raise ValueError("check_status needs a status array")
+            self.sync()
+            st = status.cpu().numpy() if hasattr(status, "cpu") else np.asarray(status)
+            st = st.reshape(-1, 2).view(np.uint32) if st.dtype.itemsize == 4 else st.reshape(-1, 2)
+            bad = np.nonzero(st[:, 0])[0]
+            if len(bad):
+                b, code = int(bad[0]), int(st[bad[0], 0])
+                if code == _lib.BK_PRICE:
+                    raise ValueError(f"book {b}: a price of its batch was not a multiple of the tick size "
+                                     f"(element {int(st[b, 1])} of the book's batch; earlier elements are queued)")
+                raise _lib.CapacityError(code, f"book {b}: event queue / id space exhausted after {int(st[b, 1])} elements")
+        return out_ids, status
 
     def flags_summary(self) -> Tuple[int, int]:
         """(OR of every book's sticky flags, largest number of trade records a book retains): one small reduction on

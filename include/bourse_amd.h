@@ -174,6 +174,33 @@ int bk_submit_instructions_csr(bk_env* env, const uint64_t* book_offsets, const 
 int bk_enable_trading(bk_env* env, int enabled);         /* Env::{enable,disable}_trading, env.rs:138-145 */
 /* Env::step, env.rs:116-135, for every book: shuffle + process the queued events, snapshot L2 */
 int bk_step(bk_env* env);
+
+/* ------------------------------------------------------------- device-resident instruction ingress
+ * For agent layers that already run on the GPU: `submit_instructions` (rust/src/step_sim_numpy.rs:233-275) and the
+ * host half of Env::place_order / cancel_order / modify_order (crates/step_sim/src/env.rs:166-219) for EVERY book in one
+ * kernel launch, the six SoA arrays taken as DEVICE pointers - nothing of a step passes through host memory.
+ * bk_device_ingress_enable: switches a fresh env to this flow (before any order; an env runs one flow: the per-order
+ *   host entries and bk_run are refused from then on) and allocates the per-book (per-market) event queues of
+ *   `queue_capacity` events per step (1..8192).
+ * bk_submit_instructions_device: book b's instructions are elements [book_offsets_dev[b], book_offsets_dev[b+1]) of the
+ *   arrays (all in device memory, u64 offsets over n_books + 1).  action 0 = none, 1 = new limit order, 2 = cancel
+ *   (as the reference's), 3 = Env::modify_order (extension: side bit 1 = has price, bit 2 = has volume; bit 0 is the bid
+ *   flag of a new order).  Per book exactly the reference's semantics: ids are dense in element order (an exclusive prefix
+ *   sum over action == 1 on the device), the first price that is not a multiple of the book's tick size stops THAT
+ *   book's batch - earlier elements stay created and queued (:255-268) - and the other books are unaffected.
+ *   out_ids_dev (optional, one u64 per element): the created order's id, u64::MAX otherwise; untouched from the failing
+ *   element on.  status_dev (optional, 2 u32 per book): {bk_status code - BK_OK, BK_PRICE_NOT_TICK_MULTIPLE, BK_CAPACITY
+ *   (queue full / id space) -, number of the book's elements applied}.  Asynchronous on the env's stream.
+ *   A cancel / modify of an id that was never created (the reference panics while processing, orderbook.rs:642; the
+ *   host-driven bk_step refuses the step) is dropped at the step and the book flagged BK_FLAG_UNKNOWN_ORDER.
+ * bk_step_async: Env::step over the device-resident queues without waiting (bk_step on such an env = this + a wait).
+ * Readers (bk_get_orders, bk_order_status, bk_get_trades, bk_history ...) work as on the host-driven flow. */
+int bk_device_ingress_enable(bk_env* env, uint32_t queue_capacity);
+int bk_submit_instructions_device(bk_env* env, const uint64_t* book_offsets_dev, const uint32_t* action_dev,
+                                  const uint8_t* side_dev, const uint32_t* vol_dev, const uint32_t* trader_dev,
+                                  const uint32_t* price_dev, const uint64_t* order_id_dev, uint64_t* out_ids_dev,
+                                  uint32_t* status_dev);
+int bk_step_async(bk_env* env);
 /* Env::order_status / Env::order, env.rs:283-290 (needs max_orders > 0) */
 int bk_order_status(bk_env* env, uint32_t book, uint64_t order_id, uint8_t* out_status);
 int bk_order_count(bk_env* env, uint32_t book, uint64_t* out);

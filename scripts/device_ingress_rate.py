@@ -1,0 +1,54 @@
+"""Device-resident ingress at scale: every step an agent layer ON THE GPU hands over N instructions per book for ALL books
+(six SoA arrays in device memory), bk_submit_instructions_device assigns ids and queues them, bk_step_async shuffles and
+matches - nothing passes through the host (compare scripts/host_driven_rate.py: the same workload through the host half of
+Env).  GPU box:  python scripts/device_ingress_rate.py [books]"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np, torch, bourse_amd as bk
+B, N, T = int(sys.argv[1]) if len(sys.argv) > 1 else 8192, 48, 30  # (as scripts/host_driven_rate.py)
+env = bk.ManyBookEnv(B, 1, 0, 1, 100_000, levels=16, max_live_orders=256, max_orders=N * (T + 8), trade_capacity=64 * (T + 8), strict=False,
+                     history_capacity=0, stream=torch.cuda.current_stream().cuda_stream)
+env.enable_device_ingress(N)
+g = torch.Generator(device="cuda").manual_seed(0)
+off = (torch.arange(B + 1, dtype=torch.int64, device="cuda") * N)
+n = B * N
+
+
+def make(s):
+    """the agent layer: random instructions generated on the device (70 % new limit orders around 100, 30 % cancels of ids
+    created in earlier steps)"""
+    canc = (torch.rand(n, device="cuda", generator=g) < 0.3) if s else torch.zeros(n, dtype=torch.bool, device="cuda")
+    action = torch.where(canc, 2, 1).to(torch.int32)
+    ids = (torch.rand(n, device="cuda", generator=g) * max(1, int(s * N * 0.6))).to(torch.int64) * canc
+    side = torch.randint(0, 2, (n,), device="cuda", generator=g, dtype=torch.uint8)
+    vol = torch.randint(1, 30, (n,), device="cuda", generator=g, dtype=torch.int32)
+    price = torch.randint(90, 111, (n,), device="cuda", generator=g, dtype=torch.int32)
+    trader = torch.zeros(n, dtype=torch.int32, device="cuda")
+    return action, side, vol, trader, price, ids
+
+
+out_ids = torch.empty(n, dtype=torch.int64, device="cuda")
+status = torch.empty((B, 2), dtype=torch.int32, device="cuda")
+batches = [make(s) for s in range(T + 3)]  # generated ahead: the rate below is the library's, not torch's RNG
+torch.cuda.synchronize()
+for s in range(3):
+    env.submit_instructions_device(off, *batches[s], out_ids=out_ids, status=status)
+    env.step(sync=False)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for s in range(3, T + 3):
+    env.submit_instructions_device(off, *batches[s], out_ids=out_ids, status=status)
+    env.step(sync=False)
+torch.cuda.synchronize()
+dt = time.perf_counter() - t0
+assert int(status[:, 0].max()) == 0, status[:, 0].unique()
+print(f"device ingress: B={B} x {N} instructions/book/step, {T} steps: {dt / T * 1e3:.3f} ms/step -> {B * T / dt / 1e6:.1f} M book-steps/s "
+      f"({n * T / dt / 1e6:.0f} M instructions/s), flags {np.unique(env.flags())}, trades/book-step {env.trade_counts().sum() / (B * (T + 3)):.1f}")
+env.profile(1)
+for s in range(5):
+    env.submit_instructions_device(off, *batches[s % len(batches)], out_ids=out_ids, status=status)
+    env.step(sync=False)
+env.sync()
+ms, nl = env.profile_read_kind(3)
+print(f"k_step_events: {ms / max(nl, 1):.3f} ms per launch ({nl} launches)")

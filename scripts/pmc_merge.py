@@ -33,8 +33,9 @@ for key, cfg in summ.items():
         if "wave_cycles" in v:
             wc = dict(v["wave_cycles"])
             if p.get("SQ_BUSY_CYCLES"):
-                # SQ_WAVE_CYCLES sums the resident waves' (quad-)cycles, SQ_BUSY_CYCLES the busy (quad-)cycles of the 32 shader engines
-                wc["resident_waves_avg"] = p["SQ_WAVE_CYCLES"] / (p["SQ_BUSY_CYCLES"] / 32.0)
+                # SQ_WAVE_CYCLES sums the resident waves' QUAD-cycles (MI355X_MICROARCH.md, cycle constants), SQ_BUSY_CYCLES the busy
+                # cycles of the 32 shader engines
+                wc["resident_waves_avg"] = 4.0 * p["SQ_WAVE_CYCLES"] / (p["SQ_BUSY_CYCLES"] / 32.0)
                 wc["waves_per_simd_avg"] = wc["resident_waves_avg"] / 1024.0
             if p.get("SQ_THREAD_CYCLES_VALU") and p.get("SQ_INSTS_VALU"):
                 wc["valu_lane_utilisation"] = p["SQ_THREAD_CYCLES_VALU"] / (256.0 * p["SQ_INSTS_VALU"])

@@ -1,0 +1,266 @@
+"""Device-resident instruction ingress: `bk_submit_instructions_device` takes the six SoA arrays of
+`submit_instructions` (ref rust/src/step_sim_numpy.rs:233-275) as DEVICE pointers for every book at once - tick check,
+dense per-book id assignment by a prefix sum on the GPU, the reference's partial-application semantics per book - and
+feeds `Env::step` (ref crates/step_sim/src/env.rs:116-135,166-219) without the host half of `Env`.
+
+Checked three ways on the same random instruction stream: the device entry == the per-book host calls == the oracle."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+U64MAX = 2**64 - 1
+
+
+@pytest.fixture(scope="module")
+def bk():
+    import bourse_amd
+
+    return bourse_amd
+
+
+def _dev(torch, a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def _stream_step(rng, B, counts, max_per_book, tick, bad_books=()):
+    """One step's ragged SoA batch for B books: action 0 / 1 (new) / 2 (cancel) / 3 (modify), targets among the ids the
+    book has created so far (so they hit live, filled and cancelled orders alike); `bad_books`: an odd price is planted
+    in the middle of those books' batches."""
+    n_b = rng.integers(0, max_per_book + 1, size=B)
+    n_b[rng.random(B) < 0.05] = 0  # some books sit a step out
+    off = np.zeros(B + 1, dtype=np.uint64)
+    off[1:] = np.cumsum(n_b)
+    n = int(off[-1])
+    book_of = np.repeat(np.arange(B), n_b)
+    action = rng.choice([0, 1, 2, 3], size=n, p=[0.05, 0.6, 0.2, 0.15]).astype(np.uint32)
+    have = counts[book_of]
+    action[(action >= 2) & (have == 0)] = 1  # nothing to cancel / modify yet
+    bid = rng.integers(0, 2, size=n).astype(np.uint8)
+    has_p, has_v = rng.integers(0, 2, size=n).astype(np.uint8), rng.integers(0, 2, size=n).astype(np.uint8)
+    side = np.where(action == 3, (has_p << 1) | (has_v << 2), bid).astype(np.uint8)
+    vol = rng.integers(1, 30, size=n).astype(np.uint32)
+    trader = rng.integers(0, 1000, size=n).astype(np.uint32)
+    price = (rng.integers(45, 56, size=n) * tick).astype(np.uint32)
+    target = (rng.random(n) * np.maximum(have, 1)).astype(np.uint64)
+    order_id = np.where(action >= 2, target, 0).astype(np.uint64)
+    for b in bad_books:
+        lo, hi = int(off[b]), int(off[b + 1])
+        news = [i for i in range(lo, hi) if action[i] == 1]
+        if news:
+            price[news[len(news) // 2]] += 1  # not a multiple of the tick size
+    return off, book_of, (action, side, vol, trader, price, order_id)
+
+
+def _apply_host(env, book_of, off, ins, B):
+    """The same batch through the per-order host entries, book by book, with the reference's stop-at-first-error rule.
+    Returns (ids per element, elements applied per book, error code per book)."""
+    action, side, vol, trader, price, order_id = ins
+    ids = np.full(len(action), U64MAX, dtype=np.uint64)
+    applied, code = np.zeros(B, dtype=np.uint32), np.zeros(B, dtype=np.uint32)
+    for b in range(B):
+        for i in range(int(off[b]), int(off[b + 1])):
+            a = int(action[i])
+            try:
+                if a == 1:
+                    ids[i] = env.place_order(b, bool(side[i] & 1), int(vol[i]), int(trader[i]), int(price[i]))
+                elif a == 2:
+                    env.cancel_order(b, int(order_id[i]))
+                elif a == 3:
+                    env.modify_order(b, int(order_id[i]), int(price[i]) if side[i] & 2 else None, int(vol[i]) if side[i] & 4 else None)
+            except ValueError:
+                code[b] = 1
+                break
+            applied[b] += 1
+    return ids, applied, code
+
+
+def _apply_oracle(ref, lo, hi, ins):
+    action, side, vol, trader, price, order_id = ins
+    for i in range(lo, hi):
+        a = int(action[i])
+        try:
+            if a == 1:
+                ref.place_order(bool(side[i] & 1), int(vol[i]), int(trader[i]), price=int(price[i]))
+            elif a == 2:
+                ref.cancel_order(int(order_id[i]))
+            elif a == 3:
+                ref.modify_order(int(order_id[i]), new_price=int(price[i]) if side[i] & 2 else None,
+                                 new_vol=int(vol[i]) if side[i] & 4 else None)
+        except ValueError:
+            return
+
+
+def test_device_ingress_equals_host_calls_and_oracle_on_8192_books(bk, oracle):
+    import torch
+
+    B, T, TICK, NMAX = 8192, 5, 2, 14
+    kw = dict(levels=10, max_live_orders=128, max_orders=NMAX * T + 8, trade_capacity=NMAX * T * 2, history_capacity=T)
+    dev = bk.ManyBookEnv(B, 77, 0, TICK, 100_000, stream=torch.cuda.current_stream().cuda_stream, **kw)
+    host = bk.ManyBookEnv(B, 77, 0, TICK, 100_000, **kw)
+    dev.enable_device_ingress(queue_capacity=NMAX)
+    sample = sorted(set(range(0, B, 67)) | {5, 4097, B - 1})
+    bad_plan = {1: (5, 4097), 3: (B - 1, 134)}  # step -> books whose batch carries a bad price
+    refs = {b: oracle.StepEnv(77 + b, 0, TICK, 100_000) for b in sample}
+    rng = np.random.default_rng(2024)
+    counts = np.zeros(B, dtype=np.int64)
+    with pytest.raises(bk.BourseError, match="device memory"):
+        dev.place_order(0, True, 1, 0, 100)  # one flow per env
+    for s in range(T):
+        off, book_of, ins = _stream_step(rng, B, counts, NMAX, TICK, bad_plan.get(s, ()))
+        n = len(ins[0])
+        d_ins = [_dev(torch, x) for x in ins]
+        out_ids = torch.full((n,), -1, dtype=torch.int64, device="cuda")
+        status = torch.full((B, 2), 99, dtype=torch.int32, device="cuda")
+        dev.submit_instructions_device(_dev(torch, off.astype(np.int64)), *d_ins, out_ids=out_ids, status=status)
+        want_ids, want_applied, want_code = _apply_host(host, book_of, off, ins, B)
+        dev.step(sync=False)
+        host.step()
+        got_ids = out_ids.cpu().numpy().view(np.uint64)
+        st = status.cpu().numpy().view(np.uint32)
+        assert np.array_equal(st[:, 0], want_code), (s, np.nonzero(st[:, 0] != want_code)[0][:5])
+        assert np.array_equal(st[:, 1], want_applied), s
+        bad = set(int(b) for b in np.nonzero(want_code)[0])
+        assert bad <= set(bad_plan.get(s, ())) and (bool(bad) or s not in bad_plan)  # (a planted book may hold no new order)
+        assert np.array_equal(got_ids, want_ids), s  # untouched (still -1 = u64::MAX) from a failing element on
+        for b in sample:
+            _apply_oracle(refs[b], int(off[b]), int(off[b + 1]), ins)
+            refs[b].step()
+        counts += np.bincount(book_of[want_ids != U64MAX], minlength=B)
+    dev.sync()
+    assert not dev.flags().any() and not host.flags().any()
+    hd, hh = dev.history(), host.history()
+    assert np.array_equal(hd, hh)
+    assert np.array_equal(dev.trade_counts(), host.trade_counts()) and int(host.trade_counts().sum()) > 10_000
+    assert [dev.order_count(b) for b in sample] == [int(counts[b]) for b in sample]
+    for b in sample:
+        assert np.array_equal(hd[:, b], refs[b].history()), b
+        gd, gh, e = dev.trades(b, first=0), host.trades(b, first=0), refs[b].book.trades_array()
+        od, oh, eo = dev.orders(b), host.orders(b), refs[b].book.orders_array()
+        for f in gd.dtype.names:
+            assert np.array_equal(gd[f], e[f]) and np.array_equal(gh[f], e[f]), (b, f)
+        for f in od.dtype.names:
+            assert np.array_equal(od[f], eo[f]) and np.array_equal(oh[f], eo[f]), (b, f)
+        kd, kh = dev.order_keys(b), host.order_keys(b)
+        assert np.array_equal(kd[0], kh[0]) and np.array_equal(kd[1], kh[1]), b
+    # a second submit before the step appends (one submit per agent and step, ref src/bourse/step_sim/runner.py:108-112)
+    off = np.arange(B + 1, dtype=np.int64) * 2
+    one = lambda v, dt: _dev(torch, np.full(2 * B, v, dtype=dt))  # noqa: E731
+    for k in range(2):
+        dev.submit_instructions_device(_dev(torch, off), one(1, np.uint32), one(k, np.uint8), one(3, np.uint32), one(k, np.uint32),
+                                       one(100, np.uint32), one(0, np.uint64))
+    host.submit_instructions_all(off.astype(np.uint64), (np.ones(2 * B, np.uint32), np.zeros(2 * B, bool), np.full(2 * B, 3, np.uint32),
+                                                         np.zeros(2 * B, np.uint32), np.full(2 * B, 100, np.uint32), np.zeros(2 * B, np.uint64)))
+    host.submit_instructions_all(off.astype(np.uint64), (np.ones(2 * B, np.uint32), np.ones(2 * B, bool), np.full(2 * B, 3, np.uint32),
+                                                         np.ones(2 * B, np.uint32), np.full(2 * B, 100, np.uint32), np.zeros(2 * B, np.uint64)))
+    dev.step()
+    host.step()
+    assert np.array_equal(dev.level2(), host.level2())
+    assert np.array_equal(dev.trade_counts(), host.trade_counts())
+    dev.close()
+    host.close()
+
+
+def test_device_ingress_capacity_unknown_ids_and_argument_checks(bk):
+    import torch
+
+    B = 4
+    dev = bk.ManyBookEnv(B, 3, 0, 1, 1000, levels=10, max_live_orders=64, max_orders=64, trade_capacity=64, history_capacity=8,
+                         stream=torch.cuda.current_stream().cuda_stream, strict=False)
+    with pytest.raises(bk.BourseError, match="bk_device_ingress_enable"):
+        dev.step(sync=False)
+    with pytest.raises(bk.BourseError, match="1..8192"):
+        dev.enable_device_ingress(0)
+    dev.enable_device_ingress(6)
+    dev.enable_device_ingress(6)  # idempotent
+    with pytest.raises(bk.BourseError, match="another queue capacity"):
+        dev.enable_device_ingress(7)
+    with pytest.raises(ValueError, match="CUDA tensor"):
+        dev.submit_instructions_device(torch.zeros(B + 1, dtype=torch.int64), *[None] * 6)
+    # book 0: 4 new orders; book 1: 8 (queue capacity 6 -> two dropped, BK_CAPACITY); book 2: nothing; book 3: a cancel of an id
+    # that was never created between two new orders
+    off = np.array([0, 4, 12, 12, 15], dtype=np.int64)
+    n = 15
+    action = np.ones(n, dtype=np.uint32)
+    action[13] = 2
+    order_id = np.zeros(n, dtype=np.uint64)
+    order_id[13] = 40
+    side = (np.arange(n) % 2).astype(np.uint8)
+    args = [_dev(torch, x) for x in (off, action, side, np.full(n, 2, np.uint32), np.arange(n, dtype=np.uint32),
+                                     np.where(side == 1, 99, 101).astype(np.uint32), order_id)]
+    out_ids = torch.full((n,), -1, dtype=torch.int64, device="cuda")
+    status = torch.zeros((B, 2), dtype=torch.int32, device="cuda")
+    with pytest.raises(bk.CapacityError, match="book 1"):
+        dev.submit_instructions_device(*args, out_ids=out_ids, status=status, check_status=True)
+    st = status.cpu().numpy()
+    assert st.tolist() == [[0, 4], [3, 6], [0, 0], [0, 3]]
+    ids = out_ids.cpu().numpy().view(np.uint64)
+    assert ids[:4].tolist() == [0, 1, 2, 3] and ids[4:10].tolist() == [0, 1, 2, 3, 4, 5] and (ids[10:12] == U64MAX).all()
+    assert ids[12] == 0 and ids[13] == U64MAX and ids[14] == 1
+    dev.step()
+    f = dev.flags()
+    assert f.tolist() == [0, 0, 0, 16]  # BK_FLAG_UNKNOWN_ORDER on book 3 only; its two orders rest
+    assert [dev.order_count(b) for b in range(B)] == [4, 6, 0, 2]
+    assert len(dev.live_orders(3)) == 2 and len(dev.live_orders(1)) == 6
+    # the same id once it exists (a filled / cancelled / live order): no flag
+    dev.clear_flags()
+    off2 = np.array([0, 0, 0, 0, 1], dtype=np.int64)
+    a2 = [_dev(torch, x) for x in (off2, np.array([2], np.uint32), np.zeros(1, np.uint8), np.zeros(1, np.uint32), np.zeros(1, np.uint32),
+                                   np.zeros(1, np.uint32), np.array([1], np.uint64))]
+    dev.submit_instructions_device(*a2)
+    dev.step()
+    assert not dev.flags().any() and len(dev.live_orders(3)) == 1
+    with pytest.raises(bk.BourseError):
+        dev.run(1)  # one flow per env
+    dev.close()
+
+
+def test_device_ingress_markets_match_host_calls(bk):
+    """MarketEnv mode (assets = 2): the queue is the MARKET's - asset 0's batch then asset 1's, as the per-book host calls
+    queue them - ids stay per book, ticks per asset."""
+    import torch
+
+    NM, M = 300, 2
+    kw = dict(levels=10, max_live_orders=64, max_orders=80, trade_capacity=128, history_capacity=4)
+    dev = bk.ManyMarketEnv(NM, 9, 0, [1, 2], 100_000, stream=torch.cuda.current_stream().cuda_stream, **kw)
+    host = bk.ManyMarketEnv(NM, 9, 0, [1, 2], 100_000, **kw)
+    dev.enable_device_ingress(32)
+    rng = np.random.default_rng(5)
+    B = NM * M
+    counts = np.zeros(B, dtype=np.int64)
+    for s in range(4):
+        off, book_of, ins = _stream_step(rng, B, counts, 9, 2, bad_books=(7,) if s == 2 else ())
+        # prices are multiples of 2: fine for both assets (ticks 1 and 2); the planted odd price only offends asset 1 (book 7)
+        out_ids = torch.full((len(ins[0]),), -1, dtype=torch.int64, device="cuda")
+        status = torch.zeros((B, 2), dtype=torch.int32, device="cuda")
+        dev.submit_instructions_device(_dev(torch, off.astype(np.int64)), *[_dev(torch, x) for x in ins], out_ids=out_ids, status=status)
+        want_ids, want_applied, want_code = _apply_host(_BookView(host), book_of, off, ins, B)
+        dev.step()
+        host.step()
+        assert np.array_equal(out_ids.cpu().numpy().view(np.uint64), want_ids), s
+        st = status.cpu().numpy().view(np.uint32)
+        assert np.array_equal(st[:, 0], want_code) and np.array_equal(st[:, 1], want_applied), s
+        counts += np.bincount(book_of[want_ids != U64MAX], minlength=B)
+    assert np.array_equal(dev.history(), host.history())
+    assert np.array_equal(dev.trade_counts(), host.trade_counts()) and int(host.trade_counts().sum()) > 100
+    for b in (0, 1, 7, B - 1):
+        gd, gh = dev.trades(b, first=0), host.trades(b, first=0)
+        for f in gd.dtype.names:
+            assert np.array_equal(gd[f], gh[f]), (b, f)
+
+
+class _BookView:
+    """ManyMarketEnv addressed by flat book index (its own methods take (market, asset))."""
+
+    def __init__(self, env):
+        from bourse_amd.env import ManyBookEnv
+
+        self.env, self.base = env, ManyBookEnv
+
+    def place_order(self, b, *a):
+        return self.base.place_order(self.env, b, *a)
+
+    def cancel_order(self, b, i):
+        return self.base.cancel_order(self.env, b, i)
+
+    def modify_order(self, b, i, p, v):
+        return self.base.modify_order(self.env, b, i, p, v)
