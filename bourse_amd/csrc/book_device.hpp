@@ -724,7 +724,7 @@ __device__ __forceinline__ bool key_window(const Book<R>& B, const uint64_t (&ne
 template <int R>
 struct KeyState {
   uint32_t key[R];
-  uint32_t sq, sbase;
+  uint32_t sq, sbase, pbase;
   // alo <= best ask key, bhi >= best bid key: exact after a reduction of that side, still valid after any removal, pulled
   // in when an order rests beyond them - a new order on the far side of the bound cannot cross and skips the reduction
   uint32_t alo, bhi;
@@ -740,6 +740,7 @@ __device__ __forceinline__ bool keys_begin(const Book<R>& B, const uint64_t (&ne
   for (int r = 0; r < R; ++r)
     lim[r] = MARKETS ? newm[r] & ~__ballot(B.price[r] == (lane_bit(B.bid[r]) ? 0xFFFFFFFFu : 0u)) : newm[r];
   if (!key_window<R>(B, lim, n_ev, pbase, K.sbase)) return false;
+  K.pbase = pbase;
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     const bool bidl = lane_bit(B.bid[r]);
@@ -781,7 +782,10 @@ __device__ __forceinline__ bool match_side_keyed(Book<R>& B, KeyState<R>& K, con
     const uint32_t best = agg_bid ? wave_umin(m) : wave_umax(m);
     (agg_bid ? K.alo : K.bhi) = best;
     if (agg_bid ? (best > kp) : (best < kp)) break;  // inclusive crossing test (:430 / :463) in key space
-    uint32_t pv = 0, pid = 0, tv = 0, price = 0;
+    uint32_t pv = 0, pid = 0, tv = 0;
+    // the trade's price is the matched key's price field (no read of the pool's price register: those are not live
+    // across the loop any more, which is worth registers at R = 8)
+    const uint32_t price = K.pbase + (best >> (KEY_SB + 1u));
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const uint64_t eq = __ballot(K.key[r] == best);  // the key is unique: exactly one lane of one register
@@ -789,7 +793,6 @@ __device__ __forceinline__ bool match_side_keyed(Book<R>& B, KeyState<R>& K, con
         const uint32_t l = __builtin_ctzll(eq);
         pv = rdl(B.vol[r], l);
         pid = rdl(B.id[r], l);
-        price = rdl(B.price[r], l);
         tv = v < pv ? v : pv;
         pv -= tv;
         B.vol[r] = wrl(pv, l, B.vol[r]);
@@ -1280,6 +1283,10 @@ __global__ __launch_bounds__(64) void k_agents_fsm(DevArgs a) {
   }
 }
 
+template <int R, bool MKT, bool POOLPEND>
+__device__ __forceinline__ void step_batch_book(const DevArgs& a, uint32_t book, int lane, uint32_t* lds, uint64_t step_index,
+                                                uint32_t write_last, Book<R>& B, Rng& rng);
+
 // POOLPEND (split pipeline of AgentSets with Noise/Momentum members, k_agents_mixed): the new orders already sit in the
 // pool with their pend bit and id (created by the members' update); the batch only carries the shuffled event list.
 template <int R, bool MKT, bool POOLPEND = false>
@@ -1288,15 +1295,24 @@ template <int R, bool MKT, bool POOLPEND = false>
 __global__ __launch_bounds__(64, R >= 8 ? 5 : 1) void k_step_batch(DevArgs a, uint64_t step_index, uint32_t write_last) {
   // one-wave workgroups: the dispatcher places every wave independently, so the wave slots left beside the
   // co-running k_agents_fsm waves are all usable (4-wave workgroups needed a free slot on every SIMD)
-  __shared__ uint32_t lds[1][LDS_DW_PER_WAVE];
+  __shared__ uint32_t lds[LDS_DW_PER_WAVE];
   // behind the wave-parallel decode of a LARGE batch the event waves go first (bourse_amd.hip launch_split: +5-7 % at
   // 16 384 - 24 576 books, -2 % at 8 192, nothing beside k_agents_fsm, which runs at priority 3 anyway)
   if (a.step_prio) __builtin_amdgcn_s_setprio(1);
   const int lane = threadIdx.x;
-  const int wv = 0;
   // MKT: book = market * assets + asset; the step batch is the market's (stored at the market's first book)
   const uint32_t book = MKT ? a.book_begin * a.assets + blockIdx.x : a.book_begin + blockIdx.x;
   if (book >= (MKT ? a.book_end * a.assets : a.book_end)) return;
+  Book<R> B;
+  Rng rng;
+  step_batch_book<R, MKT, POOLPEND>(a, book, lane, lds, step_index, write_last, B, rng);
+}
+
+// One book's Env::step from its step batch (the body of k_step_batch; k_step_decode runs it in front of the next step's
+// decode).  lds: LDS_DW_PER_WAVE dwords of this wave's.  Leaves the stored book in B / rng for a caller that goes on.
+template <int R, bool MKT, bool POOLPEND>
+__device__ __forceinline__ void step_batch_book(const DevArgs& a, uint32_t book, int lane, uint32_t* lds, uint64_t step_index,
+                                                uint32_t write_last, Book<R>& B, Rng& rng) {
   const uint32_t mkt_book0 = MKT ? (book / a.assets) * a.assets : book;
   const uint32_t asset = book - mkt_book0;
   uint32_t* st = a.state + (size_t)book * a.state_stride;
@@ -1319,8 +1335,6 @@ __global__ __launch_bounds__(64, R >= 8 ? 5 : 1) void k_step_batch(DevArgs a, ui
     }
   }
 
-  Book<R> B;
-  Rng rng;
   load_book<R>(B, rng, st, lane);
   // the step batch: header words, event list (u16), new-order {price, vol} per agent slot
   const uint32_t bh = bt[lane];
@@ -1334,7 +1348,7 @@ __global__ __launch_bounds__(64, R >= 8 ? 5 : 1) void k_step_batch(DevArgs a, ui
   // bid, slot below) - two LDS atomics per list register scatter the bits, lanes 0 .. 4R-1 read the words back.
   uint32_t mw = 0;
   if (!POOLPEND) {
-    uint32_t* pm = lds[wv];  // 2R words placing, 2R words bid side (the level bins are not in use yet)
+    uint32_t* pm = lds;  // 2R words placing, 2R words bid side (the level bins are not in use yet)
     if (lane < 4 * R) pm[lane] = 0;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -1365,7 +1379,7 @@ __global__ __launch_bounds__(64, R >= 8 ? 5 : 1) void k_step_batch(DevArgs a, ui
   }
   B.next_id = base;
   uint32_t n_own = 0;
-  const uint32_t ntr = step_from_list<R, MKT, MKT && POOLPEND, !POOLPEND, POOLPEND && !MKT>(B, a, book, lane, ev, n_ev, lds[wv], a.hist_slot0,
+  const uint32_t ntr = step_from_list<R, MKT, MKT && POOLPEND, !POOLPEND, POOLPEND && !MKT>(B, a, book, lane, ev, n_ev, lds, a.hist_slot0,
                                                                write_last != 0, MKT ? a.asset_div[asset] : a.tick_div,
                                                                mine, n_own, asset);
   store_book<R>(B, rng, st, lane, step_index + 1, ntr, n_own);

@@ -149,6 +149,12 @@ struct bk_env {
   uint32_t wave_lookahead = 64;
   uint32_t stagger_us = ~0u;    // parts of a split launch start i x stagger_us apart; ~0 = default rule, 0 = by events
   int wave_parts = 0;           // 0 = as the lane split (n_parts / min_part)
+  // wave_split: the events of step s and the decode of step s + 1 of a part in ONE launch (k_step_decode) instead of two.
+  // MEASURED AND NOT THE DEFAULT (round 4, VERDICT r3 item 1c "cut the launches per step"; parity-green): 8 192 books 113.7 M
+  // with two launches, 112.7 - 114.5 M with one (occupancy 6 / 7 / 8, 2 - 4 parts); 16 384 books 133.5 -> 124 - 128 M (the
+  // event half then runs at the decode's 72-VGPR footprint instead of its own 38).  Launch boundaries are not what the
+  // shard loses its time to.  BOURSE_AMD_FUSE_STEPS=1 switches it on.
+  bool fuse_wave_steps = false;
   bool wave_ok() const { return !n_mixed && M == 1 && !groups.empty(); }  // RandomAgents on independent books
   // AgentSets with Noise / Momentum members on independent books: wave-parallel decode of the members' update
   bool wl_valid = false;    // the wave-per-book members' lists (wl_list) describe the pools as of steps_done
@@ -296,8 +302,11 @@ struct bk_env {
     }
     return e;
   }
-  double prof_ms[4] = {0, 0, 0, 0};  // per kernel kind: 0 k_run_random, 1 k_agents_fsm, 2 k_step_batch, 3 k_step_events
-  uint64_t prof_launches[4] = {0, 0, 0, 0};
+  // per kernel kind: 0 the fused kernels, 1 the agents kernel of a split pipeline, 2 k_step_batch, 3 k_step_events,
+  // 4 k_step_decode (events of step s + decode of step s + 1 in one launch)
+  static constexpr int PROF_KINDS = 5;
+  double prof_ms[PROF_KINDS] = {0, 0, 0, 0, 0};
+  uint64_t prof_launches[PROF_KINDS] = {0, 0, 0, 0, 0};
 
   DevArgs args() const {
     DevArgs a{};
@@ -562,6 +571,8 @@ int launch_split(bk_env* env, const DevArgs& a0, uint64_t first_step, uint32_t n
   if (MIXED == 1 || MIXED == 2) env->wl_valid = false;  // (the wave-per-book lists no longer describe the pools)
   const MixedLists ml = env->lists();
   const bool wave = (MIXED == 0 && env->use_wave()) || MIXED == 3;
+  // (pools of more than 128 slots: the fused kernel's register footprint costs more occupancy than the launch saves)
+  const bool fuse = MIXED == 0 && wave && env->M == 1 && env->fuse_wave_steps && R <= 2;
   WaveArgs wva{};
   if (wave)
     if (int rc = wave_args(env, &wva)) return rc;
@@ -640,9 +651,11 @@ int launch_split(bk_env* env, const DevArgs& a0, uint64_t first_step, uint32_t n
                      a, ma, ml);
       else if (MIXED == 1)
         launch_timed(env, 1, &k_agents_mixed<R>, dim3((nb + 3) / 4), dim3(256), 0u, st, a, ma);
-      else if (wave)
-        launch_timed(env, 1, &k_agents_wave<R>, dim3((nb + 3) / 4), dim3(256), 0u, st, a, wva);
-      else
+      else if (wave) {
+        // (fused steps: only the launch's first step decodes on its own - every later decode rides behind the previous
+        // step's events in k_step_decode)
+        if (!fuse || s == 0) launch_timed(env, 1, &k_agents_wave<R>, dim3((nb + 3) / 4), dim3(256), 0u, st, a, wva);
+      } else
         launch_timed(env, 1, &k_agents_fsm<R>, dim3((nb + 63) / 64), dim3(64), fsm_lds, st, a);
       if (P > 1 && s == 0) HIPCHK(hipEventRecord(env->ev_first[i], st));
       // the lane-per-book members' update reads the touches from the latest level-2 record: keep it current
@@ -653,6 +666,8 @@ int launch_split(bk_env* env, const DevArgs& a0, uint64_t first_step, uint32_t n
         launch_timed(env, 2, &k_step_batch<R, false, true>, dim3(nb), dim3(64), 0u, st, a, step_no, write_last);
       else if (M > 1)
         launch_timed(env, 2, &k_step_batch<R, true>, dim3(nb * M), dim3(64), 0u, st, a, step_no, write_last);
+      else if (fuse && s + 1 < n_steps)  // events of this step + decode of the next one, one wave per book, 4 books per workgroup
+        launch_timed(env, 4, &k_step_decode<R>, dim3((nb + 3) / 4), dim3(256), 0u, st, a, wva, step_no, write_last);
       else
         launch_timed(env, 2, &k_step_batch<R, false>, dim3(nb), dim3(64), 0u, st, a, step_no, write_last);
     }
@@ -845,6 +860,7 @@ int bk_env_create(const bk_config* cfg, bk_env** out) {
     const int v = std::atoi(np);
     if (v >= 1 && v <= bk_env::MAX_PARTS) env->n_parts = v;
   }
+  if (const char* fs = std::getenv("BOURSE_AMD_FUSE_STEPS")) env->fuse_wave_steps = std::atoi(fs) != 0;
   if (const char* su = std::getenv("BOURSE_AMD_STAGGER_US")) env->stagger_us = static_cast<uint32_t>(std::max(0, std::atoi(su)));
   if (const char* mp = std::getenv("BOURSE_AMD_MIN_PART")) {
     const int v = std::atoi(mp);
@@ -2062,7 +2078,7 @@ int bk_profile_read(bk_env* env, double* total_ms, uint64_t* n_launches, int res
   if (int rc = prof_collect(env)) return rc;
   double ms = 0;
   uint64_t n = 0;
-  for (int k = 0; k < 4; ++k) {
+  for (int k = 0; k < bk_env::PROF_KINDS; ++k) {
     ms += env->prof_ms[k];
     n += env->prof_launches[k];
     if (reset) {
@@ -2076,7 +2092,7 @@ int bk_profile_read(bk_env* env, double* total_ms, uint64_t* n_launches, int res
 }
 
 int bk_profile_read_kind(bk_env* env, int kind, double* total_ms, uint64_t* n_launches) {
-  if (!env || kind < 0 || kind > 3) return fail(BK_INVALID_ARGUMENT, "bad argument");
+  if (!env || kind < 0 || kind >= bk_env::PROF_KINDS) return fail(BK_INVALID_ARGUMENT, "bad argument");
   if (int rc = use_device(env)) return rc;
   if (int rc = prof_collect(env)) return rc;
   if (total_ms) *total_ms = env->prof_ms[kind];

@@ -632,42 +632,45 @@ struct WaveDecoder {
 #ifndef BOURSE_AMD_AW_OCC
 #define BOURSE_AMD_AW_OCC(R) ((R) <= 2 ? 6 : 8)
 #endif
+// LDS of one workgroup of the wave-parallel decode (4 books): the T^256 table + per book the ring of generated draws, the
+// step's event list, placing / side masks and the shuffle's targets (and buckets, pools of more than 128 slots)
 template <int R>
-__global__ __launch_bounds__(256, BOURSE_AMD_AW_OCC(R)) void k_agents_wave(DevArgs a, WaveArgs wa) {
-  __shared__ uint4 tab[512];
-  __shared__ uint32_t ring_s[4][WV_RING];
-  __shared__ uint16_t evl_s[4][64 * R];
-  __shared__ uint32_t pm_s[4][2 * R], sm_s[4][2 * R];
-  __shared__ uint16_t jarr_s[4][64 * R];
-  __shared__ uint16_t bucket_s[4][R > 2 ? 64 * R : 1];  // bucketed shuffle resolution of the large pools
-  const int lane = threadIdx.x & 63;
-  const int wv = (int)rfl(threadIdx.x >> 6);  // wave-uniform: the per-wave LDS regions get scalar base addresses
-  for (int i = threadIdx.x; i < 512; i += 256) tab[i] = wa.jt_block[i];
-  __syncthreads();
-  const uint32_t book = rfl(a.book_begin + blockIdx.x * 4 + wv);
-  if (book >= a.book_end) return;
+struct WaveLds {
+  uint4 tab[512];
+  uint32_t ring[4][WV_RING];
+  uint16_t evl[4][64 * R];
+  uint32_t pm[4][2 * R], sm[4][2 * R];
+  uint16_t jarr[4][64 * R];
+  uint16_t bucket[4][R > 2 ? 64 * R : 1];
+};
+
+// One book's RNG-serial half of a step: RandomAgents::update for every group + the shuffle, written as the book's step
+// batch; the body of k_agents_wave (and the second half of k_step_decode).  hdr: lane i holds dword i of the book's header
+// (RNG state, live masks at H_LIVE0 ..).
+template <int R>
+__device__ __forceinline__ void agents_wave_book(const DevArgs& a, const WaveArgs& wa, WaveLds<R>& L, int wv, uint32_t book, int lane,
+                                                 uint32_t hdr) {
   uint32_t* st = a.state + (size_t)book * a.state_stride;
   uint32_t* bt = a.batch + (size_t)book * a.batch_stride;
   uint32_t* wc = wa.wcache + (size_t)book * WC_STRIDE;
 
   WaveDecoder<R> D;
-  D.tab = tab;
-  D.ring = ring_s[wv];
-  D.evl = evl_s[wv];
-  D.pm = pm_s[wv];
-  D.sm = sm_s[wv];
+  D.tab = L.tab;
+  D.ring = L.ring[wv];
+  D.evl = L.evl[wv];
+  D.pm = L.pm[wv];
+  D.sm = L.sm[wv];
   D.pv = reinterpret_cast<uint2*>(bt + BT_EV + 32 * R);
-  D.jarr = jarr_s[wv];
-  D.wmask = reinterpret_cast<uint4*>(ring_s[wv]);  // the generated draws are dead once the shuffle's windows are resolved
+  D.jarr = L.jarr[wv];
+  D.wmask = reinterpret_cast<uint4*>(L.ring[wv]);  // the generated draws are dead once the shuffle's windows are resolved
   if (R > 2) {  // (64 R count|offset words = 2 KB at R = 8: the ring's memory, like the masks of the small pools)
     static_assert(R <= 8, "the bucket words alias the 2 KB ring");
-    D.co = ring_s[wv];
-    D.bucket = bucket_s[wv];
+    D.co = L.ring[wv];
+    D.bucket = L.bucket[wv];
   }
   D.wcs = reinterpret_cast<uint4*>(wc + WC_HDR);
   D.lane = lane;
   // the book's RNG state and live masks (header dwords H_LIVE0 + w hold bits [32 w, 32 w + 32) of the pool's live mask)
-  const uint32_t hdr = st[lane];
   D.load_cache(wc, rdl(hdr, H_S0_LO), rdl(hdr, H_S0_HI), rdl(hdr, H_S1_LO), rdl(hdr, H_S1_HI), wa.jt_lane);
   if (lane < 2 * R) {
     D.pm[lane] = 0;
@@ -689,6 +692,61 @@ __global__ __launch_bounds__(256, BOURSE_AMD_AW_OCC(R)) void k_agents_wave(DevAr
     const uint32_t lo = 2u * k < n_ev ? D.evl[2u * k] : 0u, hi = 2u * k + 1u < n_ev ? D.evl[2u * k + 1u] : 0u;
     bt[BT_EV + k] = lo | (hi << 16);
   }
+}
+
+template <int R>
+__global__ __launch_bounds__(256, BOURSE_AMD_AW_OCC(R)) void k_agents_wave(DevArgs a, WaveArgs wa) {
+  __shared__ WaveLds<R> L;
+  const int lane = threadIdx.x & 63;
+  const int wv = (int)rfl(threadIdx.x >> 6);  // wave-uniform: the per-wave LDS regions get scalar base addresses
+  for (int i = threadIdx.x; i < 512; i += 256) L.tab[i] = wa.jt_block[i];
+  __syncthreads();
+  const uint32_t book = rfl(a.book_begin + blockIdx.x * 4 + wv);
+  if (book >= a.book_end) return;
+  const uint32_t hdr = (a.state + (size_t)book * a.state_stride)[lane];
+  agents_wave_book<R>(a, wa, L, wv, book, lane, hdr);
+}
+
+// ==================================================================================
+// k_step_decode: Env::step of step s (the body of k_step_batch) FOLLOWED BY the decode of step s + 1 (the body of
+// k_agents_wave) for the same book, in one launch - the wave_split pipeline's inner steps.  A part's step is then ONE
+// launch instead of two (round 4: at 8 192 books every book is resident, so every launch boundary is a barrier on the
+// part's slowest wave plus a ~5 us gap; with both halves in one kernel a wave goes from its events straight to its next
+// decode).  Nothing is carried between the halves but the header words a decode reads (RNG state, live masks), taken
+// from the registers the store just wrote.  The level bins of the event half live in the ring's LDS (dead until the
+// decode generates into it).
+// ==================================================================================
+#ifndef BOURSE_AMD_SD_OCC
+#define BOURSE_AMD_SD_OCC(R) ((R) <= 2 ? 7 : BOURSE_AMD_AW_OCC(R))
+#endif
+template <int R>
+__global__ __launch_bounds__(256, BOURSE_AMD_SD_OCC(R)) void k_step_decode(DevArgs a, WaveArgs wa, uint64_t step_index, uint32_t write_last) {
+  __shared__ WaveLds<R> L;
+  static_assert(WV_RING >= (uint32_t)LDS_DW_PER_WAVE, "the level bins alias the ring");
+  const int lane = threadIdx.x & 63;
+  const int wv = (int)rfl(threadIdx.x >> 6);
+  for (int i = threadIdx.x; i < 512; i += 256) L.tab[i] = wa.jt_block[i];
+  __syncthreads();
+  const uint32_t book = rfl(a.book_begin + blockIdx.x * 4 + wv);
+  if (book >= a.book_end) return;
+  uint32_t hdr = 0;
+  {
+    Book<R> B;
+    Rng rng;
+    step_batch_book<R, false, false>(a, book, lane, L.ring[wv], step_index, write_last, B, rng);
+    // the header words the decode reads, from the registers (store_book has just written exactly these)
+    hdr = wrl((uint32_t)rng.s0, H_S0_LO, hdr);
+    hdr = wrl((uint32_t)(rng.s0 >> 32), H_S0_HI, hdr);
+    hdr = wrl((uint32_t)rng.s1, H_S1_LO, hdr);
+    hdr = wrl((uint32_t)(rng.s1 >> 32), H_S1_HI, hdr);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      hdr = wrl((uint32_t)B.live[r], H_LIVE0 + 2 * r, hdr);
+      hdr = wrl((uint32_t)(B.live[r] >> 32), H_LIVE0 + 2 * r + 1, hdr);
+    }
+  }
+  wave_sync();  // the bins' LDS becomes the ring
+  agents_wave_book<R>(a, wa, L, wv, book, lane, hdr);
 }
 
 // ==================================================================================

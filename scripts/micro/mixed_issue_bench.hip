@@ -45,15 +45,21 @@ __global__ __launch_bounds__(64) void k(unsigned long long* out, unsigned* sink,
     if (V == 12) asm volatile(R16("v_cmp_gt_u32_e64 s[40:41], %2, %3\n\ts_and_b64 s[42:43], s[40:41], exec\n\tv_cndmask_b32_e64 %2, %2, %3, s[42:43]\n\t") : "+s"(a), "+s"(b), "+v"(v), "+v"(w) : : "scc", "s40", "s41", "s42", "s43");
     if (V == 13) asm volatile(R16("v_readlane_b32 s40, %2, 3\n\ts_add_u32 %0, %0, s40\n\t" V2) : "+s"(a), "+s"(b), "+v"(v), "+v"(w) : : "scc", "s40");  // s depends on readlane, v independent
     if (V == 14) asm volatile(R16("v_readlane_b32 s40, %2, 3\n\ts_add_u32 %0, %0, s40\n\t" S2 S2 V2 V2) : "+s"(a), "+s"(b), "+v"(v), "+v"(w) : : "scc", "s40");  // 96: one hand-over per 6
+    if (V == 16) asm volatile(R32("s_cbranch_scc1 3f\n\t" "s_cbranch_scc1 3f\n\t") "3:\n\t" : "+s"(a), "+s"(b), "+v"(v), "+v"(w) : : "scc");  // untaken branches only (scc = 0)
+    if (V == 17) asm volatile(R32(S1 "s_cbranch_scc1 4f\n\t") "4:\n\t" : "+s"(a), "+s"(b), "+v"(v), "+v"(w) : : "scc");  // s_add : untaken branch 1:1
+    if (V == 18) asm volatile(R16(S1 V1 "s_cbranch_scc1 5f\n\t" V2) "5:\n\t" : "+s"(a), "+s"(b), "+v"(v), "+v"(w) : : "scc");  // 1 s : 2 v : 1 untaken branch
+    if (V == 19) asm volatile(R16(S1 V1 S2 "s_cbranch_scc1 6f\n\t") "6:\n\t" : "+s"(a), "+s"(b), "+v"(v), "+v"(w) : : "scc");  // 2 s : 1 v : 1 branch (the kernels' mix)
+    if (V == 20) asm volatile(R8("s_branch 7f\n\t7:\n\t" S1 S2 V1 V2 S1 V1 V2) : "+s"(a), "+s"(b), "+v"(v), "+v"(w) : : "scc");  // a TAKEN branch (to the next instruction) per 8
+    if (V == 21) asm volatile(R16("s_cmp_eq_u32 %0, 0\n\t" "s_cbranch_scc1 8f\n\t" V1 V2) "8:\n\t" : "+s"(a), "+s"(b), "+v"(v), "+v"(w) : : "scc");  // compare -> dependent branch, 2 v
     if (V == 15) asm volatile(R16(S1 "v_add_u32 %2, %0, %2\n\t" S2 "v_add_u32 %3, %1, %3\n\t") : "+s"(a), "+s"(b), "+v"(v), "+v"(w) : : "scc");  // SALU -> VALU operand only
   }
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1));
   if (threadIdx.x == 0) out[blockIdx.x] = t1 - t0;
   if (a + b + v + w == 0x12345u) sink[0] = a;
 }
-static const int N_INSTR[16] = {64, 64, 64, 64, 64, 72, 48, 64, 48, 64, 48, 96, 48, 48, 96, 64};
-static const char* NAME[16] = {"s_add only", "v_add only", "s:v 1:1", "s:v 3:1", "s:v 1:3", "1:1 + untaken branch /9", "readlane->s_add->v_add",
-                               "1:1 + taken branch /16", "v_add,writelane,s_add", "s_add,s_nop 1:1", "readlane,s_add,v_add indep", "readlane,4 v_add,dep s_add", "v_cmp->s_and->cndmask", "readlane->s_add, indep v", "hand-over per 6 instr", "s_add->v_add operand"};
+static const int N_INSTR[22] = {64, 64, 64, 64, 64, 72, 48, 64, 48, 64, 48, 96, 48, 48, 96, 64, 64, 64, 64, 64, 64, 64};
+static const char* NAME[22] = {"s_add only", "v_add only", "s:v 1:1", "s:v 3:1", "s:v 1:3", "1:1 + untaken branch /9", "readlane->s_add->v_add",
+                               "1:1 + taken branch /16", "v_add,writelane,s_add", "s_add,s_nop 1:1", "readlane,s_add,v_add indep", "readlane,4 v_add,dep s_add", "v_cmp->s_and->cndmask", "readlane->s_add, indep v", "hand-over per 6 instr", "s_add->v_add operand", "untaken branches only", "s_add : untaken branch 1:1", "s : v : branch 1:2:1", "s : v : branch 2:1:1", "taken branch per 8 (2s:... mix)", "s_cmp->branch, 2 v (per 4)"};
 template <int V> void run(unsigned long long* d, unsigned* sink, int waves_per_simd, int iters) {
   const int blocks = 256 * 4 * waves_per_simd;
   hipLaunchKernelGGL(k<V>, dim3(blocks), dim3(64), 0, 0, d, sink, 10);
@@ -77,6 +83,7 @@ int main() {
   for (int w : {8, 1}) {
     run<0>(d, sink, w, it); run<1>(d, sink, w, it); run<2>(d, sink, w, it); run<3>(d, sink, w, it); run<4>(d, sink, w, it);
     run<5>(d, sink, w, it); run<6>(d, sink, w, it); run<7>(d, sink, w, it); run<8>(d, sink, w, it); run<9>(d, sink, w, it);
+    run<16>(d, sink, w, it); run<17>(d, sink, w, it); run<18>(d, sink, w, it); run<19>(d, sink, w, it); run<20>(d, sink, w, it); run<21>(d, sink, w, it);
     run<10>(d, sink, w, it); run<11>(d, sink, w, it); run<12>(d, sink, w, it); run<13>(d, sink, w, it); run<14>(d, sink, w, it); run<15>(d, sink, w, it);
     printf("\n");
   }
