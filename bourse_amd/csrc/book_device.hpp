@@ -288,6 +288,7 @@ struct Book {
   // this step's trade records, one per lane (flushed when 64 are buffered)
   uint32_t tr_k, tr_price, tr_vol, tr_act, tr_pas;
   uint32_t tr_n;  // records buffered
+  uint32_t hdr0;  // this lane's header dword as loaded (store_book<KEEP_HDR> rewrites it without reading it again)
 };
 
 template <int R>
@@ -617,18 +618,33 @@ __device__ __forceinline__ void snapshot(const Book<R>& B, const DevArgs& a, uin
 // ----------------------------------------------------------------------------------
 // state load / store (coalesced: lane-contiguous dwords)
 // ----------------------------------------------------------------------------------
+// What one step of one book reads from memory, as loaded (nothing unpacked yet): issued together, so that the one exposed
+// memory round trip of a wave covers all of it - and k_step_batch issues the NEXT book's while this one's events run.
 template <int R>
-__device__ __forceinline__ void load_book(Book<R>& B, Rng& rng, const uint32_t* __restrict__ st, int lane) {
-  const uint32_t hdr = st[lane];
-  uint32_t meta[R];
+struct StepRaw {
+  uint32_t hdr, f[R][POOL_FIELDS];
+  uint32_t bh, ev[R];  // step batch: header words, event list
+  uint2 pv[R];         // step batch: new orders {price, vol} by slot
+};
+template <int R>
+__device__ __forceinline__ void load_state_raw(StepRaw<R>& w, const uint32_t* __restrict__ st, int lane) {
+  w.hdr = st[lane];
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     const uint32_t* p = st + HDR_DW + r * POOL_FIELDS * 64;
-    B.price[r] = p[0 * 64 + lane];
-    B.vol[r] = p[1 * 64 + lane];
-    B.id[r] = p[2 * 64 + lane];
-    B.seq[r] = p[3 * 64 + lane];
-    meta[r] = p[4 * 64 + lane];
+#pragma unroll
+    for (int f = 0; f < POOL_FIELDS; ++f) w.f[r][f] = p[f * 64 + lane];
+  }
+}
+template <int R>
+__device__ __forceinline__ void unpack_book(Book<R>& B, Rng& rng, const StepRaw<R>& w) {
+  const uint32_t hdr = w.hdr;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    B.price[r] = w.f[r][0];
+    B.vol[r] = w.f[r][1];
+    B.id[r] = w.f[r][2];
+    B.seq[r] = w.f[r][3];
   }
   B.t = mk64(rdl(hdr, H_T_LO), rdl(hdr, H_T_HI));
   rng.s0 = mk64(rdl(hdr, H_S0_LO), rdl(hdr, H_S0_HI));
@@ -643,18 +659,29 @@ __device__ __forceinline__ void load_book(Book<R>& B, Rng& rng, const uint32_t* 
   B.trade_base = mk64(rdl(hdr, H_TRADE_BASE_LO), rdl(hdr, H_TRADE_BASE_HI));
 #pragma unroll
   for (int r = 0; r < R; ++r) {
-    B.live[r] = __ballot((meta[r] & 1u) != 0);
-    B.bid[r] = __ballot((meta[r] & 2u) != 0);
-    B.pend[r] = __ballot((meta[r] & 4u) != 0);  // only the split mixed-agent pipeline stores books with pending orders
+    const uint32_t meta = w.f[r][4];
+    B.live[r] = __ballot((meta & 1u) != 0);
+    B.bid[r] = __ballot((meta & 2u) != 0);
+    B.pend[r] = __ballot((meta & 4u) != 0);  // only the split mixed-agent pipeline stores books with pending orders
   }
   B.tr_k = B.tr_price = B.tr_vol = B.tr_act = B.tr_pas = 0;
   B.tr_n = 0;
+  B.hdr0 = hdr;
+}
+template <int R>
+__device__ __forceinline__ void load_book(Book<R>& B, Rng& rng, const uint32_t* __restrict__ st, int lane) {
+  StepRaw<R> w;
+  load_state_raw<R>(w, st, lane);
+  unpack_book<R>(B, rng, w);
 }
 
-template <int R>
+// KEEP_HDR: the reserved / untouched header words come from the copy load_book took (k_step_batch: one register across the
+// step instead of a second, exposed memory round trip in every wave's tail - at 8 waves per SIMD the event kernel is bound
+// by the waves' chain latency).  The kernels that keep a book for a whole launch re-read the line instead.
+template <int R, bool KEEP_HDR = false>
 __device__ __forceinline__ void store_book(const Book<R>& B, const Rng& rng, uint32_t* __restrict__ st, int lane,
                                            uint64_t steps_done, uint32_t last_ntrades, uint32_t last_nevents) {
-  uint32_t hdr = st[lane];  // keep reserved words
+  uint32_t hdr = KEEP_HDR ? B.hdr0 : st[lane];  // keep reserved words
   // (wave-uniform values into their lanes with one v_writelane each - a compare + select per field before)
   auto put = [&](int idx, uint32_t v) { hdr = wrl(rfl(v), (uint32_t)idx, hdr); };
   put(H_T_LO, (uint32_t)B.t);
@@ -1286,16 +1313,27 @@ __global__ __launch_bounds__(64) void k_agents_fsm(DevArgs a) {
 template <int R, bool MKT, bool POOLPEND>
 __device__ __forceinline__ void step_batch_book(const DevArgs& a, uint32_t book, int lane, uint32_t* lds, uint64_t step_index,
                                                 uint32_t write_last, Book<R>& B, Rng& rng);
-
+template <int R, bool MKT, bool POOLPEND>
+__device__ __forceinline__ void step_batch_raw(const DevArgs& a, uint32_t book, int lane, uint32_t* lds, uint64_t step_index,
+                                               uint32_t write_last, const StepRaw<R>& w, Book<R>& B, Rng& rng);
 // POOLPEND (split pipeline of AgentSets with Noise/Momentum members, k_agents_mixed): the new orders already sit in the
 // pool with their pend bit and id (created by the members' update); the batch only carries the shuffled event list.
 template <int R, bool MKT, bool POOLPEND = false>
 // (512-slot pools: asked to fit 5 waves per SIMD - 96 VGPRs, 44-52 B of scratch - instead of the 119 VGPRs / 4 waves the
-// compiler takes by itself: C5 stand-in 272 -> 186 us per launch, 19.0 -> 21.1 M book-steps/s; 6 waves: 201 us)
+// compiler takes by itself: C5 stand-in 272 -> 186 us per launch, 19.0 -> 21.1 M book-steps/s; 6 waves: 201 us.  Since
+// round 4's load restructuring the compiler reaches 80 VGPRs / 6 waves without scratch by itself, which is that slower
+// 201 us form (20.2 instead of 21.3 M): the kernel CLAIMS 96 registers - a clobber of v95, as k_agents_fsm claims its
+// footprint - so that the hardware places five waves per SIMD again; -DBOURSE_AMD_SB8_TOP_VGPR=0 drops the claim)
+#ifndef BOURSE_AMD_SB8_TOP_VGPR
+#define BOURSE_AMD_SB8_TOP_VGPR 95
+#endif
 __global__ __launch_bounds__(64, R >= 8 ? 5 : 1) void k_step_batch(DevArgs a, uint64_t step_index, uint32_t write_last) {
   // one-wave workgroups: the dispatcher places every wave independently, so the wave slots left beside the
   // co-running k_agents_fsm waves are all usable (4-wave workgroups needed a free slot on every SIMD)
   __shared__ uint32_t lds[LDS_DW_PER_WAVE];
+#if BOURSE_AMD_SB8_TOP_VGPR > 0
+  if constexpr (R >= 8) asm volatile("" ::: "v" BK_STR(BOURSE_AMD_SB8_TOP_VGPR));
+#endif
   // behind the wave-parallel decode of a LARGE batch the event waves go first (bourse_amd.hip launch_split: +5-7 % at
   // 16 384 - 24 576 books, -2 % at 8 192, nothing beside k_agents_fsm, which runs at priority 3 anyway)
   if (a.step_prio) __builtin_amdgcn_s_setprio(1);
@@ -1305,6 +1343,10 @@ __global__ __launch_bounds__(64, R >= 8 ? 5 : 1) void k_step_batch(DevArgs a, ui
   if (book >= (MKT ? a.book_end * a.assets : a.book_end)) return;
   Book<R> B;
   Rng rng;
+  // (Round 4 tried TWO books per wave, the second one's loads in flight while the first one's events run - the memory
+  // round trip at a wave's start is the longest single link of its chain: the 18 registers of the second book take the
+  // kernel from 40 to 64 VGPRs, only four event waves then fit beside a k_agents_fsm wave, and C3 fell from 281 to
+  // 221 - 236 M whatever the lane kernel's own footprint was set to: docs/EXPERIMENTS.md.)
   step_batch_book<R, MKT, POOLPEND>(a, book, lane, lds, step_index, write_last, B, rng);
 }
 
@@ -1313,10 +1355,26 @@ __global__ __launch_bounds__(64, R >= 8 ? 5 : 1) void k_step_batch(DevArgs a, ui
 template <int R, bool MKT, bool POOLPEND>
 __device__ __forceinline__ void step_batch_book(const DevArgs& a, uint32_t book, int lane, uint32_t* lds, uint64_t step_index,
                                                 uint32_t write_last, Book<R>& B, Rng& rng) {
+  StepRaw<R> w;
+  const uint32_t mkt_book0 = MKT ? (book / a.assets) * a.assets : book;
+  const uint32_t* st = a.state + (size_t)book * a.state_stride;
+  const uint32_t* bt = a.batch + (size_t)mkt_book0 * a.batch_stride;
+  load_state_raw<R>(w, st, lane);
+  w.bh = bt[lane];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    w.ev[r] = reinterpret_cast<const uint16_t*>(bt + BT_EV)[r * 64 + lane];
+    w.pv[r] = POOLPEND ? make_uint2(0u, 0u) : reinterpret_cast<const uint2*>(bt + BT_EV + 32 * R)[r * 64 + lane];
+  }
+  step_batch_raw<R, MKT, POOLPEND>(a, book, lane, lds, step_index, write_last, w, B, rng);
+}
+// ... from what load_step_raw / the wrapper above loaded
+template <int R, bool MKT, bool POOLPEND>
+__device__ __forceinline__ void step_batch_raw(const DevArgs& a, uint32_t book, int lane, uint32_t* lds, uint64_t step_index,
+                                               uint32_t write_last, const StepRaw<R>& w, Book<R>& B, Rng& rng) {
   const uint32_t mkt_book0 = MKT ? (book / a.assets) * a.assets : book;
   const uint32_t asset = book - mkt_book0;
   uint32_t* st = a.state + (size_t)book * a.state_stride;
-  const uint32_t* bt = a.batch + (size_t)mkt_book0 * a.batch_stride;
   uint64_t mine[R];  // MKT: the pool slots (= agent indices) of the groups trading this asset
 #pragma unroll
   for (int r = 0; r < R; ++r) mine[r] = MKT ? 0ull : ~0ull;
@@ -1335,15 +1393,14 @@ __device__ __forceinline__ void step_batch_book(const DevArgs& a, uint32_t book,
     }
   }
 
-  load_book<R>(B, rng, st, lane);
+  unpack_book<R>(B, rng, w);
   // the step batch: header words, event list (u16), new-order {price, vol} per agent slot
-  const uint32_t bh = bt[lane];
-  const uint32_t n_ev = rdl(bh, BT_NEV);
+  const uint32_t n_ev = rdl(w.bh, BT_NEV);
   uint32_t ev[R];
   uint32_t owner[R];  // POOLPEND: the members' owner tags ride in meta bits 8..15 and must survive the store
   uint32_t base = B.next_id;
 #pragma unroll
-  for (int r = 0; r < R; ++r) ev[r] = reinterpret_cast<const uint16_t*>(bt + BT_EV)[r * 64 + lane];
+  for (int r = 0; r < R; ++r) ev[r] = w.ev[r];
   // Which agent slots place an order in this step, and on which side: rebuilt from the event words (bit 15 New, bit 14
   // bid, slot below) - two LDS atomics per list register scatter the bits, lanes 0 .. 4R-1 read the words back.
   uint32_t mw = 0;
@@ -1362,12 +1419,12 @@ __device__ __forceinline__ void step_batch_book(const DevArgs& a, uint32_t book,
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     if (POOLPEND) {
-      owner[r] = st[HDR_DW + r * POOL_FIELDS * 64 + 4 * 64 + lane] & 0xFF00u;
+      owner[r] = w.f[r][4] & 0xFF00u;
       continue;
     }
     const uint64_t pend = mk64(rdl(mw, 2 * r), rdl(mw, 2 * r + 1)) & mine[r];
     const uint64_t side = mk64(rdl(mw, 2 * R + 2 * r), rdl(mw, 2 * R + 2 * r + 1));
-    const uint2 pv = reinterpret_cast<const uint2*>(bt + BT_EV + 32 * R)[r * 64 + lane];
+    const uint2 pv = w.pv[r];
     B.price[r] = sel(pend, pv.x, B.price[r]);
     B.vol[r] = sel(pend, pv.y, B.vol[r]);
     // create_order ids: dense, in agent order (orderbook.rs:363): base + #placing agents below this slot
@@ -1382,7 +1439,7 @@ __device__ __forceinline__ void step_batch_book(const DevArgs& a, uint32_t book,
   const uint32_t ntr = step_from_list<R, MKT, MKT && POOLPEND, !POOLPEND, POOLPEND && !MKT>(B, a, book, lane, ev, n_ev, lds, a.hist_slot0,
                                                                write_last != 0, MKT ? a.asset_div[asset] : a.tick_div,
                                                                mine, n_own, asset);
-  store_book<R>(B, rng, st, lane, step_index + 1, ntr, n_own);
+  store_book<R, !POOLPEND>(B, rng, st, lane, step_index + 1, ntr, n_own);
   if (POOLPEND) {
 #pragma unroll
     for (int r = 0; r < R; ++r) {

@@ -254,7 +254,15 @@ class ManyBookEnv:
         written on (``ManyBookEnv(stream=torch.cuda.current_stream().cuda_stream)``).  ``check_status=True`` waits and
         raises the reference's ``ValueError`` for the first book whose batch stopped at a bad price."""
         P = self._dev_ptr
-        check(self._L.bk_submit_instructions_device(self._h, P(book_offsets, 8, "book_offsets"), P(action, 4, "action"),
+        off_ptr = P(book_offsets, 8, "book_offsets")  # (validates the first argument before anything is looked at)
+        if action is None:
+            raise ValueError("action: a contiguous CUDA tensor of 4-byte elements is needed")
+        n_elem = action.numel() if hasattr(action, "numel") else int(np.prod(action.__cuda_array_interface__["shape"]))
+        if n_elem == 0:  # nothing to submit for any book (an empty device array has no address to hand over)
+            if status is not None and hasattr(status, "zero_"):
+                status.zero_()
+            return out_ids, status
+        check(self._L.bk_submit_instructions_device(self._h, off_ptr, P(action, 4, "action"),
                                                     P(side, 1, "side"), P(vol, 4, "vol"), P(trader_id, 4, "trader_id"),
                                                     P(price, 4, "price"), P(order_id, 8, "order_id"), P(out_ids, 8, "out_ids"),
                                                     P(status, 4, "status")))

@@ -193,6 +193,7 @@ int bk_step(bk_env* env);
  *   (queue full / id space) -, number of the book's elements applied}.  Asynchronous on the env's stream.
  *   A cancel / modify of an id that was never created (the reference panics while processing, orderbook.rs:642; the
  *   host-driven bk_step refuses the step) is dropped at the step and the book flagged BK_FLAG_UNKNOWN_ORDER.
+ *   All seven input arrays must be non-null (a step with no instruction for any book: do not call).
  * bk_step_async: Env::step over the device-resident queues without waiting (bk_step on such an env = this + a wait).
  * Readers (bk_get_orders, bk_order_status, bk_get_trades, bk_history ...) work as on the host-driven flow. */
 int bk_device_ingress_enable(bk_env* env, uint32_t queue_capacity);

@@ -1727,6 +1727,16 @@ def _full_size_vs_oracle(bk, oracle, B, levels, T, groups=None, members=None, po
         g, e = env.trades(b, first=0), ref.book(b).trades_array()
         for fld in g.dtype.names:
             assert np.array_equal(g[fld], e[fld]), (b, fld)
+    # EVERY book's trade records (t, side, price, vol, both ids): the device's dense CSR stream (bk_trades_compact) against
+    # the oracle's per-book vectors, concatenated
+    off, rec = env.drain_trades()
+    assert np.array_equal(np.diff(off), ref.trade_counts().astype(np.uint64))
+    want_rec = np.concatenate([ref.book(b).trades_array() for b in range(B)])
+    assert len(rec) == len(want_rec) > 0
+    for fld in rec.dtype.names:
+        if not np.array_equal(rec[fld], want_rec[fld]):
+            i = int(np.argmax(rec[fld] != want_rec[fld]))
+            raise AssertionError(f"trade field {fld} differs first at record {i} (book {int(np.searchsorted(off, i, 'right')) - 1})")
     env.close()
     return used
 
