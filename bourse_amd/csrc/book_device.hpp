@@ -32,6 +32,37 @@
 
 namespace bkd {
 
+// -DBOURSE_AMD_STAMPS=1 (a diagnostic build, never the shipped library): every wave of k_step_batch / k_agents_wave adds
+// the shader-clock length of its phases to g_stamps[kernel * 8 + phase] and its count to [.. + 7]
+// (scripts/wave_phases.py reads them through bk_debug_stamps): where a wave's time goes UNDER the real pipeline's load.
+#ifndef BOURSE_AMD_STAMPS
+#define BOURSE_AMD_STAMPS 0
+#endif
+#if BOURSE_AMD_STAMPS && !defined(BOURSE_AMD_FSM_UNIT)
+// per-book accumulators, [book][kernel * 8 + phase] (plain read-modify-write by lane 0: one wave per book and kernel at a
+// time; contended atomics on a few shared words made the first version of this build 14x slower than the library)
+__device__ unsigned int* g_stamp_ptr;
+#define BK_STAMP_FIELD    \
+  unsigned long long stamp_t; \
+  unsigned int stamp_book;
+#define BK_STAMP_START(obj, book)                  \
+  (obj).stamp_t = __builtin_amdgcn_s_memtime(); \
+  (obj).stamp_book = (book)
+#define BK_STAMP(obj, kernel, phase, lane)                                                           \
+  do {                                                                                               \
+    const unsigned long long n_ = __builtin_amdgcn_s_memtime();                                      \
+    if ((lane) == 0) g_stamp_ptr[(size_t)(obj).stamp_book * 16 + (kernel) * 8 + (phase)] += (unsigned int)(n_ - (obj).stamp_t); \
+    (obj).stamp_t = n_;                                                                              \
+  } while (0)
+#define BK_STAMP_COUNT(obj, kernel, lane) \
+  if ((lane) == 0) g_stamp_ptr[(size_t)(obj).stamp_book * 16 + (kernel) * 8 + 7] += 1u
+#else
+#define BK_STAMP_FIELD
+#define BK_STAMP_START(obj, book)
+#define BK_STAMP(obj, kernel, phase, lane)
+#define BK_STAMP_COUNT(obj, kernel, lane)
+#endif
+
 constexpr int HDR_DW = 64;  // per-book header: 64 dwords, lane i holds dword i
 enum Hdr : int {
   H_T_LO = 0, H_T_HI, H_S0_LO, H_S0_HI, H_S1_LO, H_S1_HI,
@@ -289,6 +320,7 @@ struct Book {
   uint32_t tr_k, tr_price, tr_vol, tr_act, tr_pas;
   uint32_t tr_n;  // records buffered
   uint32_t hdr0;  // this lane's header dword as loaded (store_book<KEEP_HDR> rewrites it without reading it again)
+  BK_STAMP_FIELD
 };
 
 template <int R>
@@ -1035,12 +1067,14 @@ __device__ __forceinline__ uint32_t step_from_list(Book<R>& B, const DevArgs& a,
     }
   }
   if (!MKT) n_own = n_ev;
+  BK_STAMP(B, 0, 3, lane);  // key set-up + event loop
   B.n_events += n_own;
   B.t = t0 + step_size;  // env.rs:129
   // env.rs:132-134.  Env::level_2_data (the "latest" record) only needs a launch's final snapshot;
   // with no history buffer every step's record is written there.
   snapshot<R>(B, a, book, lane, bins, hist_slot, B.flags, write_last, tick);
   flush_trades<R>(B, a, book, t0, lane);
+  BK_STAMP(B, 0, 4, lane);  // level-2 snapshot + trade flush
   return (uint32_t)(B.n_trades - trades_before);
 }
 
@@ -1355,6 +1389,7 @@ __global__ __launch_bounds__(64, R >= 8 ? 5 : 1) void k_step_batch(DevArgs a, ui
 template <int R, bool MKT, bool POOLPEND>
 __device__ __forceinline__ void step_batch_book(const DevArgs& a, uint32_t book, int lane, uint32_t* lds, uint64_t step_index,
                                                 uint32_t write_last, Book<R>& B, Rng& rng) {
+  BK_STAMP_START(B, book);
   StepRaw<R> w;
   const uint32_t mkt_book0 = MKT ? (book / a.assets) * a.assets : book;
   const uint32_t* st = a.state + (size_t)book * a.state_stride;
@@ -1366,7 +1401,13 @@ __device__ __forceinline__ void step_batch_book(const DevArgs& a, uint32_t book,
     w.ev[r] = reinterpret_cast<const uint16_t*>(bt + BT_EV)[r * 64 + lane];
     w.pv[r] = POOLPEND ? make_uint2(0u, 0u) : reinterpret_cast<const uint2*>(bt + BT_EV + 32 * R)[r * 64 + lane];
   }
+#if BOURSE_AMD_STAMPS && !defined(BOURSE_AMD_FSM_UNIT)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // phase 0 = the loads' round trip
+#endif
+  BK_STAMP(B, 0, 0, lane);
   step_batch_raw<R, MKT, POOLPEND>(a, book, lane, lds, step_index, write_last, w, B, rng);
+  BK_STAMP(B, 0, 5, lane);  // store
+  BK_STAMP_COUNT(B, 0, lane);
 }
 // ... from what load_step_raw / the wrapper above loaded
 template <int R, bool MKT, bool POOLPEND>
@@ -1436,6 +1477,7 @@ __device__ __forceinline__ void step_batch_raw(const DevArgs& a, uint32_t book, 
   }
   B.next_id = base;
   uint32_t n_own = 0;
+  BK_STAMP(B, 0, 1, lane);  // unpack + placing masks + new orders into the pool
   const uint32_t ntr = step_from_list<R, MKT, MKT && POOLPEND, !POOLPEND, POOLPEND && !MKT>(B, a, book, lane, ev, n_ev, lds, a.hist_slot0,
                                                                write_last != 0, MKT ? a.asset_div[asset] : a.tick_div,
                                                                mine, n_own, asset);

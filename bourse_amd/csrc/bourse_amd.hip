@@ -2246,6 +2246,26 @@ int bk_checkpoint_load(bk_env* env, const void* in, uint64_t nbytes) {
 
 uint64_t bk_state_bytes_per_book(const bk_env* env) { return env ? static_cast<uint64_t>(env->stride) * 4 : 0; }
 
+#if BOURSE_AMD_STAMPS
+// diagnostic build only (book_device.hpp BK_STAMP): per-book phase accumulators, 16 u32 per book.  bk_debug_stamps(n_books,
+// out): the first call allocates + zeroes them and returns nothing; later calls copy them out (out: n_books * 16) and zero.
+int bk_debug_stamps(uint32_t n_books, unsigned int* out) {
+  static unsigned int* dev = nullptr;
+  static uint32_t cap = 0;
+  HIPCHK(hipDeviceSynchronize());
+  if (!dev || cap < n_books) {
+    if (dev) (void)hipFree(dev);
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&dev), static_cast<size_t>(n_books) * 64));
+    cap = n_books;
+    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(bkd::g_stamp_ptr), &dev, sizeof(dev)));
+  } else if (out) {
+    HIPCHK(hipMemcpy(out, dev, static_cast<size_t>(n_books) * 64, hipMemcpyDeviceToHost));
+  }
+  HIPCHK(hipMemset(dev, 0, static_cast<size_t>(cap) * 64));
+  return BK_OK;
+}
+#endif
+
 // DPP reduction self-test (tests only): in[n_waves*64] -> out[n_waves*4] = {min, max, sum, sel-sum}
 int bk_selftest_reduce(const uint32_t* in_host, uint32_t n_waves, uint32_t* out_host) {
   if (!in_host || !out_host) return fail(BK_INVALID_ARGUMENT, "null argument");

@@ -133,6 +133,7 @@ struct WaveDecoder {
   uint4 cs;            // this lane's chunk-start state in the last generated block
   uint32_t gen_end;    // draws generated so far (stream origin = start of the cached block)
   uint32_t pos;        // stream position: draws consumed so far
+  BK_STAMP_FIELD
 
   // cached lane states valid for the book's RNG state (s0l..s1h)?  else lane j = T^(4 j) of it, by doubling
   __device__ __forceinline__ void load_cache(const uint32_t* wc, uint32_t s0l, uint32_t s0h, uint32_t s1l, uint32_t s1h,
@@ -655,6 +656,7 @@ __device__ __forceinline__ void agents_wave_book(const DevArgs& a, const WaveArg
   uint32_t* wc = wa.wcache + (size_t)book * WC_STRIDE;
 
   WaveDecoder<R> D;
+  BK_STAMP_START(D, book);
   D.tab = L.tab;
   D.ring = L.ring[wv];
   D.evl = L.evl[wv];
@@ -677,8 +679,11 @@ __device__ __forceinline__ void agents_wave_book(const DevArgs& a, const WaveArg
     D.sm[lane] = 0;
   }
   const uint32_t lim = 64u + (wa.lookahead < 1u ? 1u : (wa.lookahead > 64u ? 64u : wa.lookahead));
+  BK_STAMP(D, 1, 0, lane);  // lane-state cache in
   const uint32_t n_ev = D.agents(a, lim, hdr, H_LIVE0);
+  BK_STAMP(D, 1, 1, lane);  // agents.update: generation, windows, walk
   D.shuffle(n_ev);
+  BK_STAMP(D, 1, 2, lane);  // shuffle
 
   // ---- publish: RNG state, lane-state cache, step batch
   uint32_t n0, n1, n2, n3;
@@ -692,6 +697,8 @@ __device__ __forceinline__ void agents_wave_book(const DevArgs& a, const WaveArg
     const uint32_t lo = 2u * k < n_ev ? D.evl[2u * k] : 0u, hi = 2u * k + 1u < n_ev ? D.evl[2u * k + 1u] : 0u;
     bt[BT_EV + k] = lo | (hi << 16);
   }
+  BK_STAMP(D, 1, 3, lane);  // publish
+  BK_STAMP_COUNT(D, 1, lane);
 }
 
 template <int R>

@@ -1,0 +1,39 @@
+"""Where does a wave's time go UNDER THE REAL PIPELINE'S LOAD?  Needs the diagnostic build (-DBOURSE_AMD_STAMPS=1:
+build_variants/lib_stamps.so, `BOURSE_AMD_LIBRARY=...`): every k_step_batch / k_agents_wave wave adds the shader-clock
+length of its phases to a device array.   GPU box:  BOURSE_AMD_LIBRARY=build_variants/lib_stamps.so python scripts/wave_phases.py [books] [pipeline]"""
+import ctypes as C, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np, bourse_amd as bk
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+pipe = sys.argv[2] if len(sys.argv) > 2 else "auto"
+G = [(64, (32, 64), (10, 20), 2, 0.8), (64, (32, 64), (50, 70), 2, 0.2)]
+env = bk.ManyBookEnv(B, 101, 0, 2, 100_000, levels=32, max_live_orders=128, trade_capacity=64 * 50, history_capacity=50, strict=False)
+env.set_random_agents(G)
+env.set_pipeline(pipe)
+L = env._L
+L.bk_debug_stamps.argtypes = [C.c_uint32, C.c_void_p]
+buf = np.zeros((B, 16), dtype=np.uint32)
+L.bk_debug_stamps(B, None)  # allocate + zero BEFORE the first launch (the kernels write through the pointer)
+env.run(50); env.clear_history(); env.clear_trades()
+L.bk_debug_stamps(B, buf.ctypes.data_as(C.c_void_p))  # (reads the warm-up's stamps and zeroes)
+t0 = time.perf_counter()
+T = 100
+for _ in range(T // 50):
+    env.run(50, sync=False); env.clear_history(); env.clear_trades()
+env.sync()
+dt = time.perf_counter() - t0
+L.bk_debug_stamps(B, buf.ctypes.data_as(C.c_void_p))
+a = buf.astype(np.float64).sum(axis=0).reshape(2, 8)
+print(f"{B} books, pipeline {env.pipeline()}: {B * T / dt / 1e6:.1f} M book-steps/s with the stamps in (s_memtime per phase)")
+names = {0: ("k_step_batch", ["loads' round trip", "unpack + masks + new orders", "-", "keys + event loop", "snapshot + trade flush", "store"]),
+         1: ("k_agents_wave", ["lane-state cache in", "agents.update (generate, windows, walk)", "shuffle", "publish"])}
+for k, (kn, ph) in names.items():
+    n = a[k, 7]
+    if not n:
+        continue
+    tot = a[k, :7].sum()
+    print(f"  {kn}: {int(n)} waves, {tot / n:.0f} clocks per wave = {tot / n / 2.4e3:.1f} us at 2.4 GHz (s_memtime ticks; if 100 MHz: x24)")
+    for i, p in enumerate(ph):
+        if p != "-":
+            print(f"     {p:42s} {a[k, i] / n:9.0f} clocks  {100 * a[k, i] / tot:5.1f} %")
