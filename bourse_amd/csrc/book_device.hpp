@@ -405,6 +405,33 @@ __device__ __forceinline__ void emit_trade(Book<R>& B, const DevArgs& a, uint32_
   B.tr_n = l + 1;
 }
 
+// Compact records of the keyed assembly loop (event_asm.hpp EK_PICK): lane i < tr_n holds {tr_k = event position |
+// passive side << 31, tr_vol, tr_pas = the passive order's pool slot}.  The trade's price is the passive order's
+// (match_orders, orderbook.rs:843-870), its ids are the aggressor's - the order of the event at that position - and the
+// passive order's: all three sit in pool registers that do not change inside a step, so they are gathered here, once per
+// flush, instead of being read and written lane by lane for every trade.  ev: the step's (shuffled) event list.
+template <int R>
+__device__ __forceinline__ uint32_t pool_gather(const uint32_t (&v)[R], uint32_t idx) {
+  uint32_t out = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((idx & 63u) << 2), (int)v[0]);
+#pragma unroll
+  for (int r = 1; r < R; ++r) {
+    const uint32_t x = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((idx & 63u) << 2), (int)v[r]);
+    out = (idx >> 6) == (uint32_t)r ? x : out;
+  }
+  return out;
+}
+template <int R>
+__device__ __forceinline__ void flush_trades_compact(Book<R>& B, const DevArgs& a, uint32_t book, uint64_t t0, int lane,
+                                                     const uint32_t (&ev)[R]) {
+  if (B.tr_n == 0) return;
+  const uint32_t k = B.tr_k & 0x7FFFFFFFu, ps = B.tr_pas & (64u * R - 1u);
+  const uint32_t as = pool_gather<R>(ev, k < 64u * R ? k : 0u) & EV_SLOT & (64u * R - 1u);  // the aggressor's slot
+  B.tr_price = pool_gather<R>(B.price, ps);
+  B.tr_pas = pool_gather<R>(B.id, ps);
+  B.tr_act = pool_gather<R>(B.id, as);
+  flush_trades<R>(B, a, book, t0, lane);
+}
+
 // ----------------------------------------------------------------------------------
 // order log (host-driven path only): single-lane scattered 32-byte updates
 // ----------------------------------------------------------------------------------
@@ -992,16 +1019,15 @@ __device__ __forceinline__ uint32_t step_from_list(Book<R>& B, const DevArgs& a,
       for (;;) {
         uint32_t full;
         if constexpr (R == 2)
-          full = events_key_r2(checked, k, n_list, tmask, B.tr_n, K.sq, B.live[0], B.live[1], B.bid[0], B.bid[1], B.price[0],
-                               B.price[1], B.vol[0], B.vol[1], B.id[0], B.id[1], K.key[0], K.key[1], evl[0], evl[1], B.tr_k,
-                               B.tr_price, B.tr_vol, B.tr_act, B.tr_pas
+          full = events_key_r2(checked, k, n_list, tmask, B.tr_n, K.sq, B.live[0], B.live[1], B.bid[0], B.bid[1], B.vol[0],
+                               B.vol[1], K.key[0], K.key[1], evl[0], evl[1], B.tr_k, B.tr_vol, B.tr_pas
 #if BOURSE_AMD_LAZY_CANCEL
                                , dt[0], dt[1]
 #endif
           );
         else
-          full = events_key_r1(checked, k, n_list, tmask, B.tr_n, K.sq, B.live[0], B.bid[0], B.price[0], B.vol[0], B.id[0],
-                               K.key[0], evl[0], B.tr_k, B.tr_price, B.tr_vol, B.tr_act, B.tr_pas
+          full = events_key_r1(checked, k, n_list, tmask, B.tr_n, K.sq, B.live[0], B.bid[0], B.vol[0], K.key[0], evl[0],
+                               B.tr_k, B.tr_vol, B.tr_pas
 #if BOURSE_AMD_LAZY_CANCEL
                                , dt[0]
 #endif
@@ -1013,8 +1039,10 @@ __device__ __forceinline__ uint32_t step_from_list(Book<R>& B, const DevArgs& a,
 #endif
         // Env::get_trade_vol: the loop leaves the sum to the vector unit (one reduction per flush, not an add per trade)
         if (B.tr_n) B.trade_vol += wave_add((uint32_t)lane < B.tr_n ? B.tr_vol : 0u);
+        // (the records are compact - k word, volume, passive slot: price and ids are gathered from the pool at the flush,
+        // which therefore happens HERE, before the step's snapshot / store, also for the last buffer of the step)
+        flush_trades_compact<R>(B, a, book, t0, lane, ev);
         if (!full) break;
-        flush_trades<R>(B, a, book, t0, lane);
       }
 #if BOURSE_AMD_LAZY_CANCEL
 #pragma unroll

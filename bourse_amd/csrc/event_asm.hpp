@@ -337,7 +337,8 @@ __device__ __forceinline__ uint32_t events_asm_r1(uint32_t& k, uint32_t n_ev, ui
 //   aggressor exhausted   -> trade = aggressor's volume, next event (the passive order dies too iff nothing is left)
 // and the trade-buffer index is kept biased by -64: `s_add_u32 trn, trn, 1` carries out exactly when the buffer is full
 // (lane selects read the low 6 bits).  The step's traded volume is summed from the buffer at every flush (book_device.hpp)
-// instead of one scalar add per trade.  Per trade: 16 scalar + branch instructions (loop above: 32).
+// instead of one scalar add per trade.  Per trade: 16 scalar + branch instructions (loop above: 32); since round 4 three
+// vector lane writes + one lane read per trade instead of five + three (compact records, EK_PICK).
 // ==================================================================================
 // LAZY CANCELLATIONS (round 3).  A cancellation is ~10 scalar-port instructions of pure loop overhead (fetch the word, two
 // tests, a 64-bit shift, an and-not, the loop's own three) and the scalar port is what binds these kernels at small
@@ -369,37 +370,41 @@ __device__ __forceinline__ uint32_t events_asm_r1(uint32_t& k, uint32_t n_ev, ui
 #define EK_ALO "s62"
 #define EK_BHI "s63"
 
-#define EK_TRADE_REC(TV)                                                                              \
-  "s_mov_b32 m0, %[trn]\n\t"                                                                          \
-  "v_writelane_b32 %[trk], " EA_KK ", m0\n\t"                                                         \
-  "v_writelane_b32 %[trp], " EA_BEST ", m0\n\t"                                                       \
-  "v_writelane_b32 %[trv], " TV ", m0\n\t"                                                            \
-  "v_writelane_b32 %[tra], " EA_ID ", m0\n\t"                                                         \
-  "v_writelane_b32 %[trs], " EA_PID ", m0\n\t"                                                        \
-  "s_add_u32 %[trn], %[trn], 1\n\t"                     /* SCC = carry = buffer full */
-
-// the passive order is the single lane of mask EQ in pool register Q
-#define EK_PICK(Q, EQ, L, PH, KEND)                                                                   \
+// COMPACT TRADE RECORDS (round 4).  The loop writes THREE words per trade - the k word (event position | passive side),
+// the volume, and the passive order's POOL SLOT - instead of five, and reads ONE lane of the passive order (its volume)
+// instead of three: the trade's price and both order ids are gathered from the pool registers when the buffer is flushed
+// (book_device.hpp flush_trades_compact; ids and prices of pool slots never change inside a step: a slot gets its new order
+// before the loop and is never re-used in the step).  The record words that do not depend on the passive order's volume
+// are written right behind its v_readlane, in front of the scalar subtract that needs it: a scalar instruction issued
+// right after a VALU write of an SGPR waits ~16 clocks for it (scripts/micro/mixed_issue_bench.hip), dependent or not.
+//   EK_PICK: the passive order is the single lane of mask EQ in pool register Q; SLOTW = its slot word (Q = 0: the lane;
+//   Q = 1: lane | 64, formed by SLOTI)
+#define EK_PICK(Q, EQ, L, PH, KEND, SLOTI, SLOTW)                                                     \
   "s_ff1_i32_b64 " EA_LS ", " EQ "\n\t"                                                               \
+  SLOTI                                                                                               \
+  "s_mov_b32 m0, %[trn]\n\t"                                                                          \
   "v_readlane_b32 " EA_PV ", %[vol" Q "], " EA_LS "\n\t"                                              \
-  "v_readlane_b32 " EA_PID ", %[id" Q "], " EA_LS "\n\t"                                              \
-  "v_readlane_b32 " EA_BEST ", %[price" Q "], " EA_LS "\n\t"  /* the trade's price */                 \
-  "s_mov_b32 m0, " EA_LS "\n\t"                                                                       \
-  "s_sub_u32 " EA_X ", " EA_PV ", " EA_V "\n\t"                                                       \
+  "v_writelane_b32 %[trk], " EA_KK ", m0\n\t"                                                         \
+  "v_writelane_b32 %[trs], " SLOTW ", m0\n\t"                                                         \
+  "s_sub_u32 " EA_X ", " EA_PV ", " EA_V "\n\t"         /* SCC = borrow: the passive order is the smaller one */ \
   "s_cbranch_scc1 L_A" Q "_" L "\n\t"                                                                 \
-  "v_writelane_b32 %[vol" Q "], " EA_X ", m0\n\t"       /* aggressor exhausted; X = passive remainder */ \
+  "v_writelane_b32 %[trv], " EA_V ", m0\n\t"            /* aggressor exhausted; X = passive remainder */ \
+  "s_mov_b32 m0, " EA_LS "\n\t"                                                                       \
+  "v_writelane_b32 %[vol" Q "], " EA_X ", m0\n\t"                                                     \
   "s_cmp_eq_u32 " EA_X ", 0\n\t"                                                                      \
   "s_cbranch_scc0 L_B" Q "_" L "\n\t"                                                                 \
   "s_andn2_b64 %[live" Q "], %[live" Q "], " EQ "\n\t"                                                \
   "L_B" Q "_" L ":\n\t"                                                                               \
-  EK_TRADE_REC(EA_V)                                                                                  \
+  "s_add_u32 %[trn], %[trn], 1\n\t"                     /* SCC = carry = buffer full */               \
   "s_cbranch_scc1 L_fullnext_%=\n\t"                                                                  \
   EA_LOOP(PH, KEND)                                                                                   \
   "L_A" Q "_" L ":\n\t"                                 /* passive order exhausted, aggressor goes on */ \
+  "v_writelane_b32 %[trv], " EA_PV ", m0\n\t"                                                         \
+  "s_mov_b32 m0, " EA_LS "\n\t"                                                                       \
   "v_writelane_b32 %[vol" Q "], 0, m0\n\t"                                                            \
   "s_andn2_b64 %[live" Q "], %[live" Q "], " EQ "\n\t"                                                \
   "s_sub_u32 " EA_V ", " EA_V ", " EA_PV "\n\t"                                                       \
-  EK_TRADE_REC(EA_PV)                                                                                 \
+  "s_add_u32 %[trn], %[trn], 1\n\t"                                                                   \
   "s_cbranch_scc1 L_fullA_" L "\n\t"                                                                  \
   "s_branch L_match_" L "\n\t"
 
@@ -413,8 +418,7 @@ __device__ __forceinline__ uint32_t events_asm_r1(uint32_t& k, uint32_t n_ev, ui
   VCHK                                                                                                \
   SKIP " " EK_KP ", " OPPB "\n\t"                      /* beyond the bound: cannot cross */           \
   "s_cbranch_scc1 L_restq_" L "\n\t"                                                                  \
-  "v_readlane_b32 " EA_ID ", %[id" RG "], " EA_EW "\n\t" /* (only a trade needs the id and the k word) */ \
-  EK_NLC(KKI "\n\t")                                                                                  \
+  EK_NLC(KKI "\n\t")                                  /* (only a trade needs the k word) */          \
   EK_LC("s_lshr_b32 " EA_KK ", " EA_EW ", 16\n\t"     /* k | passive side << 7, as the list word carries them */ \
         "s_and_b32 " EK_KT ", " EA_KK ", 0x7f\n\t")                                                   \
   "L_match_" L ":\n\t"                                                                                \
@@ -429,16 +433,19 @@ __device__ __forceinline__ uint32_t events_asm_r1(uint32_t& k, uint32_t n_ev, ui
               VOP " %[vm], %[vm], %[vm2]\n\t")                                                        \
   EA_DPP(DOP)                                                                                         \
   "v_readlane_b32 " EA_BEST ", %[vm], 63\n\t"                                                         \
+  "s_nop 1\n\t"                                        /* BEST as a VALU operand: 2 wait states */    \
+  /* both "which lane is it" compares BEFORE any scalar instruction: one wait for the vector unit's SGPR writes   \
+     instead of one behind the v_readlane and one behind the compares */                             \
+  "v_cmp_eq_u32_e64 " EA_E0 ", " EA_BEST ", %[key0]\n\t"                                              \
+  EA_IF2_##NR("v_cmp_eq_u32_e64 " EA_E1 ", " EA_BEST ", %[key1]\n\t")                                 \
   "s_mov_b32 " OPPB ", " EA_BEST "\n\t"                /* the bound is exact now */                   \
   NOX " " EA_BEST ", " EK_KP "\n\t"                                                                   \
   "s_cbranch_scc1 L_rest_" L "\n\t"                                                                   \
-  "v_cmp_eq_u32_e64 " EA_E0 ", " EA_BEST ", %[key0]\n\t"                                              \
-  EA_IF2_##NR("v_cmp_eq_u32_e64 " EA_E1 ", " EA_BEST ", %[key1]\n\t"                                  \
-              "s_cmp_lg_u64 " EA_E0 ", 0\n\t"                                                         \
+  EA_IF2_##NR("s_cmp_lg_u64 " EA_E0 ", 0\n\t"                                                         \
               "s_cbranch_scc0 L_pick1_" L "\n\t")                                                     \
-  EK_PICK("0", EA_E0, L, PH, KEND)                                                                    \
+  EK_PICK("0", EA_E0, L, PH, KEND, "", EA_LS)                                                         \
   EA_IF2_##NR("L_pick1_" L ":\n\t"                                                                    \
-              EK_PICK("1", EA_E1, L, PH, KEND))                                                       \
+              EK_PICK("1", EA_E1, L, PH, KEND, "s_or_b32 " EA_PID ", " EA_LS ", 64\n\t", EA_PID))        \
   "L_fullA_" L ":\n\t"                                  /* buffer full, volume left: the event restarts */ \
   "s_mov_b32 m0, " EA_EW "\n\t"                                                                       \
   "v_writelane_b32 %[vol" RG "], " EA_V ", m0\n\t"                                                    \
@@ -539,8 +546,8 @@ __device__ __forceinline__ uint32_t events_asm_r1(uint32_t& k, uint32_t n_ev, ui
       EK_TAIL \
       : [st] "=&s"(st), [vm] "=&v"(vm), [vm2] "=&v"(vm2), [k] "+s"(k), [trn] "+s"(trn), [sq] "+s"(sq), \
         [live0] "+s"(live0), [live1] "+s"(live1), [vol0] "+v"(vol0), [vol1] "+v"(vol1), [key0] "+v"(key0), \
-        [key1] "+v"(key1), [trk] "+v"(trk), [trp] "+v"(trp), [trv] "+v"(trv), [tra] "+v"(tra), [trs] "+v"(trs) \
-      : [price0] "v"(price0), [price1] "v"(price1), [id0] "v"(id0), [id1] "v"(id1), [ev0] "v"(ev0), [ev1] "v"(ev1), \
+        [key1] "+v"(key1), [trk] "+v"(trk), [trv] "+v"(trv), [trs] "+v"(trs) \
+      : [ev0] "v"(ev0), [ev1] "v"(ev1), \
         [bid0] "s"(bid0), [bid1] "s"(bid1), [nev] "s"(n_ev), [kend0] "s"(kend0), [tmask] "s"(tmask), [dt0] "v"(dt0), \
         [dt1] "v"(dt1), [chk] "s"(checked) \
       : EK_CLOBBERS);
@@ -560,20 +567,19 @@ __device__ __forceinline__ uint32_t events_asm_r1(uint32_t& k, uint32_t n_ev, ui
       "L_end_2_%=:\n\t" \
       EK_TAIL \
       : [st] "=&s"(st), [vm] "=&v"(vm), [k] "+s"(k), [trn] "+s"(trn), [sq] "+s"(sq), [live0] "+s"(live0), \
-        [vol0] "+v"(vol0), [key0] "+v"(key0), [trk] "+v"(trk), [trp] "+v"(trp), [trv] "+v"(trv), [tra] "+v"(tra), \
-        [trs] "+v"(trs) \
-      : [price0] "v"(price0), [id0] "v"(id0), [ev0] "v"(ev0), [bid0] "s"(bid0), [nev] "s"(n_ev), [tmask] "s"(tmask), \
+        [vol0] "+v"(vol0), [key0] "+v"(key0), [trk] "+v"(trk), [trv] "+v"(trv), [trs] "+v"(trs) \
+      : [ev0] "v"(ev0), [bid0] "s"(bid0), [nev] "s"(n_ev), [tmask] "s"(tmask), \
         [dt0] "v"(dt0), [chk] "s"(checked) \
       : EK_CLOBBERS);
 
 // Keyed form of events_asm_r2: `sq` = (seq_ctr - sbase) << 1 (the caller converts back), key0/key1 as described above.
 // checked = 0: the caller guarantees trading is enabled and every new order of the step has volume > 0
+// (trk / trv / trs: the compact trade records - k word, volume, passive order's pool slot; book_device.hpp flush_trades_compact)
 __device__ __forceinline__ uint32_t events_key_r2(uint32_t checked, uint32_t& k, uint32_t n_ev, uint32_t tmask, uint32_t& tr_n, uint32_t& sq,
                                                   uint64_t& live0, uint64_t& live1, uint64_t bid0, uint64_t bid1,
-                                                  uint32_t price0, uint32_t price1, uint32_t& vol0, uint32_t& vol1,
-                                                  uint32_t id0, uint32_t id1, uint32_t& key0, uint32_t& key1, uint32_t ev0,
-                                                  uint32_t ev1, uint32_t& trk, uint32_t& trp, uint32_t& trv, uint32_t& tra,
-                                                  uint32_t& trs, uint32_t dt0 = 0xFFFFFFFFu, uint32_t dt1 = 0xFFFFFFFFu) {
+                                                  uint32_t& vol0, uint32_t& vol1, uint32_t& key0, uint32_t& key1, uint32_t ev0,
+                                                  uint32_t ev1, uint32_t& trk, uint32_t& trv, uint32_t& trs,
+                                                  uint32_t dt0 = 0xFFFFFFFFu, uint32_t dt1 = 0xFFFFFFFFu) {
   uint32_t st, vm, vm2;
   auto u32 = [](uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane(x); };
   auto u64 = [&](uint64_t x) { return ((uint64_t)u32((uint32_t)(x >> 32)) << 32) | u32((uint32_t)x); };
@@ -594,9 +600,8 @@ __device__ __forceinline__ uint32_t events_key_r2(uint32_t checked, uint32_t& k,
 }
 
 __device__ __forceinline__ uint32_t events_key_r1(uint32_t checked, uint32_t& k, uint32_t n_ev, uint32_t tmask, uint32_t& tr_n, uint32_t& sq,
-                                                  uint64_t& live0, uint64_t bid0, uint32_t price0, uint32_t& vol0,
-                                                  uint32_t id0, uint32_t& key0, uint32_t ev0, uint32_t& trk, uint32_t& trp,
-                                                  uint32_t& trv, uint32_t& tra, uint32_t& trs, uint32_t dt0 = 0xFFFFFFFFu) {
+                                                  uint64_t& live0, uint64_t bid0, uint32_t& vol0, uint32_t& key0, uint32_t ev0,
+                                                  uint32_t& trk, uint32_t& trv, uint32_t& trs, uint32_t dt0 = 0xFFFFFFFFu) {
   uint32_t st, vm;
   auto u32 = [](uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane(x); };
   auto u64 = [&](uint64_t x) { return ((uint64_t)u32((uint32_t)(x >> 32)) << 32) | u32((uint32_t)x); };
