@@ -858,9 +858,12 @@ __device__ __forceinline__ uint32_t key_touch(const Book<R>& B, const KeyState<R
 
 // The keyed loop in C++ (pools of more than 128 slots - the assembly covers R <= 2 - and the -DBOURSE_AMD_ASM_EVENTS=0
 // build): same semantics as match_side / slot_event_at with ONE reduction per match step and no tie handling.
+template <int R>
+__device__ __forceinline__ void flush_trades_compact(Book<R>& B, const DevArgs& a, uint32_t book, uint64_t t0, int lane,
+                                                     const uint32_t (&ev)[R]);
 template <int R, bool agg_bid>
 __device__ __forceinline__ bool match_side_keyed(Book<R>& B, KeyState<R>& K, const DevArgs& a, uint32_t book, uint64_t t0,
-                                                 int lane, uint32_t k, uint32_t kp, uint32_t& v, uint32_t agg_id) {
+                                                 int lane, uint32_t k, uint32_t kp, uint32_t& v, const uint32_t (&ev)[R]) {
   const uint32_t v0 = v;
   while (v > 0) {
     // an empty side returns the neutral element: "no cross" by the same compare
@@ -868,32 +871,36 @@ __device__ __forceinline__ bool match_side_keyed(Book<R>& B, KeyState<R>& K, con
     const uint32_t best = agg_bid ? wave_umin(m) : wave_umax(m);
     (agg_bid ? K.alo : K.bhi) = best;
     if (agg_bid ? (best > kp) : (best < kp)) break;  // inclusive crossing test (:430 / :463) in key space
-    uint32_t pv = 0, pid = 0, tv = 0;
-    // the trade's price is the matched key's price field (no read of the pool's price register: those are not live
-    // across the loop any more, which is worth registers at R = 8)
-    const uint32_t price = K.pbase + (best >> (KEY_SB + 1u));
+    uint32_t pv = 0, tv = 0, slot = 0;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const uint64_t eq = __ballot(K.key[r] == best);  // the key is unique: exactly one lane of one register
       if (eq) {
         const uint32_t l = __builtin_ctzll(eq);
         pv = rdl(B.vol[r], l);
-        pid = rdl(B.id[r], l);
         tv = v < pv ? v : pv;
         pv -= tv;
         B.vol[r] = wrl(pv, l, B.vol[r]);
         if (pv == 0) B.live[r] &= ~eq;  // passive Filled -> remove_order
+        slot = (uint32_t)r * 64u + l;
       }
     }
     v -= tv;
-    emit_trade(B, a, book, t0, lane, k, !agg_bid, price, tv, agg_id, pid);
+    // compact record (as the assembly loop's): position | passive side, volume, passive slot - price and ids are gathered
+    // from the pool at the flush (flush_trades_compact)
+    if (B.tr_n == 64) flush_trades_compact<R>(B, a, book, t0, lane, ev);
+    const uint32_t tl = B.tr_n;
+    B.tr_k = wrl(k | (agg_bid ? 0u : 0x80000000u), tl, B.tr_k);
+    B.tr_vol = wrl(tv, tl, B.tr_vol);
+    B.tr_pas = wrl(slot, tl, B.tr_pas);
+    B.tr_n = tl + 1;
     B.trade_vol += tv;
   }
   return v0 != 0 && v == 0;
 }
 template <int R, int RS, bool CLS = true>
 __device__ __forceinline__ void slot_event_keyed_at(Book<R>& B, KeyState<R>& K, const DevArgs& a, uint32_t book, uint64_t t0,
-                                                    int lane, uint32_t k, uint32_t sl, uint32_t ew) {
+                                                    int lane, uint32_t k, uint32_t sl, uint32_t ew, const uint32_t (&ev)[R]) {
   const uint64_t bit = 1ull << sl;
   if (CLS ? !(ew & EV_NEW) : !(B.pend[RS] & bit)) {
     B.live[RS] &= ~bit;  // Cancellation
@@ -901,14 +908,14 @@ __device__ __forceinline__ void slot_event_keyed_at(Book<R>& B, KeyState<R>& K, 
   }
   if (!CLS) B.pend[RS] &= ~bit;
   const bool is_bid = CLS ? (ew & EV_BID) != 0 : (B.bid[RS] & bit) != 0;
-  const uint32_t kp = rdl(K.key[RS], sl), id = rdl(B.id[RS], sl);
+  const uint32_t kp = rdl(K.key[RS], sl);
   uint32_t v = rdl(B.vol[RS], sl);
   // a market order's remainder is dropped (orderbook.rs:521-524); the event words' lists (CLS) carry none
   const bool market = !CLS && kp == (is_bid ? 0xFFFFFFFEu : 1u);
   bool filled = false;
   if (B.trading && !(is_bid ? kp < K.alo : kp > K.bhi))  // (beyond the bound: cannot cross)
-    filled = is_bid ? match_side_keyed<R, true>(B, K, a, book, t0, lane, k, kp, v, id)
-                    : match_side_keyed<R, false>(B, K, a, book, t0, lane, k, kp, v, id);
+    filled = is_bid ? match_side_keyed<R, true>(B, K, a, book, t0, lane, k, kp, v, ev)
+                    : match_side_keyed<R, false>(B, K, a, book, t0, lane, k, kp, v, ev);
   if (!market && !filled) {  // rest the remainder with a fresh arrival field
     B.vol[RS] = wrl(v, sl, B.vol[RS]);
     if (is_bid)
@@ -922,14 +929,14 @@ __device__ __forceinline__ void slot_event_keyed_at(Book<R>& B, KeyState<R>& K, 
 }
 template <int R, int RS = 0, bool CLS = true>
 __device__ __forceinline__ void slot_event_keyed(Book<R>& B, KeyState<R>& K, const DevArgs& a, uint32_t book, uint64_t t0,
-                                                 int lane, uint32_t k, uint32_t n, uint32_t ew) {
+                                                 int lane, uint32_t k, uint32_t n, uint32_t ew, const uint32_t (&ev)[R]) {
   if constexpr (RS + 1 < R) {  // ONE uniform branch per pool register, every pool access below with a compile-time index
     if ((n >> 6) == (uint32_t)RS)
-      slot_event_keyed_at<R, RS, CLS>(B, K, a, book, t0, lane, k, n & 63, ew);
+      slot_event_keyed_at<R, RS, CLS>(B, K, a, book, t0, lane, k, n & 63, ew, ev);
     else
-      slot_event_keyed<R, RS + 1, CLS>(B, K, a, book, t0, lane, k, n, ew);
+      slot_event_keyed<R, RS + 1, CLS>(B, K, a, book, t0, lane, k, n, ew, ev);
   } else {
-    slot_event_keyed_at<R, RS, CLS>(B, K, a, book, t0, lane, k, n & 63, ew);
+    slot_event_keyed_at<R, RS, CLS>(B, K, a, book, t0, lane, k, n & 63, ew, ev);
   }
 }
 
@@ -1067,10 +1074,11 @@ __device__ __forceinline__ uint32_t step_from_list(Book<R>& B, const DevArgs& a,
         const uint32_t cnt = rfl((n_ev - kb) < 64u ? (n_ev - kb) : 64u);
         for (uint32_t l = 0; l < cnt; ++l) {
           const uint32_t ew = rdl(ev[re], l);
-          slot_event_keyed<R, 0, CLS>(B, K, a, book, t0, lane, kb + l, CLS ? (ew & EV_SLOT) : ew, ew);
+          slot_event_keyed<R, 0, CLS>(B, K, a, book, t0, lane, kb + l, CLS ? (ew & EV_SLOT) : ew, ew, ev);
         }
       }
     }
+    flush_trades_compact<R>(B, a, book, t0, lane, ev);  // (the loop's records are compact: filled in before the snapshot)
     keys_end<R>(B, K);
   } else
 #pragma unroll
