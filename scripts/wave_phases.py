@@ -7,8 +7,12 @@ sys.path.insert(0, ROOT)
 import numpy as np, bourse_amd as bk
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 pipe = sys.argv[2] if len(sys.argv) > 2 else "auto"
-G = [(64, (32, 64), (10, 20), 2, 0.8), (64, (32, 64), (50, 70), 2, 0.2)]
-env = bk.ManyBookEnv(B, 101, 0, 2, 100_000, levels=32, max_live_orders=128, trade_capacity=64 * 50, history_capacity=50, strict=False)
+WL = sys.argv[3] if len(sys.argv) > 3 else "C3"
+if WL == "C5":
+    G, LV, POOL = [(256, (100, 164), (10, 20), 2, 0.8), (256, (100, 164), (50, 70), 2, 0.2)], 64, 512
+else:
+    G, LV, POOL = [(64, (32, 64), (10, 20), 2, 0.8), (64, (32, 64), (50, 70), 2, 0.2)], 32, 128
+env = bk.ManyBookEnv(B, 101, 0, 2, 100_000, levels=LV, max_live_orders=POOL, trade_capacity=POOL // 2 * 50, history_capacity=50, strict=False)
 env.set_random_agents(G)
 env.set_pipeline(pipe)
 L = env._L
