@@ -23,11 +23,17 @@
 #include <stdint.h>
 
 #include "event_asm.hpp"
+#include "event_asm_gen.hpp"
 
 // 1: the event loop of a 128-slot pool runs the hand-written gfx950 code of event_asm.hpp; 0: the compiled C++ below
 // (same semantics; the parity suite passes on both - build with -DBOURSE_AMD_ASM_EVENTS=0 to compare)
 #ifndef BOURSE_AMD_ASM_EVENTS
 #define BOURSE_AMD_ASM_EVENTS 1
+#endif
+// 1: pools of 256 / 512 slots (R = 4, 8) run the generated assembly loop of event_asm_gen.hpp (round 4); 0: the compiled
+// C++ keyed loop (match_side_keyed / slot_event_keyed), which stays the path of the members' lists and of markets
+#ifndef BOURSE_AMD_ASM_R48
+#define BOURSE_AMD_ASM_R48 1
 #endif
 
 namespace bkd {
@@ -1067,6 +1073,29 @@ __device__ __forceinline__ uint32_t step_from_list(Book<R>& B, const DevArgs& a,
         flush_trades<R>(B, a, book, t0, lane);
     }
   } else if (KeyState<R> K; (CLS || PENDKEY) && !MKT && BOURSE_AMD_KEYED_EVENTS && keys_begin<R, !CLS>(B, newm, rfl(n_ev), K)) {
+   if constexpr ((R == 4 || R == 8) && CLS && BOURSE_AMD_ASM_EVENTS && BOURSE_AMD_ASM_R48) {
+    // the generated assembly loop (event_asm_gen.hpp): live asks / live bids as two mask sets, compact trade records
+    uint64_t askm[R], bidm[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      askm[r] = B.live[r] & ~B.bid[r];
+      bidm[r] = B.live[r] & B.bid[r];
+    }
+    uint32_t k = 0;
+    const uint32_t nev = rfl(n_ev), tmask = B.trading ? 0xFFFFFFFFu : 0u;
+    for (;;) {
+      uint32_t full;
+      if constexpr (R == 4)
+        full = events_key_r4(k, nev, tmask, B.tr_n, K.sq, askm, bidm, B.vol, K.key, ev, B.tr_k, B.tr_vol, B.tr_pas);
+      else
+        full = events_key_r8(k, nev, tmask, B.tr_n, K.sq, askm, bidm, B.vol, K.key, ev, B.tr_k, B.tr_vol, B.tr_pas);
+      if (B.tr_n) B.trade_vol += wave_add((uint32_t)lane < B.tr_n ? B.tr_vol : 0u);
+      flush_trades_compact<R>(B, a, book, t0, lane, ev);
+      if (!full) break;
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) B.live[r] = askm[r] | bidm[r];
+   } else {
 #pragma unroll
     for (int re = 0; re < R; ++re) {
       const uint32_t kb = re * 64;
@@ -1079,6 +1108,7 @@ __device__ __forceinline__ uint32_t step_from_list(Book<R>& B, const DevArgs& a,
       }
     }
     flush_trades_compact<R>(B, a, book, t0, lane, ev);  // (the loop's records are compact: filled in before the snapshot)
+   }
     keys_end<R>(B, K);
   } else
 #pragma unroll
