@@ -1073,8 +1073,35 @@ __device__ __forceinline__ uint32_t step_from_list(Book<R>& B, const DevArgs& a,
         flush_trades<R>(B, a, book, t0, lane);
     }
   } else if (KeyState<R> K; (CLS || PENDKEY) && !MKT && BOURSE_AMD_KEYED_EVENTS && keys_begin<R, !CLS>(B, newm, rfl(n_ev), K)) {
-   if constexpr ((R == 4 || R == 8) && CLS && BOURSE_AMD_ASM_EVENTS && BOURSE_AMD_ASM_R48) {
-    // the generated assembly loop (event_asm_gen.hpp): live asks / live bids as two mask sets, compact trade records
+   if constexpr ((R == 4 || R == 8) && BOURSE_AMD_ASM_EVENTS && BOURSE_AMD_ASM_R48) {
+    // the generated assembly loop (event_asm_gen.hpp): live asks / live bids as two mask sets, compact trade records.
+    // It reads SELF-CLASSIFYING event words (slot | EV_NEW | EV_BID).  The members' lists of an AgentSet (PENDKEY) hold
+    // bare slots - New iff the slot's pend bit is set, the side in its bid bit - and are converted here, one vector pass
+    // per list register in use: a slot holds at most one event per step (a pending order sits in a slot that was free
+    // when the step began), so classifying up front is the same as classifying at the event.
+    uint32_t evw[R];
+#pragma unroll
+    for (int re = 0; re < R; ++re) {
+      evw[re] = ev[re];
+      if (!CLS && n_ev > (uint32_t)re * 64u) {
+        const uint32_t sl = ev[re] & EV_SLOT;
+        uint32_t pl = 0, ph = 0, bl = 0, bh = 0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const bool here = (sl >> 6) == (uint32_t)r;
+          pl = here ? (uint32_t)newm[r] : pl;
+          ph = here ? (uint32_t)(newm[r] >> 32) : ph;
+          bl = here ? (uint32_t)B.bid[r] : bl;
+          bh = here ? (uint32_t)(B.bid[r] >> 32) : bh;
+        }
+        const uint32_t pb = (uint32_t)(mk64(pl, ph) >> (sl & 63u)) & 1u, bb = (uint32_t)(mk64(bl, bh) >> (sl & 63u)) & 1u;
+        evw[re] = sl | (pb ? EV_NEW | (bb ? EV_BID : 0u) : 0u);
+      }
+    }
+    if (!CLS) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) B.pend[r] = 0;  // every pending order is an event of this step
+    }
     uint64_t askm[R], bidm[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -1086,11 +1113,11 @@ __device__ __forceinline__ uint32_t step_from_list(Book<R>& B, const DevArgs& a,
     for (;;) {
       uint32_t full;
       if constexpr (R == 4)
-        full = events_key_r4(k, nev, tmask, B.tr_n, K.sq, askm, bidm, B.vol, K.key, ev, B.tr_k, B.tr_vol, B.tr_pas);
+        full = events_key_r4(k, nev, tmask, B.tr_n, K.sq, askm, bidm, B.vol, K.key, evw, B.tr_k, B.tr_vol, B.tr_pas);
       else
-        full = events_key_r8(k, nev, tmask, B.tr_n, K.sq, askm, bidm, B.vol, K.key, ev, B.tr_k, B.tr_vol, B.tr_pas);
+        full = events_key_r8(k, nev, tmask, B.tr_n, K.sq, askm, bidm, B.vol, K.key, evw, B.tr_k, B.tr_vol, B.tr_pas);
       if (B.tr_n) B.trade_vol += wave_add((uint32_t)lane < B.tr_n ? B.tr_vol : 0u);
-      flush_trades_compact<R>(B, a, book, t0, lane, ev);
+      flush_trades_compact<R>(B, a, book, t0, lane, evw);
       if (!full) break;
     }
 #pragma unroll

@@ -6,7 +6,8 @@ What limits an asm statement is its 30 OPERANDS, not its size: the pool rows tra
 physical registers (`"+{v[40:47]}"`), so the text below names v40.. / s36.. directly, and one statement takes 14 operands.
 Semantics are event_asm.hpp's keyed loop (orderbook.rs:429-487, 583-611, 622-644, 843-870 through the 32-bit keys of
 book_device.hpp keys_begin): cancellation, new order with the bound test, match against the best key of the other side,
-compact trade records {k word, volume, passive slot}, rest with a fresh arrival field.  Differences, all forced by R:
+compact trade records {k word, volume, passive slot}, rest with a fresh arrival field (a market order - the members' lists
+of an AgentSet carry them - never rests).  Differences, all forced by R:
   * live asks / live bids are kept as TWO mask sets (askm, bidm: no `live & ~bid` algebra per match step);
   * the slot's own pool row (its key / volume / mask words) is addressed DYNAMICALLY - s_set_gpr_idx_on for the vector rows,
     s_movrels / s_movreld for the mask pairs - instead of one copy of the code per pool register (8 x 2 x 8 copies);
@@ -175,14 +176,21 @@ def gen(N):
         e(f"v_writelane_b32 %[vm], {S['V']}, m0")
         row_write(VB, "%[vm]")
         e("s_branch L_flush_%=")
-        # rests with what the trades left ...
+        # rests with what the trades left ... (a market order's remainder is dropped: orderbook.rs:521-524; its prefix is
+        # the sentinel of book_device.hpp keys_begin<MARKETS> - 0xFFFFFFFE for a bid, 1 for an ask - which no limit order has)
         e(f"L_rest_{tag}_%=:")
+        e(f"s_cmp_eq_u32 {S['KP']}, {'0xfffffffe' if agg_bid else '1'}")
+        e("s_cbranch_scc1 L_loop_%=")
         row_read("%[vm]", VB)
         e(f"s_mov_b32 m0, {S['EW']}")
         e(f"v_writelane_b32 %[vm], {S['V']}, m0")
         row_write(VB, "%[vm]")
-        # ... or untouched
+        e(f"s_branch L_restk_{tag}_%=")
+        # ... or untouched (no volume / trading disabled / beyond the bound; a market order can only get here by the first two)
         e(f"L_restq_{tag}_%=:")
+        e(f"s_cmp_eq_u32 {S['KP']}, {'0xfffffffe' if agg_bid else '1'}")
+        e("s_cbranch_scc1 L_loop_%=")
+        e(f"L_restk_{tag}_%=:")
         e(f"s_xor_b32 {S['X']}, {S['KP']}, %[sq]")
         e(f"{'s_max_u32' if agg_bid else 's_min_u32'} {ownb}, {ownb}, {S['X']}")   # this side's bound covers the new order
         row_read("%[vt]", KB)
