@@ -182,9 +182,11 @@ struct bk_env {
   int wave_split_parts() const {
     if (wave_parts > 0)  // set explicitly (tests, sweeps): any batch of >= 64 books per part
       return static_cast<int>(std::max(1u, std::min(static_cast<uint32_t>(wave_parts), cfg.n_books / 64u)));
-    // (AgentSets of Noise / Momentum members: two parts - scripts sweep at C5 as written, 8 192 books: 1 part 21.9 M,
-    // 2: 26.1, 3: 25.2, 4: 25.2, 6: 19.2, 8: 20.4 M book-steps/s)
-    return static_cast<int>(std::max(1u, std::min(n_mixed ? 2u : 3u, cfg.n_books / 2048u)));
+    // One part per hardware queue (four) once a part holds 2 048 books.  Re-swept in round 4, after the event loops got
+    // faster (scripts/exp_c5p.sh): C5 as written 32.3 / 32.8 / 34.0 / 21.9 M in 2 / 3 / 4 / 5 parts (round 3: two parts), C5
+    // stand-in 26.1 / 27.0 / 19.3 M in 3 / 4 / 5, the C3 shards 116.7 / 117.7 M (8 192 books) and 140.0 / 139.7 M (16 384) in
+    // 3 / 4; a fifth part shares a queue and halves the rate.
+    return static_cast<int>(std::max(1u, std::min(4u, cfg.n_books / 2048u)));
   }
   // THE pipeline choice: the one function bk_run launches from and bk_get_pipeline reports from (they duplicated the rule
   // until round 4).  `pipeline` is the caller's request (0 auto); a request the env's agents cannot take (e.g. "wave" for

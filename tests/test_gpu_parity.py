@@ -1761,7 +1761,7 @@ def test_full_size_c4_shard_as_written_exact_parity_vs_oracle(bk, oracle, n_gpus
 
 # the auto rule at the C4 shard sizes (bourse_amd.hip bk_get_pipeline); the test above pins it so that a change of the
 # thresholds is a visible decision
-C4_AUTO_PIPELINE = {8192: ("wave_split", 3), 16384: ("wave_split", 3), 32768: ("split", 4)}
+C4_AUTO_PIPELINE = {8192: ("wave_split", 4), 16384: ("wave_split", 4), 32768: ("split", 4)}
 
 
 def test_full_size_c5_standin_exact_parity_vs_oracle(bk, oracle):
@@ -1875,7 +1875,7 @@ def test_bk_warm_leaves_no_trace_on_agent_sets_and_multi_part_launches(bk, oracl
     the restored block) and multi-part launches (the fork / join of the parts' streams around the snapshot and restore
     copies) - between two run() chunks, against the oracle."""
     members = [("momentum", 0, 10, MOM_P), ("noise", 10, 20, NOISE_P)]
-    for pipeline, B, parts in (("auto", 4096, 2), ("wave_split", 600, 1), ("split", 4096, 1)):
+    for pipeline, B, parts in (("auto", 4096, 2), ("wave_split", 600, 1), ("split", 4096, 1)):  # (4 096 / 2 048 = 2 parts)
         env = bk.ManyBookEnv(B, 101, 0, 1, 1_000_000, True, levels=10, max_live_orders=128, trade_capacity=64 * 14,
                              history_capacity=14)
         env.set_agents(members)
