@@ -215,7 +215,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--l1-gather", action="store_true", help="also all-gather every book's L1 record per launch (SURVEY 8e ii)")
     ap.add_argument("--no-history", action="store_true", help="keep only the latest L2 record (diagnostic)")
-    ap.add_argument("--pipeline", default="auto", choices=["auto", "fused", "split", "wave_split", "wave"])
+    ap.add_argument("--pipeline", default="auto", choices=["auto", "fused", "split", "wave_split", "wave", "wave_persist"])
     ap.add_argument("--wave-parts", type=int, default=0, help="parts the wave pipeline cuts the batch in (0 = library default)")
     ap.add_argument("--profile-every", type=int, default=8, help="HIP-event-time every Nth step's kernels (0 = none)")
     ap.add_argument("--preheat-steps", type=int, default=100,
@@ -340,7 +340,7 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
     env.profile(False)
-    kind0 = "k_run_mixed" if mixed else ("k_run_wave" if pipe == "wave" else "k_run_random")
+    kind0 = "k_run_mixed" if mixed else ("k_run_wave" if pipe == "wave" else ("k_run_split" if pipe == "wave_persist" else "k_run_random"))
     kind1 = ("k_agents_mixed_wave" if pipe == "wave_split" else "k_agents_mixed_lanes") if mixed else (
         "k_agents_wave" if pipe == "wave_split" else "k_agents_fsm")
     per_kind = {k: env.profile_read_kind(i) for i, k in enumerate((kind0, kind1, "k_step_batch", "k_step_events"))}

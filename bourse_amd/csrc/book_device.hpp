@@ -1439,10 +1439,10 @@ __global__ __launch_bounds__(64) void k_agents_fsm(DevArgs a) {
 
 template <int R, bool MKT, bool POOLPEND>
 __device__ __forceinline__ void step_batch_book(const DevArgs& a, uint32_t book, int lane, uint32_t* lds, uint64_t step_index,
-                                                uint32_t write_last, Book<R>& B, Rng& rng);
+                                                uint32_t write_last, Book<R>& B, Rng& rng, uint32_t hist_slot);
 template <int R, bool MKT, bool POOLPEND>
 __device__ __forceinline__ void step_batch_raw(const DevArgs& a, uint32_t book, int lane, uint32_t* lds, uint64_t step_index,
-                                               uint32_t write_last, const StepRaw<R>& w, Book<R>& B, Rng& rng);
+                                               uint32_t write_last, const StepRaw<R>& w, Book<R>& B, Rng& rng, uint32_t hist_slot);
 // POOLPEND (split pipeline of AgentSets with Noise/Momentum members, k_agents_mixed): the new orders already sit in the
 // pool with their pend bit and id (created by the members' update); the batch only carries the shuffled event list.
 template <int R, bool MKT, bool POOLPEND = false>
@@ -1474,14 +1474,14 @@ __global__ __launch_bounds__(64, R >= 8 ? 5 : 1) void k_step_batch(DevArgs a, ui
   // round trip at a wave's start is the longest single link of its chain: the 18 registers of the second book take the
   // kernel from 40 to 64 VGPRs, only four event waves then fit beside a k_agents_fsm wave, and C3 fell from 281 to
   // 221 - 236 M whatever the lane kernel's own footprint was set to: docs/EXPERIMENTS.md.)
-  step_batch_book<R, MKT, POOLPEND>(a, book, lane, lds, step_index, write_last, B, rng);
+  step_batch_book<R, MKT, POOLPEND>(a, book, lane, lds, step_index, write_last, B, rng, a.hist_slot0);
 }
 
 // One book's Env::step from its step batch (the body of k_step_batch; k_step_decode runs it in front of the next step's
 // decode).  lds: LDS_DW_PER_WAVE dwords of this wave's.  Leaves the stored book in B / rng for a caller that goes on.
 template <int R, bool MKT, bool POOLPEND>
 __device__ __forceinline__ void step_batch_book(const DevArgs& a, uint32_t book, int lane, uint32_t* lds, uint64_t step_index,
-                                                uint32_t write_last, Book<R>& B, Rng& rng) {
+                                                uint32_t write_last, Book<R>& B, Rng& rng, uint32_t hist_slot) {
   BK_STAMP_START(B, book);
   StepRaw<R> w;
   const uint32_t mkt_book0 = MKT ? (book / a.assets) * a.assets : book;
@@ -1498,14 +1498,14 @@ __device__ __forceinline__ void step_batch_book(const DevArgs& a, uint32_t book,
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // phase 0 = the loads' round trip
 #endif
   BK_STAMP(B, 0, 0, lane);
-  step_batch_raw<R, MKT, POOLPEND>(a, book, lane, lds, step_index, write_last, w, B, rng);
+  step_batch_raw<R, MKT, POOLPEND>(a, book, lane, lds, step_index, write_last, w, B, rng, hist_slot);
   BK_STAMP(B, 0, 5, lane);  // store
   BK_STAMP_COUNT(B, 0, lane);
 }
 // ... from what load_step_raw / the wrapper above loaded
 template <int R, bool MKT, bool POOLPEND>
 __device__ __forceinline__ void step_batch_raw(const DevArgs& a, uint32_t book, int lane, uint32_t* lds, uint64_t step_index,
-                                               uint32_t write_last, const StepRaw<R>& w, Book<R>& B, Rng& rng) {
+                                               uint32_t write_last, const StepRaw<R>& w, Book<R>& B, Rng& rng, uint32_t hist_slot) {
   const uint32_t mkt_book0 = MKT ? (book / a.assets) * a.assets : book;
   const uint32_t asset = book - mkt_book0;
   uint32_t* st = a.state + (size_t)book * a.state_stride;
@@ -1571,7 +1571,7 @@ __device__ __forceinline__ void step_batch_raw(const DevArgs& a, uint32_t book, 
   B.next_id = base;
   uint32_t n_own = 0;
   BK_STAMP(B, 0, 1, lane);  // unpack + placing masks + new orders into the pool
-  const uint32_t ntr = step_from_list<R, MKT, MKT && POOLPEND, !POOLPEND, POOLPEND && !MKT>(B, a, book, lane, ev, n_ev, lds, a.hist_slot0,
+  const uint32_t ntr = step_from_list<R, MKT, MKT && POOLPEND, !POOLPEND, POOLPEND && !MKT>(B, a, book, lane, ev, n_ev, lds, hist_slot,
                                                                write_last != 0, MKT ? a.asset_div[asset] : a.tick_div,
                                                                mine, n_own, asset);
   store_book<R, !POOLPEND>(B, rng, st, lane, step_index + 1, ntr, n_own);

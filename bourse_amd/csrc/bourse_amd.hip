@@ -176,6 +176,11 @@ struct bk_env {
   bool use_wave() const {        // split form: k_agents_wave + k_step_batch
     return wave_ok() && (pipeline == 4 || (pipeline == 0 && cfg.n_books > wave_fused_max() && cfg.n_books < lane_split_min_books(R)));
   }
+  // persistent split form (k_run_split, mode 6): on request - and by itself where it wins (set below once measured)
+  uint32_t persist_min = 0, persist_max = 0;  // auto: books in [persist_min, persist_max] take it (0, 0 = never)
+  bool use_persist_split() const {
+    return wave_ok() && (pipeline == 6 || (pipeline == 0 && R <= 2 && cfg.n_books >= persist_min && cfg.n_books <= persist_max && persist_max));
+  }
   bool use_wave_fused() const {  // persistent fused form: k_run_wave
     return wave_ok() && (pipeline == 5 || (pipeline == 0 && cfg.n_books <= wave_fused_max()));
   }
@@ -194,6 +199,7 @@ struct bk_env {
   enum PlanKind {
     PL_FUSED_RANDOM,  // k_run_random: one wave per book, all phases, n_steps per launch (also: no agents = plain steps)
     PL_FUSED_WAVE,    // k_run_wave: wave-parallel decode + events, persistent
+    PL_PERSIST_SPLIT, // k_run_split: the same two halves per step, persistent, the book parked in memory in between
     PL_SPLIT_LANES,   // k_agents_fsm (one lane per book / market) + k_step_batch
     PL_SPLIT_WAVE,    // k_agents_wave (one wave per book, stream decoded 64 draws at a time) + k_step_batch
     PL_MIXED_FUSED,   // k_run_mixed: AgentSet members, fused
@@ -212,6 +218,7 @@ struct bk_env {
       if (pipeline == 3) return {PL_MIXED_WPB, parts()};
       return {PL_MIXED_FUSED, 1};
     }
+    if (use_persist_split()) return {PL_PERSIST_SPLIT, 1};
     if (use_wave_fused()) return {PL_FUSED_WAVE, 1};
     if (use_wave()) return {PL_SPLIT_WAVE, wave_split_parts()};
     // (auto with RandomAgents on independent books never gets here below lane_split_min_books: the wave forms take it)
@@ -456,6 +463,17 @@ int launch_wave_fused(bk_env* env, const DevArgs& a, uint64_t first_step, uint32
   env->prof_now = env->profile > 0;
   ProfScope ps(env, 0);
   hipLaunchKernelGGL(k_run_wave<R>, dim3((env->cfg.n_books + 7) / 8), dim3(512), 0, env->stream, a, wva, first_step, n_steps);
+  HIPCHK(hipGetLastError());
+  return BK_OK;
+}
+
+template <int R>
+int launch_persist_split(bk_env* env, const DevArgs& a, uint64_t first_step, uint32_t n_steps) {
+  WaveArgs wva{};
+  if (int rc = wave_args(env, &wva)) return rc;
+  env->prof_now = env->profile > 0;
+  ProfScope ps(env, 0);
+  hipLaunchKernelGGL(k_run_split<R>, dim3((env->cfg.n_books + 3) / 4), dim3(256), 0, env->stream, a, wva, first_step, n_steps);
   HIPCHK(hipGetLastError());
   return BK_OK;
 }
@@ -857,6 +875,7 @@ int bk_env_create(const bk_config* cfg, bk_env** out) {
     if (std::strcmp(pm, "split") == 0) env->pipeline = 2;
     if (std::strcmp(pm, "wave_split") == 0) env->pipeline = 4;
     if (std::strcmp(pm, "wave") == 0) env->pipeline = 5;
+    if (std::strcmp(pm, "wave_persist") == 0) env->pipeline = 6;
   }
   if (const char* np = std::getenv("BOURSE_AMD_SPLIT_PARTS")) {
     const int v = std::atoi(np);
@@ -1471,6 +1490,10 @@ int bk_run(bk_env* env, uint64_t n_steps) {
       env->ml_valid = false;
       BK_BY_R(launch_mixed<1>(env, a, env->steps_done, ns), launch_mixed<2>(env, a, env->steps_done, ns),
               launch_mixed<4>(env, a, env->steps_done, ns), launch_mixed<8>(env, a, env->steps_done, ns))
+      break;
+    case bk_env::PL_PERSIST_SPLIT:
+      BK_BY_R(launch_persist_split<1>(env, a, env->steps_done, ns), launch_persist_split<2>(env, a, env->steps_done, ns),
+              launch_persist_split<4>(env, a, env->steps_done, ns), launch_persist_split<8>(env, a, env->steps_done, ns))
       break;
     case bk_env::PL_FUSED_WAVE:
       BK_BY_R(launch_wave_fused<1>(env, a, env->steps_done, ns), launch_wave_fused<2>(env, a, env->steps_done, ns),
@@ -2116,6 +2139,7 @@ int bk_get_pipeline(bk_env* env, int* split, int* n_parts) {
     case bk_env::PL_SPLIT_WAVE:
     case bk_env::PL_MIXED_WAVE: code = 2; break;
     case bk_env::PL_FUSED_WAVE: code = 3; break;
+    case bk_env::PL_PERSIST_SPLIT: code = 4; break;
   }
   if (split) *split = code;
   if (n_parts) *n_parts = pl.parts;
@@ -2123,10 +2147,11 @@ int bk_get_pipeline(bk_env* env, int* split, int* n_parts) {
 }
 
 int bk_set_pipeline(bk_env* env, int mode) {
-  if (!env || mode < 0 || mode > 5)
+  if (!env || mode < 0 || mode > 6)
     return fail(BK_INVALID_ARGUMENT,
                 "pipeline mode must be 0 (auto), 1 (fused), 2 (split), 3 (split, wave-per-book AgentSet members), 4 (wave_split: "
-                "wave-parallel RNG decode kernel + event kernel) or 5 (wave: both fused in one persistent kernel)");
+                "wave-parallel RNG decode kernel + event kernel), 5 (wave: both fused in one persistent kernel) or 6 (wave_persist: "
+                "both halves per step in one persistent kernel, the book parked in memory in between)");
   env->pipeline = mode;
   return BK_OK;
 }
