@@ -215,7 +215,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--l1-gather", action="store_true", help="also all-gather every book's L1 record per launch (SURVEY 8e ii)")
     ap.add_argument("--no-history", action="store_true", help="keep only the latest L2 record (diagnostic)")
-    ap.add_argument("--pipeline", default="auto", choices=["auto", "fused", "split", "wave_split", "wave", "wave_persist"])
+    ap.add_argument("--pipeline", default="auto", choices=["auto", "fused", "split", "wave_split", "wave"])
     ap.add_argument("--wave-parts", type=int, default=0, help="parts the wave pipeline cuts the batch in (0 = library default)")
     ap.add_argument("--profile-every", type=int, default=8, help="HIP-event-time every Nth step's kernels (0 = none)")
     ap.add_argument("--preheat-steps", type=int, default=100,
@@ -340,7 +340,7 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
     env.profile(False)
-    kind0 = "k_run_mixed" if mixed else ("k_run_wave" if pipe == "wave" else ("k_run_split" if pipe == "wave_persist" else "k_run_random"))
+    kind0 = "k_run_mixed" if mixed else ("k_run_wave" if pipe == "wave" else "k_run_random")
     kind1 = ("k_agents_mixed_wave" if pipe == "wave_split" else "k_agents_mixed_lanes") if mixed else (
         "k_agents_wave" if pipe == "wave_split" else "k_agents_fsm")
     per_kind = {k: env.profile_read_kind(i) for i, k in enumerate((kind0, kind1, "k_step_batch", "k_step_events"))}
@@ -396,12 +396,9 @@ def main():
         "k_step_batch": 2.0 * S + 64.0 + 2.0 * ev_per_bs + 8.0 * new_per_bs + W4 + 32.0 * tr_per_bs,
         "k_step_events": 2.0 * S + 2.0 * W4 + 20.0 * ev_per_bs + 32.0 * tr_per_bs,
     }
-    # wave_split's inner steps: events of step s + decode of step s + 1 in one launch = both kernels' bytes minus the
-    # header line the decode no longer re-reads
-    per_bs["k_step_decode"] = per_bs["k_step_batch"] + per_bs["k_agents_wave"] - 256.0
     bs_per_launch = {kind0: B * spl, "k_agents_fsm": B / parts, "k_agents_wave": B / parts, "k_agents_mixed_lanes": B / parts,
                      "k_agents_mixed_wave": B / parts,
-                     "k_step_batch": B / parts, "k_step_decode": B / parts,
+                     "k_step_batch": B / parts,
                      "k_step_events": B}
     # PMC figures (HBM traffic, instruction counts) cannot be collected inside this process: they are rocprofv3 --pmc
     # passes of this same command (scripts/profile_round.sh), committed under profiles/ and REPLAYED here, keyed by
@@ -438,10 +435,6 @@ def main():
     issue = None
     SCALAR_PEAK, VECTOR_PEAK, MIX_1TO1_PEAK = 0.95, 1.65, 1.70
     ins = {k: pmc.get(k, {}).get("insts_per_book_step") for k in kernels}
-    if "k_step_decode" in kernels:
-        # one step = one k_step_decode (the launch's first / last step: k_agents_wave / k_step_batch, whose instructions are
-        # the same code): count the fused kernel alone
-        ins = {"k_step_decode": pmc.get("k_step_decode", {}).get("insts_per_book_step")}
     if all(ins.values()) and ins:
         salu = sum(v["salu"] for v in ins.values())
         valu = sum(v["valu"] for v in ins.values())
@@ -479,10 +472,7 @@ def main():
                            f"collective, 64 B stats all-gather per launch" if world > 1 else "single GPU",
             "trades_per_book_step": tr_per_bs, "events_per_book_step": ev_per_bs,
             "events_per_s": ev_per_bs * value, "trades_per_s": tr_per_bs * value,
-            "pipeline": (f"{pipe} (k_step_decode per step = events of step s + decode of step s + 1 in one launch; k_agents_wave / "
-                         f"k_step_batch at a launch's ends; {parts} book parts on separate streams)"
-                         if per_kind.get("k_step_decode", (0, 0))[1] else
-                         f"{pipe} ({kind1} + k_step_batch per step, {parts} book parts on separate streams)")
+            "pipeline": f"{pipe} ({kind1} + k_step_batch per step, {parts} book parts on separate streams)"
             if pipe in ("split", "wave_split") else f"fused ({kind0})",
         },
         "roofline": {
@@ -514,10 +504,7 @@ def main():
     # stretches every launch.  Two unambiguous figures beside it: (1) aggregate = the algorithmic bytes of ALL step
     # kernels per step / the step's wall time; (2) the dominant kernel launched ALONE over the whole batch (one part).
     R = out["roofline"]
-    if "k_step_decode" in kernels:  # a launch of spl steps = 1 decode + (spl - 1) fused steps + 1 event kernel per part
-        step_bytes = ((spl - 1) * per_bs["k_step_decode"] + per_bs["k_agents_wave"] + per_bs["k_step_batch"]) / spl * B
-    else:
-        step_bytes = sum(kernels[k]["bytes_per_book_step"] for k in kernels) * B  # every kernel visits every book once per step
+    step_bytes = sum(kernels[k]["bytes_per_book_step"] for k in kernels) * B  # every kernel visits every book once per step
     R["achieved_node"] = step_bytes * world / (out["ms_per_step"] * 1e-3) / 1e9
     R["peak_node"] = HBM_PEAK_GBPS * world
     R["frac_node"] = R["achieved_node"] / R["peak_node"]

@@ -1477,7 +1477,7 @@ __global__ __launch_bounds__(64, R >= 8 ? 5 : 1) void k_step_batch(DevArgs a, ui
   step_batch_book<R, MKT, POOLPEND>(a, book, lane, lds, step_index, write_last, B, rng, a.hist_slot0);
 }
 
-// One book's Env::step from its step batch (the body of k_step_batch; k_step_decode runs it in front of the next step's
+// One book's Env::step from its step batch (the body of k_step_batch; round 4's two experimental kernels ran it in front of the next step's
 // decode).  lds: LDS_DW_PER_WAVE dwords of this wave's.  Leaves the stored book in B / rng for a caller that goes on.
 template <int R, bool MKT, bool POOLPEND>
 __device__ __forceinline__ void step_batch_book(const DevArgs& a, uint32_t book, int lane, uint32_t* lds, uint64_t step_index,

@@ -149,12 +149,6 @@ struct bk_env {
   uint32_t wave_lookahead = 64;
   uint32_t stagger_us = ~0u;    // parts of a split launch start i x stagger_us apart; ~0 = default rule, 0 = by events
   int wave_parts = 0;           // 0 = as the lane split (n_parts / min_part)
-  // wave_split: the events of step s and the decode of step s + 1 of a part in ONE launch (k_step_decode) instead of two.
-  // MEASURED AND NOT THE DEFAULT (round 4, VERDICT r3 item 1c "cut the launches per step"; parity-green): 8 192 books 113.7 M
-  // with two launches, 112.7 - 114.5 M with one (occupancy 6 / 7 / 8, 2 - 4 parts); 16 384 books 133.5 -> 124 - 128 M (the
-  // event half then runs at the decode's 72-VGPR footprint instead of its own 38).  Launch boundaries are not what the
-  // shard loses its time to.  BOURSE_AMD_FUSE_STEPS=1 switches it on.
-  bool fuse_wave_steps = false;
   bool wave_ok() const { return !n_mixed && M == 1 && !groups.empty(); }  // RandomAgents on independent books
   // AgentSets with Noise / Momentum members on independent books: wave-parallel decode of the members' update
   bool wl_valid = false;    // the wave-per-book members' lists (wl_list) describe the pools as of steps_done
@@ -176,11 +170,6 @@ struct bk_env {
   bool use_wave() const {        // split form: k_agents_wave + k_step_batch
     return wave_ok() && (pipeline == 4 || (pipeline == 0 && cfg.n_books > wave_fused_max() && cfg.n_books < lane_split_min_books(R)));
   }
-  // persistent split form (k_run_split, mode 6): on request - and by itself where it wins (set below once measured)
-  uint32_t persist_min = 0, persist_max = 0;  // auto: books in [persist_min, persist_max] take it (0, 0 = never)
-  bool use_persist_split() const {
-    return wave_ok() && (pipeline == 6 || (pipeline == 0 && R <= 2 && cfg.n_books >= persist_min && cfg.n_books <= persist_max && persist_max));
-  }
   bool use_wave_fused() const {  // persistent fused form: k_run_wave
     return wave_ok() && (pipeline == 5 || (pipeline == 0 && cfg.n_books <= wave_fused_max()));
   }
@@ -199,7 +188,6 @@ struct bk_env {
   enum PlanKind {
     PL_FUSED_RANDOM,  // k_run_random: one wave per book, all phases, n_steps per launch (also: no agents = plain steps)
     PL_FUSED_WAVE,    // k_run_wave: wave-parallel decode + events, persistent
-    PL_PERSIST_SPLIT, // k_run_split: the same two halves per step, persistent, the book parked in memory in between
     PL_SPLIT_LANES,   // k_agents_fsm (one lane per book / market) + k_step_batch
     PL_SPLIT_WAVE,    // k_agents_wave (one wave per book, stream decoded 64 draws at a time) + k_step_batch
     PL_MIXED_FUSED,   // k_run_mixed: AgentSet members, fused
@@ -218,7 +206,6 @@ struct bk_env {
       if (pipeline == 3) return {PL_MIXED_WPB, parts()};
       return {PL_MIXED_FUSED, 1};
     }
-    if (use_persist_split()) return {PL_PERSIST_SPLIT, 1};
     if (use_wave_fused()) return {PL_FUSED_WAVE, 1};
     if (use_wave()) return {PL_SPLIT_WAVE, wave_split_parts()};
     // (auto with RandomAgents on independent books never gets here below lane_split_min_books: the wave forms take it)
@@ -311,11 +298,10 @@ struct bk_env {
     }
     return e;
   }
-  // per kernel kind: 0 the fused kernels, 1 the agents kernel of a split pipeline, 2 k_step_batch, 3 k_step_events,
-  // 4 k_step_decode (events of step s + decode of step s + 1 in one launch)
-  static constexpr int PROF_KINDS = 5;
-  double prof_ms[PROF_KINDS] = {0, 0, 0, 0, 0};
-  uint64_t prof_launches[PROF_KINDS] = {0, 0, 0, 0, 0};
+  // per kernel kind: 0 the fused kernels, 1 the agents kernel of a split pipeline, 2 k_step_batch, 3 k_step_events
+  static constexpr int PROF_KINDS = 4;
+  double prof_ms[PROF_KINDS] = {0, 0, 0, 0};
+  uint64_t prof_launches[PROF_KINDS] = {0, 0, 0, 0};
 
   DevArgs args() const {
     DevArgs a{};
@@ -467,17 +453,6 @@ int launch_wave_fused(bk_env* env, const DevArgs& a, uint64_t first_step, uint32
   return BK_OK;
 }
 
-template <int R>
-int launch_persist_split(bk_env* env, const DevArgs& a, uint64_t first_step, uint32_t n_steps) {
-  WaveArgs wva{};
-  if (int rc = wave_args(env, &wva)) return rc;
-  env->prof_now = env->profile > 0;
-  ProfScope ps(env, 0);
-  hipLaunchKernelGGL(k_run_split<R>, dim3((env->cfg.n_books + 3) / 4), dim3(256), 0, env->stream, a, wva, first_step, n_steps);
-  HIPCHK(hipGetLastError());
-  return BK_OK;
-}
-
 // The parts' streams: one process-wide set per device, every member PROBED to sit on a hardware queue of its own.
 // HIP multiplexes streams onto GPU_MAX_HW_QUEUES (4) hardware queues - a new stream joins the least-referenced queue
 // once four exist - and two parts that share a queue run back to back: the pipeline loses its overlap (C3 220 -> 124 M
@@ -591,8 +566,6 @@ int launch_split(bk_env* env, const DevArgs& a0, uint64_t first_step, uint32_t n
   if (MIXED == 1 || MIXED == 2) env->wl_valid = false;  // (the wave-per-book lists no longer describe the pools)
   const MixedLists ml = env->lists();
   const bool wave = (MIXED == 0 && env->use_wave()) || MIXED == 3;
-  // (pools of more than 128 slots: the fused kernel's register footprint costs more occupancy than the launch saves)
-  const bool fuse = MIXED == 0 && wave && env->M == 1 && env->fuse_wave_steps && R <= 2;
   WaveArgs wva{};
   if (wave)
     if (int rc = wave_args(env, &wva)) return rc;
@@ -671,11 +644,9 @@ int launch_split(bk_env* env, const DevArgs& a0, uint64_t first_step, uint32_t n
                      a, ma, ml);
       else if (MIXED == 1)
         launch_timed(env, 1, &k_agents_mixed<R>, dim3((nb + 3) / 4), dim3(256), 0u, st, a, ma);
-      else if (wave) {
-        // (fused steps: only the launch's first step decodes on its own - every later decode rides behind the previous
-        // step's events in k_step_decode)
-        if (!fuse || s == 0) launch_timed(env, 1, &k_agents_wave<R>, dim3((nb + 3) / 4), dim3(256), 0u, st, a, wva);
-      } else
+      else if (wave)
+        launch_timed(env, 1, &k_agents_wave<R>, dim3((nb + 3) / 4), dim3(256), 0u, st, a, wva);
+      else
         launch_timed(env, 1, &k_agents_fsm<R>, dim3((nb + 63) / 64), dim3(64), fsm_lds, st, a);
       if (P > 1 && s == 0) HIPCHK(hipEventRecord(env->ev_first[i], st));
       // the lane-per-book members' update reads the touches from the latest level-2 record: keep it current
@@ -686,8 +657,6 @@ int launch_split(bk_env* env, const DevArgs& a0, uint64_t first_step, uint32_t n
         launch_timed(env, 2, &k_step_batch<R, false, true>, dim3(nb), dim3(64), 0u, st, a, step_no, write_last);
       else if (M > 1)
         launch_timed(env, 2, &k_step_batch<R, true>, dim3(nb * M), dim3(64), 0u, st, a, step_no, write_last);
-      else if (fuse && s + 1 < n_steps)  // events of this step + decode of the next one, one wave per book, 4 books per workgroup
-        launch_timed(env, 4, &k_step_decode<R>, dim3((nb + 3) / 4), dim3(256), 0u, st, a, wva, step_no, write_last);
       else
         launch_timed(env, 2, &k_step_batch<R, false>, dim3(nb), dim3(64), 0u, st, a, step_no, write_last);
     }
@@ -875,13 +844,11 @@ int bk_env_create(const bk_config* cfg, bk_env** out) {
     if (std::strcmp(pm, "split") == 0) env->pipeline = 2;
     if (std::strcmp(pm, "wave_split") == 0) env->pipeline = 4;
     if (std::strcmp(pm, "wave") == 0) env->pipeline = 5;
-    if (std::strcmp(pm, "wave_persist") == 0) env->pipeline = 6;
   }
   if (const char* np = std::getenv("BOURSE_AMD_SPLIT_PARTS")) {
     const int v = std::atoi(np);
     if (v >= 1 && v <= bk_env::MAX_PARTS) env->n_parts = v;
   }
-  if (const char* fs = std::getenv("BOURSE_AMD_FUSE_STEPS")) env->fuse_wave_steps = std::atoi(fs) != 0;
   if (const char* su = std::getenv("BOURSE_AMD_STAGGER_US")) env->stagger_us = static_cast<uint32_t>(std::max(0, std::atoi(su)));
   if (const char* mp = std::getenv("BOURSE_AMD_MIN_PART")) {
     const int v = std::atoi(mp);
@@ -1490,10 +1457,6 @@ int bk_run(bk_env* env, uint64_t n_steps) {
       env->ml_valid = false;
       BK_BY_R(launch_mixed<1>(env, a, env->steps_done, ns), launch_mixed<2>(env, a, env->steps_done, ns),
               launch_mixed<4>(env, a, env->steps_done, ns), launch_mixed<8>(env, a, env->steps_done, ns))
-      break;
-    case bk_env::PL_PERSIST_SPLIT:
-      BK_BY_R(launch_persist_split<1>(env, a, env->steps_done, ns), launch_persist_split<2>(env, a, env->steps_done, ns),
-              launch_persist_split<4>(env, a, env->steps_done, ns), launch_persist_split<8>(env, a, env->steps_done, ns))
       break;
     case bk_env::PL_FUSED_WAVE:
       BK_BY_R(launch_wave_fused<1>(env, a, env->steps_done, ns), launch_wave_fused<2>(env, a, env->steps_done, ns),
@@ -2139,7 +2102,6 @@ int bk_get_pipeline(bk_env* env, int* split, int* n_parts) {
     case bk_env::PL_SPLIT_WAVE:
     case bk_env::PL_MIXED_WAVE: code = 2; break;
     case bk_env::PL_FUSED_WAVE: code = 3; break;
-    case bk_env::PL_PERSIST_SPLIT: code = 4; break;
   }
   if (split) *split = code;
   if (n_parts) *n_parts = pl.parts;
@@ -2147,11 +2109,10 @@ int bk_get_pipeline(bk_env* env, int* split, int* n_parts) {
 }
 
 int bk_set_pipeline(bk_env* env, int mode) {
-  if (!env || mode < 0 || mode > 6)
+  if (!env || mode < 0 || mode > 5)
     return fail(BK_INVALID_ARGUMENT,
                 "pipeline mode must be 0 (auto), 1 (fused), 2 (split), 3 (split, wave-per-book AgentSet members), 4 (wave_split: "
-                "wave-parallel RNG decode kernel + event kernel), 5 (wave: both fused in one persistent kernel) or 6 (wave_persist: "
-                "both halves per step in one persistent kernel, the book parked in memory in between)");
+                "wave-parallel RNG decode kernel + event kernel) or 5 (wave: both fused in one persistent kernel)");
   env->pipeline = mode;
   return BK_OK;
 }

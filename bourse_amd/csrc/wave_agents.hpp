@@ -646,7 +646,7 @@ struct WaveLds {
 };
 
 // One book's RNG-serial half of a step: RandomAgents::update for every group + the shuffle, written as the book's step
-// batch; the body of k_agents_wave (and the second half of k_step_decode).  hdr: lane i holds dword i of the book's header
+// batch; the body of k_agents_wave.  hdr: lane i holds dword i of the book's header
 // (RNG state, live masks at H_LIVE0 ..).
 template <int R>
 __device__ __forceinline__ void agents_wave_book(const DevArgs& a, const WaveArgs& wa, WaveLds<R>& L, int wv, uint32_t book, int lane,
@@ -714,93 +714,10 @@ __global__ __launch_bounds__(256, BOURSE_AMD_AW_OCC(R)) void k_agents_wave(DevAr
   agents_wave_book<R>(a, wa, L, wv, book, lane, hdr);
 }
 
-// ==================================================================================
-// k_step_decode: Env::step of step s (the body of k_step_batch) FOLLOWED BY the decode of step s + 1 (the body of
-// k_agents_wave) for the same book, in one launch - the wave_split pipeline's inner steps.  A part's step is then ONE
-// launch instead of two (round 4: at 8 192 books every book is resident, so every launch boundary is a barrier on the
-// part's slowest wave plus a ~5 us gap; with both halves in one kernel a wave goes from its events straight to its next
-// decode).  Nothing is carried between the halves but the header words a decode reads (RNG state, live masks), taken
-// from the registers the store just wrote.  The level bins of the event half live in the ring's LDS (dead until the
-// decode generates into it).
-// ==================================================================================
-#ifndef BOURSE_AMD_SD_OCC
-#define BOURSE_AMD_SD_OCC(R) ((R) <= 2 ? 7 : BOURSE_AMD_AW_OCC(R))
-#endif
-template <int R>
-__global__ __launch_bounds__(256, BOURSE_AMD_SD_OCC(R)) void k_step_decode(DevArgs a, WaveArgs wa, uint64_t step_index, uint32_t write_last) {
-  __shared__ WaveLds<R> L;
-  static_assert(WV_RING >= (uint32_t)LDS_DW_PER_WAVE, "the level bins alias the ring");
-  const int lane = threadIdx.x & 63;
-  const int wv = (int)rfl(threadIdx.x >> 6);
-  for (int i = threadIdx.x; i < 512; i += 256) L.tab[i] = wa.jt_block[i];
-  __syncthreads();
-  const uint32_t book = rfl(a.book_begin + blockIdx.x * 4 + wv);
-  if (book >= a.book_end) return;
-  uint32_t hdr = 0;
-  {
-    Book<R> B;
-    Rng rng;
-    step_batch_book<R, false, false>(a, book, lane, L.ring[wv], step_index, write_last, B, rng, a.hist_slot0);
-    // the header words the decode reads, from the registers (store_book has just written exactly these)
-    hdr = wrl((uint32_t)rng.s0, H_S0_LO, hdr);
-    hdr = wrl((uint32_t)(rng.s0 >> 32), H_S0_HI, hdr);
-    hdr = wrl((uint32_t)rng.s1, H_S1_LO, hdr);
-    hdr = wrl((uint32_t)(rng.s1 >> 32), H_S1_HI, hdr);
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      hdr = wrl((uint32_t)B.live[r], H_LIVE0 + 2 * r, hdr);
-      hdr = wrl((uint32_t)(B.live[r] >> 32), H_LIVE0 + 2 * r + 1, hdr);
-    }
-  }
-  wave_sync();  // the bins' LDS becomes the ring
-  agents_wave_book<R>(a, wa, L, wv, book, lane, hdr);
-}
-
-// ==================================================================================
-// k_run_split: the wave_split pipeline as ONE PERSISTENT launch - n_steps x { decode of step s (agents_wave_book); Env::step
-// of step s (step_batch_book) } per book, the book parked in its state block between the two halves instead of being
-// held in registers (k_run_wave holds it: 80 VGPRs + scratch, six waves per SIMD, 6 144 books resident).  Parked, the kernel
-// fits EIGHT waves per SIMD (64 VGPRs, 18.5 KB of LDS per four books): all 8 192 books of a C4 shard are resident for the
-// whole launch and every wave runs its own chain back to back - no launch boundary, hence no waiting for the slowest of
-// a part's books twice per step (a wave's mean chain is 24 + 21 us per book-step, the kernels that contain it last
-// 33 + 31 us: docs/EXPERIMENTS.md, round 4).  The halves hand over through global memory exactly as the two kernels do
-// (step batch, RNG words, lane-state record), made visible by workgroup-scope fences: the same wave reads them back.
-// ==================================================================================
-template <int R>
-__global__ __launch_bounds__(256, R <= 2 ? 8 : 4) void k_run_split(DevArgs a, WaveArgs wa, uint64_t first_step, uint32_t n_steps) {
-  __shared__ WaveLds<R> L;
-  static_assert(WV_RING >= (uint32_t)LDS_DW_PER_WAVE, "the level bins alias the ring");
-  const int lane = threadIdx.x & 63;
-  const int wv = (int)rfl(threadIdx.x >> 6);
-  for (int i = threadIdx.x; i < 512; i += 256) L.tab[i] = wa.jt_block[i];
-  __syncthreads();
-  const uint32_t book = rfl(blockIdx.x * 4 + wv);
-  if (book >= a.n_books) return;
-  uint32_t hdr = (a.state + (size_t)book * a.state_stride)[lane];
-  for (uint32_t s = 0; s < n_steps; ++s) {
-    agents_wave_book<R>(a, wa, L, wv, book, lane, hdr);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // the step batch / RNG words / lane-state record: written, then
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");  // read back by this same wave
-    wave_sync();  // the ring's LDS becomes the level bins
-    Book<R> B;
-    Rng rng;
-    step_batch_book<R, false, false>(a, book, lane, L.ring[wv], first_step + s, (s + 1 == n_steps || a.hist_cap == 0) ? 1u : 0u, B,
-                                     rng, a.hist_cap ? (a.hist_slot0 + s) % a.hist_cap : 0u);
-    hdr = 0;  // the header words the next decode reads, from the registers the store has just written
-    hdr = wrl((uint32_t)rng.s0, H_S0_LO, hdr);
-    hdr = wrl((uint32_t)(rng.s0 >> 32), H_S0_HI, hdr);
-    hdr = wrl((uint32_t)rng.s1, H_S1_LO, hdr);
-    hdr = wrl((uint32_t)(rng.s1 >> 32), H_S1_HI, hdr);
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      hdr = wrl((uint32_t)B.live[r], H_LIVE0 + 2 * r, hdr);
-      hdr = wrl((uint32_t)(B.live[r] >> 32), H_LIVE0 + 2 * r + 1, hdr);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    wave_sync();
-  }
-}
+// (Round 4 built and measured two more arrangements of these two halves, both parity-green, neither faster - removed again,
+//  docs/EXPERIMENTS.md "Tried and not shipped": k_step_decode = the events of step s and the decode of step s + 1 of a part in
+//  ONE launch (commit 1526074..03eed16), and k_run_split = the whole launch persistent with the book parked in its state block
+//  between the halves, eight waves per SIMD, every book of a C4 shard resident (commit 0ff3c3c): 112.5 M against 118.0 M.)
 
 // ==================================================================================
 // Fused form: n_steps x { agents.update (wave-parallel decode); Env::step } per book with the book in registers and the

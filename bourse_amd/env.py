@@ -713,7 +713,7 @@ class ManyBookEnv:
         decode - k_agents_mixed_wave - in front of the event kernel, the auto choice from 512 books.)  ('split_wave':
         AgentSets with Noise/Momentum members keep their update one wave per book as scalar code; for RandomAgents it
         equals 'split'.)"""
-        check(self._L.bk_set_pipeline(self._h, {"auto": 0, "fused": 1, "split": 2, "split_wave": 3, "wave_split": 4, "wave": 5, "wave_persist": 6}[mode]))
+        check(self._L.bk_set_pipeline(self._h, {"auto": 0, "fused": 1, "split": 2, "split_wave": 3, "wave_split": 4, "wave": 5}[mode]))
 
     def set_wave_options(self, lookahead: int = 64, parts: int = 0):
         """'wave' pipeline knobs: look-ahead of the vector decode path (1..64; small = exercise the scalar slow path)
@@ -738,10 +738,10 @@ class ManyBookEnv:
         return int(out.value)
 
     def pipeline(self) -> Tuple[str, int]:
-        """('fused' | 'split' | 'wave_split' | 'wave' | 'wave_persist', number of book parts on separate streams) that run() will use."""
+        """('fused' | 'split' | 'wave_split' | 'wave', number of book parts on separate streams) that run() will use."""
         a, b = C.c_int(0), C.c_int(1)
         check(self._L.bk_get_pipeline(self._h, C.byref(a), C.byref(b)))
-        return ("fused", "split", "wave_split", "wave", "wave_persist")[a.value], int(b.value)
+        return ("fused", "split", "wave_split", "wave")[a.value], int(b.value)
 
     def checkpoint(self) -> np.ndarray:
         """Complete simulation state (pool, clock, counters, RNG of every book) as a byte array."""

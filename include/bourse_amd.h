@@ -317,8 +317,7 @@ int bk_level2_device_ptr(bk_env* env, void** out);
 int bk_profile_enable(bk_env* env, int on);
 int bk_profile_read(bk_env* env, double* total_ms, uint64_t* n_launches, int reset);
 /* per kernel: kind 0 the fused kernels (k_run_random / k_run_wave / k_run_mixed), 1 the agents kernel of a split pipeline
- * (k_agents_fsm / k_agents_wave / k_agents_mixed_*), 2 k_step_batch, 3 k_step_events (host-driven flow), 4 k_step_decode
- * (wave_split's inner steps: the events of step s and the decode of step s + 1 of a part in one launch) */
+ * (k_agents_fsm / k_agents_wave / k_agents_mixed_*), 2 k_step_batch, 3 k_step_events (host-driven flow) */
 int bk_profile_read_kind(bk_env* env, int kind, double* total_ms, uint64_t* n_launches);
 /* bk_run kernel pipeline: 0 auto (by shape and batch size), 1 fused (one wave per book, all phases),
  * 2 split (RNG-serial phases one lane per book + event phase one wave per book), 3 split with the members of an AgentSet

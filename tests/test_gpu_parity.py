@@ -101,7 +101,7 @@ def _compare_random(bk, oracle, n_books, groups, levels, n_steps, seed=101, tick
 
 # one wave per book for everything / RNG phases one lane per book + event kernel / RNG phases one wave per book with the
 # wave-parallel stream decode (k_agents_wave) + event kernel
-PIPELINES = ["fused", "split", "wave_split", "wave", "wave_persist"]
+PIPELINES = ["fused", "split", "wave_split", "wave"]
 
 
 @pytest.mark.parametrize("pipeline", PIPELINES)
