@@ -193,6 +193,14 @@ __device__ __forceinline__ uint32_t wave_umax(uint32_t x) {
   BK_DPP_REDUCE("v_max_u32_dpp");
   return rdl(x, 63);
 }
+__device__ __forceinline__ int32_t wave_imin(int32_t x) {
+  BK_DPP_REDUCE("v_min_i32_dpp");
+  return (int32_t)rdl((uint32_t)x, 63);
+}
+__device__ __forceinline__ int32_t wave_imax(int32_t x) {
+  BK_DPP_REDUCE("v_max_i32_dpp");
+  return (int32_t)rdl((uint32_t)x, 63);
+}
 __device__ __forceinline__ uint32_t wave_add(uint32_t x) {  // wrapping u32 sum
   BK_DPP_REDUCE("v_add_u32_dpp");
   return rdl(x, 63);
@@ -784,16 +792,43 @@ __device__ __forceinline__ void store_book(const Book<R>& B, const Rng& rng, uin
   }
 }
 
-// Can this step run on the keyed event loop (event_asm.hpp)?  Yes iff the prices of the live and the new orders span
-// <= 32 764 (and none is 0 or u32::MAX) and the live arrival stamps plus this step's (at most n_ev) new ones span < 65 534.
-// pbase / sbase: the key fields are price - pbase (>= 1) and seq - sbase (>= 1).  Three interleaved wave reductions.
+// ==================================================================================
+// SIGNED KEYS (round 4).  One 32-bit sort key per resting order:
+//     ask:  1 | price - pbase (15 bits) | seq - sbase (16 bits)          -> NEGATIVE as an i32
+//     bid:  0 | price - pbase (15 bits) | 0xFFFF - (seq - sbase)         -> POSITIVE (price field >= 2)
+//     every other pool lane (free, cancelled, filled, or holding an order that is still pending): 0
+// so the best ask is the signed MINIMUM over all pool lanes and the best bid the signed MAXIMUM - with no mask, select or
+// neutral element in front of the reduction: an empty side answers with a value of the wrong sign (>= 0 for the asks,
+// <= 0 for the bids), which fails the crossing test by the same signed compare.  Price-time priority (orderbook.rs:429-487)
+// is the order of the keys: lower price then earlier arrival among the asks, higher price then earlier arrival (the
+// complemented field) among the bids.  An order leaves the book by zeroing its key; the live masks are rebuilt from
+// `key != 0` after the loop (keys_end).  Round 3's keys carried the side in bit 0 and needed `live & ~bid` / `live & bid`
+// as a select in front of every reduction (2 scalar + 2 vector instructions per pool register and match step).
+//   A NEW order's compare value does not sit in the key array (it would be found): it travels in the upper half of its
+//   event word (`pk` below, per pool slot, gathered into the list by key_event_words): pk = 0x8000 | price field for a bid,
+//   the price field for an ask, and
+//     bid:  kp = pk << 16 | 0xFFFF   crosses the best ask a iff a <= kp (signed: a >= 0 - no ask - never does)
+//     ask:  kp = pk << 16            crosses the best bid b iff b >= kp (b <= 0 - no bid - never does)
+//     rests as kp ^ sq, sq = 0x80000000 | (seq_ctr - sbase): the sign flips and the arrival field lands (complemented for a
+//     bid by the 0xFFFF it XORs with).
+//   Market orders (price u32::MAX for a bid, 0 for an ask: the members of an AgentSet place them): pk = 0xFFFF / 1, i.e.
+//   kp = -1 (at or above every ask key) / 0x10000 (at or below every bid key: limit orders have a price field >= 2);
+//   they never rest (orderbook.rs:521-524).
+// Can this step run on the keyed loop?  Yes iff the prices of the live and the new LIMIT orders span <= 32 762 (and none is
+// 0 or u32::MAX) and the live arrival stamps plus this step's (at most n_ev) new ones span < 65 534.
 #ifndef BOURSE_AMD_KEYED_EVENTS
 #define BOURSE_AMD_KEYED_EVENTS 1
 #endif
-#ifndef BOURSE_AMD_KEY_SEQ_BITS  // arrival field of the key; test builds shrink it so that ordinary runs leave the window
+// Test builds shrink the windows so that ordinary runs leave them (tests/test_build_variants.py): a value below 16 narrows
+// the ARRIVAL window to that many bits, a value above 16 the PRICE window to 31 - value bits.  The key layout is fixed.
+#ifndef BOURSE_AMD_KEY_SEQ_BITS
 #define BOURSE_AMD_KEY_SEQ_BITS 16
 #endif
-constexpr uint32_t KEY_SB = BOURSE_AMD_KEY_SEQ_BITS, KEY_SMASK = (1u << KEY_SB) - 1u, KEY_PSPAN = (1u << (31 - KEY_SB)) - 4u;
+constexpr uint32_t KEY_SB = BOURSE_AMD_KEY_SEQ_BITS;
+constexpr uint32_t KEY_SMASK = (1u << (KEY_SB < 16u ? KEY_SB : 16u)) - 1u;       // arrival window
+constexpr uint32_t KEY_PSPAN = (1u << (31u - (KEY_SB > 16u ? KEY_SB : 16u))) - 6u;  // price window
+constexpr uint32_t KEY_ASK = 0x80000000u;
+constexpr uint32_t KP_MKT_BID = 0xFFFFFFFFu, KP_MKT_ASK = 0x10000u;
 template <int R>
 __device__ __forceinline__ bool key_window(const Book<R>& B, const uint64_t (&newm)[R], uint32_t n_ev, uint32_t& pbase,
                                            uint32_t& sbase) {
@@ -806,24 +841,23 @@ __device__ __forceinline__ bool key_window(const Book<R>& B, const uint64_t (&ne
     age = max(age, lv ? B.seq_ctr - B.seq[r] : 0u);
   }
   wave_reduce3(pmax, pmin, age);
-  pbase = pmin - 1u;
+  pbase = pmin - 2u;  // price field >= 2: 1 is the market ask's
   sbase = B.seq_ctr - age - 1u;
-  return pmin != 0u && pmax != 0xFFFFFFFFu && pmax - pmin <= KEY_PSPAN && age + n_ev < KEY_SMASK - 1u;
+  return pmin >= 2u && pmax != 0xFFFFFFFFu && pmax - pmin <= KEY_PSPAN && age + n_ev < KEY_SMASK - 1u;
 }
 
-// The keys of one step (event_asm.hpp "KEYED event loop"): key[r] per pool lane, sq = the running arrival field in key
-// position (advances by 2 per resting order).
+// The keys of one step: key[r] per pool lane, pk[r] = the compare value (upper half) of the lane's PENDING order,
+// sq = KEY_ASK | the running arrival field (advances by 1 per resting order).
 template <int R>
 struct KeyState {
-  uint32_t key[R];
+  uint32_t key[R], pk[R];
   uint32_t sq, sbase, pbase;
-  // alo <= best ask key, bhi >= best bid key: exact after a reduction of that side, still valid after any removal, pulled
-  // in when an order rests beyond them - a new order on the far side of the bound cannot cross and skips the reduction
-  uint32_t alo, bhi;
+  // alo <= best ask key, bhi >= best bid key (as i32): exact after a reduction of that side, still valid after any
+  // removal, pulled in when an order rests beyond them - a new order on the far side of the bound cannot cross and skips
+  // the reduction
+  int32_t alo, bhi;
 };
-// MARKETS: the new orders may include market orders (price sentinel u32::MAX for a bid, 0 for an ask; the members of an
-// AgentSet place them): they stay out of the window test, never rest, and get a prefix that crosses whatever is there -
-// 0xFFFFFFFE (above every ask key, below the empty side's -1) / 1 (below every bid key, above the empty side's 0).
+// MARKETS: the new orders may include market orders; they stay out of the window test
 template <int R, bool MARKETS = false>
 __device__ __forceinline__ bool keys_begin(const Book<R>& B, const uint64_t (&newm)[R], uint32_t n_ev, KeyState<R>& K) {
   uint32_t pbase;
@@ -836,58 +870,73 @@ __device__ __forceinline__ bool keys_begin(const Book<R>& B, const uint64_t (&ne
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     const bool bidl = lane_bit(B.bid[r]);
-    const uint32_t kp = ((((B.price[r] - pbase) << KEY_SB) | (bidl ? KEY_SMASK : 0u)) << 1) | (bidl ? 1u : 0u);
-    K.key[r] = lane_bit(B.live[r]) ? (kp ^ ((B.seq[r] - K.sbase) << 1)) : lane_bit(lim[r]) ? kp : 0xFFFFFFFFu;
-    if (MARKETS) K.key[r] = lane_bit(newm[r] & ~lim[r]) ? (bidl ? 0xFFFFFFFEu : 1u) : K.key[r];
+    const uint32_t pf = B.price[r] - pbase, sf = B.seq[r] - K.sbase;
+    K.key[r] = lane_bit(B.live[r]) ? ((pf << 16) | (bidl ? 0xFFFFu - sf : KEY_ASK | sf)) : 0u;
+    K.pk[r] = bidl ? 0x8000u | pf : pf;
+    if (MARKETS) K.pk[r] = lane_bit(newm[r] & ~lim[r]) ? (bidl ? 0xFFFFu : 1u) : K.pk[r];
   }
-  K.sq = (B.seq_ctr - K.sbase) << 1;
-  K.alo = 0u;
-  K.bhi = 0xFFFFFFFFu;
+  K.sq = KEY_ASK | (B.seq_ctr - K.sbase);
+  K.alo = (int32_t)0x80000000u;
+  K.bhi = 0x7FFFFFFF;
   return true;
 }
+// after the loop: the live masks and the arrival stamps of the orders resting now (the others' are never read again)
 template <int R>
 __device__ __forceinline__ void keys_end(Book<R>& B, const KeyState<R>& K) {
-  B.seq_ctr = K.sbase + (K.sq >> 1);
+  B.seq_ctr = K.sbase + (K.sq & 0x7FFFFFFFu);
 #pragma unroll
-  for (int r = 0; r < R; ++r)  // arrival stamps of the orders resting now (the others' are never read again)
-    B.seq[r] = lane_bit(B.live[r]) ? K.sbase + (((K.key[r] >> 1) ^ (lane_bit(B.bid[r]) ? KEY_SMASK : 0u)) & KEY_SMASK) : B.seq[r];
+  for (int r = 0; r < R; ++r) {
+    B.live[r] = __ballot(K.key[r] != 0u);
+    const uint32_t f = K.key[r] & 0xFFFFu;
+    B.seq[r] = K.key[r] != 0u ? K.sbase + ((int32_t)K.key[r] < 0 ? f : 0xFFFFu - f) : B.seq[r];
+  }
+}
+// The step's event words for the assembly loops: slot | EV_NEW | EV_BID in the lower half (as the decode kernels write
+// them), the event's compare value pk[slot] in the upper half (one ds_bpermute per pool register and list register in use).
+template <int R>
+__device__ __forceinline__ void key_event_words(const KeyState<R>& K, const uint32_t (&ev)[R], uint32_t n_ev, uint32_t (&evw)[R]) {
+#pragma unroll
+  for (int re = 0; re < R; ++re) {
+    evw[re] = ev[re] & 0xFFFFu;
+    if (n_ev > (uint32_t)re * 64u) evw[re] |= pool_gather<R>(K.pk, ev[re] & EV_SLOT & (64u * R - 1u)) << 16;
+  }
 }
 
 // (a pack expansion, not a loop: `#pragma unroll` was not honoured here in the R = 8 instantiation, and a rolled loop indexes
 // the pool dynamically, which sends the whole Book to scratch memory - C5 15 -> 3 M book-steps/s)
 template <int R, bool agg_bid, int... I>
-__device__ __forceinline__ uint32_t key_touch(const Book<R>& B, const KeyState<R>& K, std::integer_sequence<int, I...>) {
-  uint32_t m = agg_bid ? 0xFFFFFFFFu : 0u;
-  ((m = agg_bid ? min(m, sel(B.live[I] & ~B.bid[I], K.key[I], 0xFFFFFFFFu)) : max(m, sel(B.live[I] & B.bid[I], K.key[I], 0u))), ...);
+__device__ __forceinline__ int32_t key_touch(const KeyState<R>& K, std::integer_sequence<int, I...>) {
+  int32_t m = (int32_t)K.key[0];
+  ((m = agg_bid ? min(m, (int32_t)K.key[I]) : max(m, (int32_t)K.key[I])), ...);
   return m;
 }
 
-// The keyed loop in C++ (pools of more than 128 slots - the assembly covers R <= 2 - and the -DBOURSE_AMD_ASM_EVENTS=0
+// The keyed loop in C++ (pool sizes the assembly does not cover, market books' own lists, the -DBOURSE_AMD_ASM_EVENTS=0
 // build): same semantics as match_side / slot_event_at with ONE reduction per match step and no tie handling.
 template <int R>
 __device__ __forceinline__ void flush_trades_compact(Book<R>& B, const DevArgs& a, uint32_t book, uint64_t t0, int lane,
                                                      const uint32_t (&ev)[R]);
 template <int R, bool agg_bid>
 __device__ __forceinline__ bool match_side_keyed(Book<R>& B, KeyState<R>& K, const DevArgs& a, uint32_t book, uint64_t t0,
-                                                 int lane, uint32_t k, uint32_t kp, uint32_t& v, const uint32_t (&ev)[R]) {
+                                                 int lane, uint32_t k, int32_t kp, uint32_t& v, const uint32_t (&ev)[R]) {
   const uint32_t v0 = v;
   while (v > 0) {
-    // an empty side returns the neutral element: "no cross" by the same compare
-    const uint32_t m = key_touch<R, agg_bid>(B, K, std::make_integer_sequence<int, R>());
-    const uint32_t best = agg_bid ? wave_umin(m) : wave_umax(m);
+    // an empty side answers with a value of the wrong sign: "no cross" by the same compare
+    const int32_t m = key_touch<R, agg_bid>(K, std::make_integer_sequence<int, R>());
+    const int32_t best = agg_bid ? wave_imin(m) : wave_imax(m);
     (agg_bid ? K.alo : K.bhi) = best;
     if (agg_bid ? (best > kp) : (best < kp)) break;  // inclusive crossing test (:430 / :463) in key space
     uint32_t pv = 0, tv = 0, slot = 0;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      const uint64_t eq = __ballot(K.key[r] == best);  // the key is unique: exactly one lane of one register
+      const uint64_t eq = __ballot(K.key[r] == (uint32_t)best);  // the key is unique: exactly one lane of one register
       if (eq) {
         const uint32_t l = __builtin_ctzll(eq);
         pv = rdl(B.vol[r], l);
         tv = v < pv ? v : pv;
         pv -= tv;
         B.vol[r] = wrl(pv, l, B.vol[r]);
-        if (pv == 0) B.live[r] &= ~eq;  // passive Filled -> remove_order
+        if (pv == 0) K.key[r] = wrl(0u, l, K.key[r]);  // passive Filled -> remove_order
         slot = (uint32_t)r * 64u + l;
       }
     }
@@ -909,28 +958,29 @@ __device__ __forceinline__ void slot_event_keyed_at(Book<R>& B, KeyState<R>& K, 
                                                     int lane, uint32_t k, uint32_t sl, uint32_t ew, const uint32_t (&ev)[R]) {
   const uint64_t bit = 1ull << sl;
   if (CLS ? !(ew & EV_NEW) : !(B.pend[RS] & bit)) {
-    B.live[RS] &= ~bit;  // Cancellation
+    K.key[RS] = wrl(0u, sl, K.key[RS]);  // Cancellation
     return;
   }
   if (!CLS) B.pend[RS] &= ~bit;
   const bool is_bid = CLS ? (ew & EV_BID) != 0 : (B.bid[RS] & bit) != 0;
-  const uint32_t kp = rdl(K.key[RS], sl);
+  const uint32_t kpu = (rdl(K.pk[RS], sl) << 16) | (is_bid ? 0xFFFFu : 0u);
+  const int32_t kp = (int32_t)kpu;
   uint32_t v = rdl(B.vol[RS], sl);
   // a market order's remainder is dropped (orderbook.rs:521-524); the event words' lists (CLS) carry none
-  const bool market = !CLS && kp == (is_bid ? 0xFFFFFFFEu : 1u);
+  const bool market = !CLS && kpu == (is_bid ? KP_MKT_BID : KP_MKT_ASK);
   bool filled = false;
   if (B.trading && !(is_bid ? kp < K.alo : kp > K.bhi))  // (beyond the bound: cannot cross)
     filled = is_bid ? match_side_keyed<R, true>(B, K, a, book, t0, lane, k, kp, v, ev)
                     : match_side_keyed<R, false>(B, K, a, book, t0, lane, k, kp, v, ev);
   if (!market && !filled) {  // rest the remainder with a fresh arrival field
     B.vol[RS] = wrl(v, sl, B.vol[RS]);
+    const uint32_t x = kpu ^ K.sq;
     if (is_bid)
-      K.bhi = max(K.bhi, kp ^ K.sq);
+      K.bhi = max(K.bhi, (int32_t)x);
     else
-      K.alo = min(K.alo, kp ^ K.sq);
-    K.key[RS] = wrl(kp ^ K.sq, sl, K.key[RS]);
-    B.live[RS] |= bit;
-    K.sq += 2;
+      K.alo = min(K.alo, (int32_t)x);
+    K.key[RS] = wrl(x, sl, K.key[RS]);
+    K.sq += 1;
   }
 }
 template <int R, int RS = 0, bool CLS = true>
@@ -944,40 +994,6 @@ __device__ __forceinline__ void slot_event_keyed(Book<R>& B, KeyState<R>& K, con
   } else {
     slot_event_keyed_at<R, RS, CLS>(B, K, a, book, t0, lane, k, n & 63, ew, ev);
   }
-}
-
-// Lazy cancellations of the keyed assembly loop (event_asm.hpp): from the step's (shuffled, self-classifying) event list
-//   dt[r]  per pool lane: the list position at which that slot's order is cancelled in this step, else all ones;
-//   evc[r] the NEW orders only, in list order, each word = event word | position << 16 | (passive side is bid) << 23.
-// A slot is cancelled at most once per step and never re-used in it (one event per agent).  lds: >= 128 R dwords.
-template <int R>
-__device__ __forceinline__ uint32_t lc_prepare(const uint32_t (&ev)[R], uint32_t n_ev, int lane, uint32_t* lds, uint32_t (&dt)[R],
-                                               uint32_t (&evc)[R]) {
-#pragma unroll
-  for (int r = 0; r < R; ++r) lds[r * 64 + lane] = 0xFFFFFFFFu;
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  uint32_t base = 0;
-#pragma unroll
-  for (int re = 0; re < R; ++re) {
-    const uint32_t k = (uint32_t)(re * 64 + lane), ew = ev[re];
-    const bool valid = k < n_ev, is_new = valid && (ew & EV_NEW) != 0u;
-    if (valid && !is_new) lds[ew & EV_SLOT] = k;
-    const uint64_t nm = __ballot(is_new);
-    const uint32_t idx = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(nm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)nm, 0u));
-    if (is_new) lds[64 * R + idx] = (ew & 0xFFFFu) | (k << 16) | ((ew & EV_BID) ? 0u : (1u << 23));
-    base += (uint32_t)__builtin_popcountll(nm);
-  }
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-#pragma unroll
-  for (int r = 0; r < R; ++r) {
-    dt[r] = lds[r * 64 + lane];
-    evc[r] = lds[64 * R + r * 64 + lane];
-  }
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  return base;
 }
 
 // ----------------------------------------------------------------------------------
@@ -1014,15 +1030,10 @@ __device__ __forceinline__ uint32_t step_from_list(Book<R>& B, const DevArgs& a,
     const uint32_t nev = rfl(n_ev), tmask = B.trading ? 0xFFFFFFFFu : 0u;
     KeyState<R> K;
     if (BOURSE_AMD_KEYED_EVENTS && keys_begin<R>(B, newm, nev, K)) {
-      // keyed loop: one sort key per order (price field | arrival field | side), rebuilt from {price, seq} every step
-#if BOURSE_AMD_LAZY_CANCEL
-      // ... over the NEW orders only: cancellations become a death time per pool lane (event_asm.hpp, lc_prepare)
-      uint32_t dt[R], evl[R];
-      const uint32_t n_list = rfl(lc_prepare<R>(ev, nev, lane, bins, dt, evl));
-#else
-      const uint32_t(&evl)[R] = ev;
-      const uint32_t n_list = nev;
-#endif
+      // keyed loop: one signed sort key per order (side | price field | arrival field), rebuilt from {price, seq} every
+      // step; the event words get their new orders' compare values here
+      uint32_t evw[R];
+      key_event_words<R>(K, ev, nev, evw);
       // the loop tests "no volume or trading disabled" on every new order (two scalar instructions) unless this step is
       // known not to need it: trading enabled and no new order with volume 0 (one ballot per pool register here)
       uint64_t zero_vol = 0;
@@ -1032,35 +1043,17 @@ __device__ __forceinline__ uint32_t step_from_list(Book<R>& B, const DevArgs& a,
       for (;;) {
         uint32_t full;
         if constexpr (R == 2)
-          full = events_key_r2(checked, k, n_list, tmask, B.tr_n, K.sq, B.live[0], B.live[1], B.bid[0], B.bid[1], B.vol[0],
-                               B.vol[1], K.key[0], K.key[1], evl[0], evl[1], B.tr_k, B.tr_vol, B.tr_pas
-#if BOURSE_AMD_LAZY_CANCEL
-                               , dt[0], dt[1]
-#endif
-          );
+          full = events_key_r2(checked, k, nev, tmask, B.tr_n, K.sq, B.vol[0], B.vol[1], K.key[0], K.key[1], evw[0], evw[1],
+                               B.tr_k, B.tr_vol, B.tr_pas);
         else
-          full = events_key_r1(checked, k, n_list, tmask, B.tr_n, K.sq, B.live[0], B.bid[0], B.vol[0], K.key[0], evl[0],
-                               B.tr_k, B.tr_vol, B.tr_pas
-#if BOURSE_AMD_LAZY_CANCEL
-                               , dt[0]
-#endif
-          );
-#if BOURSE_AMD_LAZY_CANCEL
-        // the loop wrote the records' k words as the list carries them (position | passive side << 7): into the record
-        // format (position | side << 31); only the lanes filled since the last flush are touched
-        B.tr_k = (B.tr_k & 0xFFFFFF00u) == 0u ? ((B.tr_k & 0x7Fu) | ((B.tr_k & 0x80u) << 24)) : B.tr_k;
-#endif
+          full = events_key_r1(checked, k, nev, tmask, B.tr_n, K.sq, B.vol[0], K.key[0], evw[0], B.tr_k, B.tr_vol, B.tr_pas);
         // Env::get_trade_vol: the loop leaves the sum to the vector unit (one reduction per flush, not an add per trade)
         if (B.tr_n) B.trade_vol += wave_add((uint32_t)lane < B.tr_n ? B.tr_vol : 0u);
         // (the records are compact - k word, volume, passive slot: price and ids are gathered from the pool at the flush,
         // which therefore happens HERE, before the step's snapshot / store, also for the last buffer of the step)
-        flush_trades_compact<R>(B, a, book, t0, lane, ev);
+        flush_trades_compact<R>(B, a, book, t0, lane, evw);
         if (!full) break;
       }
-#if BOURSE_AMD_LAZY_CANCEL
-#pragma unroll
-      for (int r = 0; r < R; ++r) B.live[r] &= ~__ballot(dt[r] != 0xFFFFFFFFu);  // the step's cancellations, all at once
-#endif
       keys_end<R>(B, K);
     } else if constexpr (R == 2) {
       while (events_asm_r2(k, nev, tmask, B.tr_n, B.seq_ctr, B.trade_vol, B.live[0], B.live[1], B.bid[0], B.bid[1],
@@ -1074,11 +1067,12 @@ __device__ __forceinline__ uint32_t step_from_list(Book<R>& B, const DevArgs& a,
     }
   } else if (KeyState<R> K; (CLS || PENDKEY) && !MKT && BOURSE_AMD_KEYED_EVENTS && keys_begin<R, !CLS>(B, newm, rfl(n_ev), K)) {
    if constexpr ((R == 4 || R == 8) && BOURSE_AMD_ASM_EVENTS && BOURSE_AMD_ASM_R48) {
-    // the generated assembly loop (event_asm_gen.hpp): live asks / live bids as two mask sets, compact trade records.
-    // It reads SELF-CLASSIFYING event words (slot | EV_NEW | EV_BID).  The members' lists of an AgentSet (PENDKEY) hold
-    // bare slots - New iff the slot's pend bit is set, the side in its bid bit - and are converted here, one vector pass
-    // per list register in use: a slot holds at most one event per step (a pending order sits in a slot that was free
-    // when the step began), so classifying up front is the same as classifying at the event.
+    // the generated assembly loop (event_asm_gen.hpp): signed keys, compact trade records.
+    // It reads SELF-CLASSIFYING event words (slot | EV_NEW | EV_BID) with the new order's compare value in the upper half.
+    // The members' lists of an AgentSet (PENDKEY) hold bare slots - New iff the slot's pend bit is set, the side in its bid
+    // bit - and are converted here, one vector pass per list register in use: a slot holds at most one event per step (a
+    // pending order sits in a slot that was free when the step began), so classifying up front is the same as
+    // classifying at the event.
     uint32_t evw[R];
 #pragma unroll
     for (int re = 0; re < R; ++re) {
@@ -1102,26 +1096,19 @@ __device__ __forceinline__ uint32_t step_from_list(Book<R>& B, const DevArgs& a,
 #pragma unroll
       for (int r = 0; r < R; ++r) B.pend[r] = 0;  // every pending order is an event of this step
     }
-    uint64_t askm[R], bidm[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      askm[r] = B.live[r] & ~B.bid[r];
-      bidm[r] = B.live[r] & B.bid[r];
-    }
+    key_event_words<R>(K, evw, rfl(n_ev), evw);
     uint32_t k = 0;
     const uint32_t nev = rfl(n_ev), tmask = B.trading ? 0xFFFFFFFFu : 0u;
     for (;;) {
       uint32_t full;
       if constexpr (R == 4)
-        full = events_key_r4(k, nev, tmask, B.tr_n, K.sq, askm, bidm, B.vol, K.key, evw, B.tr_k, B.tr_vol, B.tr_pas);
+        full = events_key_r4(k, nev, tmask, B.tr_n, K.sq, B.vol, K.key, evw, B.tr_k, B.tr_vol, B.tr_pas);
       else
-        full = events_key_r8(k, nev, tmask, B.tr_n, K.sq, askm, bidm, B.vol, K.key, evw, B.tr_k, B.tr_vol, B.tr_pas);
+        full = events_key_r8(k, nev, tmask, B.tr_n, K.sq, B.vol, K.key, evw, B.tr_k, B.tr_vol, B.tr_pas);
       if (B.tr_n) B.trade_vol += wave_add((uint32_t)lane < B.tr_n ? B.tr_vol : 0u);
       flush_trades_compact<R>(B, a, book, t0, lane, evw);
       if (!full) break;
     }
-#pragma unroll
-    for (int r = 0; r < R; ++r) B.live[r] = askm[r] | bidm[r];
    } else {
 #pragma unroll
     for (int re = 0; re < R; ++re) {

@@ -313,58 +313,36 @@ __device__ __forceinline__ uint32_t events_asm_r1(uint32_t& k, uint32_t n_ev, ui
 // ==================================================================================
 // KEYED event loop: price-time priority as ONE 32-bit sort key per resting order, so a match step is a single DPP
 // reduction - no "how many orders at the touch" test, no second reduction over the arrival stamps, no candidate-mask
-// algebra after it (the key is unique, so `key == best` selects exactly one lane).
+// algebra before or after it (the key is unique, so `key == best` selects exactly one lane).
 //
-//   key = (price - pbase) << 17 | s << 1 | side     asks (side 0):  s = seq - sbase       best = MIN key
-//                                                   bids (side 1):  s = ~(seq - sbase)    best = MAX key (max price, oldest)
-//   pbase = (lowest price among the live and the new orders) - 1, sbase = (oldest live stamp) - 1: every live key has a
-//   price field in 1..32765 and 1 <= seq - sbase <= 65533.  book_device.hpp (key_window) checks that the step's prices
-//   and stamps fit - if not, the step runs on the loop above - and rebuilds the keys from {price, seq} at the start of
-//   every step, so nothing about them is persistent state.
-//   A NEW order's lane holds the key PREFIX kp = (price - pbase) << 17 | (bid ? 0x1FFFF : 0) until it is processed:
-//     * as an aggressor it crosses iff best ask key <= kp (bid) / best bid key >= kp (ask) - with no candidates the
-//       reduction returns its neutral element (-1 / 0) and the same compare says "no cross";
-//     * when it rests its key is kp ^ (seq_ctr - sbase) << 1 (`sq` below is kept pre-shifted and advances by 2).
-//   `key == best` needs no live / side mask: keys of one side differ in the arrival field (every order that ever rested
-//   in the window has its own), the side bit separates the two sides (WITHOUT it a dead bid and a live ask at one price
-//   collide when their arrival fields are complements), a prefix never equals a live key (those have seq - sbase >= 1)
-//   and lanes that were dead at the start of the step hold -1.
-//   Prices 0 and u32::MAX (a market order's sentinels) fail the window test, so the "market remainder is dropped" exit
-//   is not needed here.
+// SIGNED keys (round 4; book_device.hpp "SIGNED KEYS" has the layout and the proof obligations):
+//   ask:  1 | price - pbase (15 bits) | seq - sbase            negative as an i32    best ask = signed MIN over all lanes
+//   bid:  0 | price - pbase           | 0xFFFF - (seq - sbase) positive              best bid = signed MAX over all lanes
+//   any other pool lane (free, cancelled, filled, still pending): 0 - invisible to both searches, so the reduction
+//   starts from the raw key registers: round 3's side-in-bit-0 keys needed `live & ~bid` / `live & bid` (scalar) and a
+//   select of the neutral element (vector) per pool register in front of EVERY reduction, and live masks kept current
+//   by every cancellation, fill and rest.  Here an order leaves by a zero written to its key lane and the live masks are
+//   rebuilt once per step from `key != 0` (keys_end).
+//   book_device.hpp (key_window) checks that the step's prices and stamps fit - if not, the step runs on the loop above -
+//   and rebuilds the keys from {price, seq} at the start of every step, so nothing about them is persistent state.
+//   A NEW order's compare value kp comes from the upper half of its event word (key_event_words), one scalar instruction:
+//     bid: kp = ew | 0xFFFF (sign bit set by the set-up)  crosses iff best ask <= kp;   ask: kp = ew & 0xFFFF0000  crosses
+//     iff best bid >= kp; with nothing on the other side the reduction returns a value of the wrong sign and the same
+//     signed compare says "no cross".  It rests as kp ^ sq, sq = 0x80000000 | (seq_ctr - sbase), advancing by 1.
+//   These lists (the event words of RandomAgents) carry no market orders.
 //
 // The fill itself is specialised three ways on one scalar subtract (SCC = borrow of passive - aggressor volume):
 //   aggressor wants more  -> passive order gone, trade = its volume, match again (unconditional branch)
 //   aggressor exhausted   -> trade = aggressor's volume, next event (the passive order dies too iff nothing is left)
 // and the trade-buffer index is kept biased by -64: `s_add_u32 trn, trn, 1` carries out exactly when the buffer is full
 // (lane selects read the low 6 bits).  The step's traded volume is summed from the buffer at every flush (book_device.hpp)
-// instead of one scalar add per trade.  Per trade: 16 scalar + branch instructions (loop above: 32); since round 4 three
-// vector lane writes + one lane read per trade instead of five + three (compact records, EK_PICK).
+// instead of one scalar add per trade.
+// (Round 3's LAZY CANCELLATIONS - cancellations as a death time per pool lane instead of loop iterations - were measured
+// twice and never shipped: C3 253 -> 250 M, round 4 279.9 -> 262.9 M; docs/EXPERIMENTS.md.  The code left with the
+// side-in-bit-0 keys it was written for.)
 // ==================================================================================
-// LAZY CANCELLATIONS (round 3).  A cancellation is ~10 scalar-port instructions of pure loop overhead (fetch the word, two
-// tests, a 64-bit shift, an and-not, the loop's own three) and the scalar port is what binds these kernels at small
-// batches.  With BOURSE_AMD_LAZY_CANCEL the caller (book_device.hpp lc_prepare) hands over a list of the NEW orders only
-// - each word carrying its original position k in bits 16..22 and the passive side in bit 23 - plus, per pool lane, the
-// position dt at which that slot's order is cancelled this step (else all ones).  An order is a candidate of a match at
-// position k iff it is live AND k < dt: two vector instructions per pool register and reduction (v_cmp into VCC + a
-// VCC-select of the neutral element) instead of one loop iteration per cancellation; the live bits of the cancelled
-// orders are cleared after the loop.  Exact because a slot is cancelled at most once per step and never re-used in it.
-// MEASURED AND NOT SHIPPED (parity-green on the whole suite): -0.4 k scalar-port instructions per book-step, but the
-// prologue's two LDS passes and +4 vector instructions per reduction cost as much: C3 253 -> 250 M (k_step_batch 103 ->
-// 110 us per launch), 8 192-book shard 110.5 -> 110.0 M, 32 768 books 158 -> 160 M, C2 168 -> 171 M.  -D...=1 builds it.
-#ifndef BOURSE_AMD_LAZY_CANCEL
-#define BOURSE_AMD_LAZY_CANCEL 0
-#endif
-#if BOURSE_AMD_LAZY_CANCEL
-#define EK_LC(x) x
-#define EK_NLC(x) ""
-#else
-#define EK_LC(x) ""
-#define EK_NLC(x) x
-#endif
-#define EK_KT "s61"  // position of the event being matched (lazy cancellations)
-
-#define EK_KP EA_P  // the aggressor's key prefix lives where the loop above keeps its price
-// Bounds that let a new order that cannot cross skip the reduction: EK_ALO <= best ask key, EK_BHI >= best bid key.
+#define EK_KP EA_P  // the aggressor's compare value lives where the loop above keeps its price
+// Bounds that let a new order that cannot cross skip the reduction: EK_ALO <= best ask key, EK_BHI >= best bid key (i32).
 // Exact right after a reduction of that side, still valid after any removal (the best only moves away), pulled in when
 // an order rests beyond them; the loosest values at statement entry.
 #define EK_ALO "s62"
@@ -393,7 +371,7 @@ __device__ __forceinline__ uint32_t events_asm_r1(uint32_t& k, uint32_t n_ev, ui
   "v_writelane_b32 %[vol" Q "], " EA_X ", m0\n\t"                                                     \
   "s_cmp_eq_u32 " EA_X ", 0\n\t"                                                                      \
   "s_cbranch_scc0 L_B" Q "_" L "\n\t"                                                                 \
-  "s_andn2_b64 %[live" Q "], %[live" Q "], " EQ "\n\t"                                                \
+  "v_writelane_b32 %[key" Q "], 0, m0\n\t"              /* ... and the passive order with it */       \
   "L_B" Q "_" L ":\n\t"                                                                               \
   "s_add_u32 %[trn], %[trn], 1\n\t"                     /* SCC = carry = buffer full */               \
   "s_cbranch_scc1 L_fullnext_%=\n\t"                                                                  \
@@ -402,35 +380,29 @@ __device__ __forceinline__ uint32_t events_asm_r1(uint32_t& k, uint32_t n_ev, ui
   "v_writelane_b32 %[trv], " EA_PV ", m0\n\t"                                                         \
   "s_mov_b32 m0, " EA_LS "\n\t"                                                                       \
   "v_writelane_b32 %[vol" Q "], 0, m0\n\t"                                                            \
-  "s_andn2_b64 %[live" Q "], %[live" Q "], " EQ "\n\t"                                                \
+  "v_writelane_b32 %[key" Q "], 0, m0\n\t"                                                            \
   "s_sub_u32 " EA_V ", " EA_V ", " EA_PV "\n\t"                                                       \
   "s_add_u32 %[trn], %[trn], 1\n\t"                                                                   \
   "s_cbranch_scc1 L_fullA_" L "\n\t"                                                                  \
   "s_branch L_match_" L "\n\t"
 
-//   NOX  "s_cmp_gt_u32" (bid: best ask key > kp) / "s_cmp_lt_u32" (ask: best bid key < kp): no cross
 // VCHK: EK_VCHK(L) - "no volume or trading disabled: no match" - or "" when the caller has established that trading is
 // enabled and no new order of this step has volume 0 (two scalar instructions per new order; book_device.hpp)
 #define EK_VCHK(L)                                   \
   "s_and_b32 " EA_X ", " EA_V ", %[tmask]\n\t"       \
   "s_cbranch_scc0 L_restq_" L "\n\t"
-#define EK_SIDE(L, PH, KEND, RG, NR, CAND, SENT, VOP, DOP, NOX, KKI, OPPB, SKIP, OWNB, PULL, VCHK)    \
+//   KPI   the compare value from the event word;  SKIP / OPPB "beyond the other side's bound: cannot cross";
+//   VOP / DOP the reduction (v_min_i32 / v_max_i32 and its DPP form);  NOX "no cross" on the reduction's result;
+//   KKI   the trade records' k word;  OWNB / PULL this side's bound covers the order that rests
+#define EK_SIDE(L, PH, KEND, RG, NR, KPI, VOP, DOP, NOX, KKI, OPPB, SKIP, OWNB, PULL, VCHK)            \
+  KPI "\n\t"                                                                                          \
   VCHK                                                                                                \
   SKIP " " EK_KP ", " OPPB "\n\t"                      /* beyond the bound: cannot cross */           \
   "s_cbranch_scc1 L_restq_" L "\n\t"                                                                  \
-  EK_NLC(KKI "\n\t")                                  /* (only a trade needs the k word) */          \
-  EK_LC("s_lshr_b32 " EA_KK ", " EA_EW ", 16\n\t"     /* k | passive side << 7, as the list word carries them */ \
-        "s_and_b32 " EK_KT ", " EA_KK ", 0x7f\n\t")                                                   \
+  KKI "\n\t"                                           /* (only a trade needs the k word) */          \
   "L_match_" L ":\n\t"                                                                                \
-  CAND " " EA_C0 ", %[live0], %[bid0]\n\t"                                                            \
-  EA_IF2_##NR(CAND " " EA_C1 ", %[live1], %[bid1]\n\t")                                               \
-  "v_cndmask_b32_e64 %[vm], " SENT ", %[key0], " EA_C0 "\n\t"                                         \
-  EK_LC("v_cmp_lt_u32_e32 vcc, " EK_KT ", %[dt0]\n\t"   /* not cancelled yet at this position? */     \
-        "v_cndmask_b32_e32 %[vm], " SENT ", %[vm], vcc\n\t")                                          \
-  EA_IF2_##NR("v_cndmask_b32_e64 %[vm2], " SENT ", %[key1], " EA_C1 "\n\t"                            \
-              EK_LC("v_cmp_lt_u32_e32 vcc, " EK_KT ", %[dt1]\n\t"                                     \
-                    "v_cndmask_b32_e32 %[vm2], " SENT ", %[vm2], vcc\n\t")                            \
-              VOP " %[vm], %[vm], %[vm2]\n\t")                                                        \
+  EA_IF1_##NR("v_mov_b32 %[vm], %[key0]\n\t")                                                         \
+  EA_IF2_##NR(VOP " %[vm], %[key0], %[key1]\n\t")                                                     \
   EA_DPP(DOP)                                                                                         \
   "v_readlane_b32 " EA_BEST ", %[vm], 63\n\t"                                                         \
   "s_nop 1\n\t"                                        /* BEST as a VALU operand: 2 wait states */    \
@@ -458,39 +430,38 @@ __device__ __forceinline__ uint32_t events_asm_r1(uint32_t& k, uint32_t n_ev, ui
   "s_xor_b32 " EA_X ", " EK_KP ", %[sq]\n\t"                                                          \
   PULL " " OWNB ", " OWNB ", " EA_X "\n\t"             /* this side's bound covers the new order */  \
   "v_writelane_b32 %[key" RG "], " EA_X ", m0\n\t"                                                    \
-  "s_bitset1_b64 %[live" RG "], " EA_EW "\n\t"         /* (bit ew[5:0]) */                             \
-  "s_add_u32 %[sq], %[sq], 2\n\t"                                                                     \
+  "s_add_u32 %[sq], %[sq], 1\n\t"                                                                     \
   EA_LOOP(PH, KEND)
 
 #define EK_NEW(PH, KEND, RG, NR, CHK)                                                                 \
-  "v_readlane_b32 " EK_KP ", %[key" RG "], " EA_EW "\n\t"                                             \
   "v_readlane_b32 " EA_V ", %[vol" RG "], " EA_EW "\n\t"                                              \
   "s_bitcmp1_b32 " EA_EW ", 14\n\t"                                                                   \
   "s_cbranch_scc1 L_bid_" PH RG "_%=\n\t"                                                             \
   /* an ask: searches the bids (cannot cross if kp > bid bound), rests among the asks (ask bound = min) */ \
-  EK_SIDE("a" PH RG "_%=", PH, KEND, RG, NR, "s_and_b64", "0", "v_max_u32", "v_max_u32_dpp", "s_cmp_lt_u32", \
-          "s_or_b32 " EA_KK ", %[k], 0x80000000", EK_BHI, "s_cmp_gt_u32", EK_ALO, "s_min_u32",          \
+  EK_SIDE("a" PH RG "_%=", PH, KEND, RG, NR, "s_and_b32 " EK_KP ", " EA_EW ", 0xffff0000", "v_max_i32", "v_max_i32_dpp", \
+          "s_cmp_lt_i32", "s_or_b32 " EA_KK ", %[k], 0x80000000", EK_BHI, "s_cmp_gt_i32", EK_ALO, "s_min_i32", \
           CHK("a" PH RG "_%="))                                                                        \
   "L_bid_" PH RG "_%=:\n\t"                                                                           \
-  EK_SIDE("b" PH RG "_%=", PH, KEND, RG, NR, "s_andn2_b64", "-1", "v_min_u32", "v_min_u32_dpp", "s_cmp_gt_u32", \
-          "s_mov_b32 " EA_KK ", %[k]", EK_ALO, "s_cmp_lt_u32", EK_BHI, "s_max_u32", CHK("b" PH RG "_%="))
+  EK_SIDE("b" PH RG "_%=", PH, KEND, RG, NR, "s_or_b32 " EK_KP ", " EA_EW ", 0xffff", "v_min_i32", "v_min_i32_dpp", \
+          "s_cmp_gt_i32", "s_mov_b32 " EA_KK ", %[k]", EK_ALO, "s_cmp_lt_i32", EK_BHI, "s_max_i32", CHK("b" PH RG "_%="))
 
 #define EK_NOCHK(L) ""
 #define EK_PHASE(PH, EVN, KEND, NR, CHK)                                                              \
   "L_top_" PH "_%=:\n\t"                                                                              \
   "v_readlane_b32 " EA_EW ", %[ev" EVN "], %[k]\n\t"                                                  \
-  EK_LC("s_nop 1\n\t")          /* (stands in for the two instructions of the New test: ew becomes a lane select) */ \
-  EK_NLC("s_bitcmp1_b32 " EA_EW ", 15\n\t"                                                            \
-         "s_cbranch_scc1 L_new_" PH "_%=\n\t"                                                         \
-         /* Cancellation: s_bitset0_b64 clears bit ew[5:0] of the slot's live mask (one instruction for shift + and-not) */ \
-         EA_IF2_##NR("s_bitcmp1_b32 " EA_EW ", 6\n\t"                                                 \
-                     "s_cbranch_scc1 L_can1_" PH "_%=\n\t")                                           \
-         "s_bitset0_b64 %[live0], " EA_EW "\n\t"                                                      \
-         EA_IF2_##NR(EA_LOOP(PH, KEND)                                                                \
-                     "L_can1_" PH "_%=:\n\t"                                                          \
-                     "s_bitset0_b64 %[live1], " EA_EW "\n\t")                                         \
-         EA_LOOP(PH, KEND)                                                                            \
-         "L_new_" PH "_%=:\n\t")                                                                      \
+  "s_bitcmp1_b32 " EA_EW ", 15\n\t"                                                                   \
+  "s_cbranch_scc1 L_new_" PH "_%=\n\t"                                                                \
+  /* Cancellation: a zero into the slot's key lane, whichever side it rests on (ew as a lane select: 4 wait states   \
+     behind its v_readlane) */                                                                        \
+  EA_IF2_##NR("s_bitcmp1_b32 " EA_EW ", 6\n\t"                                                        \
+              "s_cbranch_scc1 L_can1_" PH "_%=\n\t")                                                  \
+  EA_IF1_##NR("s_nop 1\n\t")                                                                          \
+  "v_writelane_b32 %[key0], 0, " EA_EW "\n\t"                                                         \
+  EA_IF2_##NR(EA_LOOP(PH, KEND)                                                                       \
+              "L_can1_" PH "_%=:\n\t"                                                                 \
+              "v_writelane_b32 %[key1], 0, " EA_EW "\n\t")                                            \
+  EA_LOOP(PH, KEND)                                                                                   \
+  "L_new_" PH "_%=:\n\t"                                                                              \
   EA_IF2_##NR("s_bitcmp1_b32 " EA_EW ", 6\n\t"                                                        \
               "s_cbranch_scc1 L_new1_" PH "_%=\n\t")                                                  \
   EA_IF1_##NR("s_nop 1\n\t")                            /* ew as a lane select: 4 wait states */      \
@@ -519,8 +490,8 @@ __device__ __forceinline__ uint32_t events_asm_r1(uint32_t& k, uint32_t n_ev, ui
 // seven event waves that fit beside a k_agents_fsm wave on a SIMD: C3 277 -> 210 M.
 #define EK_R2_STMT \
   asm volatile( \
-      "s_mov_b32 " EK_ALO ", 0\n\t" \
-      "s_mov_b32 " EK_BHI ", -1\n\t" \
+      "s_mov_b32 " EK_ALO ", 0x80000000\n\t" \
+      "s_mov_b32 " EK_BHI ", 0x7fffffff\n\t" \
       "s_cmp_eq_u32 %[chk], 0\n\t" \
       "s_cbranch_scc1 L_fast_%=\n\t" \
       "s_cmp_lt_u32 %[k], %[kend0]\n\t" \
@@ -544,18 +515,17 @@ __device__ __forceinline__ uint32_t events_asm_r1(uint32_t& k, uint32_t n_ev, ui
       EK_PHASE("3", "1", "%[nev]", 2, EK_NOCHK) \
       "L_end_3_%=:\n\t" \
       EK_TAIL \
-      : [st] "=&s"(st), [vm] "=&v"(vm), [vm2] "=&v"(vm2), [k] "+s"(k), [trn] "+s"(trn), [sq] "+s"(sq), \
-        [live0] "+s"(live0), [live1] "+s"(live1), [vol0] "+v"(vol0), [vol1] "+v"(vol1), [key0] "+v"(key0), \
+      : [st] "=&s"(st), [vm] "=&v"(vm), [k] "+s"(k), [trn] "+s"(trn), [sq] "+s"(sq), \
+        [vol0] "+v"(vol0), [vol1] "+v"(vol1), [key0] "+v"(key0), \
         [key1] "+v"(key1), [trk] "+v"(trk), [trv] "+v"(trv), [trs] "+v"(trs) \
       : [ev0] "v"(ev0), [ev1] "v"(ev1), \
-        [bid0] "s"(bid0), [bid1] "s"(bid1), [nev] "s"(n_ev), [kend0] "s"(kend0), [tmask] "s"(tmask), [dt0] "v"(dt0), \
-        [dt1] "v"(dt1), [chk] "s"(checked) \
+        [nev] "s"(n_ev), [kend0] "s"(kend0), [tmask] "s"(tmask), [chk] "s"(checked) \
       : EK_CLOBBERS);
 
 #define EK_R1_STMT \
   asm volatile( \
-      "s_mov_b32 " EK_ALO ", 0\n\t" \
-      "s_mov_b32 " EK_BHI ", -1\n\t" \
+      "s_mov_b32 " EK_ALO ", 0x80000000\n\t" \
+      "s_mov_b32 " EK_BHI ", 0x7fffffff\n\t" \
       "s_cmp_lt_u32 %[k], %[nev]\n\t" \
       "s_cbranch_scc0 L_done_%=\n\t" \
       "s_cmp_eq_u32 %[chk], 0\n\t" \
@@ -566,33 +536,26 @@ __device__ __forceinline__ uint32_t events_asm_r1(uint32_t& k, uint32_t n_ev, ui
       EK_PHASE("2", "0", "%[nev]", 1, EK_NOCHK) \
       "L_end_2_%=:\n\t" \
       EK_TAIL \
-      : [st] "=&s"(st), [vm] "=&v"(vm), [k] "+s"(k), [trn] "+s"(trn), [sq] "+s"(sq), [live0] "+s"(live0), \
+      : [st] "=&s"(st), [vm] "=&v"(vm), [k] "+s"(k), [trn] "+s"(trn), [sq] "+s"(sq), \
         [vol0] "+v"(vol0), [key0] "+v"(key0), [trk] "+v"(trk), [trv] "+v"(trv), [trs] "+v"(trs) \
-      : [ev0] "v"(ev0), [bid0] "s"(bid0), [nev] "s"(n_ev), [tmask] "s"(tmask), \
-        [dt0] "v"(dt0), [chk] "s"(checked) \
+      : [ev0] "v"(ev0), [nev] "s"(n_ev), [tmask] "s"(tmask), [chk] "s"(checked) \
       : EK_CLOBBERS);
 
-// Keyed form of events_asm_r2: `sq` = (seq_ctr - sbase) << 1 (the caller converts back), key0/key1 as described above.
+// Keyed form of events_asm_r2: `sq` = 0x80000000 | (seq_ctr - sbase) (the caller converts back), key0 / key1 and the event
+// words (compare value in the upper half) as described above.
 // checked = 0: the caller guarantees trading is enabled and every new order of the step has volume > 0
 // (trk / trv / trs: the compact trade records - k word, volume, passive order's pool slot; book_device.hpp flush_trades_compact)
 __device__ __forceinline__ uint32_t events_key_r2(uint32_t checked, uint32_t& k, uint32_t n_ev, uint32_t tmask, uint32_t& tr_n, uint32_t& sq,
-                                                  uint64_t& live0, uint64_t& live1, uint64_t bid0, uint64_t bid1,
                                                   uint32_t& vol0, uint32_t& vol1, uint32_t& key0, uint32_t& key1, uint32_t ev0,
-                                                  uint32_t ev1, uint32_t& trk, uint32_t& trv, uint32_t& trs,
-                                                  uint32_t dt0 = 0xFFFFFFFFu, uint32_t dt1 = 0xFFFFFFFFu) {
-  uint32_t st, vm, vm2;
+                                                  uint32_t ev1, uint32_t& trk, uint32_t& trv, uint32_t& trs) {
+  uint32_t st, vm;
   auto u32 = [](uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane(x); };
-  auto u64 = [&](uint64_t x) { return ((uint64_t)u32((uint32_t)(x >> 32)) << 32) | u32((uint32_t)x); };
   checked = u32(checked);
   k = u32(k);
   n_ev = u32(n_ev);
   tmask = u32(tmask);
   uint32_t trn = u32(tr_n) - 64u;  // biased: see above
   sq = u32(sq);
-  live0 = u64(live0);
-  live1 = u64(live1);
-  bid0 = u64(bid0);
-  bid1 = u64(bid1);
   const uint32_t kend0 = n_ev < 64u ? n_ev : 64u;
   EK_R2_STMT
   tr_n = trn + 64u;
@@ -600,19 +563,16 @@ __device__ __forceinline__ uint32_t events_key_r2(uint32_t checked, uint32_t& k,
 }
 
 __device__ __forceinline__ uint32_t events_key_r1(uint32_t checked, uint32_t& k, uint32_t n_ev, uint32_t tmask, uint32_t& tr_n, uint32_t& sq,
-                                                  uint64_t& live0, uint64_t bid0, uint32_t& vol0, uint32_t& key0, uint32_t ev0,
-                                                  uint32_t& trk, uint32_t& trv, uint32_t& trs, uint32_t dt0 = 0xFFFFFFFFu) {
+                                                  uint32_t& vol0, uint32_t& key0, uint32_t ev0, uint32_t& trk, uint32_t& trv,
+                                                  uint32_t& trs) {
   uint32_t st, vm;
   auto u32 = [](uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane(x); };
-  auto u64 = [&](uint64_t x) { return ((uint64_t)u32((uint32_t)(x >> 32)) << 32) | u32((uint32_t)x); };
   checked = u32(checked);
   k = u32(k);
   n_ev = u32(n_ev);
   tmask = u32(tmask);
   uint32_t trn = u32(tr_n) - 64u;
   sq = u32(sq);
-  live0 = u64(live0);
-  bid0 = u64(bid0);
   EK_R1_STMT
   tr_n = trn + 64u;
   return st;
