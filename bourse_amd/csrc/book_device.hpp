@@ -50,9 +50,10 @@ namespace bkd {
 __device__ unsigned int* g_stamp_ptr;
 #define BK_STAMP_FIELD    \
   unsigned long long stamp_t; \
-  unsigned int stamp_book;
+  unsigned int stamp_book, stamp_t0;
 #define BK_STAMP_START(obj, book)                  \
   (obj).stamp_t = __builtin_amdgcn_s_memtime(); \
+  (obj).stamp_t0 = (unsigned int)(obj).stamp_t;   \
   (obj).stamp_book = (book)
 #define BK_STAMP(obj, kernel, phase, lane)                                                           \
   do {                                                                                               \
@@ -60,8 +61,14 @@ __device__ unsigned int* g_stamp_ptr;
     if ((lane) == 0) g_stamp_ptr[(size_t)(obj).stamp_book * 16 + (kernel) * 8 + (phase)] += (unsigned int)(n_ - (obj).stamp_t); \
     (obj).stamp_t = n_;                                                                              \
   } while (0)
-#define BK_STAMP_COUNT(obj, kernel, lane) \
-  if ((lane) == 0) g_stamp_ptr[(size_t)(obj).stamp_book * 16 + (kernel) * 8 + 7] += 1u
+// (+ the wave's absolute start / end of its LATEST run, low 32 bits of the clock: words 6 / 2 of k_step_batch's eight, 4 / 5
+// of k_agents_wave's - scripts/wave_phases.py --skew)
+#define BK_STAMP_COUNT(obj, kernel, lane)                                                                       \
+  if ((lane) == 0) {                                                                                            \
+    g_stamp_ptr[(size_t)(obj).stamp_book * 16 + (kernel) * 8 + 7] += 1u;                                        \
+    g_stamp_ptr[(size_t)(obj).stamp_book * 16 + (kernel) * 8 + ((kernel) ? 4 : 6)] = (obj).stamp_t0;            \
+    g_stamp_ptr[(size_t)(obj).stamp_book * 16 + (kernel) * 8 + ((kernel) ? 5 : 2)] = (unsigned int)(obj).stamp_t; \
+  }
 #else
 #define BK_STAMP_FIELD
 #define BK_STAMP_START(obj, book)
@@ -1097,14 +1104,29 @@ __device__ __forceinline__ uint32_t step_from_list(Book<R>& B, const DevArgs& a,
       for (int r = 0; r < R; ++r) B.pend[r] = 0;  // every pending order is an event of this step
     }
     key_event_words<R>(K, evw, rfl(n_ev), evw);
+    // ... and the new orders' volumes by event position (the loop reads an event's volume by the lane it reads the event
+    // word from instead of addressing the slot's pool row)
+    uint32_t evq[R];
+#pragma unroll
+    for (int re = 0; re < R; ++re)
+      evq[re] = n_ev > (uint32_t)re * 64u ? pool_gather<R>(B.vol, evw[re] & EV_SLOT & (64u * R - 1u)) : 0u;
     uint32_t k = 0;
     const uint32_t nev = rfl(n_ev), tmask = B.trading ? 0xFFFFFFFFu : 0u;
+    // (as for the smaller pools: the "no volume or trading disabled" test only in steps that need it)
+    uint64_t zero_vol = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) zero_vol |= __ballot(lane_bit(newm[r]) && B.vol[r] == 0u);
+    const uint32_t checked = (!B.trading || zero_vol != 0) ? 1u : 0u;
     for (;;) {
       uint32_t full;
-      if constexpr (R == 4)
-        full = events_key_r4(k, nev, tmask, B.tr_n, K.sq, B.vol, K.key, evw, B.tr_k, B.tr_vol, B.tr_pas);
+      if constexpr (R == 4 && CLS)
+        full = events_key_r4(checked, k, nev, tmask, B.tr_n, K.sq, B.vol, K.key, evw, evq, B.tr_k, B.tr_vol, B.tr_pas);
+      else if constexpr (R == 4)
+        full = events_key_r4m(checked, k, nev, tmask, B.tr_n, K.sq, B.vol, K.key, evw, evq, B.tr_k, B.tr_vol, B.tr_pas);
+      else if constexpr (CLS)
+        full = events_key_r8(checked, k, nev, tmask, B.tr_n, K.sq, B.vol, K.key, evw, evq, B.tr_k, B.tr_vol, B.tr_pas);
       else
-        full = events_key_r8(k, nev, tmask, B.tr_n, K.sq, B.vol, K.key, evw, B.tr_k, B.tr_vol, B.tr_pas);
+        full = events_key_r8m(checked, k, nev, tmask, B.tr_n, K.sq, B.vol, K.key, evw, evq, B.tr_k, B.tr_vol, B.tr_pas);
       if (B.tr_n) B.trade_vol += wave_add((uint32_t)lane < B.tr_n ? B.tr_vol : 0u);
       flush_trades_compact<R>(B, a, book, t0, lane, evw);
       if (!full) break;

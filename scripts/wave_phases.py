@@ -8,6 +8,7 @@ import numpy as np, bourse_amd as bk
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 pipe = sys.argv[2] if len(sys.argv) > 2 else "auto"
 WL = sys.argv[3] if len(sys.argv) > 3 else "C3"
+SKEW = "--skew" in sys.argv  # also: one step on its own, every wave's absolute start / end inside its launch
 if WL == "C5":
     G, LV, POOL = [(256, (100, 164), (10, 20), 2, 0.8), (256, (100, 164), (50, 70), 2, 0.2)], 64, 512
 else:
@@ -28,7 +29,9 @@ for _ in range(T // 50):
 env.sync()
 dt = time.perf_counter() - t0
 L.bk_debug_stamps(B, buf.ctypes.data_as(C.c_void_p))
-a = buf.astype(np.float64).sum(axis=0).reshape(2, 8)
+a = buf.astype(np.float64)
+a[:, [2, 6, 12, 13]] = 0  # (the absolute stamps of --skew)
+a = a.sum(axis=0).reshape(2, 8)
 print(f"{B} books, pipeline {env.pipeline()}: {B * T / dt / 1e6:.1f} M book-steps/s with the stamps in (s_memtime per phase)")
 names = {0: ("k_step_batch", ["loads' round trip", "unpack + masks + new orders", "-", "keys + event loop", "snapshot + trade flush", "store"]),
          1: ("k_agents_wave", ["lane-state cache in", "agents.update (generate, windows, walk)", "shuffle", "publish"])}
@@ -41,3 +44,31 @@ for k, (kn, ph) in names.items():
     for i, p in enumerate(ph):
         if p != "-":
             print(f"     {p:42s} {a[k, i] / n:9.0f} clocks  {100 * a[k, i] / tot:5.1f} %")
+
+def skew(title):
+    parts = max(1, env.pipeline()[1])
+    print(title)
+    for k, (kn, st, en) in {0: ("k_step_batch", 6, 2), 1: ("k_agents_wave", 12, 13)}.items():
+        if not buf[:, k * 8 + 7].any():
+            continue
+        per = (B + parts - 1) // parts
+        for pi in range(parts):
+            sl = slice(pi * per, min(B, (pi + 1) * per))
+            s0 = buf[sl, st].astype(np.int64)
+            e0 = buf[sl, en].astype(np.int64)
+            base = s0.min()
+            s_rel = (s0 - base) & 0xFFFFFFFF
+            e_rel = (e0 - base) & 0xFFFFFFFF
+            d = (e0 - s0) & 0xFFFFFFFF
+            q = lambda x, p: float(np.percentile(x, p)) / 2.24e3
+            print(f"  {kn} part {pi} ({sl.stop - sl.start} waves), us at 2.24 GHz: wave life p50 {q(d, 50):.1f} p90 {q(d, 90):.1f} max {q(d, 100):.1f};"
+                  f" start p50 {q(s_rel, 50):.1f} p90 {q(s_rel, 90):.1f} max {q(s_rel, 100):.1f}; end p50 {q(e_rel, 50):.1f} p99 {q(e_rel, 99):.1f} max {q(e_rel, 100):.1f}")
+
+
+if SKEW:
+    skew("last step of the run above (all parts in flight):")
+    env.sync()
+    env.run(1)
+    env.sync()
+    L.bk_debug_stamps(B, buf.ctypes.data_as(C.c_void_p))
+    skew("one step alone on the device:")

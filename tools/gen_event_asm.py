@@ -25,11 +25,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "bourse_amd", "csrc", "event_asm_gen.hpp")
 
 
-def gen(N):
+VOL_LIST = True  # the new orders' volumes travel in a second list (by event position) instead of being read from the slot
+
+
+def gen(N, markets):
     KB, VB, EB = 40, 40 + N, 40 + 2 * N                     # VGPR rows: key, vol, event list
+    QB = 40 + 3 * N                                           # ... and the new orders' volumes by event position
     EQB = 36                                                  # SGPR: row-compare results, scratch
     SC = EQB + 2 * N
-    names = ["EW", "KP", "V", "KK", "BEST", "PV", "LS", "X", "SLOT", "ALO", "BHI", "RG"]
+    names = ["EW", "KP", "V", "KK", "BEST", "PV", "LS", "X", "SLOT", "ALO", "BHI", "RG", "KEND"]
     S = {n: f"s{SC + i}" for i, n in enumerate(names)}
     last_s = SC + len(names) - 1
     bits = {4: 2, 8: 3}[N]
@@ -45,9 +49,6 @@ def gen(N):
            "row_half_mirror row_mask:0xf bank_mask:0xf", "row_mirror row_mask:0xf bank_mask:0xf",
            "row_bcast:15 row_mask:0xa bank_mask:0xf", "row_bcast:31 row_mask:0xc bank_mask:0xf"]
 
-    def loop():
-        e("s_branch L_loop_%=")
-
     def slot_write(pairs):     # row RG, lane EW[5:0] of the given arrays := the given scalars (EXEC = that one lane)
         e(f"s_lshl_b64 exec, 1, {S['EW']}")
         e(f"s_set_gpr_idx_on {S['RG']}, gpr_idx(DST)")
@@ -61,128 +62,159 @@ def gen(N):
     e(f"s_mov_b32 {S['BHI']}, 0x7fffffff")
     e("s_cmp_lt_u32 %[k], %[nev]")
     e("s_cbranch_scc0 L_done_%=")
-    e("L_reload_%=:")                                       # evc = ev[k >> 6]
-    e(f"s_lshr_b32 {S['RG']}, %[k], 6")
-    e(f"s_set_gpr_idx_on {S['RG']}, gpr_idx(SRC0)")
-    e(f"v_mov_b32 %[evc], v{EB}")
-    e("s_set_gpr_idx_off")
-    e("s_nop 0")
-    # ---------------------------------------------------------------- one event
-    e("L_top_%=:")
-    e(f"v_readlane_b32 {S['EW']}, %[evc], %[k]")
-    e(f"s_bfe_u32 {S['RG']}, {S['EW']}, {hex((bits << 16) | 6)}")   # the slot's pool row
-    e(f"s_bitcmp1_b32 {S['EW']}, 15")
-    e("s_cbranch_scc1 L_new_%=")
-    slot_write([(KB, "0")])                                 # Cancellation: the key goes (whichever side it rests on)
-    e("L_loop_%=:")
-    e("s_add_u32 %[k], %[k], 1")
-    e("s_cmp_lt_u32 %[k], %[nev]")
-    e("s_cbranch_scc0 L_done_%=")
-    e(f"s_and_b32 {S['X']}, %[k], 63")
-    e("s_cbranch_scc1 L_top_%=")
-    e("s_branch L_reload_%=")
-    # New order: its volume from the slot (ew as a lane select: 4 wait states behind its v_readlane - bfe, bitcmp, branch, idx_on)
-    e("L_new_%=:")
-    e(f"s_set_gpr_idx_on {S['RG']}, gpr_idx(SRC0)")
-    e(f"v_mov_b32 %[vm], v{VB}")
-    e("s_set_gpr_idx_off")
-    e(f"v_readlane_b32 {S['V']}, %[vm], {S['EW']}")
-    e(f"s_bitcmp1_b32 {S['EW']}, 14")
-    e("s_cbranch_scc1 L_bid_%=")
+    e("s_cmp_eq_u32 %[chk], 0")
+    e("s_cbranch_scc1 L_reload_f_%=")
 
-    def side(tag, agg_bid):
-        # agg_bid: searches the asks (signed min), rests among the bids
-        op3 = "v_min3_i32" if agg_bid else "v_max3_i32"
-        op2 = "v_min_i32" if agg_bid else "v_max_i32"
-        oppb, ownb = (S["ALO"], S["BHI"]) if agg_bid else (S["BHI"], S["ALO"])
-        mkt = "-1" if agg_bid else "0x10000"
-        # the compare value from the event word's upper half (book_device.hpp "SIGNED KEYS")
-        e(f"s_or_b32 {S['KP']}, {S['EW']}, 0xffff" if agg_bid else f"s_and_b32 {S['KP']}, {S['EW']}, 0xffff0000")
-        e(f"s_and_b32 {S['X']}, {S['V']}, %[tmask]")            # no volume or trading disabled: no match
-        e(f"s_cbranch_scc0 L_restq_{tag}_%=")
-        e(f"{'s_cmp_lt_i32' if agg_bid else 's_cmp_gt_i32'} {S['KP']}, {oppb}")   # beyond the bound: cannot cross
-        e(f"s_cbranch_scc1 L_restq_{tag}_%=")
-        e(f"s_mov_b32 {S['KK']}, %[k]" if agg_bid else f"s_or_b32 {S['KK']}, %[k], 0x80000000")
-        e(f"L_match_{tag}_%=:")
-        if N == 4:
-            e(f"{op3} %[vm], {key(0)}, {key(1)}, {key(2)}")
-            e(f"{op2} %[vm], %[vm], {key(3)}")
+    def copy(c, vchk):
+        # c: label suffix of this copy of the loop; vchk: test "no volume or trading disabled" on every new order (the
+        # caller has established that no step of this statement needs it when %[chk] = 0)
+        def loop():
+            e(f"s_branch L_loop_{c}_%=")
+
+        e(f"L_reload_{c}_%=:")                                  # evc = ev[k >> 6]; this list register ends at KEND
+        e(f"s_lshr_b32 {S['RG']}, %[k], 6")
+        e(f"s_set_gpr_idx_on {S['RG']}, gpr_idx(SRC0)")
+        e(f"v_mov_b32 %[evc], v{EB}")
+        if VOL_LIST:
+            e(f"v_mov_b32 %[evq], v{QB}")
+        e("s_set_gpr_idx_off")
+        e(f"s_or_b32 {S['X']}, %[k], 63")
+        e(f"s_add_u32 {S['X']}, {S['X']}, 1")
+        e(f"s_min_u32 {S['KEND']}, {S['X']}, %[nev]")
+        # ------------------------------------------------------------ one event
+        e(f"L_top_{c}_%=:")
+        e(f"v_readlane_b32 {S['EW']}, %[evc], %[k]")
+        e(f"s_bfe_u32 {S['RG']}, {S['EW']}, {hex((bits << 16) | 6)}")   # the slot's pool row
+        e(f"s_bitcmp1_b32 {S['EW']}, 15")
+        e(f"s_cbranch_scc1 L_new_{c}_%=")
+        slot_write([(KB, "0")])                                 # Cancellation: the key goes (whichever side it rests on)
+        e(f"L_loop_{c}_%=:")
+        e("s_add_u32 %[k], %[k], 1")
+        e(f"s_cmp_lt_u32 %[k], {S['KEND']}")
+        e(f"s_cbranch_scc1 L_top_{c}_%=")
+        e("s_cmp_lt_u32 %[k], %[nev]")
+        e(f"s_cbranch_scc1 L_reload_{c}_%=")
+        e("s_branch L_done_%=")
+        # New order: its volume from the slot (ew as a lane select: 4 wait states behind its v_readlane - bfe, bitcmp, branch, idx_on)
+        e(f"L_new_{c}_%=:")
+        if VOL_LIST:
+            e(f"v_readlane_b32 {S['V']}, %[evq], %[k]")
         else:
-            e(f"{op3} %[vm], {key(0)}, {key(1)}, {key(2)}")
-            e(f"{op3} %[vt], {key(3)}, {key(4)}, {key(5)}")
-            e(f"{op3} %[vm], %[vm], {key(6)}, {key(7)}")
-            e(f"{op2} %[vm], %[vm], %[vt]")
-        for ctl in DPP:
-            e("s_nop 1")
-            e(f"{op2}_dpp %[vm], %[vm], %[vm] {ctl}")
-        e("s_nop 1")
-        e(f"v_readlane_b32 {S['BEST']}, %[vm], 63")
-        e("s_nop 1")                                            # BEST as a VALU operand: 2 wait states
-        for r in range(N):
-            e(f"v_cmp_eq_u32_e64 {eq(r)}, {S['BEST']}, {key(r)}")
-        e(f"s_mov_b32 {oppb}, {S['BEST']}")                     # the bound is exact now
-        e(f"{'s_cmp_gt_i32' if agg_bid else 's_cmp_lt_i32'} {S['BEST']}, {S['KP']}")   # no cross (or nothing there)
-        e(f"s_cbranch_scc1 L_rest_{tag}_%=")
-        for r in range(N - 1):
-            e(f"s_cmp_lg_u64 {eq(r)}, 0")
-            e(f"s_cbranch_scc1 L_pick{r}_{tag}_%=")
-        for r in reversed(range(N)):                            # (the last row falls through into its block)
-            e(f"L_pick{r}_{tag}_%=:")
-            e(f"s_ff1_i32_b64 {S['LS']}, {eq(r)}")
-            if r:
-                e(f"s_or_b32 {S['SLOT']}, {S['LS']}, {64 * r}")
-            slot = S["SLOT"] if r else S["LS"]
-            e("s_mov_b32 m0, %[trn]")
-            e(f"v_readlane_b32 {S['PV']}, {vol(r)}, {S['LS']}")
-            e(f"v_writelane_b32 %[trk], {S['KK']}, m0")
-            e(f"v_writelane_b32 %[trs], {slot}, m0")
-            e(f"s_sub_u32 {S['X']}, {S['PV']}, {S['V']}")       # SCC = borrow: the passive order is the smaller one
-            e(f"s_cbranch_scc1 L_A{r}_{tag}_%=")
-            e(f"v_writelane_b32 %[trv], {S['V']}, m0")          # aggressor exhausted; X = passive remainder
-            e(f"s_mov_b32 m0, {S['LS']}")
-            e(f"v_writelane_b32 {vol(r)}, {S['X']}, m0")
-            e(f"s_cmp_eq_u32 {S['X']}, 0")
-            e(f"s_cbranch_scc0 L_B{r}_{tag}_%=")
-            e(f"v_writelane_b32 {key(r)}, 0, m0")               # ... and the passive order with it
-            e(f"L_B{r}_{tag}_%=:")
-            e("s_add_u32 %[trn], %[trn], 1")                    # SCC = carry = buffer full
-            e("s_cbranch_scc1 L_fullnext_%=")
-            loop()
-            e(f"L_A{r}_{tag}_%=:")                              # passive order exhausted, aggressor goes on
-            e(f"v_writelane_b32 %[trv], {S['PV']}, m0")
-            e(f"s_mov_b32 m0, {S['LS']}")
-            e(f"v_writelane_b32 {vol(r)}, 0, m0")
-            e(f"v_writelane_b32 {key(r)}, 0, m0")
-            e(f"s_sub_u32 {S['V']}, {S['V']}, {S['PV']}")
-            e("s_add_u32 %[trn], %[trn], 1")
-            e(f"s_cbranch_scc1 L_fullA_{tag}_%=")
-            e(f"s_branch L_match_{tag}_%=")
-        # buffer full, volume left: the event restarts with what remains
-        e(f"L_fullA_{tag}_%=:")
-        slot_write([(VB, S["V"])])
-        e("s_branch L_flush_%=")
-        # rests with what the trades left ... (a market order's remainder is dropped: orderbook.rs:521-524)
-        e(f"L_rest_{tag}_%=:")
-        e(f"s_cmp_eq_u32 {S['KP']}, {mkt}")
-        e("s_cbranch_scc1 L_loop_%=")
-        e(f"s_xor_b32 {S['X']}, {S['KP']}, %[sq]")
-        e(f"{'s_max_i32' if agg_bid else 's_min_i32'} {ownb}, {ownb}, {S['X']}")   # this side's bound covers the new order
-        slot_write([(VB, S["V"]), (KB, S["X"])])
-        e("s_add_u32 %[sq], %[sq], 1")
-        loop()
-        # ... or untouched (no volume / trading disabled / beyond the bound; a market order can only get here by the first two)
-        e(f"L_restq_{tag}_%=:")
-        e(f"s_cmp_eq_u32 {S['KP']}, {mkt}")
-        e("s_cbranch_scc1 L_loop_%=")
-        e(f"s_xor_b32 {S['X']}, {S['KP']}, %[sq]")
-        e(f"{'s_max_i32' if agg_bid else 's_min_i32'} {ownb}, {ownb}, {S['X']}")
-        slot_write([(KB, S["X"])])
-        e("s_add_u32 %[sq], %[sq], 1")
-        loop()
+            e(f"s_set_gpr_idx_on {S['RG']}, gpr_idx(SRC0)")
+            e(f"v_mov_b32 %[vm], v{VB}")
+            e("s_set_gpr_idx_off")
+            e(f"v_readlane_b32 {S['V']}, %[vm], {S['EW']}")
+        e(f"s_bitcmp1_b32 {S['EW']}, 14")
+        e(f"s_cbranch_scc1 L_bid_{c}_%=")
 
-    side("a", False)
-    e("L_bid_%=:")
-    side("b", True)
+        def side(tag, agg_bid):
+            # agg_bid: searches the asks (signed min), rests among the bids
+            tag = tag + c
+            op3 = "v_min3_i32" if agg_bid else "v_max3_i32"
+            op2 = "v_min_i32" if agg_bid else "v_max_i32"
+            oppb, ownb = (S["ALO"], S["BHI"]) if agg_bid else (S["BHI"], S["ALO"])
+            mkt = "-1" if agg_bid else "0x10000"
+            # the compare value from the event word's upper half (book_device.hpp "SIGNED KEYS")
+            e(f"s_or_b32 {S['KP']}, {S['EW']}, 0xffff" if agg_bid else f"s_and_b32 {S['KP']}, {S['EW']}, 0xffff0000")
+            if vchk:
+                e(f"s_and_b32 {S['X']}, {S['V']}, %[tmask]")        # no volume or trading disabled: no match
+                e(f"s_cbranch_scc0 L_restq_{tag}_%=")
+            e(f"{'s_cmp_lt_i32' if agg_bid else 's_cmp_gt_i32'} {S['KP']}, {oppb}")   # beyond the bound: cannot cross
+            e(f"s_cbranch_scc1 L_restq_{tag}_%=")
+            e(f"s_mov_b32 {S['KK']}, %[k]" if agg_bid else f"s_or_b32 {S['KK']}, %[k], 0x80000000")
+            e(f"L_match_{tag}_%=:")
+            if N == 4:
+                e(f"{op3} %[vm], {key(0)}, {key(1)}, {key(2)}")
+                e(f"{op2} %[vm], %[vm], {key(3)}")
+            else:
+                e(f"{op3} %[vm], {key(0)}, {key(1)}, {key(2)}")
+                e(f"{op3} %[vt], {key(3)}, {key(4)}, {key(5)}")
+                e(f"{op3} %[vm], %[vm], {key(6)}, {key(7)}")
+                e(f"{op2} %[vm], %[vm], %[vt]")
+            for ctl in DPP:
+                e("s_nop 1")
+                e(f"{op2}_dpp %[vm], %[vm], %[vm] {ctl}")
+            e("s_nop 1")
+            e(f"v_readlane_b32 {S['BEST']}, %[vm], 63")
+            e("s_nop 1")                                            # BEST as a VALU operand: 2 wait states
+            for r in range(N):
+                e(f"v_cmp_eq_u32_e64 {eq(r)}, {S['BEST']}, {key(r)}")
+            e(f"s_mov_b32 {oppb}, {S['BEST']}")                     # the bound is exact now
+            e(f"{'s_cmp_gt_i32' if agg_bid else 's_cmp_lt_i32'} {S['BEST']}, {S['KP']}")   # no cross (or nothing there)
+            e(f"s_cbranch_scc1 L_rest_{tag}_%=")
+            for r in range(N - 1):
+                e(f"s_cmp_lg_u64 {eq(r)}, 0")
+                e(f"s_cbranch_scc1 L_pick{r}_{tag}_%=")
+            for r in reversed(range(N)):                            # (the last row falls through into its block)
+                e(f"L_pick{r}_{tag}_%=:")
+                e(f"s_ff1_i32_b64 {S['LS']}, {eq(r)}")
+                if r:
+                    e(f"s_or_b32 {S['SLOT']}, {S['LS']}, {64 * r}")
+                slot = S["SLOT"] if r else S["LS"]
+                e("s_mov_b32 m0, %[trn]")
+                e(f"v_readlane_b32 {S['PV']}, {vol(r)}, {S['LS']}")
+                e(f"v_writelane_b32 %[trk], {S['KK']}, m0")
+                e(f"v_writelane_b32 %[trs], {slot}, m0")
+                e(f"s_sub_u32 {S['X']}, {S['PV']}, {S['V']}")       # SCC = borrow: the passive order is the smaller one
+                e(f"s_cbranch_scc1 L_A{r}_{tag}_%=")
+                e(f"v_writelane_b32 %[trv], {S['V']}, m0")          # aggressor exhausted; X = passive remainder
+                e(f"s_mov_b32 m0, {S['LS']}")
+                e(f"v_writelane_b32 {vol(r)}, {S['X']}, m0")
+                e(f"s_cmp_eq_u32 {S['X']}, 0")
+                e(f"s_cbranch_scc0 L_B{r}_{tag}_%=")
+                e(f"v_writelane_b32 {key(r)}, 0, m0")               # ... and the passive order with it
+                e(f"L_B{r}_{tag}_%=:")
+                e("s_add_u32 %[trn], %[trn], 1")                    # SCC = carry = buffer full
+                e("s_cbranch_scc1 L_fullnext_%=")
+                loop()
+                e(f"L_A{r}_{tag}_%=:")                              # passive order exhausted, aggressor goes on
+                e(f"v_writelane_b32 %[trv], {S['PV']}, m0")
+                e(f"s_mov_b32 m0, {S['LS']}")
+                e(f"v_writelane_b32 {vol(r)}, 0, m0")
+                e(f"v_writelane_b32 {key(r)}, 0, m0")
+                e(f"s_sub_u32 {S['V']}, {S['V']}, {S['PV']}")
+                e("s_add_u32 %[trn], %[trn], 1")
+                e(f"s_cbranch_scc1 L_fullA_{tag}_%=")
+                e(f"s_branch L_match_{tag}_%=")
+            # buffer full, volume left: the event restarts with what remains
+            e(f"L_fullA_{tag}_%=:")
+            slot_write([(VB, S["V"])])
+            if VOL_LIST:                                            # ... also where the restarted event reads it
+                e(f"s_lshl_b64 exec, 1, %[k]")
+                e(f"s_lshr_b32 {S['RG']}, %[k], 6")
+                e(f"s_set_gpr_idx_on {S['RG']}, gpr_idx(DST)")
+                e(f"v_mov_b32 v{QB}, {S['V']}")
+                e("s_set_gpr_idx_off")
+                e("s_mov_b64 exec, -1")
+            e("s_branch L_flush_%=")
+            # rests with what the trades left ... (a market order's remainder is dropped: orderbook.rs:521-524)
+            e(f"L_rest_{tag}_%=:")
+            if markets:
+                e(f"s_cmp_eq_u32 {S['KP']}, {mkt}")
+                e(f"s_cbranch_scc1 L_loop_{c}_%=")
+            e(f"s_xor_b32 {S['X']}, {S['KP']}, %[sq]")
+            e(f"{'s_max_i32' if agg_bid else 's_min_i32'} {ownb}, {ownb}, {S['X']}")   # this side's bound covers the new order
+            slot_write([(VB, S["V"]), (KB, S["X"])])
+            e("s_add_u32 %[sq], %[sq], 1")
+            loop()
+            # ... or untouched (no volume / trading disabled / beyond the bound - which an EMPTY other side also is: a
+            # market order that finds nobody gets here)
+            e(f"L_restq_{tag}_%=:")
+            if markets:
+                e(f"s_cmp_eq_u32 {S['KP']}, {mkt}")
+                e(f"s_cbranch_scc1 L_loop_{c}_%=")
+            e(f"s_xor_b32 {S['X']}, {S['KP']}, %[sq]")
+            e(f"{'s_max_i32' if agg_bid else 's_min_i32'} {ownb}, {ownb}, {S['X']}")
+            slot_write([(KB, S["X"])])
+            e("s_add_u32 %[sq], %[sq], 1")
+            loop()
+
+        side("a", False)
+        e(f"L_bid_{c}_%=:")
+        side("b", True)
+
+    copy("c", True)
+    copy("f", False)
     e("L_done_%=:")
     e("s_mov_b32 %[st], 0")
     e("s_branch L_out_%=")
@@ -197,34 +229,37 @@ def gen(N):
     clob = ", ".join(f'"s{i}"' for i in range(EQB, last_s + 1))
     vt = {4: "u32x4", 8: "u32x8"}[N]
     return f'''
-// ---- R = {N}: {len(L)} instructions; rows key v[{KB}:{KB + N - 1}], vol v[{VB}:{VB + N - 1}], list v[{EB}:{EB + N - 1}];
+// ---- R = {N}{', lists that may carry market orders' if markets else ''}: {len(L)} instructions; rows key v[{KB}:{KB + N - 1}], vol v[{VB}:{VB + N - 1}], lists v[{EB}:{EB + N - 1}] (event words), v[{QB}:{QB + N - 1}] (volumes);
 // row-compare results s[{EQB}:{EQB + 2 * N - 1}]; scratch s{SC}..s{last_s}.  EXEC must be all ones on entry (it is restored to that).
-__device__ __forceinline__ uint32_t events_key_r{N}(uint32_t& k, uint32_t n_ev, uint32_t tmask, uint32_t& tr_n, uint32_t& sq,
-                                                  uint32_t (&vol)[{N}], uint32_t (&key)[{N}], const uint32_t (&ev)[{N}],
+__device__ __forceinline__ uint32_t events_key_r{N}{'m' if markets else ''}(uint32_t checked, uint32_t& k, uint32_t n_ev, uint32_t tmask, uint32_t& tr_n, uint32_t& sq,
+                                                  uint32_t (&vol)[{N}], uint32_t (&key)[{N}], const uint32_t (&ev)[{N}], uint32_t (&evq)[{N}],
                                                   uint32_t& trk, uint32_t& trv, uint32_t& trs) {{
-  uint32_t st, vm, vt, evc;
+  uint32_t st, vm, vt, evc, evqc;
   auto u32 = [](uint32_t x) {{ return (uint32_t)__builtin_amdgcn_readfirstlane(x); }};
+  checked = u32(checked);
   k = u32(k);
   n_ev = u32(n_ev);
   tmask = u32(tmask);
   uint32_t trn = u32(tr_n) - 64u;  // biased: the increment carries out exactly when the buffer is full
   sq = u32(sq);
-  {vt} kv, vv, evv;
+  {vt} kv, vv, evv, evqv;
 #pragma unroll
   for (int r = 0; r < {N}; ++r) {{
     kv[r] = key[r];
     vv[r] = vol[r];
     evv[r] = ev[r];
+    evqv[r] = evq[r];
   }}
   asm volatile(
-{text}      : [st] "=&s"(st), [vm] "=&v"(vm), [vt] "=&v"(vt), [evc] "=&v"(evc), [k] "+s"(k), [trn] "+s"(trn), [sq] "+s"(sq),
-        [key] "+{{v[{KB}:{KB + N - 1}]}}"(kv), [vol] "+{{v[{VB}:{VB + N - 1}]}}"(vv), [trk] "+v"(trk), [trv] "+v"(trv), [trs] "+v"(trs)
-      : [ev] "{{v[{EB}:{EB + N - 1}]}}"(evv), [nev] "s"(n_ev), [tmask] "s"(tmask)
+{text}      : [st] "=&s"(st), [vm] "=&v"(vm), [vt] "=&v"(vt), [evc] "=&v"(evc), [evq] "=&v"(evqc), [k] "+s"(k), [trn] "+s"(trn), [sq] "+s"(sq),
+        [key] "+{{v[{KB}:{KB + N - 1}]}}"(kv), [vol] "+{{v[{VB}:{VB + N - 1}]}}"(vv), [evqr] "+{{v[{QB}:{QB + N - 1}]}}"(evqv), [trk] "+v"(trk), [trv] "+v"(trv), [trs] "+v"(trs)
+      : [ev] "{{v[{EB}:{EB + N - 1}]}}"(evv), [nev] "s"(n_ev), [tmask] "s"(tmask), [chk] "s"(checked)
       : {clob}, "vcc", "scc", "memory");
 #pragma unroll
   for (int r = 0; r < {N}; ++r) {{
     key[r] = kv[r];
     vol[r] = vv[r];
+    evq[r] = evqv[r];
   }}
   tr_n = trn + 64u;
   return st;
@@ -246,7 +281,7 @@ typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
 '''
 
 if __name__ == "__main__":
-    src = HEADER + gen(4) + gen(8) + "\n}  // namespace bkd\n"
+    src = HEADER + gen(4, False) + gen(4, True) + gen(8, False) + gen(8, True) + "\n}  // namespace bkd\n"
     if "--check" in sys.argv:
         sys.exit(0 if os.path.exists(OUT) and open(OUT).read() == src else 1)
     open(OUT, "w").write(src)
