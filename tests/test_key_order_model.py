@@ -1,7 +1,8 @@
-"""Invariants of the order keys of the keyed event loop, on the integer model tools/key_model.py (the specification
-bourse_amd/csrc/event_asm.hpp and book_device.hpp keys_begin follow): the best key IS the order the reference's
-price-time priority picks, the prefix compare IS the inclusive crossing test, keys never collide - and they do without
-the side bit (the bug the 8-bit test build of the library found)."""
+"""Invariants of the order keys of the keyed event loops, on the integer model tools/key_model.py (the specification
+bourse_amd/csrc/event_asm.hpp, the generated R = 4, 8 loop and book_device.hpp keys_begin follow): the signed minimum /
+maximum over ALL pool lanes - dead lanes (0) and the other side included - IS the order the reference's price-time
+priority picks, the signed compare against the event word's value IS the inclusive crossing test (an empty side
+included), keys never collide, and the skip bounds never skip an order that crosses."""
 import os
 import random
 import sys
@@ -18,11 +19,11 @@ def _book(rng, n, lo, span, seq_ctr, max_age):
     return orders
 
 
-def test_best_key_is_price_time_priority_and_prefix_compare_is_the_crossing_test():
+def test_best_key_is_price_time_priority_and_the_signed_compare_is_the_crossing_test():
     rng = random.Random(7)
     for _ in range(3000):
         seq_ctr = rng.randrange(1000, 2**31)
-        lo = rng.choice([1, 50, 2**31, 2**32 - 40_000])
+        lo = rng.choice([2, 50, 2**31, 2**32 - 40_000])
         span = rng.choice([1, 2, 7, 40, K.PSPAN + 1])
         orders = _book(rng, rng.randrange(0, 40), lo, span, seq_ctr, rng.choice([5, 300, K.SMASK - 200]))
         new_price, new_bid = lo + rng.randrange(span), rng.random() < 0.5
@@ -30,53 +31,62 @@ def test_best_key_is_price_time_priority_and_prefix_compare_is_the_crossing_test
         assert K.window_ok(prices, [o[1] for o in orders], seq_ctr, 128)
         pbase, sbase = K.bases(prices, [o[1] for o in orders], seq_ctr)
         keys = [K.key(p, s, b, pbase, sbase) for p, s, b in orders]
-        assert len(set(keys)) == len(keys) and all(k < K.MARKET_BID and k > K.MARKET_ASK for k in keys)
+        assert len(set(keys)) == len(keys) and K.DEAD not in keys
+        assert all((K.i32(k) < 0) == (not o[2]) for k, o in zip(keys, orders))  # asks negative, bids positive
+        lanes = keys + [K.DEAD] * 3  # the reduction runs over every pool lane: dead ones, pending ones (0), both sides
         asks = [(o, k) for o, k in zip(orders, keys) if not o[2]]
         bids = [(o, k) for o, k in zip(orders, keys) if o[2]]
         if asks:  # best ask: lowest price, then oldest (side.rs:300-313)
-            assert min(asks, key=lambda x: x[1])[0] == min((o for o, _ in asks), key=lambda o: (o[0], o[1]))
+            want = min((o for o, _ in asks), key=lambda o: (o[0], o[1]))
+            assert orders[keys.index(K.best_of(lanes, True))] == want
         if bids:  # best bid: highest price, then oldest
-            assert max(bids, key=lambda x: x[1])[0] == min((o for o, _ in bids), key=lambda o: (-o[0], o[1]))
+            want = min((o for o, _ in bids), key=lambda o: (-o[0], o[1]))
+            assert orders[keys.index(K.best_of(lanes, False))] == want
         for k, (p, s, b) in zip(keys, orders):
-            assert K.seq_of(k, b, sbase) == s
+            assert K.seq_of(k, sbase) == s
         # inclusive crossing test (orderbook.rs:430 / :463) in key space, the empty side included
         kp = K.prefix(new_price, new_bid, pbase)
-        assert kp not in keys
-        opp = [(o, k) for o, k in zip(orders, keys) if o[2] != new_bid]
-        best = (min(k for _, k in opp) if new_bid else max(k for _, k in opp)) if opp else (K.DEAD if new_bid else 0)
-        want = bool(opp) and (min(o[0] for o, _ in opp) <= new_price if new_bid else max(o[0] for o, _ in opp) >= new_price)
+        assert kp not in keys and kp >> 16 == K.event_word_half(new_price, new_bid, pbase)
+        opp = [o for o in orders if o[2] != new_bid]
+        best = K.best_of(lanes, new_bid)
+        want = bool(opp) and (min(o[0] for o in opp) <= new_price if new_bid else max(o[0] for o in opp) >= new_price)
         assert K.crosses(kp, best, new_bid) == want
-        # a market order's prefix crosses whatever is there and nothing when the side is empty
+        # a market order's compare value crosses whatever is there and nothing when the side is empty; no limit order has it
         assert K.crosses(K.MARKET_BID if new_bid else K.MARKET_ASK, best, new_bid) == bool(opp)
-        # the order rests: prefix ^ arrival field, newer than everything live
-        rested = kp ^ ((seq_ctr - sbase) << 1)
+        assert kp != (K.MARKET_BID if new_bid else K.MARKET_ASK)
+        # the order rests: compare value ^ (sign | arrival field), newer than everything live
+        rested = K.rest(kp, seq_ctr - sbase)
         assert rested == K.key(new_price, seq_ctr, new_bid, pbase, sbase) and rested not in keys
 
 
-def test_without_the_side_bit_a_bid_and_an_ask_at_one_price_collide():
-    pbase, sbase = 99, 0
-    a = K.key(100, 100, False, pbase, sbase, side_bit=False)
-    b = K.key(100, K.SMASK - 100, True, pbase, sbase, side_bit=False)
-    assert a == b  # complementary arrival fields: the collision behind the zero-volume trades / endless match loop
-    assert K.key(100, 100, False, pbase, sbase) != K.key(100, K.SMASK - 100, True, pbase, sbase)
+def test_a_bid_and_an_ask_at_one_price_never_collide():
+    # (round 2's first keys had no side bit: complementary arrival fields collided - zero-volume trades, an endless match
+    # loop; the sign separates the sides here whatever the fields are)
+    pbase, sbase = 98, 0
+    for s in (1, 100, K.SMASK - 100, K.SMASK - 2):
+        for t in (1, 100, K.SMASK - 100, K.SMASK - 2):
+            assert K.key(100, s, False, pbase, sbase) != K.key(100, t, True, pbase, sbase)
 
 
 def test_window_limits():
     assert not K.window_ok([0, 5], [], 10, 4)                      # price 0 is the ask market sentinel
+    assert not K.window_ok([1, 5], [], 10, 4)                      # (pbase = lowest - 2 must not wrap)
     assert not K.window_ok([5, 0xFFFFFFFF], [], 10, 4)             # u32::MAX the bid one
-    assert K.window_ok([1, 1 + K.PSPAN], [], 10, 4) and not K.window_ok([1, 2 + K.PSPAN], [], 10, 4)
+    assert K.window_ok([2, 2 + K.PSPAN], [], 10, 4) and not K.window_ok([2, 3 + K.PSPAN], [], 10, 4)
     assert K.window_ok([5], [10], 10 + K.SMASK - 2 - 5, 4) and not K.window_ok([5], [10], 10 + K.SMASK - 1 - 4, 4)
+    # the widest window still leaves the market bid's field (0x7FFF) to itself
+    assert K.event_word_half(2 + K.PSPAN, True, 0) < 0xFFFF
 
 
 def test_skip_bounds_stay_valid_and_never_skip_a_crossing_order():
-    """The two bounds of the keyed loops (alo <= best ask key, bhi >= best bid key; event_asm.hpp EK_ALO / EK_BHI,
+    """The two bounds of the keyed loops (alo <= best ask key, bhi >= best bid key as i32; event_asm.hpp EK_ALO / EK_BHI,
     book_device.hpp KeyState): exact after a reduction, valid after removals, pulled in at a rest.  Whatever the
     sequence of cancels, fills and new orders, a new order is only ever skipped when it really cannot cross."""
     rng = random.Random(11)
     for _ in range(300):
-        pbase, sbase, seq = 99, 0, 1
+        pbase, sbase, seq = 98, 0, 1
         asks, bids = {}, {}          # key -> volume
-        alo, bhi = 0, K.DEAD         # loosest
+        alo, bhi = -(1 << 31), (1 << 31) - 1   # loosest
         for _step in range(200):
             op = rng.random()
             if op < 0.35 and (asks or bids):          # a cancellation / a fill: removals never touch the bounds
@@ -86,37 +96,34 @@ def test_skip_bounds_stay_valid_and_never_skip_a_crossing_order():
                 is_bid = rng.random() < 0.5
                 kp = K.prefix(100 + rng.randrange(12), is_bid, pbase)
                 opp = asks if is_bid else bids
-                truly = bool(opp) and (min(opp) <= kp if is_bid else max(opp) >= kp)
-                skipped = kp < alo if is_bid else kp > bhi
+                lanes = list(asks) + list(bids) + [K.DEAD]
+                best = K.best_of(lanes, is_bid)
+                truly = bool(opp) and K.crosses(kp, best, is_bid)
+                skipped = K.i32(kp) < alo if is_bid else K.i32(kp) > bhi
                 assert not (skipped and truly)
                 vol = 1 + rng.randrange(3)
                 if not skipped:
-                    while vol and opp:                 # match loop: every reduction makes the bound exact
-                        best = min(opp) if is_bid else max(opp)
+                    while vol:                         # match loop: every reduction makes the bound exact
+                        best = K.best_of(list(asks) + list(bids) + [K.DEAD], is_bid)
                         if is_bid:
-                            alo = best
+                            alo = K.i32(best)
                         else:
-                            bhi = best
+                            bhi = K.i32(best)
                         if not K.crosses(kp, best, is_bid):
                             break
+                        assert best in opp             # a cross is always against a live order of the other side
                         t = min(vol, opp[best])
                         vol -= t
                         opp[best] -= t
                         if opp[best] == 0:
                             del opp[best]
-                    else:
-                        if vol and not opp:            # the reduction over an empty side returns its neutral element
-                            if is_bid:
-                                alo = K.DEAD
-                            else:
-                                bhi = 0
                 if vol:                                # rests: its side's bound covers it
-                    k = kp ^ (seq << 1)
+                    k = K.rest(kp, seq)
                     seq += 1
                     if is_bid:
                         bids[k] = vol
-                        bhi = max(bhi, k)
+                        bhi = max(bhi, K.i32(k))
                     else:
                         asks[k] = vol
-                        alo = min(alo, k)
-            assert alo <= (min(asks) if asks else K.DEAD) and bhi >= (max(bids) if bids else 0)
+                        alo = min(alo, K.i32(k))
+            assert alo <= (min(map(K.i32, asks)) if asks else 0) and bhi >= (max(map(K.i32, bids)) if bids else 0)
