@@ -394,11 +394,15 @@ __device__ __forceinline__ uint32_t events_asm_r1(uint32_t& k, uint32_t n_ev, ui
 //   KPI   the compare value from the event word;  SKIP / OPPB "beyond the other side's bound: cannot cross";
 //   VOP / DOP the reduction (v_min_i32 / v_max_i32 and its DPP form);  NOX "no cross" on the reduction's result;
 //   KKI   the trade records' k word;  OWNB / PULL this side's bound covers the order that rests
-#define EK_SIDE(L, PH, KEND, RG, NR, KPI, VOP, DOP, NOX, KKI, OPPB, SKIP, OWNB, PULL, VCHK)            \
+//   VLATE the order's volume, read only once it is known to reach the reduction (the copies without VCHK: an order beyond
+//   the bound rests with the volume its slot already holds - one lane read and one hand-over wait less)
+#define EK_VRD(RG) "v_readlane_b32 " EA_V ", %[vol" RG "], " EA_EW "\n\t"
+#define EK_SIDE(L, PH, KEND, RG, NR, KPI, VOP, DOP, NOX, KKI, OPPB, SKIP, OWNB, PULL, VCHK, VLATE)     \
   KPI "\n\t"                                                                                          \
   VCHK                                                                                                \
   SKIP " " EK_KP ", " OPPB "\n\t"                      /* beyond the bound: cannot cross */           \
   "s_cbranch_scc1 L_restq_" L "\n\t"                                                                  \
+  VLATE                                                                                               \
   KKI "\n\t"                                           /* (only a trade needs the k word) */          \
   "L_match_" L ":\n\t"                                                                                \
   EA_IF1_##NR("v_mov_b32 %[vm], %[key0]\n\t")                                                         \
@@ -433,20 +437,23 @@ __device__ __forceinline__ uint32_t events_asm_r1(uint32_t& k, uint32_t n_ev, ui
   "s_add_u32 %[sq], %[sq], 1\n\t"                                                                     \
   EA_LOOP(PH, KEND)
 
-#define EK_NEW(PH, KEND, RG, NR, CHK)                                                                 \
-  "v_readlane_b32 " EA_V ", %[vol" RG "], " EA_EW "\n\t"                                              \
+#define EK_NEW(PH, KEND, RG, NR, CHK, VE, VL)                                                         \
+  VE(EK_VRD(RG))                                                                                      \
   "s_bitcmp1_b32 " EA_EW ", 14\n\t"                                                                   \
   "s_cbranch_scc1 L_bid_" PH RG "_%=\n\t"                                                             \
   /* an ask: searches the bids (cannot cross if kp > bid bound), rests among the asks (ask bound = min) */ \
   EK_SIDE("a" PH RG "_%=", PH, KEND, RG, NR, "s_and_b32 " EK_KP ", " EA_EW ", 0xffff0000", "v_max_i32", "v_max_i32_dpp", \
           "s_cmp_lt_i32", "s_or_b32 " EA_KK ", %[k], 0x80000000", EK_BHI, "s_cmp_gt_i32", EK_ALO, "s_min_i32", \
-          CHK("a" PH RG "_%="))                                                                        \
+          CHK("a" PH RG "_%="), VL(EK_VRD(RG)))                                                        \
   "L_bid_" PH RG "_%=:\n\t"                                                                           \
   EK_SIDE("b" PH RG "_%=", PH, KEND, RG, NR, "s_or_b32 " EK_KP ", " EA_EW ", 0xffff", "v_min_i32", "v_min_i32_dpp", \
-          "s_cmp_gt_i32", "s_mov_b32 " EA_KK ", %[k]", EK_ALO, "s_cmp_lt_i32", EK_BHI, "s_max_i32", CHK("b" PH RG "_%="))
+          "s_cmp_gt_i32", "s_mov_b32 " EA_KK ", %[k]", EK_ALO, "s_cmp_lt_i32", EK_BHI, "s_max_i32", CHK("b" PH RG "_%="), \
+          VL(EK_VRD(RG)))
 
 #define EK_NOCHK(L) ""
-#define EK_PHASE(PH, EVN, KEND, NR, CHK)                                                              \
+#define EK_ID(x) x
+#define EK_NONE(x) ""
+#define EK_PHASE(PH, EVN, KEND, NR, CHK, VE, VL)                                                              \
   "L_top_" PH "_%=:\n\t"                                                                              \
   "v_readlane_b32 " EA_EW ", %[ev" EVN "], %[k]\n\t"                                                  \
   "s_bitcmp1_b32 " EA_EW ", 15\n\t"                                                                   \
@@ -465,9 +472,9 @@ __device__ __forceinline__ uint32_t events_asm_r1(uint32_t& k, uint32_t n_ev, ui
   EA_IF2_##NR("s_bitcmp1_b32 " EA_EW ", 6\n\t"                                                        \
               "s_cbranch_scc1 L_new1_" PH "_%=\n\t")                                                  \
   EA_IF1_##NR("s_nop 1\n\t")                            /* ew as a lane select: 4 wait states */      \
-  EK_NEW(PH, KEND, "0", NR, CHK)                                                                      \
+  EK_NEW(PH, KEND, "0", NR, CHK, VE, VL)                                                              \
   EA_IF2_##NR("L_new1_" PH "_%=:\n\t"                                                                 \
-              EK_NEW(PH, KEND, "1", NR, CHK))
+              EK_NEW(PH, KEND, "1", NR, CHK, VE, VL))
 
 #define EK_TAIL                     \
   "L_done_%=:\n\t"                  \
@@ -497,22 +504,22 @@ __device__ __forceinline__ uint32_t events_asm_r1(uint32_t& k, uint32_t n_ev, ui
       "s_cmp_lt_u32 %[k], %[kend0]\n\t" \
       "s_cbranch_scc1 L_top_0_%=\n\t" \
       "s_branch L_end_0_%=\n\t" \
-      EK_PHASE("0", "0", "%[kend0]", 2, EK_VCHK) \
+      EK_PHASE("0", "0", "%[kend0]", 2, EK_VCHK, EK_ID, EK_NONE) \
       "L_end_0_%=:\n\t" \
       "s_cmp_lt_u32 %[k], %[nev]\n\t" \
       "s_cbranch_scc0 L_done_%=\n\t" \
-      EK_PHASE("1", "1", "%[nev]", 2, EK_VCHK) \
+      EK_PHASE("1", "1", "%[nev]", 2, EK_VCHK, EK_ID, EK_NONE) \
       "L_end_1_%=:\n\t" \
       "s_branch L_done_%=\n\t" \
       "L_fast_%=:\n\t" \
       "s_cmp_lt_u32 %[k], %[kend0]\n\t" \
       "s_cbranch_scc1 L_top_2_%=\n\t" \
       "s_branch L_end_2_%=\n\t" \
-      EK_PHASE("2", "0", "%[kend0]", 2, EK_NOCHK) \
+      EK_PHASE("2", "0", "%[kend0]", 2, EK_NOCHK, EK_NONE, EK_ID) \
       "L_end_2_%=:\n\t" \
       "s_cmp_lt_u32 %[k], %[nev]\n\t" \
       "s_cbranch_scc0 L_done_%=\n\t" \
-      EK_PHASE("3", "1", "%[nev]", 2, EK_NOCHK) \
+      EK_PHASE("3", "1", "%[nev]", 2, EK_NOCHK, EK_NONE, EK_ID) \
       "L_end_3_%=:\n\t" \
       EK_TAIL \
       : [st] "=&s"(st), [vm] "=&v"(vm), [k] "+s"(k), [trn] "+s"(trn), [sq] "+s"(sq), \
@@ -530,10 +537,10 @@ __device__ __forceinline__ uint32_t events_asm_r1(uint32_t& k, uint32_t n_ev, ui
       "s_cbranch_scc0 L_done_%=\n\t" \
       "s_cmp_eq_u32 %[chk], 0\n\t" \
       "s_cbranch_scc1 L_top_2_%=\n\t" \
-      EK_PHASE("0", "0", "%[nev]", 1, EK_VCHK) \
+      EK_PHASE("0", "0", "%[nev]", 1, EK_VCHK, EK_ID, EK_NONE) \
       "L_end_0_%=:\n\t" \
       "s_branch L_done_%=\n\t" \
-      EK_PHASE("2", "0", "%[nev]", 1, EK_NOCHK) \
+      EK_PHASE("2", "0", "%[nev]", 1, EK_NOCHK, EK_NONE, EK_ID) \
       "L_end_2_%=:\n\t" \
       EK_TAIL \
       : [st] "=&s"(st), [vm] "=&v"(vm), [k] "+s"(k), [trn] "+s"(trn), [sq] "+s"(sq), \

@@ -97,13 +97,18 @@ def gen(N, markets):
         e("s_branch L_done_%=")
         # New order: its volume from the slot (ew as a lane select: 4 wait states behind its v_readlane - bfe, bitcmp, branch, idx_on)
         e(f"L_new_{c}_%=:")
-        if VOL_LIST:
-            e(f"v_readlane_b32 {S['V']}, %[evq], %[k]")
-        else:
-            e(f"s_set_gpr_idx_on {S['RG']}, gpr_idx(SRC0)")
-            e(f"v_mov_b32 %[vm], v{VB}")
-            e("s_set_gpr_idx_off")
-            e(f"v_readlane_b32 {S['V']}, %[vm], {S['EW']}")
+
+        def read_volume():
+            if VOL_LIST:
+                e(f"v_readlane_b32 {S['V']}, %[evq], %[k]")
+            else:
+                e(f"s_set_gpr_idx_on {S['RG']}, gpr_idx(SRC0)")
+                e(f"v_mov_b32 %[vm], v{VB}")
+                e("s_set_gpr_idx_off")
+                e(f"v_readlane_b32 {S['V']}, %[vm], {S['EW']}")
+
+        if vchk:                                                # (the copy without the test reads it once the order is
+            read_volume()                                       # known to reach the reduction: below)
         e(f"s_bitcmp1_b32 {S['EW']}, 14")
         e(f"s_cbranch_scc1 L_bid_{c}_%=")
 
@@ -121,6 +126,8 @@ def gen(N, markets):
                 e(f"s_cbranch_scc0 L_restq_{tag}_%=")
             e(f"{'s_cmp_lt_i32' if agg_bid else 's_cmp_gt_i32'} {S['KP']}, {oppb}")   # beyond the bound: cannot cross
             e(f"s_cbranch_scc1 L_restq_{tag}_%=")
+            if not vchk:
+                read_volume()
             e(f"s_mov_b32 {S['KK']}, %[k]" if agg_bid else f"s_or_b32 {S['KK']}, %[k], 0x80000000")
             e(f"L_match_{tag}_%=:")
             if N == 4:
