@@ -48,6 +48,7 @@ namespace bkd {
 // per-book accumulators, [book][kernel * 8 + phase] (plain read-modify-write by lane 0: one wave per book and kernel at a
 // time; contended atomics on a few shared words made the first version of this build 14x slower than the library)
 __device__ unsigned int* g_stamp_ptr;
+#define BK_STAMP_WORDS 24  // per book: k_step_batch's eight, k_agents_wave's eight, the decode's inner phases' eight
 #define BK_STAMP_FIELD    \
   unsigned long long stamp_t; \
   unsigned int stamp_book, stamp_t0;
@@ -58,16 +59,16 @@ __device__ unsigned int* g_stamp_ptr;
 #define BK_STAMP(obj, kernel, phase, lane)                                                           \
   do {                                                                                               \
     const unsigned long long n_ = __builtin_amdgcn_s_memtime();                                      \
-    if ((lane) == 0) g_stamp_ptr[(size_t)(obj).stamp_book * 16 + (kernel) * 8 + (phase)] += (unsigned int)(n_ - (obj).stamp_t); \
+    if ((lane) == 0) g_stamp_ptr[(size_t)(obj).stamp_book * BK_STAMP_WORDS + (kernel) * 8 + (phase)] += (unsigned int)(n_ - (obj).stamp_t); \
     (obj).stamp_t = n_;                                                                              \
   } while (0)
 // (+ the wave's absolute start / end of its LATEST run, low 32 bits of the clock: words 6 / 2 of k_step_batch's eight, 4 / 5
 // of k_agents_wave's - scripts/wave_phases.py --skew)
 #define BK_STAMP_COUNT(obj, kernel, lane)                                                                       \
   if ((lane) == 0) {                                                                                            \
-    g_stamp_ptr[(size_t)(obj).stamp_book * 16 + (kernel) * 8 + 7] += 1u;                                        \
-    g_stamp_ptr[(size_t)(obj).stamp_book * 16 + (kernel) * 8 + ((kernel) ? 4 : 6)] = (obj).stamp_t0;            \
-    g_stamp_ptr[(size_t)(obj).stamp_book * 16 + (kernel) * 8 + ((kernel) ? 5 : 2)] = (unsigned int)(obj).stamp_t; \
+    g_stamp_ptr[(size_t)(obj).stamp_book * BK_STAMP_WORDS + (kernel) * 8 + 7] += 1u;                                        \
+    g_stamp_ptr[(size_t)(obj).stamp_book * BK_STAMP_WORDS + (kernel) * 8 + ((kernel) ? 4 : 6)] = (obj).stamp_t0;            \
+    g_stamp_ptr[(size_t)(obj).stamp_book * BK_STAMP_WORDS + (kernel) * 8 + ((kernel) ? 5 : 2)] = (unsigned int)(obj).stamp_t; \
   }
 #else
 #define BK_STAMP_FIELD

@@ -2235,21 +2235,22 @@ int bk_checkpoint_load(bk_env* env, const void* in, uint64_t nbytes) {
 uint64_t bk_state_bytes_per_book(const bk_env* env) { return env ? static_cast<uint64_t>(env->stride) * 4 : 0; }
 
 #if BOURSE_AMD_STAMPS
-// diagnostic build only (book_device.hpp BK_STAMP): per-book phase accumulators, 16 u32 per book.  bk_debug_stamps(n_books,
-// out): the first call allocates + zeroes them and returns nothing; later calls copy them out (out: n_books * 16) and zero.
+// diagnostic build only (book_device.hpp BK_STAMP): per-book phase accumulators, BK_STAMP_WORDS u32 per book.
+// bk_debug_stamps(n_books, out): the first call allocates + zeroes them and returns nothing; later calls copy them out
+// (out: n_books * BK_STAMP_WORDS) and zero.
 int bk_debug_stamps(uint32_t n_books, unsigned int* out) {
   static unsigned int* dev = nullptr;
   static uint32_t cap = 0;
   HIPCHK(hipDeviceSynchronize());
   if (!dev || cap < n_books) {
     if (dev) (void)hipFree(dev);
-    HIPCHK(hipMalloc(reinterpret_cast<void**>(&dev), static_cast<size_t>(n_books) * 64));
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&dev), static_cast<size_t>(n_books) * BK_STAMP_WORDS * 4));
     cap = n_books;
     HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(bkd::g_stamp_ptr), &dev, sizeof(dev)));
   } else if (out) {
-    HIPCHK(hipMemcpy(out, dev, static_cast<size_t>(n_books) * 64, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(out, dev, static_cast<size_t>(n_books) * BK_STAMP_WORDS * 4, hipMemcpyDeviceToHost));
   }
-  HIPCHK(hipMemset(dev, 0, static_cast<size_t>(cap) * 64));
+  HIPCHK(hipMemset(dev, 0, static_cast<size_t>(cap) * BK_STAMP_WORDS * 4));
   return BK_OK;
 }
 #endif

@@ -194,6 +194,7 @@ struct WaveDecoder {
         // ---- window [w0, w0 + 64) of the stream + 64 draws of look-ahead
         const uint32_t w0 = pos & ~63u;
         ensure(w0 + 128u);
+        BK_STAMP(*this, 2, 0, lane);  // (diagnostic build) generation
         const uint32_t xc = ring[(w0 + lane) & (WV_RING - 1)], xn = ring[(w0 + 64u + lane) & (WV_RING - 1)];
         // p = gen::<f32>() < activity_rate (random_agent.rs:91-93) as an integer threshold (host_math.hpp)
         const uint64_t H = __ballot((xc >> 8) < G.thr);
@@ -236,6 +237,7 @@ struct WaveDecoder {
         uint32_t p = pos - w0;
         uint32_t agw = 0;
         bool slow = false;
+        BK_STAMP(*this, 2, 1, lane);  // the window's masks, searches, placements and continuations
         {
           // to the first hit at or after p (or the end of the window / group)
           const uint64_t m = H >> p;
@@ -387,6 +389,7 @@ struct WaveDecoder {
             }
           }
         }
+        BK_STAMP(*this, 2, 2, lane);  // the walk
         // ---- the window's events, one lane each: list entry and the new order's fields
         {
           const bool acted = (agw & WV_ACTED) != 0, placed = (agw & EV_NEW) != 0;
@@ -431,6 +434,7 @@ struct WaveDecoder {
           p = q - w0;
         }
         pos = w0 + p;
+        BK_STAMP(*this, 2, 3, lane);  // the window's events out (+ the slow path)
       }
     }
     wave_sync();
@@ -482,6 +486,7 @@ struct WaveDecoder {
       // draws consumed: up to the accepted draw that served index 1, else the whole window
       pos = w0 + ((i < 1u && acc) ? (64u - (uint32_t)__builtin_clzll(acc)) : 64u);
     }
+    BK_STAMP(*this, 2, 4, lane);  // the shuffle's draws: acceptance fixed point, swap targets
     if constexpr (R <= 2) {
       // All swap targets j_i are known: resolve the whole Fisher-Yates in parallel instead of n dependent LDS round
       // trips.  Steps run i = n-1 .. 1; the value that ends at position x was at position j_x just before step x, and a

@@ -18,7 +18,8 @@ env.set_random_agents(G)
 env.set_pipeline(pipe)
 L = env._L
 L.bk_debug_stamps.argtypes = [C.c_uint32, C.c_void_p]
-buf = np.zeros((B, 16), dtype=np.uint32)
+W = 24  # BK_STAMP_WORDS
+buf = np.zeros((B, W), dtype=np.uint32)
 L.bk_debug_stamps(B, None)  # allocate + zero BEFORE the first launch (the kernels write through the pointer)
 env.run(50); env.clear_history(); env.clear_trades()
 L.bk_debug_stamps(B, buf.ctypes.data_as(C.c_void_p))  # (reads the warm-up's stamps and zeroes)
@@ -31,10 +32,12 @@ dt = time.perf_counter() - t0
 L.bk_debug_stamps(B, buf.ctypes.data_as(C.c_void_p))
 a = buf.astype(np.float64)
 a[:, [2, 6, 12, 13]] = 0  # (the absolute stamps of --skew)
-a = a.sum(axis=0).reshape(2, 8)
+a = a.sum(axis=0).reshape(3, 8)
 print(f"{B} books, pipeline {env.pipeline()}: {B * T / dt / 1e6:.1f} M book-steps/s with the stamps in (s_memtime per phase)")
 names = {0: ("k_step_batch", ["loads' round trip", "unpack + masks + new orders", "-", "keys + event loop", "snapshot + trade flush", "store"]),
-         1: ("k_agents_wave", ["lane-state cache in", "agents.update (generate, windows, walk)", "shuffle", "publish"])}
+         1: ("k_agents_wave", ["lane-state cache in", "agents.update: group loop, the rest", "shuffle: resolution", "publish"]),
+         2: ("k_agents_wave, inside", ["generation", "window: masks, searches, continuations", "walk", "window's events out", "shuffle: draws + acceptance"])}
+a[2, 7] = a[1, 7]
 for k, (kn, ph) in names.items():
     n = a[k, 7]
     if not n:

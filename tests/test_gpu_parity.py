@@ -819,9 +819,13 @@ def test_two_envs_interleaved_on_the_shared_part_streams(bk, oracle):
 KEYED_CASES = {
     # two price windows farther apart than the 15-bit price field: every step with orders from both takes the fallback
     "wide": dict(groups=[(40, (1, 30), (1, 20), 1, 0.6), (40, (70000, 70030), (1, 20), 1, 0.6)], n_steps=40, n_books=9),
-    # the span sits right at the field's limit (32 764): steps flip between the two loops as orders come and go
-    "edge": dict(groups=[(30, (1, 4), (1, 20), 1, 0.5), (30, (32763, 32769), (1, 20), 1, 0.5),
+    # the span sits right at the field's limit (32 762 since the signed keys): steps flip between the two loops as orders
+    # come and go
+    "edge": dict(groups=[(30, (2, 5), (1, 20), 1, 0.5), (30, (32761, 32768), (1, 20), 1, 0.5),
                          (20, (15000, 15010), (5, 9), 1, 0.9)], n_steps=60, n_books=9),
+    # prices 1 and 2 at the bottom: the price field starts at 2 (1 is the market ask's), so a step with an order at
+    # price 1 takes the fallback and the others the keyed loop
+    "low": dict(groups=[(30, (1, 3), (1, 20), 1, 0.3), (40, (2, 6), (1, 20), 1, 0.7)], n_steps=60, n_books=9),
     # prices at the top of u32 (the window test must not wrap)
     "top": dict(groups=[(40, (2**32 - 40, 2**32 - 1), (1, 20), 1, 0.7), (30, (2**32 - 30, 2**32 - 2), (1, 9), 1, 0.9)],
                 n_steps=40, n_books=9),
