@@ -219,7 +219,7 @@ struct WaveDecoder {
         // set bit of H above p; after a placement the stream stands at f = fpos(p) and the next hit is the first set
         // bit of H at or above f (f itself when the placement leaves the window).  Inactive agents in between are
         // skipped by position arithmetic: one agent per activity draw.
-        //   bits 0..6 next hit after a cancellation (1..64) | 7..14 next position after a placement (<= 128) |
+        //   bits 0..6 DISTANCE to the next hit after a cancellation (1..64) | 7..14 next position after a placement (<= 128) |
         //   15..22 f | 23..29 agents consumed by the placement path | 31 placement not resolvable in the look-ahead
         uint32_t pack;
         {
@@ -229,7 +229,7 @@ struct WaveDecoder {
           const uint64_t hp = H >> fq;
           const uint32_t nP = fpos < 64u ? (hp ? fq + (uint32_t)__builtin_ctzll(hp) : 64u) : fpos;
           const uint32_t dP = fpos < 64u ? 1u + nP - fpos : 1u;
-          pack = nC | (fpos == WV_NONE ? 0x80000000u : ((nP << 7) | (fpos << 15) | (dP << 23)));
+          pack = (nC - (uint32_t)lane) | (fpos == WV_NONE ? 0x80000000u : ((nP << 7) | (fpos << 15) | (dP << 23)));
         }
         // ---- scalar walk over the activity hits of this window (p < 64 and ag < gend on entry).  Each acting lane
         // gets its event word (slot, EV_NEW, marker bit 16) by v_writelane; list positions follow from the lane order
@@ -249,142 +249,144 @@ struct WaveDecoder {
           } else {
             p += d;
             ag += d;
-            // The walk itself, hand-written (this loop is ~half of the kernel's scalar instructions; the compiled form
-            // spends 24-26 per hit on loop-exit flags and re-materialised booleans, this one 19-21).  One iteration:
-            //   w = pack[p]; live bit of agent ag; cancellation -> event word ag | ACTED into lane p, next = w[6:0];
-            //   placement -> (w[31]: not resolvable -> slow) event word ag | NEW | ACTED, next = w[14:7], agents += w[29:23];
+            // The walk itself, hand-written (this loop is ~half of the kernel's scalar instructions, and under eight
+            // waves' contention for the scalar port every one of them is a link of the wave's chain; the compiled form
+            // spends 24-26 per hit on loop-exit flags and re-materialised booleans, round 2's 19-21, this one 14-17).
+            // The position lives in m0 (lane select of the v_readlane / v_writelane, no copy), the agent index carries the
+            // event word's marker bit (bit 16: no OR per event; `gm` = the group's end with the same bit), the word's
+            // first field is the DISTANCE to the next hit.  One iteration:
+            //   w = pack[p]; live bit of agent ag; cancellation -> event word ag | ACTED into lane p, p += w[6:0];
+            //   placement -> (w[31]: not resolvable -> slow) event word ag | NEW | ACTED, p = w[14:7], agents += w[29:23];
             //   the group ends before the next hit -> position of agent `gend`'s draw from the run start (p + 1 or f).
             if constexpr (R <= 2) {
               // pools of <= 128 slots: the live masks sit in two SGPR pairs and the test is three scalar instructions (the
               // general form below reads the mask word back from a VGPR: two more scalar instructions, one more
               // v_readlane and a second vector-to-scalar hand-over on the walk's critical path)
-              uint32_t st, w, t0, t1, np, na;
+              uint32_t st, w, t0, t1, gm;
               uint64_t lm;
               asm volatile(
-                  "s_nop 0\n\t"
+                  "s_mov_b32 m0, %[p]\n\t"
+                  "s_or_b32 %[ag], %[ag], 0x10000\n\t"
+                  "s_or_b32 %[gm], %[gend], 0x10000\n\t"
                   "1:\n\t"
-                  "v_readlane_b32 %[w], %[pack], %[p]\n\t"
+                  "v_readlane_b32 %[w], %[pack], m0\n\t"
                   "s_bitcmp1_b32 %[ag], 6\n\t"                  /* agent 64..127: the second mask */
                   "s_cselect_b64 %[lm], %[lv1], %[lv0]\n\t"
-                  "s_mov_b32 m0, %[p]\n\t"
                   "s_bitcmp1_b64 %[lm], %[ag]\n\t"              /* (the bit index is ag[5:0]) */
                   "s_cbranch_scc0 2f\n\t"
-                  "s_or_b32 %[t0], %[ag], 0x10000\n\t"          /* holds an Active order: its cancellation */
-                  "v_writelane_b32 %[agw], %[t0], m0\n\t"
-                  "s_and_b32 %[np], %[w], 0x7f\n\t"
-                  "s_sub_u32 %[t0], %[np], %[p]\n\t"
-                  "s_add_u32 %[na], %[ag], %[t0]\n\t"
-                  "s_cmp_ge_u32 %[na], %[gend]\n\t"
+                  "v_writelane_b32 %[agw], %[ag], m0\n\t"     /* holds an Active order: its cancellation (agent | marker) */
+                  "s_and_b32 %[t0], %[w], 0x7f\n\t"           /* distance to the next hit */
+                  "s_add_u32 %[ag], %[ag], %[t0]\n\t"
+                  "s_cmp_ge_u32 %[ag], %[gm]\n\t"
                   "s_cbranch_scc1 5f\n\t"
-                  "s_mov_b32 %[p], %[np]\n\t"
-                  "s_mov_b32 %[ag], %[na]\n\t"
-                  "s_cmp_lt_u32 %[np], 64\n\t"
+                  "s_add_u32 m0, m0, %[t0]\n\t"
+                  "s_cmp_lt_u32 m0, 64\n\t"
                   "s_cbranch_scc1 1b\n\t"
                   "s_mov_b32 %[st], 0\n\t"
                   "s_branch 9f\n\t"
                   "2:\n\t"
                   "s_cmp_lt_i32 %[w], 0\n\t"                    /* placement not resolvable in the look-ahead */
                   "s_cbranch_scc1 8f\n\t"
-                  "s_or_b32 %[t0], %[ag], 0x18000\n\t"
+                  "s_or_b32 %[t0], %[ag], 0x8000\n\t"
                   "v_writelane_b32 %[agw], %[t0], m0\n\t"
-                  "s_bfe_u32 %[np], %[w], 0x80007\n\t"
-                  "s_bfe_u32 %[t0], %[w], 0x70017\n\t"
-                  "s_add_u32 %[na], %[ag], %[t0]\n\t"
-                  "s_cmp_ge_u32 %[na], %[gend]\n\t"
+                  "s_bfe_u32 %[t0], %[w], 0x70017\n\t"        /* agents the placement's path covers */
+                  "s_add_u32 %[ag], %[ag], %[t0]\n\t"
+                  "s_cmp_ge_u32 %[ag], %[gm]\n\t"
                   "s_cbranch_scc1 6f\n\t"
-                  "s_mov_b32 %[p], %[np]\n\t"
-                  "s_mov_b32 %[ag], %[na]\n\t"
-                  "s_cmp_lt_u32 %[np], 64\n\t"
+                  "s_bfe_u32 m0, %[w], 0x80007\n\t"           /* next position */
+                  "s_cmp_lt_u32 m0, 64\n\t"
                   "s_cbranch_scc1 1b\n\t"
                   "s_mov_b32 %[st], 0\n\t"
                   "s_branch 9f\n\t"
                   "5:\n\t"                                       /* group end behind a cancellation */
-                  "s_sub_u32 %[t0], %[gend], %[ag]\n\t"
-                  "s_add_u32 %[p], %[p], %[t0]\n\t"
-                  "s_mov_b32 %[ag], %[gend]\n\t"
+                  "s_sub_u32 %[ag], %[ag], %[t0]\n\t"
+                  "s_sub_u32 %[t0], %[gm], %[ag]\n\t"
+                  "s_add_u32 m0, m0, %[t0]\n\t"
+                  "s_mov_b32 %[ag], %[gm]\n\t"
                   "s_mov_b32 %[st], 1\n\t"
                   "s_branch 9f\n\t"
                   "6:\n\t"                                       /* group end behind a placement: from f */
+                  "s_sub_u32 %[ag], %[ag], %[t0]\n\t"
                   "s_bfe_u32 %[t1], %[w], 0x8000f\n\t"
-                  "s_sub_u32 %[t0], %[gend], %[ag]\n\t"
+                  "s_sub_u32 %[t0], %[gm], %[ag]\n\t"
                   "s_add_u32 %[t0], %[t0], %[t1]\n\t"
-                  "s_sub_u32 %[p], %[t0], 1\n\t"
-                  "s_mov_b32 %[ag], %[gend]\n\t"
+                  "s_sub_u32 m0, %[t0], 1\n\t"
+                  "s_mov_b32 %[ag], %[gm]\n\t"
                   "s_mov_b32 %[st], 1\n\t"
                   "s_branch 9f\n\t"
                   "8:\n\t"
                   "s_mov_b32 %[st], 2\n\t"
                   "9:\n\t"
-                  "s_nop 0"
-                  : [st] "=&s"(st), [w] "=&s"(w), [t0] "=&s"(t0), [t1] "=&s"(t1), [np] "=&s"(np), [na] "=&s"(na), [p] "+s"(p),
-                    [ag] "+s"(ag), [agw] "+v"(agw), [lm] "=&s"(lm)
+                  "s_mov_b32 %[p], m0\n\t"
+                  "s_and_b32 %[ag], %[ag], 0xffff"
+                  : [st] "=&s"(st), [w] "=&s"(w), [t0] "=&s"(t0), [t1] "=&s"(t1), [gm] "=&s"(gm), [p] "+s"(p), [ag] "+s"(ag),
+                    [agw] "+v"(agw), [lm] "=&s"(lm)
                   : [pack] "v"(pack), [lv0] "s"(lv0), [lv1] "s"(lv1), [gend] "s"(gend)
-                  : "scc", "memory");
+                  : "scc", "m0", "memory");
               slow = st == 2u;
             } else {
-              uint32_t st, w, t0, t1, np, na;
+              uint32_t st, w, t0, t1, gm;
               asm volatile(
-                  "s_nop 0\n\t"
-                  "1:\n\t"
-                  "s_lshr_b32 %[t0], %[ag], 5\n\t"
-                  "s_add_u32 %[t0], %[t0], %[lb]\n\t"
-                  "v_readlane_b32 %[w], %[pack], %[p]\n\t"
-                  "v_readlane_b32 %[t1], %[livev], %[t0]\n\t"
                   "s_mov_b32 m0, %[p]\n\t"
+                  "s_or_b32 %[ag], %[ag], 0x10000\n\t"
+                  "s_or_b32 %[gm], %[gend], 0x10000\n\t"
+                  "1:\n\t"
+                  "s_bfe_u32 %[t0], %[ag], 0xb0005\n\t"        /* the live word of agent ag: lane live_base + ag / 32 */
+                  "s_add_u32 %[t0], %[t0], %[lb]\n\t"
+                  "v_readlane_b32 %[w], %[pack], m0\n\t"
+                  "v_readlane_b32 %[t1], %[livev], %[t0]\n\t"
                   "s_lshr_b32 %[t1], %[t1], %[ag]\n\t"
                   "s_bitcmp1_b32 %[t1], 0\n\t"
                   "s_cbranch_scc0 2f\n\t"
-                  "s_or_b32 %[t0], %[ag], 0x10000\n\t"          /* holds an Active order: its cancellation */
-                  "v_writelane_b32 %[agw], %[t0], m0\n\t"
-                  "s_and_b32 %[np], %[w], 0x7f\n\t"
-                  "s_sub_u32 %[t0], %[np], %[p]\n\t"
-                  "s_add_u32 %[na], %[ag], %[t0]\n\t"
-                  "s_cmp_ge_u32 %[na], %[gend]\n\t"
+                  "v_writelane_b32 %[agw], %[ag], m0\n\t"     /* holds an Active order: its cancellation (agent | marker) */
+                  "s_and_b32 %[t0], %[w], 0x7f\n\t"           /* distance to the next hit */
+                  "s_add_u32 %[ag], %[ag], %[t0]\n\t"
+                  "s_cmp_ge_u32 %[ag], %[gm]\n\t"
                   "s_cbranch_scc1 5f\n\t"
-                  "s_mov_b32 %[p], %[np]\n\t"
-                  "s_mov_b32 %[ag], %[na]\n\t"
-                  "s_cmp_lt_u32 %[np], 64\n\t"
+                  "s_add_u32 m0, m0, %[t0]\n\t"
+                  "s_cmp_lt_u32 m0, 64\n\t"
                   "s_cbranch_scc1 1b\n\t"
                   "s_mov_b32 %[st], 0\n\t"
                   "s_branch 9f\n\t"
                   "2:\n\t"
                   "s_cmp_lt_i32 %[w], 0\n\t"                    /* placement not resolvable in the look-ahead */
                   "s_cbranch_scc1 8f\n\t"
-                  "s_or_b32 %[t0], %[ag], 0x18000\n\t"
+                  "s_or_b32 %[t0], %[ag], 0x8000\n\t"
                   "v_writelane_b32 %[agw], %[t0], m0\n\t"
-                  "s_bfe_u32 %[np], %[w], 0x80007\n\t"
-                  "s_bfe_u32 %[t0], %[w], 0x70017\n\t"
-                  "s_add_u32 %[na], %[ag], %[t0]\n\t"
-                  "s_cmp_ge_u32 %[na], %[gend]\n\t"
+                  "s_bfe_u32 %[t0], %[w], 0x70017\n\t"        /* agents the placement's path covers */
+                  "s_add_u32 %[ag], %[ag], %[t0]\n\t"
+                  "s_cmp_ge_u32 %[ag], %[gm]\n\t"
                   "s_cbranch_scc1 6f\n\t"
-                  "s_mov_b32 %[p], %[np]\n\t"
-                  "s_mov_b32 %[ag], %[na]\n\t"
-                  "s_cmp_lt_u32 %[np], 64\n\t"
+                  "s_bfe_u32 m0, %[w], 0x80007\n\t"           /* next position */
+                  "s_cmp_lt_u32 m0, 64\n\t"
                   "s_cbranch_scc1 1b\n\t"
                   "s_mov_b32 %[st], 0\n\t"
                   "s_branch 9f\n\t"
                   "5:\n\t"                                       /* group end behind a cancellation */
-                  "s_sub_u32 %[t0], %[gend], %[ag]\n\t"
-                  "s_add_u32 %[p], %[p], %[t0]\n\t"
-                  "s_mov_b32 %[ag], %[gend]\n\t"
+                  "s_sub_u32 %[ag], %[ag], %[t0]\n\t"
+                  "s_sub_u32 %[t0], %[gm], %[ag]\n\t"
+                  "s_add_u32 m0, m0, %[t0]\n\t"
+                  "s_mov_b32 %[ag], %[gm]\n\t"
                   "s_mov_b32 %[st], 1\n\t"
                   "s_branch 9f\n\t"
                   "6:\n\t"                                       /* group end behind a placement: from f */
+                  "s_sub_u32 %[ag], %[ag], %[t0]\n\t"
                   "s_bfe_u32 %[t1], %[w], 0x8000f\n\t"
-                  "s_sub_u32 %[t0], %[gend], %[ag]\n\t"
+                  "s_sub_u32 %[t0], %[gm], %[ag]\n\t"
                   "s_add_u32 %[t0], %[t0], %[t1]\n\t"
-                  "s_sub_u32 %[p], %[t0], 1\n\t"
-                  "s_mov_b32 %[ag], %[gend]\n\t"
+                  "s_sub_u32 m0, %[t0], 1\n\t"
+                  "s_mov_b32 %[ag], %[gm]\n\t"
                   "s_mov_b32 %[st], 1\n\t"
                   "s_branch 9f\n\t"
                   "8:\n\t"
                   "s_mov_b32 %[st], 2\n\t"
                   "9:\n\t"
-                  "s_nop 0"
-                  : [st] "=&s"(st), [w] "=&s"(w), [t0] "=&s"(t0), [t1] "=&s"(t1), [np] "=&s"(np), [na] "=&s"(na), [p] "+s"(p),
-                    [ag] "+s"(ag), [agw] "+v"(agw)
+                  "s_mov_b32 %[p], m0\n\t"
+                  "s_and_b32 %[ag], %[ag], 0xffff"
+                  : [st] "=&s"(st), [w] "=&s"(w), [t0] "=&s"(t0), [t1] "=&s"(t1), [gm] "=&s"(gm), [p] "+s"(p), [ag] "+s"(ag),
+                    [agw] "+v"(agw)
                   : [pack] "v"(pack), [livev] "v"(livev), [lb] "s"(live_base), [gend] "s"(gend)
-                  : "scc", "memory");
+                  : "scc", "m0", "memory");
               slow = st == 2u;
             }
           }
