@@ -408,14 +408,13 @@ __device__ __forceinline__ uint32_t events_asm_r1(uint32_t& k, uint32_t n_ev, ui
   EA_IF1_##NR("v_mov_b32 %[vm], %[key0]\n\t")                                                         \
   EA_IF2_##NR(VOP " %[vm], %[key0], %[key1]\n\t")                                                     \
   EA_DPP(DOP)                                                                                         \
-  "v_readlane_b32 " EA_BEST ", %[vm], 63\n\t"                                                         \
-  "s_nop 1\n\t"                                        /* BEST as a VALU operand: 2 wait states */    \
+  "v_readlane_b32 " OPPB ", %[vm], 63\n\t"             /* the best key, read INTO the bound: exact now */ \
+  "s_nop 1\n\t"                                        /* ... as a VALU operand: 2 wait states */     \
   /* both "which lane is it" compares BEFORE any scalar instruction: one wait for the vector unit's SGPR writes   \
      instead of one behind the v_readlane and one behind the compares */                             \
-  "v_cmp_eq_u32_e64 " EA_E0 ", " EA_BEST ", %[key0]\n\t"                                              \
-  EA_IF2_##NR("v_cmp_eq_u32_e64 " EA_E1 ", " EA_BEST ", %[key1]\n\t")                                 \
-  "s_mov_b32 " OPPB ", " EA_BEST "\n\t"                /* the bound is exact now */                   \
-  NOX " " EA_BEST ", " EK_KP "\n\t"                                                                   \
+  "v_cmp_eq_u32_e64 " EA_E0 ", " OPPB ", %[key0]\n\t"                                                 \
+  EA_IF2_##NR("v_cmp_eq_u32_e64 " EA_E1 ", " OPPB ", %[key1]\n\t")                                    \
+  NOX " " OPPB ", " EK_KP "\n\t"                                                                      \
   "s_cbranch_scc1 L_rest_" L "\n\t"                                                                   \
   EA_IF2_##NR("s_cmp_lg_u64 " EA_E0 ", 0\n\t"                                                         \
               "s_cbranch_scc0 L_pick1_" L "\n\t")                                                     \

@@ -114,6 +114,61 @@ __device__ __forceinline__ uint32_t first_above_near(uint64_t lo, uint64_t hi, u
   return (w0 | w1) != 0u ? n + c : 256u;
 }
 
+// The scalar walk over a window's activity hits (WaveDecoder::agents): shared text of its three forms.  WV_WALK_BEGIN ..
+// [w = pack[p]; the live test, leaving SCC = agent holds an Active order] .. WV_WALK_REST
+#define WV_WALK_BEGIN                                 \
+  "s_mov_b32 m0, %[p]\n\t"                            \
+  "s_or_b32 %[ag], %[ag], 0x10000\n\t"                \
+  "s_or_b32 %[gm], %[gend], 0x10000\n\t"              \
+  "1:\n\t"
+#define WV_WALK_REST                                                                                              \
+  "s_cbranch_scc0 2f\n\t"                                                                                         \
+  "v_writelane_b32 %[agw], %[ag], m0\n\t"     /* holds an Active order: its cancellation (agent | marker) */       \
+  "s_and_b32 %[t0], %[w], 0x7f\n\t"           /* distance to the next hit */                                       \
+  "s_add_u32 %[ag], %[ag], %[t0]\n\t"                                                                             \
+  "s_cmp_ge_u32 %[ag], %[gm]\n\t"                                                                                 \
+  "s_cbranch_scc1 5f\n\t"                                                                                         \
+  "s_add_u32 m0, m0, %[t0]\n\t"                                                                                   \
+  "s_cmp_lt_u32 m0, 64\n\t"                                                                                       \
+  "s_cbranch_scc1 1b\n\t"                                                                                         \
+  "s_mov_b32 %[st], 0\n\t"                                                                                        \
+  "s_branch 9f\n\t"                                                                                               \
+  "2:\n\t"                                                                                                        \
+  "s_cmp_lt_i32 %[w], 0\n\t"                  /* placement not resolvable in the look-ahead */                     \
+  "s_cbranch_scc1 8f\n\t"                                                                                         \
+  "s_or_b32 %[t0], %[ag], 0x8000\n\t"                                                                             \
+  "v_writelane_b32 %[agw], %[t0], m0\n\t"                                                                         \
+  "s_bfe_u32 %[t0], %[w], 0x70017\n\t"        /* agents the placement's path covers */                             \
+  "s_add_u32 %[ag], %[ag], %[t0]\n\t"                                                                             \
+  "s_cmp_ge_u32 %[ag], %[gm]\n\t"                                                                                 \
+  "s_cbranch_scc1 6f\n\t"                                                                                         \
+  "s_bfe_u32 m0, %[w], 0x80007\n\t"           /* next position */                                                  \
+  "s_cmp_lt_u32 m0, 64\n\t"                                                                                       \
+  "s_cbranch_scc1 1b\n\t"                                                                                         \
+  "s_mov_b32 %[st], 0\n\t"                                                                                        \
+  "s_branch 9f\n\t"                                                                                               \
+  "5:\n\t"                                     /* group end behind a cancellation */                                \
+  "s_sub_u32 %[ag], %[ag], %[t0]\n\t"                                                                             \
+  "s_sub_u32 %[t0], %[gm], %[ag]\n\t"                                                                             \
+  "s_add_u32 m0, m0, %[t0]\n\t"                                                                                   \
+  "s_mov_b32 %[ag], %[gm]\n\t"                                                                                    \
+  "s_mov_b32 %[st], 1\n\t"                                                                                        \
+  "s_branch 9f\n\t"                                                                                               \
+  "6:\n\t"                                     /* group end behind a placement: from f */                           \
+  "s_sub_u32 %[ag], %[ag], %[t0]\n\t"                                                                             \
+  "s_bfe_u32 %[t1], %[w], 0x8000f\n\t"                                                                            \
+  "s_sub_u32 %[t0], %[gm], %[ag]\n\t"                                                                             \
+  "s_add_u32 %[t0], %[t0], %[t1]\n\t"                                                                             \
+  "s_sub_u32 m0, %[t0], 1\n\t"                                                                                    \
+  "s_mov_b32 %[ag], %[gm]\n\t"                                                                                    \
+  "s_mov_b32 %[st], 1\n\t"                                                                                        \
+  "s_branch 9f\n\t"                                                                                               \
+  "8:\n\t"                                                                                                        \
+  "s_mov_b32 %[st], 2\n\t"                                                                                        \
+  "9:\n\t"                                                                                                        \
+  "s_mov_b32 %[p], m0\n\t"                                                                                        \
+  "s_and_b32 %[ag], %[ag], 0xffff"
+
 // The decoder state of one wave (= one book).  All pointers are wave-uniform; `pv` (new orders {price, vol} by pool
 // slot) is global memory for the split pipeline (the step batch) and LDS for the fused kernel.
 template <int R>
@@ -186,6 +241,7 @@ struct WaveDecoder {
     // (R <= 2) the pool's live masks as two scalar pairs for the walk
     const uint64_t lv0 = mk64(rdl(livev, live_base), rdl(livev, live_base + 1u));
     const uint64_t lv1 = R >= 2 ? mk64(rdl(livev, live_base + 2u), rdl(livev, live_base + 3u)) : 0ull;
+    uint32_t lblk = 0xFFFFFFFFu, lw = 0;  // (R > 2) the cached live word of the walk and which 32 agents it covers
     for (uint32_t g = 0; g < a.n_groups; ++g) {
       const Group G = a.groups[g];
       const uint32_t gend = gbase + G.n;
@@ -259,134 +315,61 @@ struct WaveDecoder {
             //   placement -> (w[31]: not resolvable -> slow) event word ag | NEW | ACTED, p = w[14:7], agents += w[29:23];
             //   the group ends before the next hit -> position of agent `gend`'s draw from the run start (p + 1 or f).
             if constexpr (R <= 2) {
-              // pools of <= 128 slots: the live masks sit in two SGPR pairs and the test is three scalar instructions (the
-              // general form below reads the mask word back from a VGPR: two more scalar instructions, one more
-              // v_readlane and a second vector-to-scalar hand-over on the walk's critical path)
+              // pools of <= 128 slots: the live masks sit in two SGPR pairs.  A walk that stays inside one 64-agent half
+              // (always, with groups of 64) tests ONE mask chosen up front - one scalar instruction per hit; else the
+              // mask is chosen per hit (three)
               uint32_t st, w, t0, t1, gm;
-              uint64_t lm;
-              asm volatile(
-                  "s_mov_b32 m0, %[p]\n\t"
-                  "s_or_b32 %[ag], %[ag], 0x10000\n\t"
-                  "s_or_b32 %[gm], %[gend], 0x10000\n\t"
-                  "1:\n\t"
-                  "v_readlane_b32 %[w], %[pack], m0\n\t"
-                  "s_bitcmp1_b32 %[ag], 6\n\t"                  /* agent 64..127: the second mask */
-                  "s_cselect_b64 %[lm], %[lv1], %[lv0]\n\t"
-                  "s_bitcmp1_b64 %[lm], %[ag]\n\t"              /* (the bit index is ag[5:0]) */
-                  "s_cbranch_scc0 2f\n\t"
-                  "v_writelane_b32 %[agw], %[ag], m0\n\t"     /* holds an Active order: its cancellation (agent | marker) */
-                  "s_and_b32 %[t0], %[w], 0x7f\n\t"           /* distance to the next hit */
-                  "s_add_u32 %[ag], %[ag], %[t0]\n\t"
-                  "s_cmp_ge_u32 %[ag], %[gm]\n\t"
-                  "s_cbranch_scc1 5f\n\t"
-                  "s_add_u32 m0, m0, %[t0]\n\t"
-                  "s_cmp_lt_u32 m0, 64\n\t"
-                  "s_cbranch_scc1 1b\n\t"
-                  "s_mov_b32 %[st], 0\n\t"
-                  "s_branch 9f\n\t"
-                  "2:\n\t"
-                  "s_cmp_lt_i32 %[w], 0\n\t"                    /* placement not resolvable in the look-ahead */
-                  "s_cbranch_scc1 8f\n\t"
-                  "s_or_b32 %[t0], %[ag], 0x8000\n\t"
-                  "v_writelane_b32 %[agw], %[t0], m0\n\t"
-                  "s_bfe_u32 %[t0], %[w], 0x70017\n\t"        /* agents the placement's path covers */
-                  "s_add_u32 %[ag], %[ag], %[t0]\n\t"
-                  "s_cmp_ge_u32 %[ag], %[gm]\n\t"
-                  "s_cbranch_scc1 6f\n\t"
-                  "s_bfe_u32 m0, %[w], 0x80007\n\t"           /* next position */
-                  "s_cmp_lt_u32 m0, 64\n\t"
-                  "s_cbranch_scc1 1b\n\t"
-                  "s_mov_b32 %[st], 0\n\t"
-                  "s_branch 9f\n\t"
-                  "5:\n\t"                                       /* group end behind a cancellation */
-                  "s_sub_u32 %[ag], %[ag], %[t0]\n\t"
-                  "s_sub_u32 %[t0], %[gm], %[ag]\n\t"
-                  "s_add_u32 m0, m0, %[t0]\n\t"
-                  "s_mov_b32 %[ag], %[gm]\n\t"
-                  "s_mov_b32 %[st], 1\n\t"
-                  "s_branch 9f\n\t"
-                  "6:\n\t"                                       /* group end behind a placement: from f */
-                  "s_sub_u32 %[ag], %[ag], %[t0]\n\t"
-                  "s_bfe_u32 %[t1], %[w], 0x8000f\n\t"
-                  "s_sub_u32 %[t0], %[gm], %[ag]\n\t"
-                  "s_add_u32 %[t0], %[t0], %[t1]\n\t"
-                  "s_sub_u32 m0, %[t0], 1\n\t"
-                  "s_mov_b32 %[ag], %[gm]\n\t"
-                  "s_mov_b32 %[st], 1\n\t"
-                  "s_branch 9f\n\t"
-                  "8:\n\t"
-                  "s_mov_b32 %[st], 2\n\t"
-                  "9:\n\t"
-                  "s_mov_b32 %[p], m0\n\t"
-                  "s_and_b32 %[ag], %[ag], 0xffff"
-                  : [st] "=&s"(st), [w] "=&s"(w), [t0] "=&s"(t0), [t1] "=&s"(t1), [gm] "=&s"(gm), [p] "+s"(p), [ag] "+s"(ag),
-                    [agw] "+v"(agw), [lm] "=&s"(lm)
-                  : [pack] "v"(pack), [lv0] "s"(lv0), [lv1] "s"(lv1), [gend] "s"(gend)
-                  : "scc", "m0", "memory");
+              if ((ag >> 6) == ((gend - 1u) >> 6)) {
+                const uint64_t lm = (ag & 64u) ? lv1 : lv0;
+                asm volatile(WV_WALK_BEGIN
+                             "v_readlane_b32 %[w], %[pack], m0\n\t"
+                             "s_bitcmp1_b64 %[lm], %[ag]\n\t"              /* (the bit index is ag[5:0]) */
+                             WV_WALK_REST
+                             : [st] "=&s"(st), [w] "=&s"(w), [t0] "=&s"(t0), [t1] "=&s"(t1), [gm] "=&s"(gm), [p] "+s"(p),
+                               [ag] "+s"(ag), [agw] "+v"(agw)
+                             : [pack] "v"(pack), [lm] "s"(lm), [gend] "s"(gend)
+                             : "scc", "m0", "memory");
+              } else {
+                uint64_t lm;
+                asm volatile(WV_WALK_BEGIN
+                             "v_readlane_b32 %[w], %[pack], m0\n\t"
+                             "s_bitcmp1_b32 %[ag], 6\n\t"                  /* agent 64..127: the second mask */
+                             "s_cselect_b64 %[lm], %[lv1], %[lv0]\n\t"
+                             "s_bitcmp1_b64 %[lm], %[ag]\n\t"
+                             WV_WALK_REST
+                             : [st] "=&s"(st), [w] "=&s"(w), [t0] "=&s"(t0), [t1] "=&s"(t1), [gm] "=&s"(gm), [p] "+s"(p),
+                               [ag] "+s"(ag), [agw] "+v"(agw), [lm] "=&s"(lm)
+                             : [pack] "v"(pack), [lv0] "s"(lv0), [lv1] "s"(lv1), [gend] "s"(gend)
+                             : "scc", "m0", "memory");
+              }
               slow = st == 2u;
             } else {
+              // larger pools: the live word of the current 32 agents is CACHED in a scalar register across hits, windows
+              // and groups (`lblk` = which; the masks do not change during the decode) and re-read from the vector
+              // register only when the walk enters another block - round 2 read it for every hit: one more v_readlane and
+              // a second vector-to-scalar hand-over on each hit's chain
               uint32_t st, w, t0, t1, gm;
-              asm volatile(
-                  "s_mov_b32 m0, %[p]\n\t"
-                  "s_or_b32 %[ag], %[ag], 0x10000\n\t"
-                  "s_or_b32 %[gm], %[gend], 0x10000\n\t"
-                  "1:\n\t"
-                  "s_bfe_u32 %[t0], %[ag], 0xb0005\n\t"        /* the live word of agent ag: lane live_base + ag / 32 */
-                  "s_add_u32 %[t0], %[t0], %[lb]\n\t"
-                  "v_readlane_b32 %[w], %[pack], m0\n\t"
-                  "v_readlane_b32 %[t1], %[livev], %[t0]\n\t"
-                  "s_lshr_b32 %[t1], %[t1], %[ag]\n\t"
-                  "s_bitcmp1_b32 %[t1], 0\n\t"
-                  "s_cbranch_scc0 2f\n\t"
-                  "v_writelane_b32 %[agw], %[ag], m0\n\t"     /* holds an Active order: its cancellation (agent | marker) */
-                  "s_and_b32 %[t0], %[w], 0x7f\n\t"           /* distance to the next hit */
-                  "s_add_u32 %[ag], %[ag], %[t0]\n\t"
-                  "s_cmp_ge_u32 %[ag], %[gm]\n\t"
-                  "s_cbranch_scc1 5f\n\t"
-                  "s_add_u32 m0, m0, %[t0]\n\t"
-                  "s_cmp_lt_u32 m0, 64\n\t"
-                  "s_cbranch_scc1 1b\n\t"
-                  "s_mov_b32 %[st], 0\n\t"
-                  "s_branch 9f\n\t"
-                  "2:\n\t"
-                  "s_cmp_lt_i32 %[w], 0\n\t"                    /* placement not resolvable in the look-ahead */
-                  "s_cbranch_scc1 8f\n\t"
-                  "s_or_b32 %[t0], %[ag], 0x8000\n\t"
-                  "v_writelane_b32 %[agw], %[t0], m0\n\t"
-                  "s_bfe_u32 %[t0], %[w], 0x70017\n\t"        /* agents the placement's path covers */
-                  "s_add_u32 %[ag], %[ag], %[t0]\n\t"
-                  "s_cmp_ge_u32 %[ag], %[gm]\n\t"
-                  "s_cbranch_scc1 6f\n\t"
-                  "s_bfe_u32 m0, %[w], 0x80007\n\t"           /* next position */
-                  "s_cmp_lt_u32 m0, 64\n\t"
-                  "s_cbranch_scc1 1b\n\t"
-                  "s_mov_b32 %[st], 0\n\t"
-                  "s_branch 9f\n\t"
-                  "5:\n\t"                                       /* group end behind a cancellation */
-                  "s_sub_u32 %[ag], %[ag], %[t0]\n\t"
-                  "s_sub_u32 %[t0], %[gm], %[ag]\n\t"
-                  "s_add_u32 m0, m0, %[t0]\n\t"
-                  "s_mov_b32 %[ag], %[gm]\n\t"
-                  "s_mov_b32 %[st], 1\n\t"
-                  "s_branch 9f\n\t"
-                  "6:\n\t"                                       /* group end behind a placement: from f */
-                  "s_sub_u32 %[ag], %[ag], %[t0]\n\t"
-                  "s_bfe_u32 %[t1], %[w], 0x8000f\n\t"
-                  "s_sub_u32 %[t0], %[gm], %[ag]\n\t"
-                  "s_add_u32 %[t0], %[t0], %[t1]\n\t"
-                  "s_sub_u32 m0, %[t0], 1\n\t"
-                  "s_mov_b32 %[ag], %[gm]\n\t"
-                  "s_mov_b32 %[st], 1\n\t"
-                  "s_branch 9f\n\t"
-                  "8:\n\t"
-                  "s_mov_b32 %[st], 2\n\t"
-                  "9:\n\t"
-                  "s_mov_b32 %[p], m0\n\t"
-                  "s_and_b32 %[ag], %[ag], 0xffff"
-                  : [st] "=&s"(st), [w] "=&s"(w), [t0] "=&s"(t0), [t1] "=&s"(t1), [gm] "=&s"(gm), [p] "+s"(p), [ag] "+s"(ag),
-                    [agw] "+v"(agw)
-                  : [pack] "v"(pack), [livev] "v"(livev), [lb] "s"(live_base), [gend] "s"(gend)
-                  : "scc", "m0", "memory");
+              asm volatile(WV_WALK_BEGIN
+                           "v_readlane_b32 %[w], %[pack], m0\n\t"
+                           "s_bfe_u32 %[t0], %[ag], 0xb0005\n\t"          /* agent / 32 (without the marker bit) */
+                           "s_cmp_lg_u32 %[t0], %[lblk]\n\t"
+                           "s_cbranch_scc1 7f\n\t"
+                           "3:\n\t"
+                           "s_bitcmp1_b32 %[lw], %[ag]\n\t"               /* (the bit index is ag[4:0]) */
+                           WV_WALK_REST
+                           "\n\t"
+                           "s_branch 4f\n\t"
+                           "7:\n\t"
+                           "s_mov_b32 %[lblk], %[t0]\n\t"
+                           "s_add_u32 %[t0], %[t0], %[lb]\n\t"
+                           "v_readlane_b32 %[lw], %[livev], %[t0]\n\t"
+                           "s_branch 3b\n\t"
+                           "4:\n\t"
+                           "s_nop 0"
+                           : [st] "=&s"(st), [w] "=&s"(w), [t0] "=&s"(t0), [t1] "=&s"(t1), [gm] "=&s"(gm), [p] "+s"(p),
+                             [ag] "+s"(ag), [agw] "+v"(agw), [lblk] "+s"(lblk), [lw] "+s"(lw)
+                           : [pack] "v"(pack), [livev] "v"(livev), [lb] "s"(live_base), [gend] "s"(gend)
+                           : "scc", "m0", "memory");
               slow = st == 2u;
             }
           }

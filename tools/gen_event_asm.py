@@ -142,12 +142,11 @@ def gen(N, markets):
                 e("s_nop 1")
                 e(f"{op2}_dpp %[vm], %[vm], %[vm] {ctl}")
             e("s_nop 1")
-            e(f"v_readlane_b32 {S['BEST']}, %[vm], 63")
-            e("s_nop 1")                                            # BEST as a VALU operand: 2 wait states
+            e(f"v_readlane_b32 {oppb}, %[vm], 63")                  # the best key, read INTO the bound: exact now
+            e("s_nop 1")                                            # ... as a VALU operand: 2 wait states
             for r in range(N):
-                e(f"v_cmp_eq_u32_e64 {eq(r)}, {S['BEST']}, {key(r)}")
-            e(f"s_mov_b32 {oppb}, {S['BEST']}")                     # the bound is exact now
-            e(f"{'s_cmp_gt_i32' if agg_bid else 's_cmp_lt_i32'} {S['BEST']}, {S['KP']}")   # no cross (or nothing there)
+                e(f"v_cmp_eq_u32_e64 {eq(r)}, {oppb}, {key(r)}")
+            e(f"{'s_cmp_gt_i32' if agg_bid else 's_cmp_lt_i32'} {oppb}, {S['KP']}")   # no cross (or nothing there)
             e(f"s_cbranch_scc1 L_rest_{tag}_%=")
             for r in range(N - 1):
                 e(f"s_cmp_lg_u64 {eq(r)}, 0")
