@@ -171,7 +171,9 @@ __device__ __forceinline__ uint32_t first_above_near(uint64_t lo, uint64_t hi, u
 
 // The decoder state of one wave (= one book).  All pointers are wave-uniform; `pv` (new orders {price, vol} by pool
 // slot) is global memory for the split pipeline (the step batch) and LDS for the fused kernel.
-template <int R>
+// MASKS: also keep the placing / side masks of the step's new orders (the fused kernel reads them; the split form's
+// k_step_batch rebuilds them from the event words, so its decode does not pay two LDS atomics per placement for them).
+template <int R, bool MASKS = true>
 struct WaveDecoder {
   const uint4* tab;    // LDS: T^256 table
   uint32_t* ring;      // LDS: the last WV_RING generated draws, ring[q & (WV_RING - 1)] = draw q of this launch's stream
@@ -385,8 +387,10 @@ struct WaveDecoder {
           if (placed) {
             const uint32_t slot = agw & EV_SLOT;
             pv[slot] = make_uint2(fprice, fvol);
-            atomicOr(&pm[slot >> 5], 1u << (slot & 31u));
-            atomicOr(&sm[slot >> 5], fside << (slot & 31u));
+            if constexpr (MASKS) {
+              atomicOr(&pm[slot >> 5], 1u << (slot & 31u));
+              atomicOr(&sm[slot >> 5], fside << (slot & 31u));
+            }
           }
           n_ev += (uint32_t)__builtin_popcountll(am);
         }
@@ -411,8 +415,10 @@ struct WaveDecoder {
           if (lane == 0) {
             evl[n_ev] = (uint16_t)(ag | EV_NEW | (val[0] << 14));
             pv[ag] = make_uint2((G.tick_lo + val[1]) * G.tick_size, G.vol_lo + val[2]);
-            atomicOr(&pm[ag >> 5], 1u << (ag & 31u));
-            atomicOr(&sm[ag >> 5], val[0] << (ag & 31u));
+            if constexpr (MASKS) {
+              atomicOr(&pm[ag >> 5], 1u << (ag & 31u));
+              atomicOr(&sm[ag >> 5], val[0] << (ag & 31u));
+            }
           }
           n_ev += 1;
           ag += 1;
@@ -630,7 +636,6 @@ struct WaveLds {
   uint4 tab[512];
   uint32_t ring[4][WV_RING];
   uint16_t evl[4][64 * R];
-  uint32_t pm[4][2 * R], sm[4][2 * R];
   uint16_t jarr[4][64 * R];
   uint16_t bucket[4][R > 2 ? 64 * R : 1];
 };
@@ -645,13 +650,13 @@ __device__ __forceinline__ void agents_wave_book(const DevArgs& a, const WaveArg
   uint32_t* bt = a.batch + (size_t)book * a.batch_stride;
   uint32_t* wc = wa.wcache + (size_t)book * WC_STRIDE;
 
-  WaveDecoder<R> D;
+  WaveDecoder<R, false> D;
   BK_STAMP_START(D, book);
   D.tab = L.tab;
   D.ring = L.ring[wv];
   D.evl = L.evl[wv];
-  D.pm = L.pm[wv];
-  D.sm = L.sm[wv];
+  D.pm = nullptr;
+  D.sm = nullptr;
   D.pv = reinterpret_cast<uint2*>(bt + BT_EV + 32 * R);
   D.jarr = L.jarr[wv];
   D.wmask = reinterpret_cast<uint4*>(L.ring[wv]);  // the generated draws are dead once the shuffle's windows are resolved
@@ -664,10 +669,6 @@ __device__ __forceinline__ void agents_wave_book(const DevArgs& a, const WaveArg
   D.lane = lane;
   // the book's RNG state and live masks (header dwords H_LIVE0 + w hold bits [32 w, 32 w + 32) of the pool's live mask)
   D.load_cache(wc, rdl(hdr, H_S0_LO), rdl(hdr, H_S0_HI), rdl(hdr, H_S1_LO), rdl(hdr, H_S1_HI), wa.jt_lane);
-  if (lane < 2 * R) {
-    D.pm[lane] = 0;
-    D.sm[lane] = 0;
-  }
   const uint32_t lim = 64u + (wa.lookahead < 1u ? 1u : (wa.lookahead > 64u ? 64u : wa.lookahead));
   BK_STAMP(D, 1, 0, lane);  // lane-state cache in
   const uint32_t n_ev = D.agents(a, lim, hdr, H_LIVE0);
