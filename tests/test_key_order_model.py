@@ -127,3 +127,24 @@ def test_skip_bounds_stay_valid_and_never_skip_a_crossing_order():
                         asks[k] = vol
                         alo = min(alo, K.i32(k))
             assert alo <= (min(map(K.i32, asks)) if asks else 0) and bhi >= (max(map(K.i32, bids)) if bids else 0)
+
+
+def test_the_model_and_the_device_header_agree_on_the_constants():
+    """tools/key_model.py is the specification; book_device.hpp / event_asm.hpp / the generator carry the same numbers."""
+    import re
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = open(os.path.join(root, "bourse_amd", "csrc", "book_device.hpp")).read()
+    m = re.search(r"KP_MKT_BID = (0x[0-9A-Fa-f]+)u, KP_MKT_ASK = (0x[0-9A-Fa-f]+)u", hdr)
+    assert m and (int(m.group(1), 16), int(m.group(2), 16)) == (K.MARKET_BID, K.MARKET_ASK)
+    assert re.search(r"KEY_ASK = 0x80000000u", hdr) and K.ASK == 0x80000000
+    # price window: (1 << 15) - 6 at the shipped 16-bit arrival field; arrival window 0xFFFF
+    m = re.search(r"KEY_PSPAN = \(1u << \(31u - \(KEY_SB > 16u \? KEY_SB : 16u\)\)\) - (\d+)u", hdr)
+    assert m and (1 << 15) - int(m.group(1)) == K.PSPAN
+    assert "pbase = pmin - 2u" in hdr and "pmin >= 2u" in hdr
+    # the loops: a bid's compare value is ew | 0xFFFF, an ask's ew & 0xFFFF0000; both rest as kp ^ sq; a market ask's is 0x10000
+    asm = open(os.path.join(root, "bourse_amd", "csrc", "event_asm.hpp")).read()
+    gen = open(os.path.join(root, "tools", "gen_event_asm.py")).read()
+    for text in (asm, gen):
+        assert "0xffff0000" in text and ", 0xffff" in text and "s_xor_b32" in text
+    assert '"-1" if agg_bid else "0x10000"' in gen
