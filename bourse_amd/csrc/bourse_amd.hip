@@ -83,12 +83,12 @@ constexpr uint32_t MIXED_WAVE_MIN_BOOKS = 512;
 //     64-slot pools are the exception: their book-step is so short that the persistent kernel wins up to the lane split's
 //     take-over (C2: 195 M vs 170 M at 8 192, 216 vs 206 at 16 384);
 //   * `wave_split` (k_agents_wave + k_step_batch, three parts) from there;
-//   * `split` (lane-per-book k_agents_fsm + k_step_batch, four parts) from lane_split_min_books(R): its 130 us chain
-//     per step needs that many books to be hidden (crossovers re-measured after the lane kernel lost a quarter of its
-//     instructions, profiles/r03/shape_sweep_crossovers.txt: 23 k / 24.5 k / 18 k / 24.5 k books for R = 1, 2, 4, 8;
-//     they had been 26 k / 28 k / 21 k / 28 k).
+//   * `split` (lane-per-book k_agents_fsm + k_step_batch, four parts) from lane_split_min_books(R): its 125 us chain
+//     per step needs that many books to be hidden.  Crossovers re-measured at the end of round 4, after the decode and
+//     both event loops got faster (profiles/r04/shape_sweep_crossovers.txt): 25 k / 25.6 k / 24 k / 24.5 k books for R = 1, 2,
+//     4, 8 (round 3: 23 k / 24.5 k / 18 k / 24.5 k - the 256-slot pools' wave_split gained most: 53 -> 72 M).
 constexpr uint32_t WAVE_STEP_PRIO_BOOKS = 16384;
-constexpr uint32_t lane_split_min_books(int R) { return R == 1 ? 23552u : (R == 4 ? 18432u : 24576u); }
+constexpr uint32_t lane_split_min_books(int R) { return R <= 2 ? 25600u : 24576u; }
 
 struct HostOrder {  // immutable half of an order, fixed at create_order (orderbook.rs:356-396)
   uint8_t bid;
