@@ -96,22 +96,35 @@ __device__ __forceinline__ uint32_t first_above(uint64_t lo, uint64_t hi, uint32
 }
 
 // The decode's searches (agents() below) use a cheaper form that only looks 64 positions ahead: the first set bit in
-// [i + 1, min(i + 65, 128)), else 256 ("none").  A set bit further away is reported as none - the caller then treats the
-// placement as not resolvable inside the look-ahead and resolves it draw by draw on the scalar path, so the result is
-// exact either way (two accepted draws of one sample 64 draws apart: p < 2^-37 at the worst acceptance rate of 1/2).
-// One funnel shift of the 128-bit mask + one 64-bit first-set-bit search: ~24 vector instructions instead of ~45.
+// [i + 1, min(i + 65, 128)), else a value >= 128 ("none").  A set bit further away is reported as none - the caller then
+// treats the placement as not resolvable inside the look-ahead and resolves it draw by draw on the scalar path, so the
+// result is exact either way (two accepted draws of one sample 64 draws apart: p < 2^-37 at the worst acceptance rate of
+// 1/2).  One funnel shift of the 128-bit mask + one 64-bit first-set-bit search: ~19 vector instructions instead of ~45.
+// Contract: for i < 127 the result is exact or >= 128; for i >= 127 (a chained search behind a "none") it is SOME value
+// > i, i.e. still >= 128 - which is all the caller tests (q < lim <= 128).  That lets the i >= 127 guard and the
+// "nothing found" select of round 3's form go: the count of trailing zeros is min(ffbl(w0), ffbl(w1) | 32), all ones when
+// the window is empty (v_ffbl_b32 of 0 is -1, and -1 | 32 stays -1), and n + all ones wraps to i, caught by one compare.
+// min(count of trailing zeros of x, cap), cap for x = 0 (per lane; v_ffbl_b32 of 0 is all ones, and all ones | 32 too)
+__device__ __forceinline__ uint32_t ctz64_cap(uint64_t x, uint32_t cap) {
+  uint32_t f0, f1;
+  asm("v_ffbl_b32 %0, %1" : "=v"(f0) : "v"((uint32_t)x));
+  asm("v_ffbl_b32 %0, %1" : "=v"(f1) : "v"((uint32_t)(x >> 32)));
+  return min(min(f0, f1 | 32u), cap);
+}
 __device__ __forceinline__ uint32_t first_above_near(uint64_t lo, uint64_t hi, uint32_t i) {
   const uint32_t n = i + 1u;
   const uint32_t sh = n & 63u;
   const bool in_lo = n < 64u;
   const uint64_t a = in_lo ? lo : hi;          // the word n lies in
   const uint64_t b1 = in_lo ? (hi << 1) : 0ull;  // the word above it, pre-shifted so that the funnel never shifts by 64
-  uint64_t w = (a >> sh) | (b1 << (63u - sh));
-  w = n < 128u ? w : 0ull;
+  const uint64_t w = (a >> sh) | (b1 << (63u - sh));
   const uint32_t w0 = (uint32_t)w, w1 = (uint32_t)(w >> 32);
-  const uint32_t f0 = (uint32_t)__ffs(w0), f1 = (uint32_t)__ffs(w1);
-  const uint32_t c = f0 ? f0 - 1u : f1 + 31u;
-  return (w0 | w1) != 0u ? n + c : 256u;
+  // (the instruction itself: the compiler's count-trailing-zeros guards the zero input with a compare and a select of its own)
+  uint32_t f0, f1;
+  asm("v_ffbl_b32 %0, %1" : "=v"(f0) : "v"(w0));
+  asm("v_ffbl_b32 %0, %1" : "=v"(f1) : "v"(w1));
+  const uint32_t c = min(f0, f1 | 32u);
+  return c == 0xFFFFFFFFu ? 256u : n + c;
 }
 
 // The scalar walk over a window's activity hits (WaveDecoder::agents): shared text of its three forms.  WV_WALK_BEGIN ..
@@ -281,11 +294,12 @@ struct WaveDecoder {
         //   15..22 f | 23..29 agents consumed by the placement path | 31 placement not resolvable in the look-ahead
         uint32_t pack;
         {
+          // (count of trailing zeros capped at "the window's end": an empty remainder counts all ones and takes the cap)
           const uint64_t hc = (uint32_t)lane < 63u ? (H >> (lane + 1)) : 0ull;
-          const uint32_t nC = hc ? (uint32_t)lane + 1u + (uint32_t)__builtin_ctzll(hc) : 64u;
+          const uint32_t nC = (uint32_t)lane + 1u + ctz64_cap(hc, 63u - (uint32_t)lane);
           const uint32_t fq = fpos < 64u ? fpos : 0u;
           const uint64_t hp = H >> fq;
-          const uint32_t nP = fpos < 64u ? (hp ? fq + (uint32_t)__builtin_ctzll(hp) : 64u) : fpos;
+          const uint32_t nP = fpos < 64u ? fq + ctz64_cap(hp, 64u - fq) : fpos;
           const uint32_t dP = fpos < 64u ? 1u + nP - fpos : 1u;
           pack = (nC - (uint32_t)lane) | (fpos == WV_NONE ? 0x80000000u : ((nP << 7) | (fpos << 15) | (dP << 23)));
         }
