@@ -69,30 +69,23 @@ __device__ __forceinline__ uint4 wv_jump(const uint4* __restrict__ tab, uint4 s)
   return acc;
 }
 
-// index of the first set bit ABOVE position i in the 128-bit mask hi:lo (i per lane); >= 128 if there is none.
-// Branch-free on purpose (selects on 32-bit halves): the compiler turned 64-bit ternaries into divergent branches,
-// i.e. exec-mask juggling on the scalar unit - the scarce resource of this kernel.
-__device__ __forceinline__ uint32_t first_above(uint64_t lo, uint64_t hi, uint32_t i) {
-  const uint32_t n = i + 1u;
-  const uint32_t sh = n & 63u;
-  const bool in_lo = n < 64u, in_hi = n < 128u;
-  // bits >= n of `lo` (zero once n >= 64), bits >= n of `hi` (all of it while n < 64)
-  uint64_t l = lo >> sh, h = hi >> sh;
-  uint32_t l0 = (uint32_t)l, l1 = (uint32_t)(l >> 32), h0 = (uint32_t)h, h1 = (uint32_t)(h >> 32);
-  l0 = in_lo ? l0 : 0u;
-  l1 = in_lo ? l1 : 0u;
-  h0 = in_lo ? (uint32_t)hi : (in_hi ? h0 : 0u);
-  h1 = in_lo ? (uint32_t)(hi >> 32) : (in_hi ? h1 : 0u);
-  // count of trailing zeros of each 64-bit remainder from its halves (__ffs: 1-based, 0 when no bit is set)
-  const uint32_t fl0 = (uint32_t)__ffs(l0), fl1 = (uint32_t)__ffs(l1), fh0 = (uint32_t)__ffs(h0), fh1 = (uint32_t)__ffs(h1);
-  const uint32_t cl = fl0 ? fl0 - 1u : fl1 + 31u;
-  const uint32_t ch = fh0 ? fh0 - 1u : fh1 + 31u;
-  // arithmetic selection (an absent half becomes 0xFFFFFFFF, the lower position wins): no ternary for the compiler to
-  // turn back into a branch
-  const uint32_t none_l = (l0 | l1) == 0u ? 0xFFFFFFFFu : 0u, none_h = (h0 | h1) == 0u ? 0xFFFFFFFFu : 0u;
-  const uint32_t ql = (n + cl) | none_l;                       // position of the first set bit of lo's remainder
-  const uint32_t qh = ((in_lo ? 64u : n) + ch) | none_h;       // ... of hi's
-  return min(min(ql, qh), 256u);
+// index of the first set bit ABOVE position i in the 128-bit mask w3:w2:w1:w0 (all per lane); >= 128 if there is none.
+// Branch-free: word j keeps its bits at positions >= n = i + 1 - the mask is all ones shifted left by n - 32 j clamped to
+// [0, 32] (a 64-bit shift, so that 32 clears the word) - and the answer is the minimum over the four words of
+// v_ffbl_b32 | 32 j (all ones for an empty word, with or without the OR).  ~25 vector instructions (round 2's form, through
+// 64-bit halves and the compiler's guarded count-trailing-zeros: ~45).
+__device__ __forceinline__ uint32_t first_above(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, uint32_t i) {
+  const int32_t n = (int32_t)i + 1;
+  auto keep = [](uint32_t w, int32_t t) {  // bits of w at positions >= t (t clamped to 0..32)
+    const uint32_t sh = (uint32_t)max(0, min(t, 32));  // (v_med3_i32)
+    return w & (uint32_t)(~0ull << sh);
+  };
+  uint32_t f0, f1, f2, f3;
+  asm("v_ffbl_b32 %0, %1" : "=v"(f0) : "v"(keep(w0, n)));
+  asm("v_ffbl_b32 %0, %1" : "=v"(f1) : "v"(keep(w1, n - 32)));
+  asm("v_ffbl_b32 %0, %1" : "=v"(f2) : "v"(keep(w2, n - 64)));
+  asm("v_ffbl_b32 %0, %1" : "=v"(f3) : "v"(keep(w3, n - 96)));
+  return min(min(f0, f1 | 32u), min(f2 | 64u, f3 | 96u));
 }
 
 // The decode's searches (agents() below) use a cheaper form that only looks 64 positions ahead: the first set bit in
@@ -521,7 +514,7 @@ struct WaveDecoder {
           bool go = x < n_ev;
           while (__ballot(go)) {
             const uint4 m = wmask[y & 127u];
-            const uint32_t sx = first_above(mk64(m.x, m.y), mk64(m.z, m.w), t);
+            const uint32_t sx = first_above(m.x, m.y, m.z, m.w, t);
             const bool hop = go && sx < 128u;
             y = hop ? sx : y;
             t = hop ? sx : t;
