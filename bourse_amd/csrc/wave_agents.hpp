@@ -57,13 +57,13 @@ __device__ __forceinline__ uint4 wv_jump(const uint4* __restrict__ tab, uint4 s)
 #pragma unroll
   for (int d = 0; d < 4; ++d) {
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const uint32_t idx = (w[d] >> (4 * k)) & 15u;
-      const uint4 e = tab[(d * 8 + k) * 16 + idx];
-      acc.x ^= e.x;
-      acc.y ^= e.y;
-      acc.z ^= e.z;
-      acc.w ^= e.w;
+    for (int k = 0; k < 8; k += 2) {  // two entries per step: one three-input XOR (v_bitop3_b32) per word instead of two XORs
+      const uint32_t i0 = (w[d] >> (4 * k)) & 15u, i1 = (w[d] >> (4 * k + 4)) & 15u;
+      const uint4 e0 = tab[(d * 8 + k) * 16 + i0], e1 = tab[(d * 8 + k + 1) * 16 + i1];
+      acc.x = xor3(acc.x, e0.x, e1.x);
+      acc.y = xor3(acc.y, e0.y, e1.y);
+      acc.z = xor3(acc.z, e0.z, e1.z);
+      acc.w = xor3(acc.w, e0.w, e1.w);
     }
   }
   return acc;
