@@ -85,6 +85,7 @@ enum Hdr : int {
   H_TRADE_BASE_LO, H_TRADE_BASE_HI, H_LAST_NTRADES, H_LAST_NEVENTS,
   H_LIVE0 = 32,  // live masks of the pool: dwords 32 + 2r (lo), 33 + 2r (hi), r < 8 (read by k_agents_fsm)
 };
+constexpr int HDR_SCALARS = 20;  // header dwords 0 .. 19: every scalar field a step reads (Hdr, up to H_TRADE_BASE_HI)
 constexpr int POOL_FIELDS = 5;  // price, vol, id, seq, meta(bit0 live, bit1 bid, bit2 pending New, bits 8..15 owner tag)
 constexpr int MAX_GROUPS = 8;
 constexpr int MAX_ASSETS = 8;  // books per market (MarketEnv<ASSETS>)
@@ -704,12 +705,21 @@ __device__ __forceinline__ void snapshot(const Book<R>& B, const DevArgs& a, uin
 template <int R>
 struct StepRaw {
   uint32_t hdr, f[R][POOL_FIELDS];
+  uint32_t sh[HDR_SCALARS];  // the header's scalar fields once more, through the scalar cache (wave-uniform address)
   uint32_t bh, ev[R];  // step batch: header words, event list
   uint2 pv[R];         // step batch: new orders {price, vol} by slot
 };
 template <int R>
 __device__ __forceinline__ void load_state_raw(StepRaw<R>& w, const uint32_t* __restrict__ st, int lane) {
   w.hdr = st[lane];
+  // (s_load_dwordx16 + x4: sixteen-odd v_readlane of the line above and their vector-to-scalar hand-over at the head of
+  // every wave's chain otherwise; the scalar cache is invalidated at kernel start, and nothing writes the header before)
+  // (read as CONSTANT memory: the compiler only issues scalar loads where it can rule out a store in between, and the
+  // kernel's own store_book aliases `st`; every value is consumed before that store)
+  typedef const uint32_t __attribute__((address_space(4))) cu32;
+  cu32* cst = (cu32*)(uintptr_t)st;
+#pragma unroll
+  for (int i = 0; i < HDR_SCALARS; ++i) w.sh[i] = cst[i];
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     const uint32_t* p = st + HDR_DW + r * POOL_FIELDS * 64;
@@ -727,17 +737,17 @@ __device__ __forceinline__ void unpack_book(Book<R>& B, Rng& rng, const StepRaw<
     B.id[r] = w.f[r][2];
     B.seq[r] = w.f[r][3];
   }
-  B.t = mk64(rdl(hdr, H_T_LO), rdl(hdr, H_T_HI));
-  rng.s0 = mk64(rdl(hdr, H_S0_LO), rdl(hdr, H_S0_HI));
-  rng.s1 = mk64(rdl(hdr, H_S1_LO), rdl(hdr, H_S1_HI));
-  B.next_id = rdl(hdr, H_NEXT_ID);
-  B.seq_ctr = rdl(hdr, H_SEQ);
-  B.n_trades = mk64(rdl(hdr, H_TRADES_LO), rdl(hdr, H_TRADES_HI));
-  B.flags = rdl(hdr, H_FLAGS);
-  B.trading = rdl(hdr, H_TRADING);
-  B.n_events = mk64(rdl(hdr, H_EVENTS_LO), rdl(hdr, H_EVENTS_HI));
-  B.trade_vol = rdl(hdr, H_TRADE_VOL);
-  B.trade_base = mk64(rdl(hdr, H_TRADE_BASE_LO), rdl(hdr, H_TRADE_BASE_HI));
+  B.t = mk64(w.sh[H_T_LO], w.sh[H_T_HI]);
+  rng.s0 = mk64(w.sh[H_S0_LO], w.sh[H_S0_HI]);
+  rng.s1 = mk64(w.sh[H_S1_LO], w.sh[H_S1_HI]);
+  B.next_id = w.sh[H_NEXT_ID];
+  B.seq_ctr = w.sh[H_SEQ];
+  B.n_trades = mk64(w.sh[H_TRADES_LO], w.sh[H_TRADES_HI]);
+  B.flags = w.sh[H_FLAGS];
+  B.trading = w.sh[H_TRADING];
+  B.n_events = mk64(w.sh[H_EVENTS_LO], w.sh[H_EVENTS_HI]);
+  B.trade_vol = w.sh[H_TRADE_VOL];
+  B.trade_base = mk64(w.sh[H_TRADE_BASE_LO], w.sh[H_TRADE_BASE_HI]);
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     const uint32_t meta = w.f[r][4];
