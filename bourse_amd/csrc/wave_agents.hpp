@@ -201,11 +201,14 @@ struct WaveDecoder {
   // cached lane states valid for the book's RNG state (s0l..s1h)?  else lane j = T^(4 j) of it, by doubling
   __device__ __forceinline__ void load_cache(const uint32_t* wc, uint32_t s0l, uint32_t s0h, uint32_t s1l, uint32_t s1h,
                                              const uint4* jt_lane) {
-    const uint32_t wch = wc[lane];
+    // (the record's six header words through the scalar cache: it was written by the previous launch, nothing in this
+    // one writes it before finish(); as constant memory so that the compiler issues scalar loads)
+    typedef const uint32_t __attribute__((address_space(4))) cu32;
+    cu32* cwc = (cu32*)(uintptr_t)wc;
     cs = reinterpret_cast<const uint4*>(wc + WC_HDR)[lane];
-    pos = rdl(wch, WC_OFF);
-    const bool cached = rdl(wch, WC_TAG) == WC_MAGIC && rdl(wch, WC_S0_LO) == s0l && rdl(wch, WC_S0_HI) == s0h &&
-                        rdl(wch, WC_S1_LO) == s1l && rdl(wch, WC_S1_HI) == s1h && pos < WV_BLOCK;
+    pos = cwc[WC_OFF];
+    const bool cached = cwc[WC_TAG] == WC_MAGIC && cwc[WC_S0_LO] == s0l && cwc[WC_S0_HI] == s0h && cwc[WC_S1_LO] == s1l &&
+                        cwc[WC_S1_HI] == s1h && pos < WV_BLOCK;
     if (!cached) {  // another pipeline (or a restore / a fresh env) moved the RNG
       cs = make_uint4(s0l, s0h, s1l, s1h);
       for (int b = 0; b < 6; ++b) {
@@ -244,11 +247,10 @@ struct WaveDecoder {
 
   // ================= agents.update: groups in declaration order (crates/macros/src/lib.rs:57-73) =================
   // livev: lane live_base + w holds bits [32 w, 32 w + 32) of the pool's live mask.  Returns the number of events.
-  __device__ __forceinline__ uint32_t agents(const DevArgs& a, uint32_t lim, uint32_t livev, uint32_t live_base) {
+  // lv0 / lv1: (R <= 2) the pool's live masks as two scalar pairs for the walk
+  __device__ __forceinline__ uint32_t agents(const DevArgs& a, uint32_t lim, uint32_t livev, uint32_t live_base, uint64_t lv0,
+                                             uint64_t lv1) {
     uint32_t n_ev = 0, ag = 0, gbase = 0;
-    // (R <= 2) the pool's live masks as two scalar pairs for the walk
-    const uint64_t lv0 = mk64(rdl(livev, live_base), rdl(livev, live_base + 1u));
-    const uint64_t lv1 = R >= 2 ? mk64(rdl(livev, live_base + 2u), rdl(livev, live_base + 3u)) : 0ull;
     uint32_t lblk = 0xFFFFFFFFu, lw = 0;  // (R > 2) the cached live word of the walk and which 32 agents it covers
     for (uint32_t g = 0; g < a.n_groups; ++g) {
       const Group G = a.groups[g];
@@ -675,10 +677,15 @@ __device__ __forceinline__ void agents_wave_book(const DevArgs& a, const WaveArg
   D.wcs = reinterpret_cast<uint4*>(wc + WC_HDR);
   D.lane = lane;
   // the book's RNG state and live masks (header dwords H_LIVE0 + w hold bits [32 w, 32 w + 32) of the pool's live mask)
-  D.load_cache(wc, rdl(hdr, H_S0_LO), rdl(hdr, H_S0_HI), rdl(hdr, H_S1_LO), rdl(hdr, H_S1_HI), wa.jt_lane);
+  // (the header's scalars through the scalar cache, as k_step_batch reads them: book_device.hpp load_state_raw)
+  typedef const uint32_t __attribute__((address_space(4))) cu32;
+  cu32* cst = (cu32*)(uintptr_t)st;
+  D.load_cache(wc, cst[H_S0_LO], cst[H_S0_HI], cst[H_S1_LO], cst[H_S1_HI], wa.jt_lane);
   const uint32_t lim = 64u + (wa.lookahead < 1u ? 1u : (wa.lookahead > 64u ? 64u : wa.lookahead));
   BK_STAMP(D, 1, 0, lane);  // lane-state cache in
-  const uint32_t n_ev = D.agents(a, lim, hdr, H_LIVE0);
+  const uint64_t lv0 = R <= 2 ? mk64(cst[H_LIVE0], cst[H_LIVE0 + 1]) : 0ull;
+  const uint64_t lv1 = R == 2 ? mk64(cst[H_LIVE0 + 2], cst[H_LIVE0 + 3]) : 0ull;
+  const uint32_t n_ev = D.agents(a, lim, hdr, H_LIVE0, lv0, lv1);
   BK_STAMP(D, 1, 1, lane);  // agents.update: generation, windows, walk
   D.shuffle(n_ev);
   BK_STAMP(D, 1, 2, lane);  // shuffle
@@ -777,7 +784,8 @@ __global__ __launch_bounds__(512, 6) void k_run_wave(DevArgs a, WaveArgs wa, uin
       D.sm[lane] = 0;
     }
     wave_sync();
-    const uint32_t n_ev = D.agents(a, lim, livev, 0u);
+    const uint32_t n_ev = D.agents(a, lim, livev, 0u, R <= 2 ? mk64(rdl(livev, 0u), rdl(livev, 1u)) : 0ull,
+                                   R == 2 ? mk64(rdl(livev, 2u), rdl(livev, 3u)) : 0ull);
     D.shuffle(n_ev);
     // ---------------- the step's new orders into the pool (create_order ids: dense, agent order) -------------
     uint32_t ev[R];
