@@ -890,7 +890,9 @@ __device__ __forceinline__ bool keys_begin(const Book<R>& B, const uint64_t (&ne
     const bool bidl = lane_bit(B.bid[r]);
     const uint32_t pf = B.price[r] - pbase, sf = B.seq[r] - K.sbase;
     K.key[r] = lane_bit(B.live[r]) ? ((pf << 16) | (bidl ? 0xFFFFu - sf : KEY_ASK | sf)) : 0u;
-    K.pk[r] = bidl ? 0x8000u | pf : pf;
+    // (0 for a lane without a pending order: a members' list, which holds bare slots, is classified by this word alone -
+    // New iff it is not 0, a bid iff bit 15 is set)
+    K.pk[r] = lane_bit(lim[r]) ? (bidl ? 0x8000u | pf : pf) : 0u;
     if (MARKETS) K.pk[r] = lane_bit(newm[r] & ~lim[r]) ? (bidl ? 0xFFFFu : 1u) : K.pk[r];
   }
   K.sq = KEY_ASK | (B.seq_ctr - K.sbase);
@@ -1088,33 +1090,21 @@ __device__ __forceinline__ uint32_t step_from_list(Book<R>& B, const DevArgs& a,
     // the generated assembly loop (event_asm_gen.hpp): signed keys, compact trade records.
     // It reads SELF-CLASSIFYING event words (slot | EV_NEW | EV_BID) with the new order's compare value in the upper half.
     // The members' lists of an AgentSet (PENDKEY) hold bare slots - New iff the slot's pend bit is set, the side in its bid
-    // bit - and are converted here, one vector pass per list register in use: a slot holds at most one event per step (a
-    // pending order sits in a slot that was free when the step began), so classifying up front is the same as
-    // classifying at the event.
+    // bit: both are in the compare value the gather fetches anyway (0 = nothing pending, bit 15 = bid), so the lists are
+    // classified by it (round 4's first version selected the slot's mask words from 4 R scalar pairs per list register:
+    // ~100 vector instructions each).  A slot holds at most one event per step (a pending order sits in a slot that was
+    // free when the step began), so classifying up front is the same as classifying at the event.
     uint32_t evw[R];
-#pragma unroll
-    for (int re = 0; re < R; ++re) {
-      evw[re] = ev[re];
-      if (!CLS && n_ev > (uint32_t)re * 64u) {
-        const uint32_t sl = ev[re] & EV_SLOT;
-        uint32_t pl = 0, ph = 0, bl = 0, bh = 0;
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-          const bool here = (sl >> 6) == (uint32_t)r;
-          pl = here ? (uint32_t)newm[r] : pl;
-          ph = here ? (uint32_t)(newm[r] >> 32) : ph;
-          bl = here ? (uint32_t)B.bid[r] : bl;
-          bh = here ? (uint32_t)(B.bid[r] >> 32) : bh;
-        }
-        const uint32_t pb = (uint32_t)(mk64(pl, ph) >> (sl & 63u)) & 1u, bb = (uint32_t)(mk64(bl, bh) >> (sl & 63u)) & 1u;
-        evw[re] = sl | (pb ? EV_NEW | (bb ? EV_BID : 0u) : 0u);
-      }
-    }
+    key_event_words<R>(K, ev, rfl(n_ev), evw);
     if (!CLS) {
+#pragma unroll
+      for (int re = 0; re < R; ++re) {
+        const uint32_t pk = evw[re] >> 16;  // (the gather above: the slot's compare value, 0 = no pending order there)
+        evw[re] = (evw[re] & (0xFFFF0000u | EV_SLOT)) | (pk != 0u ? EV_NEW | ((pk & 0x8000u) ? EV_BID : 0u) : 0u);
+      }
 #pragma unroll
       for (int r = 0; r < R; ++r) B.pend[r] = 0;  // every pending order is an event of this step
     }
-    key_event_words<R>(K, evw, rfl(n_ev), evw);
     // ... and the new orders' volumes by event position (the loop reads an event's volume by the lane it reads the event
     // word from instead of addressing the slot's pool row)
     uint32_t evq[R];
