@@ -203,12 +203,22 @@ struct WaveDecoder {
                                              const uint4* jt_lane) {
     // (the record's six header words through the scalar cache: it was written by the previous launch, nothing in this
     // one writes it before finish(); as constant memory so that the compiler issues scalar loads)
-    typedef const uint32_t __attribute__((address_space(4))) cu32;
-    cu32* cwc = (cu32*)(uintptr_t)wc;
+    // (pools of <= 128 slots; the larger pools' kernels lose more to the extra live scalars than the lane reads cost:
+    // book_device.hpp load_state_raw)
     cs = reinterpret_cast<const uint4*>(wc + WC_HDR)[lane];
-    pos = cwc[WC_OFF];
-    const bool cached = cwc[WC_TAG] == WC_MAGIC && cwc[WC_S0_LO] == s0l && cwc[WC_S0_HI] == s0h && cwc[WC_S1_LO] == s1l &&
-                        cwc[WC_S1_HI] == s1h && pos < WV_BLOCK;
+    bool cached;
+    if constexpr (R <= 2) {
+      typedef const uint32_t __attribute__((address_space(4))) cu32;
+      cu32* cwc = (cu32*)(uintptr_t)wc;
+      pos = cwc[WC_OFF];
+      cached = cwc[WC_TAG] == WC_MAGIC && cwc[WC_S0_LO] == s0l && cwc[WC_S0_HI] == s0h && cwc[WC_S1_LO] == s1l &&
+               cwc[WC_S1_HI] == s1h && pos < WV_BLOCK;
+    } else {
+      const uint32_t wch = wc[lane];
+      pos = rdl(wch, WC_OFF);
+      cached = rdl(wch, WC_TAG) == WC_MAGIC && rdl(wch, WC_S0_LO) == s0l && rdl(wch, WC_S0_HI) == s0h &&
+               rdl(wch, WC_S1_LO) == s1l && rdl(wch, WC_S1_HI) == s1h && pos < WV_BLOCK;
+    }
     if (!cached) {  // another pipeline (or a restore / a fresh env) moved the RNG
       cs = make_uint4(s0l, s0h, s1l, s1h);
       for (int b = 0; b < 6; ++b) {
@@ -680,7 +690,10 @@ __device__ __forceinline__ void agents_wave_book(const DevArgs& a, const WaveArg
   // (the header's scalars through the scalar cache, as k_step_batch reads them: book_device.hpp load_state_raw)
   typedef const uint32_t __attribute__((address_space(4))) cu32;
   cu32* cst = (cu32*)(uintptr_t)st;
-  D.load_cache(wc, cst[H_S0_LO], cst[H_S0_HI], cst[H_S1_LO], cst[H_S1_HI], wa.jt_lane);
+  if constexpr (R <= 2)
+    D.load_cache(wc, cst[H_S0_LO], cst[H_S0_HI], cst[H_S1_LO], cst[H_S1_HI], wa.jt_lane);
+  else
+    D.load_cache(wc, rdl(hdr, H_S0_LO), rdl(hdr, H_S0_HI), rdl(hdr, H_S1_LO), rdl(hdr, H_S1_HI), wa.jt_lane);
   const uint32_t lim = 64u + (wa.lookahead < 1u ? 1u : (wa.lookahead > 64u ? 64u : wa.lookahead));
   BK_STAMP(D, 1, 0, lane);  // lane-state cache in
   const uint64_t lv0 = R <= 2 ? mk64(cst[H_LIVE0], cst[H_LIVE0 + 1]) : 0ull;
