@@ -1375,11 +1375,14 @@ __global__ __launch_bounds__(64) void k_agents_fsm(DevArgs a) {
       uint64_t w = live[0];
 #pragma unroll
       for (int r = 1; r < R; ++r) w = ((sbeg >> 6) == (uint32_t)r) ? live[r] : w;
-      uint32_t phase = PH_ACT, cur_side = 0, cur_price = 0;
+      uint32_t cur_side = 0, cur_price = 0;
+      // The phase of every lane lives in four WAVE MASKS carried across the iterations in scalar registers (one-hot per
+      // lane) and is advanced by scalar mask algebra at the end of the iteration - round 3 kept it in a vector register:
+      // four compares to get the masks and four selects to write the next phase, every draw.  Bits of lanes that have
+      // left the loop go stale, harmlessly: every predicate they are combined with is a ballot of the lanes still in it.
+      uint64_t P_ACT = ~0ull, P_SIDE = 0, P_TICK = 0, P_VOL = 0;
       while (n < send) {
         const uint32_t x = rng.output(five);
-        uint64_t P_ACT = __builtin_amdgcn_ballot_w64(phase == PH_ACT), P_SIDE = __builtin_amdgcn_ballot_w64(phase == PH_SIDE);
-        uint64_t P_TICK = __builtin_amdgcn_ballot_w64(phase == PH_TICK), P_VOL = __builtin_amdgcn_ballot_w64(phase == PH_VOL);
         // range and zone of the phase at hand, from its masks (two selects each; no loop-carried copies)
         const uint32_t range = sel(P_SIDE, 2u, sel(P_TICK, v_trng, v_vrng));
         const uint32_t zone = sel(P_SIDE, 0x7FFFFFFFu, sel(P_TICK, v_tzone, v_vzone));
@@ -1408,7 +1411,10 @@ __global__ __launch_bounds__(64) void k_agents_fsm(DevArgs a) {
         asm("v_addc_co_u32_e64 %0, vcc, 0, %0, %1" : "+v"(n_ev) : "s"(QUEUE) : "vcc");  // n_ev += lane_bit(QUEUE)
         if (lane_bit(A_VOL)) pv[n] = make_uint2(cur_price, G.vol_lo + val);       // vol drawn last (:101): the order is complete
         // next phase; an agent that is done (inactive, cancelled or placed) hands over to the next one
-        phase = sel(ADV, PH_ACT, sel(TO_SIDE, PH_SIDE, sel(A_SIDE, PH_TICK, sel(A_TICK, PH_VOL, phase))));
+        P_SIDE = TO_SIDE | (P_SIDE & ~C_ACC);
+        P_TICK = A_SIDE | (P_TICK & ~C_ACC);
+        P_VOL = A_TICK | (P_VOL & ~C_ACC);
+        P_ACT = ADV;
         asm("v_addc_co_u32_e64 %0, vcc, 0, %0, %1" : "+v"(n) : "s"(ADV) : "vcc");  // n += lane_bit(ADV)
       }
       sbeg = send;
