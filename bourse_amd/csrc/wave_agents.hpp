@@ -342,9 +342,12 @@ struct WaveDecoder {
               uint32_t st, w, t0, t1, gm;
               if ((ag >> 6) == ((gend - 1u) >> 6)) {
                 const uint64_t lm = (ag & 64u) ? lv1 : lv0;
+                // (the live test IN FRONT of the lane read: a scalar instruction issued right behind a vector write of a
+                // scalar register waits ~16 clocks for it, whether it reads it or not - the branch and the cancellation's
+                // v_writelane do not)
                 asm volatile(WV_WALK_BEGIN
-                             "v_readlane_b32 %[w], %[pack], m0\n\t"
                              "s_bitcmp1_b64 %[lm], %[ag]\n\t"              /* (the bit index is ag[5:0]) */
+                             "v_readlane_b32 %[w], %[pack], m0\n\t"
                              WV_WALK_REST
                              : [st] "=&s"(st), [w] "=&s"(w), [t0] "=&s"(t0), [t1] "=&s"(t1), [gm] "=&s"(gm), [p] "+s"(p),
                                [ag] "+s"(ag), [agw] "+v"(agw)
@@ -353,10 +356,10 @@ struct WaveDecoder {
               } else {
                 uint64_t lm;
                 asm volatile(WV_WALK_BEGIN
-                             "v_readlane_b32 %[w], %[pack], m0\n\t"
                              "s_bitcmp1_b32 %[ag], 6\n\t"                  /* agent 64..127: the second mask */
                              "s_cselect_b64 %[lm], %[lv1], %[lv0]\n\t"
                              "s_bitcmp1_b64 %[lm], %[ag]\n\t"
+                             "v_readlane_b32 %[w], %[pack], m0\n\t"
                              WV_WALK_REST
                              : [st] "=&s"(st), [w] "=&s"(w), [t0] "=&s"(t0), [t1] "=&s"(t1), [gm] "=&s"(gm), [p] "+s"(p),
                                [ag] "+s"(ag), [agw] "+v"(agw), [lm] "=&s"(lm)
@@ -371,12 +374,12 @@ struct WaveDecoder {
               // a second vector-to-scalar hand-over on each hit's chain
               uint32_t st, w, t0, t1, gm;
               asm volatile(WV_WALK_BEGIN
-                           "v_readlane_b32 %[w], %[pack], m0\n\t"
                            "s_bfe_u32 %[t0], %[ag], 0xb0005\n\t"          /* agent / 32 (without the marker bit) */
                            "s_cmp_lg_u32 %[t0], %[lblk]\n\t"
                            "s_cbranch_scc1 7f\n\t"
                            "3:\n\t"
                            "s_bitcmp1_b32 %[lw], %[ag]\n\t"               /* (the bit index is ag[4:0]) */
+                           "v_readlane_b32 %[w], %[pack], m0\n\t"
                            WV_WALK_REST
                            "\n\t"
                            "s_branch 4f\n\t"
