@@ -1483,8 +1483,9 @@ __global__ __launch_bounds__(64, R >= 8 ? 5 : 1) void k_step_batch(DevArgs a, ui
 #if BOURSE_AMD_SB8_TOP_VGPR > 0
   if constexpr (R >= 8) asm volatile("" ::: "v" BK_STR(BOURSE_AMD_SB8_TOP_VGPR));
 #endif
-  // behind the wave-parallel decode of a LARGE batch the event waves go first (bourse_amd.hip launch_split: +5-7 % at
-  // 16 384 - 24 576 books, -2 % at 8 192, nothing beside k_agents_fsm, which runs at priority 3 anyway)
+  // behind the wave-parallel decode the event waves go first from a batch size that depends on the pool (bourse_amd.hip
+  // wave_step_prio_books: +5-7 % at 16 384 - 24 576 books, +2 % at 8 192 for pools of <= 128 slots since round 4's kernels,
+  // -2 % there for the 512-slot pools; nothing beside k_agents_fsm, which runs at priority 3 anyway)
   if (a.step_prio) __builtin_amdgcn_s_setprio(1);
   const int lane = threadIdx.x;
   // MKT: book = market * assets + asset; the step batch is the market's (stored at the market's first book)

@@ -87,7 +87,10 @@ constexpr uint32_t MIXED_WAVE_MIN_BOOKS = 512;
 //     per step needs that many books to be hidden.  Crossovers re-measured at the end of round 4, after the decode and
 //     both event loops got faster (profiles/r04/shape_sweep_crossovers.txt): 25 k / 25.6 k / 24 k / 24.5 k books for R = 1, 2,
 //     4, 8 (round 3: 23 k / 24.5 k / 18 k / 24.5 k - the 256-slot pools' wave_split gained most: 53 -> 72 M).
-constexpr uint32_t WAVE_STEP_PRIO_BOOKS = 16384;
+// behind the wave-parallel decode the event waves run at priority 1 from this many books (book_device.hpp k_step_batch).  Re-swept
+// at the end of round 4: pools of <= 128 slots gain from 8 192 books now (132.5 -> 135.3 M there, +1 % at 12 288; round 3: -2 %
+// at 8 192), the 512-slot pools still lose below 16 384 (C5 stand-in 32.0 -> 31.4 M at 8 192)
+constexpr uint32_t wave_step_prio_books(int R) { return R <= 2 ? 8192u : 16384u; }
 constexpr uint32_t lane_split_min_books(int R) { return R <= 2 ? 25600u : 24576u; }
 
 struct HostOrder {  // immutable half of an order, fixed at create_order (orderbook.rs:356-396)
@@ -615,7 +618,7 @@ int launch_split(bk_env* env, const DevArgs& a0, uint64_t first_step, uint32_t n
       a.book_begin = static_cast<uint32_t>(static_cast<uint64_t>(B) * i / P) & ~3u;
       a.book_end = (i + 1 == P) ? B : (static_cast<uint32_t>(static_cast<uint64_t>(B) * (i + 1) / P) & ~3u);
       a.hist_slot0 = a.hist_cap ? static_cast<uint32_t>((first_step + s) % a.hist_cap) : 0u;
-      a.step_prio = (wave && B >= WAVE_STEP_PRIO_BOOKS) ? 1u : 0u;
+      a.step_prio = (wave && B >= wave_step_prio_books(R)) ? 1u : 0u;
       const uint32_t nb = a.book_end - a.book_begin;
       hipStream_t st = P > 1 ? env->part_stream[i] : env->stream;
       if (P > 1 && s == 0 && i > 0) {  // stagger the parts
