@@ -85,13 +85,14 @@ constexpr uint32_t MIXED_WAVE_MIN_BOOKS = 512;
 //   * `wave_split` (k_agents_wave + k_step_batch, three parts) from there;
 //   * `split` (lane-per-book k_agents_fsm + k_step_batch, four parts) from lane_split_min_books(R): its 125 us chain
 //     per step needs that many books to be hidden.  Crossovers re-measured at the end of round 4, after the decode and
-//     both event loops got faster (profiles/r04/shape_sweep_crossovers.txt): 25 k / 25.6 k / 24 k / 24.5 k books for R = 1, 2,
-//     4, 8 (round 3: 23 k / 24.5 k / 18 k / 24.5 k - the 256-slot pools' wave_split gained most: 53 -> 72 M).
+//     both event loops got faster (profiles/r04/shape_sweep_crossovers.txt, twice: the second sweep after the decode's last
+//     trims and the event waves' priority rule): 26 k / 26.4 - 27.9 k (two boxes) / 25.3 k / 26.5 k books for R = 1, 2, 4, 8 (round 3: 23 k /
+//     24.5 k / 18 k / 24.5 k - the 256-slot pools' wave_split gained most: 53 -> 76 M).
 // behind the wave-parallel decode the event waves run at priority 1 from this many books (book_device.hpp k_step_batch).  Re-swept
 // at the end of round 4: pools of <= 128 slots gain from 8 192 books now (132.5 -> 135.3 M there, +1 % at 12 288; round 3: -2 %
 // at 8 192), the 512-slot pools still lose below 16 384 (C5 stand-in 32.0 -> 31.4 M at 8 192)
 constexpr uint32_t wave_step_prio_books(int R) { return R <= 2 ? 8192u : 16384u; }
-constexpr uint32_t lane_split_min_books(int R) { return R <= 2 ? 25600u : 24576u; }
+constexpr uint32_t lane_split_min_books(int R) { return R == 4 ? 25600u : (R == 2 ? 27648u : 26624u); }
 
 struct HostOrder {  // immutable half of an order, fixed at create_order (orderbook.rs:356-396)
   uint8_t bid;
@@ -168,7 +169,8 @@ struct bk_env {
     const uint32_t res = fused_resident ? fused_resident : (R == 8 ? 2048u : 6144u);
     // (256-slot pools: a round holds 6 144 books like the 128-slot ones, but the split form is already ahead at 5 120 -
     // 37.7 vs 33.8 M - and level at 4 096)
-    return R >= 4 ? std::min(res, 4096u) : res;
+    // (512-slot pools: two workgroups per CU fit since round 4 - 4 096 books - but the split form is 4 % ahead there: 25.4 vs 24.4 M)
+    return R >= 8 ? std::min(res, 2048u) : (R >= 4 ? std::min(res, 4096u) : res);
   }
   bool use_wave() const {        // split form: k_agents_wave + k_step_batch
     return wave_ok() && (pipeline == 4 || (pipeline == 0 && cfg.n_books > wave_fused_max() && cfg.n_books < lane_split_min_books(R)));
