@@ -266,7 +266,7 @@ __device__ __forceinline__ uint32_t events_asm_r2(uint32_t& k, uint32_t n_ev, ui
       : [price0] "v"(price0), [price1] "v"(price1), [id0] "v"(id0), [id1] "v"(id1), [ev0] "v"(ev0), [ev1] "v"(ev1),
         [bid0] "s"(bid0), [bid1] "s"(bid1), [nev] "s"(n_ev), [kend0] "s"(kend0), [tmask] "s"(tmask)
       : "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55",
-        "s56", "s57", "s58", "s59", "s60", "s61", "vcc", "scc", "memory");
+        "s56", "s57", "s58", "s59", "s60", "s61", "m0", "vcc", "scc", "memory");
   return st;
 }
 
@@ -306,7 +306,7 @@ __device__ __forceinline__ uint32_t events_asm_r1(uint32_t& k, uint32_t n_ev, ui
         [tra] "+v"(tra), [trs] "+v"(trs)
       : [price0] "v"(price0), [id0] "v"(id0), [ev0] "v"(ev0), [bid0] "s"(bid0), [nev] "s"(n_ev), [tmask] "s"(tmask)
       : "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55",
-        "s56", "s57", "s58", "s59", "s60", "s61", "vcc", "scc", "memory");
+        "s56", "s57", "s58", "s59", "s60", "s61", "m0", "vcc", "scc", "memory");
   return st;
 }
 
@@ -488,7 +488,7 @@ __device__ __forceinline__ uint32_t events_asm_r1(uint32_t& k, uint32_t n_ev, ui
 
 #define EK_CLOBBERS                                                                                                 \
   "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55",  \
-      "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "vcc", "scc", "memory"
+      "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "m0", "vcc", "scc", "memory"
 
 // ONE statement holds the loop twice: with the "no volume or trading disabled" test on every new order (phases 0 / 1) and
 // without it (phases 2 / 3; %[chk] = 0: the caller has established that trading is on and no new order of the step has

@@ -260,7 +260,7 @@ __device__ __forceinline__ uint32_t events_key_r{N}{'m' if markets else ''}(uint
 {text}      : [st] "=&s"(st), [vm] "=&v"(vm), [vt] "=&v"(vt), [evc] "=&v"(evc), [evq] "=&v"(evqc), [k] "+s"(k), [trn] "+s"(trn), [sq] "+s"(sq),
         [key] "+{{v[{KB}:{KB + N - 1}]}}"(kv), [vol] "+{{v[{VB}:{VB + N - 1}]}}"(vv), [evqr] "+{{v[{QB}:{QB + N - 1}]}}"(evqv), [trk] "+v"(trk), [trv] "+v"(trv), [trs] "+v"(trs)
       : [ev] "{{v[{EB}:{EB + N - 1}]}}"(evv), [nev] "s"(n_ev), [tmask] "s"(tmask), [chk] "s"(checked)
-      : {clob}, "vcc", "scc", "memory");
+      : {clob}, "m0", "vcc", "scc", "memory");
 #pragma unroll
   for (int r = 0; r < {N}; ++r) {{
     key[r] = kv[r];
