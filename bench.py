@@ -15,12 +15,14 @@ Books are independent, so each rank steps its own contiguous shard with NO data-
 64-byte market-stats all-gather per launch.  Default = BASELINE configs[3]: STRONG scaling, 65 536 books in
 total, 65 536 / N per GPU, seeds by global book index; `--scaling weak` keeps 65 536 books per GPU.
 
-Timing: W warm-up steps, barrier + synchronize, K timed steps, synchronize + barrier (max over ranks).  Right before the
-warm-up the env's public `bk_warm` entry runs `--preheat-steps` scratch steps (default 100; 0 = off; reported as the
-top-level `preheat_steps`): the GPU's clocks fall within milliseconds of idling and need ~15 ms of load to come back,
-which a short timed region (the driver's `--steps 20 --warmup 5` = 6 ms) would otherwise measure.  bk_warm steps the
-env's own books with its own kernels and puts everything back (state, level-2 records, step counter; no history slot,
-no trade record): the simulated steps are exactly the W + K ones.
+Timing: W warm-up steps, barrier + synchronize, K timed steps, synchronize (each rank's time; the job's = the MAX over
+ranks), barrier.  Right before the warm-up the env's public `bk_warm` entry runs scratch steps in chunks (`--preheat-steps`
+per chunk, grown to >= 10 ms of load; 0 = off) until three consecutive chunk rates agree within 1 % (capped; what ran is
+reported as the top-level `preheat_steps` and `config.preheat_chunk_rates`): the GPU's clocks fall within milliseconds
+of idling and need tens of ms of load to come back - how many differs from box to box - which a short timed region (the
+driver's `--steps 20 --warmup 5` = 6 ms) would otherwise measure.  bk_warm steps the env's own books with its own
+kernels and puts everything back (state, level-2 records, step counter; no history slot, no trade record): the
+simulated steps are exactly the W + K ones.
 
 Prints ONE JSON line (rank 0) incl. `roofline` (HIP-event kernel time vs. HBM peak) and, at
 N = 1, `cpu_baseline` (the CPU oracle = literal restatement of the reference algorithm, timed on
@@ -218,9 +220,11 @@ def main():
     ap.add_argument("--pipeline", default="auto", choices=["auto", "fused", "split", "wave_split", "wave"])
     ap.add_argument("--wave-parts", type=int, default=0, help="parts the wave pipeline cuts the batch in (0 = library default)")
     ap.add_argument("--profile-every", type=int, default=8, help="HIP-event-time every Nth step's kernels (0 = none)")
-    ap.add_argument("--preheat-steps", type=int, default=100,
-                    help="scratch steps of the library's bk_warm entry right before the warm-up (state restored afterwards), "
-                         "so that the timed region starts at steady clocks (0 = none)")
+    ap.add_argument("--preheat-steps", type=int, default=50,
+                    help="scratch steps per CHUNK of the library's bk_warm entry right before the warm-up (state restored "
+                         "afterwards), so that the timed region starts at steady clocks; chunks repeat until three consecutive "
+                         "chunk rates agree within 1 %% (0 = no pre-heat)")
+    ap.add_argument("--preheat-max-chunks", type=int, default=40, help="cap of the adaptive pre-heat (1 = one fixed chunk)")
     ap.add_argument("--repeats", type=int, default=4, help="extra timed regions of --steps after the reported one (median in `runs`)")
     args = ap.parse_args()
 
@@ -311,23 +315,52 @@ def main():
                 l1.all_gather()       # optional tier: 36 B per book, queued behind the launch on the same stream
             done += c
 
-    # Pre-heat: the GPU's clocks fall within milliseconds of idling and take ~15 ms of load to come back (k_agents_fsm, a pure
+    # Pre-heat: the GPU's clocks fall within milliseconds of idling and need sustained load to come back (k_agents_fsm, a pure
     # latency chain, runs 170 us per launch cold and 155 us warm: scripts/region_trace.sh), and the driver's command line
     # (--warmup 5 = 1.7 ms of work after seconds of host-side set-up) would time the ramp.  bk_warm (a public entry of the
-    # library, include/bourse_amd.h) steps THIS env's books with its own kernels and puts the state back.
-    if args.preheat_steps > 0:
-        env.trade_counts(), env.order_counts()  # first calls allocate their staging buffers: not between warm-up and t0
-        env.profile(args.profile_every), env.profile(False)  # ... the event pool and the events' calibration neither
-        if dist is not None:  # ... and RCCL builds its communicator on the first collective (~20 ms): not there either
-            if gather is not None:
-                gather.all_gather()
-            dist.barrier()
+    # library, include/bourse_amd.h) steps THIS env's books with its own kernels and puts the state back.  How much load
+    # the ramp needs differs from box to box (round 4: 100 steps = 22 ms were enough on the builder's boxes, not on the
+    # driver's, whose regions climbed 272 -> 294 M), so the pre-heat is ADAPTIVE: chunks of --preheat-steps scratch steps
+    # until the last three chunk rates agree within 1 % (at most --preheat-max-chunks), and the line reports what ran.
+    preheat_chunk, preheat_ran = [max(1, args.preheat_steps)], [0]
+
+    def preheat(first):
+        if args.preheat_steps <= 0:
+            return []
+        rates = []
+        while len(rates) < max(1, args.preheat_max_chunks):
             torch.cuda.synchronize()
-        env.warm(args.preheat_steps)
-    # (the device counters are read BEFORE the warm-up and the rates below are per warm-up + timed step: two device-to-host
-    # reads between the warm-up and t0 idle the GPU for long enough to cost the first region 1-2 % of clock)
+            t = time.perf_counter()
+            env.warm(preheat_chunk[0])
+            torch.cuda.synchronize()
+            d = time.perf_counter() - t
+            preheat_ran[0] += preheat_chunk[0]
+            rates.append(B * preheat_chunk[0] / d)
+            if d < 8e-3 and args.preheat_max_chunks > 1:  # a chunk is >= ~10 ms of load whatever the batch size
+                preheat_chunk[0] = int(min(4000, max(preheat_chunk[0] + 1, preheat_chunk[0] * 10e-3 / d)))
+            # (every rank stops on its own clock: the ranks share nothing, and the barrier in front of t0 lines them up)
+            if len(rates) >= (3 if first else 2) and max(rates[-3:]) / min(rates[-3:]) < 1.01:
+                break
+        return rates
+
+    # Everything that reads the device or allocates happens BEFORE the pre-heat, so that nothing idles the GPU between it
+    # and t0: the counters (bk_warm leaves them alone: its scratch steps write no trade record and the order counter is
+    # part of the state it restores), their staging buffers, the event pool and its calibration, RCCL's communicator
+    # (built on the first collective, ~20 ms).
     tc0 = int(env.trade_counts().sum())
     oc0 = int(env.order_counts().sum())
+    env.profile(args.profile_every), env.profile(False)
+    if dist is not None:
+        if gather is not None:
+            gather.all_gather()
+        dist.barrier()
+        torch.cuda.synchronize()
+    preheat_rates = preheat(True)
+    if dist is not None and preheat_rates:  # ranks converge after different numbers of chunks: line them up, then one more
+        dist.barrier()                      # chunk on every rank, so that none enters the warm-up from an idle wait
+        env.warm(preheat_chunk[0])
+        preheat_ran[0] += preheat_chunk[0]
+    preheat_first_steps = preheat_ran[0]
     run_steps(args.warmup)
     env.profile(args.profile_every)  # (host-side switch: its event pool exists since the pre-heat)
     if dist is not None:
@@ -336,14 +369,15 @@ def main():
     t0 = time.perf_counter()
     run_steps(args.steps)
     torch.cuda.synchronize()
+    dt = time.perf_counter() - t0  # this rank's region; the job's is the slowest rank's (max below): no collective inside it
     if dist is not None:
         dist.barrier()
-    dt = time.perf_counter() - t0
     env.profile(False)
     kind0 = "k_run_mixed" if mixed else ("k_run_wave" if pipe == "wave" else "k_run_random")
     kind1 = ("k_agents_mixed_wave" if pipe == "wave_split" else "k_agents_mixed_lanes") if mixed else (
         "k_agents_wave" if pipe == "wave_split" else "k_agents_fsm")
-    per_kind = {k: env.profile_read_kind(i) for i, k in enumerate((kind0, kind1, "k_step_batch", "k_step_events"))}
+    KINDS = (kind0, kind1, "k_step_batch", "k_step_events")  # the library's profile slots, in its order
+    per_kind = {k: env.profile_read_kind(i) for i, k in enumerate(KINDS)}
     env.profile_read()
     dt_ranks = all_ranks(dt)  # every rank's wall time of the region: a straggler is visible in the line
     dt = max(dt_ranks)
@@ -457,7 +491,7 @@ def main():
     out = {
         "metric": "book-steps/sec", "value": value, "unit": "book-steps/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": dt * 1e3 / args.steps, "higher_is_better": True, "scaling": args.scaling,
-        "vs_baseline": None, "dtype": "u32", "data": "synthetic", "preheat_steps": args.preheat_steps,
+        "vs_baseline": None, "dtype": "u32", "data": "synthetic", "preheat_steps": preheat_ran[0],
         "rank_region_ms": {"min": min(dt_ranks) * 1e3, "median": float(np.median(dt_ranks)) * 1e3, "max": max(dt_ranks) * 1e3,
                            "all": [d * 1e3 for d in dt_ranks]},
         "config": {
@@ -466,8 +500,11 @@ def main():
                         f"seed {SEED}+book",
             "books_total": books_total, "books_per_gpu": B, "ranks": world, "agents_per_book": n_agents, "levels": levels,
             "steps_per_launch": spl,
-            "preheat": (f"bk_warm({args.preheat_steps}): scratch steps of this env right before the warm-up, state restored (clock ramp); "
+            "preheat": (f"bk_warm: scratch steps of this env right before the warm-up and before each repeated region, state "
+                        f"restored (clock ramp), in chunks until three (repeats: two) chunk rates agree within 1 %; before the "
+                        f"reported region: {len(preheat_rates)} chunks, {preheat_first_steps} steps; "
                         f"simulated: {args.warmup} warm-up + {args.steps} timed steps") if args.preheat_steps > 0 else "none",
+            "preheat_chunk_rates": preheat_rates,
             "parallelism": f"{books_total} books in {world} contiguous shards ({args.scaling} scaling), no data-path "
                            f"collective, 64 B stats all-gather per launch" if world > 1 else "single GPU",
             "trades_per_book_step": tr_per_bs, "events_per_book_step": ev_per_bs,
@@ -489,15 +526,19 @@ def main():
     # (same barriers, max over ranks) and all values are listed beside it.
     vals = [value]
     for _ in range(max(0, args.repeats)):
+        if preheat(False) and dist is not None:  # (the accounting above read the device: same footing as the reported region)
+            dist.barrier()
+            env.warm(preheat_chunk[0])
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         run_steps(args.steps)
         torch.cuda.synchronize()
+        d = time.perf_counter() - t0
         if dist is not None:
             dist.barrier()
-        d = max(all_ranks(time.perf_counter() - t0))
+        d = max(all_ranks(d))
         vals.append(books_total * args.steps / d)
     out["runs"] = {"n": len(vals), "values": vals, "median": float(np.median(vals))}
     # The per-launch roofline above is measured while the parts' kernels overlap each other on separate streams, which

@@ -1811,7 +1811,8 @@ __global__ void k_book_service(uint32_t* state, uint32_t stride, uint32_t n_book
 //     exclusive prefix count of the event-producing elements; action 0 / unknown actions produce nothing (:266);
 //   * the immutable half of every new order and its initial order-log entry (status New, arr_time = now) are written
 //     for the readers (bk_get_orders ...).
-// action 3 = Env::modify_order (env.rs:208-219; not part of the numpy API): side bit 1 = has price, bit 2 = has volume.
+// BK_ACTION_MODIFY (0x80000003, outside the numpy API's 0 / 1 / 2; the host entry takes the same code) = Env::modify_order
+// (env.rs:208-219): side bit 1 = has price, bit 2 = has volume.  Every other action is a no-op (:266).
 // ==================================================================================
 struct IngestArgs {
   const unsigned long long* off;  // [n_books + 1]
@@ -1828,6 +1829,7 @@ struct IngestArgs {
   uint32_t qcap;
   uint4* dorders;                 // [n_books][log_cap][2]: {start_vol, trader, price, bid} {create_lo, create_hi, 0, 0}
 };
+constexpr uint32_t ING_ACTION_MODIFY = 0x80000003u;  // == BK_ACTION_MODIFY (include/bourse_amd.h)
 constexpr uint32_t ING_OK = 0u, ING_PRICE = 1u, ING_CAPACITY = 3u;  // == BK_OK / BK_PRICE_NOT_TICK_MULTIPLE / BK_CAPACITY
 
 __global__ __launch_bounds__(64) void k_ingest(DevArgs a, IngestArgs g) {
@@ -1850,7 +1852,7 @@ __global__ __launch_bounds__(64) void k_ingest(DevArgs a, IngestArgs g) {
       const uint32_t act = in ? g.action[i] : 0u, sd = in ? g.side[i] : 0u, vol = in ? g.vol[i] : 0u;
       const uint32_t price = in ? g.price[i] : 0u, trader = in ? g.trader[i] : 0u;
       const unsigned long long oid = in ? g.order_id[i] : 0ull;
-      const bool is_new = act == 1u, is_ev = act >= 1u && act <= 3u;
+      const bool is_new = act == 1u, is_ev = act == 1u || act == 2u || act == ING_ACTION_MODIFY;
       // the first bad price of the chunk stops the book's batch (earlier elements are applied)
       const uint64_t badm = __ballot(is_new && price % tick != 0u);
       uint32_t cut = badm ? (uint32_t)__builtin_ctzll(badm) : 64u;

@@ -976,6 +976,9 @@ int bk_submit_instructions(bk_env* env, uint32_t book, size_t n, const uint32_t*
     } else if (action[i] == 2) {
       int rc = bk_cancel_order(env, book, order_id[i]);
       if (rc != BK_OK) return rc;
+    } else if (action[i] == BK_ACTION_MODIFY) {  // the extension both entries share (k_ingest); anything else: no-op (:266)
+      int rc = bk_modify_order(env, book, order_id[i], (side[i] & 2) != 0, price[i], (side[i] & 4) != 0, vol[i]);
+      if (rc != BK_OK) return rc;
     }
     if (out_ids) out_ids[i] = id;
     if (n_done) *n_done = i + 1;

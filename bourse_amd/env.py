@@ -104,6 +104,9 @@ class MomentumAgent:
         return ("momentum", self.agent_id_start, self.n_agents, dict(self.params.__dict__))
 
 
+_STICKY_MAGIC = b"BKSTICKY"  # trailer of ManyBookEnv.checkpoint(): flag bits already reported to a strict caller
+
+
 class ManyBookEnv:
     """B books on one GPU.  ``Env::new(start_time, tick_size, step_size, trading)`` per book."""
 
@@ -120,6 +123,7 @@ class ManyBookEnv:
         # error: the reference's Env::step never checks the event count against step_size (env.rs:116-134).
         self.strict = bool(strict)
         self._flags_sticky = None    # per-book bits a strict check has reported and moved off the device (see raise_on_flags)
+        self._warned_bits = 0        # warning-only bits (STEP_SIZE) already warned about: left on the device, not re-polled
         self.last_retained_trades = 0  # largest number of records a book retained at the last strict check
         cfg = Config()
         cfg.assets = int(assets)
@@ -293,6 +297,7 @@ class ManyBookEnv:
         check(self._L.bk_clear_flags(self._h, int(mask) & 0xFFFFFFFF))
         if self._flags_sticky is not None:
             self._flags_sticky &= np.uint32(~int(mask) & 0xFFFFFFFF)
+        self._warned_bits &= ~int(mask) & 0xFFFFFFFF
 
     def raise_on_flags(self, mask: Optional[int] = None):
         """Raise ``CapacityError`` (capacity bits) / ``BourseError`` (price-tick) for flag bits in ``mask`` that a book
@@ -303,6 +308,10 @@ class ManyBookEnv:
         import warnings
 
         m = (~_lib.FLAG_UNKNOWN_ORDER & 0xFFFFFFFF) if mask is None else (int(mask) & 0xFFFFFFFF)
+        # The warning-only STEP_SIZE bit STAYS on the device once it has been warned about: a workload that regularly queues
+        # >= step_size events (which the reference tolerates) would otherwise re-set it every step, and every strict step
+        # would fetch the per-book array, launch the clear kernel and warn again.  clear_flags() re-arms the warning.
+        m &= ~self._warned_bits & 0xFFFFFFFF
         any_or, self.last_retained_trades = self.flags_summary()
         if not (any_or & m):
             return  # nothing set anywhere (the common case): the per-book array is not fetched
@@ -312,10 +321,13 @@ class ManyBookEnv:
         if not new.any():
             return
         bits = int(np.bitwise_or.reduce(new))
-        if self._flags_sticky is None:
-            self._flags_sticky = np.zeros_like(f)
-        self._flags_sticky |= new
-        check(self._L.bk_clear_flags(self._h, bits))
+        self._warned_bits |= bits & _lib.FLAG_STEP_SIZE
+        moved = bits & ~_lib.FLAG_STEP_SIZE & 0xFFFFFFFF  # error bits move to the host-side record; the warning bit does not
+        if moved:
+            if self._flags_sticky is None:
+                self._flags_sticky = np.zeros_like(f)
+            self._flags_sticky |= new & np.uint32(moved)
+            check(self._L.bk_clear_flags(self._h, moved))
         books = np.nonzero(new)[0]
         names = "; ".join(n for b, n in _lib.FLAG_NAMES.items() if bits & b)
         msg = f"{len(books)} book(s) flagged (first: book {int(books[0])}): {names}"
@@ -746,14 +758,24 @@ class ManyBookEnv:
     def checkpoint(self) -> np.ndarray:
         """Complete simulation state (pool, clock, counters, RNG of every book) as a byte array."""
         n = int(self._L.bk_checkpoint_bytes(self._h))
-        buf = np.zeros(n, dtype=np.uint8)
+        # The flag bits a strict check has already reported live on the host (raise_on_flags moves them off the device):
+        # they travel as a trailer behind the library's image, so that flags() reads the same after a restore.
+        tail = 0 if self._flags_sticky is None else 16 + 4 * self.n_books
+        buf = np.zeros(n + tail, dtype=np.uint8)
         check(self._L.bk_checkpoint_save(self._h, buf.ctypes.data_as(C.c_void_p), n))
+        if tail:
+            buf[n:n + 16] = np.frombuffer(_STICKY_MAGIC + np.uint64(self.n_books).tobytes(), dtype=np.uint8)
+            buf[n + 16:] = self._flags_sticky.view(np.uint8)
         return buf
 
     def restore(self, buf: np.ndarray):
         """Load a checkpoint taken from an env of the same shape; the run continues bit-identically."""
         buf = np.ascontiguousarray(buf, dtype=np.uint8)
-        check(self._L.bk_checkpoint_load(self._h, buf.ctypes.data_as(C.c_void_p), buf.nbytes))
+        n = int(self._L.bk_checkpoint_bytes(self._h))
+        check(self._L.bk_checkpoint_load(self._h, buf.ctypes.data_as(C.c_void_p), min(n, buf.nbytes)))
+        self._flags_sticky, self._warned_bits = None, 0
+        if buf.nbytes == n + 16 + 4 * self.n_books and buf[n:n + 8].tobytes() == _STICKY_MAGIC:
+            self._flags_sticky = buf[n + 16:].view(np.uint32).copy()
 
     def state_bytes_per_book(self) -> int:
         return int(self._L.bk_state_bytes_per_book(self._h))

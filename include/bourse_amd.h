@@ -158,9 +158,14 @@ int bk_cancel_order(bk_env* env, uint32_t book, uint64_t order_id);
 /* Env::modify_order, env.rs:208-219 */
 int bk_modify_order(bk_env* env, uint32_t book, uint64_t order_id, int has_price, uint32_t new_price, int has_vol,
                     uint32_t new_vol);
-/* StepEnvNumpy.submit_instructions, rust/src/step_sim_numpy.rs:233-275: action 0 none / 1 new limit / 2 cancel.
+/* StepEnvNumpy.submit_instructions, rust/src/step_sim_numpy.rs:233-275: action 0 none / 1 new limit / 2 cancel; every
+ * other value is a no-op, as the reference's `_ => Ok(OrderId::MAX)` (:266) - on the host entries AND on the device
+ * entry below.  The one extension, the same on all three entries, is BK_ACTION_MODIFY (a code far outside the
+ * reference's range, so a reference-written batch can never mean it): Env::modify_order (env.rs:208-219) on
+ * order_id[i], side bit 1 = has a new price (price[i]), side bit 2 = has a new volume (vol[i]).
  * out_ids[i] = new id or UINT64_MAX.  Stops at the first bad price (earlier elements stay queued) and
  * returns BK_PRICE_NOT_TICK_MULTIPLE with *n_done = index of the offending element. */
+#define BK_ACTION_MODIFY 0x80000003u
 int bk_submit_instructions(bk_env* env, uint32_t book, size_t n, const uint32_t* action, const uint8_t* side,
                            const uint32_t* vol, const uint32_t* trader_id, const uint32_t* price,
                            const uint64_t* order_id, uint64_t* out_ids, size_t* n_done);
@@ -183,9 +188,10 @@ int bk_step(bk_env* env);
  *   host entries and bk_run are refused from then on) and allocates the per-book (per-market) event queues of
  *   `queue_capacity` events per step (1..8192).
  * bk_submit_instructions_device: book b's instructions are elements [book_offsets_dev[b], book_offsets_dev[b+1]) of the
- *   arrays (all in device memory, u64 offsets over n_books + 1).  action 0 = none, 1 = new limit order, 2 = cancel
- *   (as the reference's), 3 = Env::modify_order (extension: side bit 1 = has price, bit 2 = has volume; bit 0 is the bid
- *   flag of a new order).  Per book exactly the reference's semantics: ids are dense in element order (an exclusive prefix
+ *   arrays (all in device memory, u64 offsets over n_books + 1).  action 0 = none, 1 = new limit order, 2 = cancel,
+ *   anything else a no-op (as the reference's, :266), BK_ACTION_MODIFY = Env::modify_order (the extension of
+ *   bk_submit_instructions: side bit 1 = has price, bit 2 = has volume; bit 0 is the bid flag of a new order) - the same
+ *   arrays mean the same on the host and on the device entry.  Per book exactly the reference's semantics: ids are dense in element order (an exclusive prefix
  *   sum over action == 1 on the device), the first price that is not a multiple of the book's tick size stops THAT
  *   book's batch - earlier elements stay created and queued (:255-268) - and the other books are unaffected.
  *   out_ids_dev (optional, one u64 per element): the created order's id, u64::MAX otherwise; untouched from the failing

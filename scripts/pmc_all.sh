@@ -4,10 +4,11 @@
 #   -> gpurun_out/pmc_<tag>/summary.json   (scripts/pmc_merge.py <tag> <round> folds it into profiles/)
 set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}
-TAG=${1:-r04}
+TAG=${1:-r05}
 shift || true
 CONFIGS=${*:-"C3:65536 C3:32768 C3:16384 C3:8192 C2:4096 C5:8192 C5M:8192"}
 OUT=$R/gpurun_out/pmc_$TAG
+FAILED=""
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 # the timed region is left alone (--profile-every 0, no repeats, no pre-heat: bk_warm's one 100-step launch would mix a
@@ -15,13 +16,16 @@ cd /tmp && export TMPDIR=/tmp
 PA="--steps 40 --warmup 20 --steps-per-launch 20 --no-cpu-baseline --profile-every 0 --repeats 0 --preheat-steps 0"
 for C in $CONFIGS; do
   W=${C%%:*}; B=${C##*:}
-  run() { d=$1; shift; rocprofv3 --pmc "$@" -d $OUT/${W}_${B}_$d -o p -f csv -- python3 $R/bench.py --workload $W --books $B $PA > $OUT/${W}_${B}_$d.json 2> $OUT/${W}_${B}_$d.err; }
+  run() { d=$1; shift; rocprofv3 --pmc "$@" -d $OUT/${W}_${B}_$d -o p -f csv -- python3 $R/bench.py --workload $W --books $B $PA > $OUT/${W}_${B}_$d.json 2> $OUT/${W}_${B}_$d.err
+          # a pass whose bench died (round 4: a NameError AFTER the timed region, stdout empty) must not pass silently
+          grep -q '^{' $OUT/${W}_${B}_$d.json || { echo "pmc_all: $W:$B pass '$d' printed no bench line" >&2; grep -v "^W2\|rocprofiler" $OUT/${W}_${B}_$d.err | tail -n 8 >&2; FAILED="$FAILED ${W}_${B}_$d"; }; }
   run fetch FETCH_SIZE
   run write WRITE_SIZE
   run sq SQ_INSTS_SALU SQ_INSTS_VALU SQ_INSTS_BRANCH SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM SQ_WAVES
   run stall SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU
 done
-python3 $R/scripts/pmc_summarise.py $OUT
+python3 $R/scripts/pmc_summarise.py $OUT || FAILED="$FAILED summary"
 # the raw per-dispatch CSVs are tens of thousands of lines each: only the summary travels back
 find $OUT -name "*.csv" -delete; find $OUT -name "*.db" -delete; find $OUT -type d -empty -delete
-tail -n 2 $OUT/*.err | tail -n 30
+if [ -n "$FAILED" ]; then echo "pmc_all: FAILED passes:$FAILED" >&2; exit 1; fi
+echo "pmc_all: every pass printed its bench line"

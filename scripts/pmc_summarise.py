@@ -31,6 +31,7 @@ def book_steps(kernel, grid):
 
 
 summary = {}
+missing_bench = []
 for d in sorted(glob.glob(os.path.join(out_dir, "*_*_sq"))):
     m = re.match(r"(.+)_(\d+)_sq$", os.path.basename(d))
     wl, books = m.group(1), int(m.group(2))
@@ -62,6 +63,7 @@ for d in sorted(glob.glob(os.path.join(out_dir, "*_*_sq"))):
                          "note": "the bench line of the SQ_INSTS pass (under the profiler: slower than an unprofiled run)"}
     except Exception as ex:  # noqa: BLE001
         cfg["_bench"] = {"error": str(ex)}
+        missing_bench.append(key)
     # derived: HBM bytes (FETCH_SIZE counts 64-B units as 32 B on gfx950 -> x2; both in KiB), the wave-cycle split
     for k, e in cfg.items():
         if k.startswith("_"):
@@ -90,3 +92,5 @@ for key, cfg in summary.items():
             k, e.get("hbm_bytes_per_book_step", float("nan")), p.get("SQ_INSTS_SALU", float("nan")),
             p.get("SQ_INSTS_BRANCH", float("nan")), p.get("SQ_INSTS_VALU", float("nan")), p.get("SQ_INSTS_LDS", float("nan")),
             {a: round(b, 3) for a, b in e.get("wave_cycles", {}).items()}))
+if missing_bench:  # round 4 shipped a summary whose every config had lost its bench line to a crash after the timed region
+    sys.exit("pmc_summarise: no bench line for %s - the profiled command died; see the passes' .err files" % ", ".join(missing_bench))

@@ -1,0 +1,63 @@
+"""bench.py's options that no default run takes (VERDICT r4 Weak #2: `--profile-every 0` raised a NameError AFTER its
+timed region and every rocprofv3 --pmc pass of the round - all of which use it - printed no bench line).
+
+CPU: an undefined-name lint over every Python file of the repo (tools/lint_names.py: a name a function loads as a global
+must be bound at module level or be a builtin).  GPU: the exact option set of scripts/pmc_all.sh on a small batch, and the
+line parsed."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+
+def test_no_undefined_global_names_anywhere():
+    import lint_names
+
+    assert lint_names.main([]) == 0
+
+
+def test_lint_catches_an_undefined_name(tmp_path):
+    import lint_names
+
+    f = tmp_path / "m.py"
+    f.write_text("import os\nA = 1\n\ndef f():\n    return [A, os.sep, len, KINDS]\n")
+    assert [(l, n) for l, n, _ in lint_names.undefined_names(str(f))] == [(5, "KINDS")]
+
+
+def test_pmc_scripts_fail_loudly_without_a_bench_line(tmp_path):
+    """pmc_summarise.py exits non-zero when a configuration's SQ pass printed no bench line."""
+    d = tmp_path / "C3_4096_sq"
+    d.mkdir()
+    (tmp_path / "C3_4096_sq.json").write_text("")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "pmc_summarise.py"), str(tmp_path)], capture_output=True, text=True)
+    assert r.returncode != 0 and "no bench line" in r.stderr
+    assert json.load(open(tmp_path / "summary.json"))["C3/4096"]["_bench"].get("error")
+
+
+def _bench(*argv, timeout=600):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv], capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("books", [4096, 32768])  # the fused wave kernel / the lane split in four parts
+def test_bench_profile_every_0_prints_its_line(books):
+    out = _bench("--books", str(books), "--steps", "4", "--warmup", "2", "--profile-every", "0", "--repeats", "0",
+                 "--no-cpu-baseline", "--preheat-steps", "0", "--steps-per-launch", "2")
+    R = out["roofline"]
+    assert out["value"] > 0 and out["steps"] == 4 and R["launches"] > 0 and R["avg_launch_ms"] > 0
+    assert "after the timed region" in R["launches_sampled_in"]
+    assert 0 < R["frac"] < 1 and R["bound"] == "hbm"
+
+
+@pytest.mark.gpu
+def test_bench_default_sampling_and_adaptive_preheat():
+    out = _bench("--books", "8192", "--steps", "6", "--warmup", "2", "--repeats", "1", "--no-cpu-baseline")
+    assert out["roofline"]["launches_sampled_in"] == "the timed region" and len(out["runs"]["values"]) == 2
+    assert out["preheat_steps"] > 0 and out["config"]["preheat"].startswith("bk_warm")

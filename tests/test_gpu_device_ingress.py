@@ -18,12 +18,16 @@ def bk():
     return bourse_amd
 
 
+MOD = 0x80000003  # BK_ACTION_MODIFY (include/bourse_amd.h): the one extension of the reference's action codes
+
+
 def _dev(torch, a):
     return torch.from_numpy(np.ascontiguousarray(a)).cuda()
 
 
 def _stream_step(rng, B, counts, max_per_book, tick, bad_books=()):
-    """One step's ragged SoA batch for B books: action 0 / 1 (new) / 2 (cancel) / 3 (modify), targets among the ids the
+    """One step's ragged SoA batch for B books: action 0 / 1 (new) / 2 (cancel) / BK_ACTION_MODIFY, and 3 / 7 - which the
+    reference's submit_instructions ignores (step_sim_numpy.rs:266) and so must every entry here -, targets among the ids the
     book has created so far (so they hit live, filled and cancelled orders alike); `bad_books`: an odd price is planted
     in the middle of those books' batches."""
     n_b = rng.integers(0, max_per_book + 1, size=B)
@@ -32,12 +36,12 @@ def _stream_step(rng, B, counts, max_per_book, tick, bad_books=()):
     off[1:] = np.cumsum(n_b)
     n = int(off[-1])
     book_of = np.repeat(np.arange(B), n_b)
-    action = rng.choice([0, 1, 2, 3], size=n, p=[0.05, 0.6, 0.2, 0.15]).astype(np.uint32)
+    action = rng.choice([0, 1, 2, MOD, 3, 7], size=n, p=[0.03, 0.6, 0.2, 0.15, 0.01, 0.01]).astype(np.uint32)
     have = counts[book_of]
     action[(action >= 2) & (have == 0)] = 1  # nothing to cancel / modify yet
     bid = rng.integers(0, 2, size=n).astype(np.uint8)
     has_p, has_v = rng.integers(0, 2, size=n).astype(np.uint8), rng.integers(0, 2, size=n).astype(np.uint8)
-    side = np.where(action == 3, (has_p << 1) | (has_v << 2), bid).astype(np.uint8)
+    side = np.where(action == MOD, (has_p << 1) | (has_v << 2), bid).astype(np.uint8)
     vol = rng.integers(1, 30, size=n).astype(np.uint32)
     trader = rng.integers(0, 1000, size=n).astype(np.uint32)
     price = (rng.integers(45, 56, size=n) * tick).astype(np.uint32)
@@ -65,7 +69,7 @@ def _apply_host(env, book_of, off, ins, B):
                     ids[i] = env.place_order(b, bool(side[i] & 1), int(vol[i]), int(trader[i]), int(price[i]))
                 elif a == 2:
                     env.cancel_order(b, int(order_id[i]))
-                elif a == 3:
+                elif a == MOD:
                     env.modify_order(b, int(order_id[i]), int(price[i]) if side[i] & 2 else None, int(vol[i]) if side[i] & 4 else None)
             except ValueError:
                 code[b] = 1
@@ -83,7 +87,7 @@ def _apply_oracle(ref, lo, hi, ins):
                 ref.place_order(bool(side[i] & 1), int(vol[i]), int(trader[i]), price=int(price[i]))
             elif a == 2:
                 ref.cancel_order(int(order_id[i]))
-            elif a == 3:
+            elif a == MOD:
                 ref.modify_order(int(order_id[i]), new_price=int(price[i]) if side[i] & 2 else None,
                                  new_vol=int(vol[i]) if side[i] & 4 else None)
         except ValueError:
