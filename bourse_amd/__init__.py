@@ -6,7 +6,7 @@ behind a C ABI (include/bourse_amd.h).  See DESIGN.md / INTEGRATION.md.
 """
 from . import _lib, core, data_processing, step_sim
 from .compat import install_as_bourse, uninstall_bourse_alias
-from ._lib import BourseError, CapacityError, NoDeviceError
+from ._lib import ACTION_MODIFY, BourseError, CapacityError, NoDeviceError
 from .env import (MAX_PRICE, ManyBookEnv, ManyMarketEnv, MomentumAgent, MomentumParams, NoiseAgent, NoiseAgentParams,
                   RandomAgents, RandomMarketAgents, market_sim_runner, sim_runner)
 

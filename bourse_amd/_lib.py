@@ -16,6 +16,7 @@ BK_OK, BK_PRICE, BK_UNKNOWN_ORDER, BK_CAPACITY, BK_STEP_SIZE, BK_INVALID, BK_HIP
 FLAG_POOL_OVERFLOW, FLAG_TRADE_OVERFLOW, FLAG_STEP_SIZE, FLAG_ORDER_LOG_FULL = 1, 2, 4, 8
 FLAG_UNKNOWN_ORDER, FLAG_HIST_OVERFLOW, FLAG_PRICE_TICK, FLAG_EVENT_OVERFLOW = 16, 32, 64, 128
 FLAG_DECODE_LOOKAHEAD = 256
+ACTION_MODIFY = 0x80000003  # BK_ACTION_MODIFY: the one extension of submit_instructions' action codes (0 / 1 / 2)
 FLAG_NAMES = {1: "POOL_OVERFLOW (live-order pool full: a resting order was dropped)",
               2: "TRADE_OVERFLOW (trade_capacity exceeded: records dropped, counts exact)",
               4: "STEP_SIZE (a step queued >= step_size events)",
@@ -86,6 +87,12 @@ ORDER_DTYPE = np.dtype(
      "formats": ["u1", "u1", "<u8", "<u8", "<u4", "<u4", "<u4", "<u4", "<u8"],
      "offsets": [0, 1, 8, 16, 24, 28, 32, 36, 40], "itemsize": 48})
 
+class IngressArrays(C.Structure):
+    """bk_ingress_arrays: the pinned staging arrays of the next bk_submit_instructions_host call."""
+    _fields_ = [("capacity", C.c_uint64), ("book_offsets", C.c_void_p), ("action", C.c_void_p), ("side", C.c_void_p),
+                ("vol", C.c_void_p), ("trader_id", C.c_void_p), ("price", C.c_void_p), ("order_id", C.c_void_p)]
+
+
 # every symbol include/bourse_amd.h declares: name -> (restype, argtypes)
 _u64, _u32, _i32, _vp, _sz = C.c_uint64, C.c_uint32, C.c_int, C.c_void_p, C.c_size_t
 _p64, _p32, _p8 = C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(C.c_uint8)
@@ -106,6 +113,9 @@ SIGNATURES = {
     "bk_device_ingress_enable": (_i32, [_vp, _u32]),
     "bk_submit_instructions_device": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "bk_step_async": (_i32, [_vp]),
+    "bk_ingress_staging": (_i32, [_vp, _u64, C.POINTER(IngressArrays)]),
+    "bk_submit_instructions_host": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _p64]),
+    "bk_submit_result": (_i32, [_vp, _u64, _vp, _vp, _p32]),
     "bk_order_status": (_i32, [_vp, _u32, _u64, _p8]),
     "bk_order_count": (_i32, [_vp, _u32, _p64]),
     "bk_get_orders": (_i32, [_vp, _u32, _u64, _u64, _vp]),

@@ -188,27 +188,100 @@ class ManyBookEnv:
                                              _lib.p64(out), C.byref(done)))
         return out
 
-    def submit_instructions_all(self, book_offsets, instructions) -> np.ndarray:
-        """``submit_instructions`` for every book in one call: book b's instructions are elements
-        ``[book_offsets[b], book_offsets[b + 1])`` of the six arrays (C ABI ``bk_submit_instructions_csr``)."""
+    def _host_batch(self, book_offsets, instructions):
         action, sides, vols, traders, prices, order_ids = instructions
         off = np.ascontiguousarray(book_offsets, dtype=np.uint64)
         if len(off) != self.n_books + 1:
             raise ValueError("book_offsets needs n_books + 1 entries")
         action = np.ascontiguousarray(action, dtype=np.uint32)
-        sides = np.ascontiguousarray(np.asarray(sides).astype(np.uint8))
+        sides = np.asarray(sides)
+        sides = np.ascontiguousarray(sides if sides.dtype == np.uint8 else sides.astype(np.uint8))
         vols = np.ascontiguousarray(vols, dtype=np.uint32)
         traders = np.ascontiguousarray(traders, dtype=np.uint32)
         prices = np.ascontiguousarray(prices, dtype=np.uint32)
         order_ids = np.ascontiguousarray(order_ids, dtype=np.uint64)
         if not (len(action) == len(sides) == len(vols) == len(traders) == len(prices) == len(order_ids) == int(off[-1])):
             raise ValueError("instruction arrays must all have book_offsets[-1] elements")
+        return off, action, sides, vols, traders, prices, order_ids
+
+    def submit_instructions_all(self, book_offsets, instructions) -> np.ndarray:
+        """``submit_instructions`` (rust/src/step_sim_numpy.rs:233-275) for every book in one call: book b's instructions
+        are elements ``[book_offsets[b], book_offsets[b + 1])`` of the six HOST arrays; returns the ids (``2**64 - 1``
+        for elements that created nothing).  On a device-ingress env the arrays travel pinned staging -> async upload ->
+        ``k_ingest`` (``bk_submit_instructions_host``), and a book whose batch stopped at a bad price raises the
+        reference's ``ValueError`` AFTER every book has been applied (books are independent; earlier elements of the failing
+        book stay queued, as in the reference); otherwise the host half of ``Env`` walks them
+        (``bk_submit_instructions_csr``: stops at the first bad price of any book)."""
+        if getattr(self, "_device_ingress", False):
+            out, status, bad = self.submit_result(self.submit_instructions_all_async(book_offsets, instructions))
+            if bad is not None:
+                code, applied = int(status[bad, 0]), int(status[bad, 1])
+                if code == _lib.BK_PRICE:
+                    raise ValueError(f"book {bad}: a price of its batch was not a multiple of the tick size "
+                                     f"(element {applied} of the book's batch; earlier elements are queued)")
+                raise _lib.CapacityError(code, f"book {bad}: event queue / id space exhausted after {applied} elements")
+            return out
+        off, action, sides, vols, traders, prices, order_ids = self._host_batch(book_offsets, instructions)
         out = np.full(len(action), 2**64 - 1, dtype=np.uint64)
         done = C.c_size_t(0)
         check(self._L.bk_submit_instructions_csr(self._h, _lib.p64(off), _lib.p32(action), _lib.p8(sides), _lib.p32(vols),
                                                  _lib.p32(traders), _lib.p32(prices), _lib.p64(order_ids), _lib.p64(out),
                                                  C.byref(done)))
         return out
+
+    def submit_instructions_all_async(self, book_offsets, instructions) -> int:
+        """Device-ingress env: queue the host arrays (``bk_submit_instructions_host``) and return a TICKET at once; the ids
+        and the per-book status are fetched later with ``submit_result(ticket)`` (two tickets may be in flight: the upload
+        of one runs under the step kernel of the other).  Arrays obtained from ``ingress_staging()`` are uploaded in
+        place, anything else is first copied to pinned memory by the library's host threads."""
+        off, action, sides, vols, traders, prices, order_ids = self._host_batch(book_offsets, instructions)
+        t = C.c_uint64(0)
+        vp = lambda a: C.c_void_p(a.ctypes.data)  # noqa: E731
+        check(self._L.bk_submit_instructions_host(self._h, vp(off), vp(action), vp(sides), vp(vols), vp(traders), vp(prices),
+                                                  vp(order_ids), C.byref(t)))
+        self._ticket_n = getattr(self, "_ticket_n", {})
+        self._ticket_n[int(t.value)] = len(action)
+        self._ticket_n.pop(int(t.value) - 2, None)
+        return int(t.value)
+
+    def submit_result(self, ticket: int, ids: bool = True, out: Optional[np.ndarray] = None, status: Optional[np.ndarray] = None):
+        """(ids u64[n] or None, status u32[n_books, 2] = {code, elements applied}, lowest failing book or None) of a ticket.
+        ``out`` / ``status``: arrays to fill instead of fresh ones (a loop that fetches every step saves their page faults)."""
+        n = getattr(self, "_ticket_n", {}).get(int(ticket))
+        if n is None:  # not a ticket of this env, or two submits old: the library says which
+            check(self._L.bk_submit_result(self._h, int(ticket), None, None, None))
+            raise _lib.BourseError(_lib.BK_INVALID, f"ticket {ticket}: its element count is no longer known")
+        if ids:
+            if out is None:
+                out = np.empty(n, dtype=np.uint64)
+            elif out.dtype != np.uint64 or not out.flags.c_contiguous or len(out) < n:
+                raise ValueError("out: a contiguous uint64 array of at least the ticket's element count")
+        if status is None:
+            status = np.empty((self.n_books, 2), dtype=np.uint32)
+        elif status.dtype != np.uint32 or not status.flags.c_contiguous or status.size != 2 * self.n_books:
+            raise ValueError("status: a contiguous uint32 array of 2 x n_books")
+        bad = C.c_uint32(0)
+        check(self._L.bk_submit_result(self._h, int(ticket), C.c_void_p(out.ctypes.data) if ids and n else None,
+                                       C.c_void_p(status.ctypes.data), C.byref(bad)))
+        return (out[:n] if ids else None), status, (None if bad.value == 0xFFFFFFFF else int(bad.value))
+
+    def ingress_staging(self, min_elements: int) -> dict:
+        """Pinned staging arrays of the NEXT ``submit_instructions_all(_async)`` call (``bk_ingress_staging``), as numpy
+        views: ``book_offsets`` u64[n_books + 1], ``action`` / ``vol`` / ``trader_id`` / ``price`` u32, ``side`` u8,
+        ``order_id`` u64, each of ``capacity >= min_elements`` elements.  Fill them in place and pass slices of THESE arrays
+        to the submit call: they are uploaded without a host copy.  Valid until that submit returns."""
+        a = _lib.IngressArrays()
+        check(self._L.bk_ingress_staging(self._h, int(min_elements), C.byref(a)))
+        cap = int(a.capacity)
+
+        def view(ptr, dtype, n):
+            buf = (C.c_char * (n * np.dtype(dtype).itemsize)).from_address(ptr)
+            return np.frombuffer(buf, dtype=dtype, count=n)
+
+        return {"capacity": cap, "book_offsets": view(a.book_offsets, np.uint64, self.n_books + 1),
+                "action": view(a.action, np.uint32, cap), "side": view(a.side, np.uint8, cap),
+                "vol": view(a.vol, np.uint32, cap), "trader_id": view(a.trader_id, np.uint32, cap),
+                "price": view(a.price, np.uint32, cap), "order_id": view(a.order_id, np.uint64, cap)}
 
     def enable_trading(self):
         check(self._L.bk_enable_trading(self._h, 1))

@@ -1,2 +1,2 @@
 from .base_agent import BaseAgent, BaseNumpyAgent, InstructionArrays
-from .random_agent import NumpyRandomAgents, RandomAgent
+from .random_agent import ManyBookNumpyRandomAgents, NumpyRandomAgents, RandomAgent

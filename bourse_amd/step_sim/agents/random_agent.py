@@ -49,3 +49,23 @@ class NumpyRandomAgents(BaseNumpyAgent):
         prices = rng.integers(*self.tick_range, size=n, dtype=np.uint32) * self.tick_size
         return (np.ones(n, dtype=np.uint32), sides, vols, np.arange(n, dtype=np.uint32), prices,
                 np.zeros(n, dtype=np.uint64))
+
+
+class ManyBookNumpyRandomAgents:
+    """``NumpyRandomAgents`` vectorised over books for ``run_many``: ``update_many(rng, level_2_data[B, W])`` draws the orders
+    of ``n_agents`` agents for EVERY book in one go (same distributions as the one-book agent - including the reference's
+    quirk that volumes come from ``tick_range``, random_agent.py:151-157 - but one generator stream over all books, so the
+    draws are not those of B one-book agents called in turn)."""
+
+    def __init__(self, n_agents: int, tick_range: typing.Tuple[int, int], vol_range: typing.Tuple[int, int], tick_size: int):
+        self.n_agents, self.tick_range, self.vol_range, self.tick_size = n_agents, tick_range, vol_range, tick_size
+
+    def update_many(self, rng: np.random.Generator, level_2_data: np.ndarray):
+        n_books = level_2_data.shape[0]
+        n = n_books * self.n_agents
+        sides = rng.integers(0, 2, size=n, dtype=np.uint8)
+        vols = rng.integers(*self.tick_range, size=n, dtype=np.uint32)
+        prices = rng.integers(*self.tick_range, size=n, dtype=np.uint32) * np.uint32(self.tick_size)
+        traders = np.tile(np.arange(self.n_agents, dtype=np.uint32), n_books)
+        return (np.full(n_books, self.n_agents, dtype=np.uint64),
+                (np.ones(n, dtype=np.uint32), sides, vols, traders, prices, np.zeros(n, dtype=np.uint64)))

@@ -208,6 +208,35 @@ int bk_submit_instructions_device(bk_env* env, const uint64_t* book_offsets_dev,
                                   const uint32_t* price_dev, const uint64_t* order_id_dev, uint64_t* out_ids_dev,
                                   uint32_t* status_dev);
 int bk_step_async(bk_env* env);
+/* HOST arrays through the device ingress (a BaseNumpyAgent-style caller: src/bourse/step_sim/agents/base_agent.py:67-116
+ * returns host numpy arrays, runner.py:103-112 passes them to submit_instructions, rust/src/step_sim_numpy.rs:233-275).
+ * Same arrays, same per-book semantics as bk_submit_instructions_device, but the pointers are HOST memory: the library
+ * stages them in pinned memory (host threads), uploads them on a copy stream of its own, runs the ingest kernel on the
+ * env's stream and brings ids and per-book status back on a second copy stream.  Asynchronous: returns a ticket at
+ * once; two tickets are in flight at most (the upload of one under the step kernel of the other), and
+ * bk_submit_result(ticket) waits for that ticket only.  A ticket's results stay readable until two more submits.
+ *   bk_ingress_staging: OPTIONAL zero-copy - pinned arrays (>= min_elements each; book_offsets n_books + 1) that the NEXT
+ *     bk_submit_instructions_host call will upload from: fill them in place and pass these very pointers (any array
+ *     passed from elsewhere is copied as usual).  Valid until that submit returns.
+ *   bk_submit_result: out_ids (optional, book_offsets[n_books] u64: the created order's id, UINT64_MAX otherwise -
+ *     also from a book's failing element on), status (optional, 2 u32 per book: {bk_status code,
+ *     elements of the book's batch applied}), first_failed_book (optional: lowest book whose code is not BK_OK, UINT32_MAX
+ *     if none - the Python layer raises the reference's ValueError for it). */
+typedef struct bk_ingress_arrays {
+  uint64_t capacity;       /* elements each instruction array holds */
+  uint64_t* book_offsets;  /* n_books + 1 */
+  uint32_t* action;
+  uint8_t* side;
+  uint32_t* vol;
+  uint32_t* trader_id;
+  uint32_t* price;
+  uint64_t* order_id;
+} bk_ingress_arrays;
+int bk_ingress_staging(bk_env* env, uint64_t min_elements, bk_ingress_arrays* out);
+int bk_submit_instructions_host(bk_env* env, const uint64_t* book_offsets, const uint32_t* action, const uint8_t* side,
+                                const uint32_t* vol, const uint32_t* trader_id, const uint32_t* price,
+                                const uint64_t* order_id, uint64_t* out_ticket);
+int bk_submit_result(bk_env* env, uint64_t ticket, uint64_t* out_ids, uint32_t* status, uint32_t* first_failed_book);
 /* Env::order_status / Env::order, env.rs:283-290 (needs max_orders > 0) */
 int bk_order_status(bk_env* env, uint32_t book, uint64_t order_id, uint8_t* out_status);
 int bk_order_count(bk_env* env, uint32_t book, uint64_t* out);

@@ -164,6 +164,162 @@ def test_device_ingress_equals_host_calls_and_oracle_on_8192_books(bk, oracle):
     host.close()
 
 
+def test_host_arrays_through_device_ingress_equal_host_calls_and_oracle_on_8192_books(bk, oracle):
+    """a BaseNumpyAgent-style caller hands over HOST numpy arrays (base_agent.py:67-116, runner.py:103-112).
+    The same three-way check as above - device-ingress env == per-order host entries == oracle - with the arrays taken from
+    host memory by bk_submit_instructions_host: synchronously (ids returned, the reference's ValueError raised), as tickets
+    with two submits in flight, and filled in place in the library's pinned staging arrays."""
+    B, T, TICK, NMAX = 8192, 5, 2, 14
+    kw = dict(levels=10, max_live_orders=128, max_orders=NMAX * T + 8, trade_capacity=NMAX * T * 2, history_capacity=T)
+    devs = {k: bk.ManyBookEnv(B, 77, 0, TICK, 100_000, **kw) for k in ("sync", "tickets", "staging")}
+    for d in devs.values():
+        d.enable_device_ingress(queue_capacity=NMAX)
+    host = bk.ManyBookEnv(B, 77, 0, TICK, 100_000, **kw)
+    sample = sorted(set(range(0, B, 67)) | {5, 4097, B - 1})
+    bad_plan = {1: (5, 4097), 3: (B - 1, 134)}
+    refs = {b: oracle.StepEnv(77 + b, 0, TICK, 100_000) for b in sample}
+    rng = np.random.default_rng(2025)
+    counts = np.zeros(B, dtype=np.int64)
+    pending = None  # (ticket, want_ids, want_applied, want_code) of the previous step on the "tickets" env
+
+    def check(res, want, s):
+        ids, st, bad = res
+        want_ids, want_applied, want_code = want
+        assert np.array_equal(st[:, 0], want_code) and np.array_equal(st[:, 1], want_applied), s
+        # ids from a book's failing element on read u64::MAX (the device entry leaves them untouched; the per-order host
+        # calls never reach them)
+        assert np.array_equal(ids, want_ids), s
+        assert bad == (int(np.nonzero(want_code)[0][0]) if want_code.any() else None), s
+
+    for s in range(T):
+        off, book_of, ins = _stream_step(rng, B, counts, NMAX, TICK, bad_plan.get(s, ()))
+        n = len(ins[0])
+        want = _apply_host(host, book_of, off, ins, B)
+        # (1) synchronous: ids returned / ValueError for the first failing book, every other book applied all the same
+        if want[2].any():
+            with pytest.raises(ValueError, match=f"book {int(np.nonzero(want[2])[0][0])}: a price of its batch"):
+                devs["sync"].submit_instructions_all(off, ins)
+        else:
+            assert np.array_equal(devs["sync"].submit_instructions_all(off, ins), want[0]), s
+        # (2) tickets: this step's submit goes out BEFORE the previous step's results are fetched
+        t = devs["tickets"].submit_instructions_all_async(off, ins)
+        if pending is not None:
+            check(devs["tickets"].submit_result(pending[0]), pending[1], s - 1)
+        pending = (t, want)
+        # (3) the arrays written in place into the pinned staging of the next submit
+        st = devs["staging"].ingress_staging(n)
+        assert st["capacity"] >= n
+        st["book_offsets"][:] = off
+        for k, a in zip(("action", "side", "vol", "trader_id", "price", "order_id"), ins):
+            st[k][:n] = a
+        t3 = devs["staging"].submit_instructions_all_async(st["book_offsets"], tuple(st[k][:n] for k in ("action", "side", "vol", "trader_id", "price", "order_id")))
+        check(devs["staging"].submit_result(t3), want, s)
+        for d in devs.values():
+            d.step(sync=False)
+        host.step()
+        for b in sample:
+            _apply_oracle(refs[b], int(off[b]), int(off[b + 1]), ins)
+            refs[b].step()
+        counts += np.bincount(book_of[want[0] != U64MAX], minlength=B)
+    check(devs["tickets"].submit_result(pending[0]), pending[1], T - 1)
+    with pytest.raises(bk.BourseError, match="expired"):
+        devs["tickets"].submit_result(pending[0] - 2)
+    hh = host.history()
+    assert int(host.trade_counts().sum()) > 10_000
+    for name, d in devs.items():
+        d.sync()
+        assert not d.flags().any(), name
+        hd = d.history()
+        assert np.array_equal(hd, hh), name
+        assert np.array_equal(d.trade_counts(), host.trade_counts()), name
+        for b in sample:
+            assert np.array_equal(hd[:, b], refs[b].history()), (name, b)
+            gd, e = d.trades(b, first=0), refs[b].book.trades_array()
+            od, eo = d.orders(b), refs[b].book.orders_array()
+            for f in gd.dtype.names:
+                assert np.array_equal(gd[f], e[f]), (name, b, f)
+            for f in od.dtype.names:
+                assert np.array_equal(od[f], eo[f]), (name, b, f)
+    # an empty step (no element for any book) and a growing batch (the staging is re-allocated mid-flight)
+    d = devs["tickets"]
+    t0 = d.submit_instructions_all_async(np.zeros(B + 1, np.uint64), tuple(np.zeros(0, dt) for dt in (np.uint32, np.uint8, np.uint32, np.uint32, np.uint32, np.uint64)))
+    ids, st, bad = d.submit_result(t0)
+    assert len(ids) == 0 and not st.any() and bad is None
+    big = 40 * B
+    offb = np.arange(B + 1, dtype=np.uint64) * 40
+    dq = bk.ManyBookEnv(B, 1, 0, 1, 100_000, levels=10, max_live_orders=64, max_orders=64, trade_capacity=64)
+    dq.enable_device_ingress(64)
+    small = dq.submit_instructions_all(np.arange(B + 1, dtype=np.uint64), (np.ones(B, np.uint32), np.zeros(B, np.uint8), np.ones(B, np.uint32),
+                                                                       np.zeros(B, np.uint32), np.full(B, 90, np.uint32), np.zeros(B, np.uint64)))
+    assert (small == 0).all()
+    ids = dq.submit_instructions_all(offb, (np.ones(big, np.uint32), np.ones(big, np.uint8), np.ones(big, np.uint32), np.zeros(big, np.uint32),
+                                            np.full(big, 80, np.uint32), np.zeros(big, np.uint64)))
+    assert np.array_equal(ids.reshape(B, 40), np.tile(np.arange(1, 41, dtype=np.uint64), (B, 1)))
+    dq.step()
+    assert (dq.level2()[:, 1] == 80).all() and (dq.level2()[:, 2] == 90).all() and not dq.flags().any()
+    dq.close()
+    for d in devs.values():
+        d.close()
+    host.close()
+
+
+class _InsideTouch:
+    """A one-book numpy agent that READS its level-2 record: one order a tick inside the touch it sees (so the instruction
+    stream depends on what the books did in the step before)."""
+
+    def __init__(self, trader):
+        self.trader = trader
+
+    def update(self, rng, l2):
+        bid, ask = int(l2[1]), int(l2[2])
+        side = bool(rng.integers(0, 2))
+        px = (bid + 1 if bid > 0 else 40) if side else (ask - 1 if ask < 2**32 - 1 else 60)
+        return (np.array([1], np.uint32), np.array([side]), np.array([int(rng.integers(1, 9))], np.uint32),
+                np.array([self.trader], np.uint32), np.array([max(1, min(px, 200))], np.uint32), np.array([0], np.uint64))
+
+
+@pytest.mark.parametrize("ingress", [True, False])
+def test_run_many_numpy_agents_on_many_books_equals_one_oracle_env_per_book(bk, oracle, ingress):
+    """bourse_amd.step_sim.run_many = the reference's numpy loop (runner.py:103-112) over a ManyBookEnv: one agent set, each
+    agent's instructions for ALL books in one CSR batch of host arrays.  Against B oracle StepEnvNumpy envs driven by the
+    same loop book by book (same generator, same call order), on the device-ingress flow and on the host Env half."""
+    from bourse_amd.step_sim import agents as A
+
+    B, T, SEED = 96, 12, 7
+    mk = lambda: [A.NumpyRandomAgents(6, (40, 60), (1, 9), 1), _InsideTouch(99), A.NumpyRandomAgents(3, (45, 55), (1, 9), 1)]  # noqa: E731
+    env = bk.ManyBookEnv(B, 21, 0, 1, 100_000, levels=10, max_live_orders=192, max_orders=16 * T, trade_capacity=32 * T,
+                         history_capacity=T)
+    if ingress:
+        env.enable_device_ingress(16)
+    hist = bk.step_sim.run_many(env, mk(), T, SEED)
+    assert hist.shape == (T, B, 45)
+    refs = [oracle.StepEnvNumpy(21 + b, 0, 1, 100_000) for b in range(B)]
+    rng = np.random.default_rng(SEED)
+    agents = mk()
+    for _ in range(T):
+        l2 = [r.level_2_data() for r in refs]
+        for a in agents:
+            for b, r in enumerate(refs):
+                r.submit_instructions(a.update(rng, l2[b]))
+        for r in refs:
+            r.step()
+    for b, r in enumerate(refs):
+        assert np.array_equal(hist[:, b], r.history()), b
+        got, exp = env.trades(b, first=0), r.book.trades_array()
+        for f in got.dtype.names:
+            assert np.array_equal(got[f], exp[f]), (b, f)
+    assert int(env.trade_counts().sum()) > 1000
+    # the books-vectorised agent: one update_many call per step, 8 192 books
+    B2 = 8192
+    big = bk.ManyBookEnv(B2, 5, 0, 2, 100_000, levels=10, max_live_orders=256, max_orders=0, trade_capacity=64, history_capacity=0, strict=False)
+    if ingress:
+        big.enable_device_ingress(16)
+    last = bk.step_sim.run_many(big, [A.ManyBookNumpyRandomAgents(12, (40, 60), (1, 9), 2)], 4, 3)
+    assert last.shape == (B2, 45) and (last[:, 1] < last[:, 2]).all() and int(big.trade_counts().sum()) > B2 and not big.flags().any()
+    big.close()
+    env.close()
+
+
 def test_device_ingress_capacity_unknown_ids_and_argument_checks(bk):
     import torch
 
