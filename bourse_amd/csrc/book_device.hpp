@@ -168,6 +168,27 @@ constexpr uint32_t EV_NEW = 0x8000u, EV_BID = 0x4000u, EV_SLOT = 0x1FFu;
 // wave primitives
 // ----------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t rfl(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// Explicit scalar loads of wave-uniform words (header fields, the lane-state record's tag) that the SAME kernel stores to
+// later.  Rounds 3-4 read them through an address_space(4) ("constant") pointer so that the compiler would issue s_load -
+// which also tells it the memory never changes, although store_book / finish() write it: correct only as long as every use
+// precedes the store, and silently wrong in a persistent or several-books-per-wave kernel.  The statement is
+// volatile with a memory clobber: it is not moved across the kernel's loads and stores, not rematerialised, and the
+// scalar cache's coherence rests on what it always rested on (invalidated at kernel start; nothing in the kernel stores
+// these words before it runs).  It waits for its own loads (the compiler does not count asm-issued ones): callers issue
+// their vector loads FIRST, so the wait hides under those loads' longer round trip.
+typedef uint32_t bk_u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t bk_u32x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t bk_u32x16 __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ void sload_x16_x4(const uint32_t* p, bk_u32x16& a, bk_u32x4& b) {  // words 0..15, 16..19
+  asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx4 %1, %2, 0x40\n\ts_waitcnt lgkmcnt(0)"
+               : "=&s"(a), "=&s"(b) : "s"(p) : "memory");
+}
+__device__ __forceinline__ bk_u32x8 sload_x8(const uint32_t* p) {
+  bk_u32x8 a;
+  asm volatile("s_load_dwordx8 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(a) : "s"(p) : "memory");
+  return a;
+}
 __device__ __forceinline__ uint32_t rdl(uint32_t v, uint32_t lane) { return __builtin_amdgcn_readlane(v, lane); }
 // v_writelane_b32: clang 22 has no builtin for it; bind the LLVM intrinsic by its mangled name
 // (the compiler then legalises the operands, e.g. lane select through M0 on gfx9).
@@ -712,24 +733,29 @@ struct StepRaw {
 template <int R>
 __device__ __forceinline__ void load_state_raw(StepRaw<R>& w, const uint32_t* __restrict__ st, int lane) {
   w.hdr = st[lane];
-  // (s_load_dwordx16 + x4: sixteen-odd v_readlane of the line above and their vector-to-scalar hand-over at the head of
-  // every wave's chain otherwise; the scalar cache is invalidated at kernel start, and nothing writes the header before)
-  // (read as CONSTANT memory: the compiler only issues scalar loads where it can rule out a store in between, and the
-  // kernel's own store_book aliases `st`; every value is consumed before that store)
-  // Pools of <= 128 slots only: k_step_batch<8> sits at the scalar-register limit already, and twenty more live scalars
-  // cost the C5 stand-in 3 % (31.6 -> 30.6 M, same box) where the smaller pools gain ~1 %; the larger pools read the
-  // fields from the vector copy (unpack_book).
-  if constexpr (R <= 2) {
-    typedef const uint32_t __attribute__((address_space(4))) cu32;
-    cu32* cst = (cu32*)(uintptr_t)st;
-#pragma unroll
-    for (int i = 0; i < HDR_SCALARS; ++i) w.sh[i] = cst[i];
-  }
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     const uint32_t* p = st + HDR_DW + r * POOL_FIELDS * 64;
 #pragma unroll
     for (int f = 0; f < POOL_FIELDS; ++f) w.f[r][f] = p[f * 64 + lane];
+  }
+}
+// The header's scalar fields once more through the scalar cache (s_load_dwordx16 + x4: sixteen-odd v_readlane of the line
+// above and their vector-to-scalar hand-over at the head of every wave's chain otherwise).  Call it AFTER the wave's vector
+// loads have been issued (sload_x16_x4 waits for its own loads).
+// Pools of <= 128 slots only: k_step_batch<8> sits at the scalar-register limit already, and twenty more live scalars
+// cost the C5 stand-in 3 % (31.6 -> 30.6 M, same box) where the smaller pools gain ~1 %; the larger pools read the
+// fields from the vector copy (unpack_book).
+template <int R>
+__device__ __forceinline__ void load_state_scalars(StepRaw<R>& w, const uint32_t* __restrict__ st) {
+  if constexpr (R <= 2) {
+    bk_u32x16 a;
+    bk_u32x4 b;
+    sload_x16_x4(st, a, b);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) w.sh[i] = a[i];
+#pragma unroll
+    for (int i = 16; i < HDR_SCALARS; ++i) w.sh[i] = b[i - 16];
   }
 }
 template <int R>
@@ -769,6 +795,7 @@ template <int R>
 __device__ __forceinline__ void load_book(Book<R>& B, Rng& rng, const uint32_t* __restrict__ st, int lane) {
   StepRaw<R> w;
   load_state_raw<R>(w, st, lane);
+  load_state_scalars<R>(w, st);
   unpack_book<R>(B, rng, w);
 }
 
@@ -1517,6 +1544,7 @@ __device__ __forceinline__ void step_batch_book(const DevArgs& a, uint32_t book,
     w.ev[r] = reinterpret_cast<const uint16_t*>(bt + BT_EV)[r * 64 + lane];
     w.pv[r] = POOLPEND ? make_uint2(0u, 0u) : reinterpret_cast<const uint2*>(bt + BT_EV + 32 * R)[r * 64 + lane];
   }
+  load_state_scalars<R>(w, st);  // (behind the vector loads: its wait hides under their round trip)
 #if BOURSE_AMD_STAMPS && !defined(BOURSE_AMD_FSM_UNIT)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // phase 0 = the loads' round trip
 #endif

@@ -202,14 +202,13 @@ struct WaveDecoder {
   __device__ __forceinline__ void load_cache(const uint32_t* wc, uint32_t s0l, uint32_t s0h, uint32_t s1l, uint32_t s1h,
                                              const uint4* jt_lane) {
     // (the record's six header words through the scalar cache: it was written by the previous launch, nothing in this
-    // one writes it before finish(); as constant memory so that the compiler issues scalar loads)
+    // one writes it before finish())
     // (pools of <= 128 slots; the larger pools' kernels lose more to the extra live scalars than the lane reads cost:
     // book_device.hpp load_state_raw)
     cs = reinterpret_cast<const uint4*>(wc + WC_HDR)[lane];
     bool cached;
     if constexpr (R <= 2) {
-      typedef const uint32_t __attribute__((address_space(4))) cu32;
-      cu32* cwc = (cu32*)(uintptr_t)wc;
+      const bk_u32x8 cwc = sload_x8(wc);  // (explicit s_load: finish() stores these words at the end of the launch)
       pos = cwc[WC_OFF];
       cached = cwc[WC_TAG] == WC_MAGIC && cwc[WC_S0_LO] == s0l && cwc[WC_S0_HI] == s0h && cwc[WC_S1_LO] == s1l &&
                cwc[WC_S1_HI] == s1h && pos < WV_BLOCK;
@@ -690,17 +689,22 @@ __device__ __forceinline__ void agents_wave_book(const DevArgs& a, const WaveArg
   D.wcs = reinterpret_cast<uint4*>(wc + WC_HDR);
   D.lane = lane;
   // the book's RNG state and live masks (header dwords H_LIVE0 + w hold bits [32 w, 32 w + 32) of the pool's live mask)
-  // (the header's scalars through the scalar cache, as k_step_batch reads them: book_device.hpp load_state_raw)
-  typedef const uint32_t __attribute__((address_space(4))) cu32;
-  cu32* cst = (cu32*)(uintptr_t)st;
-  if constexpr (R <= 2)
-    D.load_cache(wc, cst[H_S0_LO], cst[H_S0_HI], cst[H_S1_LO], cst[H_S1_HI], wa.jt_lane);
-  else
+  // (the header's scalars through the scalar cache, as k_step_batch reads them: book_device.hpp load_state_scalars; the RNG
+  // state is dwords 2..5, the live masks 32..35 - explicit s_loads, this kernel stores the RNG state at its end)
+  bk_u32x8 h0 = {};
+  bk_u32x4 hl = {};
+  if constexpr (R <= 2) {
+    h0 = sload_x8(st);
+    asm volatile("s_load_dwordx4 %0, %1, 0x80\n\ts_waitcnt lgkmcnt(0)" : "=&s"(hl) : "s"(st) : "memory");
+    D.load_cache(wc, h0[H_S0_LO], h0[H_S0_HI], h0[H_S1_LO], h0[H_S1_HI], wa.jt_lane);
+  } else {
     D.load_cache(wc, rdl(hdr, H_S0_LO), rdl(hdr, H_S0_HI), rdl(hdr, H_S1_LO), rdl(hdr, H_S1_HI), wa.jt_lane);
+  }
   const uint32_t lim = 64u + (wa.lookahead < 1u ? 1u : (wa.lookahead > 64u ? 64u : wa.lookahead));
   BK_STAMP(D, 1, 0, lane);  // lane-state cache in
-  const uint64_t lv0 = R <= 2 ? mk64(cst[H_LIVE0], cst[H_LIVE0 + 1]) : 0ull;
-  const uint64_t lv1 = R == 2 ? mk64(cst[H_LIVE0 + 2], cst[H_LIVE0 + 3]) : 0ull;
+  static_assert(H_LIVE0 == 32, "the live masks are read at byte offset 0x80 above");
+  const uint64_t lv0 = R <= 2 ? mk64(hl[0], hl[1]) : 0ull;
+  const uint64_t lv1 = R == 2 ? mk64(hl[2], hl[3]) : 0ull;
   const uint32_t n_ev = D.agents(a, lim, hdr, H_LIVE0, lv0, lv1);
   BK_STAMP(D, 1, 1, lane);  // agents.update: generation, windows, walk
   D.shuffle(n_ev);

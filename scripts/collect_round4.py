@@ -10,7 +10,7 @@ tag, rnd = sys.argv[1], sys.argv[2]
 src, dst = os.path.join(ROOT, "gpurun_out", "prof_" + tag), os.path.join(ROOT, "profiles", rnd)
 os.makedirs(dst, exist_ok=True)
 for f in sorted(os.listdir(src)):
-    if (f.startswith("bench_") and f.endswith(".json")) or f.startswith("kernel_stats_") or f.endswith("_rate.txt") or f == "mixed_issue_bench.txt":
+    if (f.startswith("bench_") and f.endswith(".json")) or f.startswith("kernel_stats_") or f.endswith("_rate.txt") or f.endswith("_profile.txt") or f == "mixed_issue_bench.txt":
         shutil.copy(os.path.join(src, f), os.path.join(dst, f))
         print("copied", f)
 subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "pmc_merge.py"), tag, rnd], check=True)
