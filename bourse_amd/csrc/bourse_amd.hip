@@ -603,10 +603,20 @@ int launch_split(bk_env* env, const DevArgs& a0, uint64_t first_step, uint32_t n
   WaveArgs wva{};
   if (wave)
     if (int rc = wave_args(env, &wva)) return rc;
+  // (diagnostic: BOURSE_AMD_MW_LDS_PAD=bytes of unused dynamic LDS added to every k_agents_mixed_wave workgroup - an occupancy
+  // sensitivity probe: how much does the members' decode lose at FEWER waves per SIMD, i.e. what could more buy?)
+  static const uint32_t mw_pad = [] {
+    const char* e = std::getenv("BOURSE_AMD_MW_LDS_PAD");
+    return e ? static_cast<uint32_t>(std::max(0, std::atoi(e))) & ~3u : 0u;
+  }();
+  static const uint32_t wave_pad = [] {  // (the same probe for k_agents_wave: BOURSE_AMD_WAVE_LDS_PAD)
+    const char* e = std::getenv("BOURSE_AMD_WAVE_LDS_PAD");
+    return e ? static_cast<uint32_t>(std::max(0, std::atoi(e))) & ~3u : 0u;
+  }();
   if (MIXED == 3) {
     if (!env->mw_attr_set) {  // > 64 KB of dynamic LDS at R = 8 (160 KB per workgroup on MI355X); per device
       HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_agents_mixed_wave<R>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 static_cast<int>(mixed_wave_lds_bytes(R))));
+                                 static_cast<int>(mixed_wave_lds_bytes(R) + mw_pad)));
       env->mw_attr_set = true;
     }
     if (!env->wl_list.p) {
@@ -668,7 +678,7 @@ int launch_split(bk_env* env, const DevArgs& a0, uint64_t first_step, uint32_t n
       const uint64_t step_no = first_step + s;
       if (MIXED == 3)
         launch_timed(env, 1, &k_agents_mixed_wave<R>, dim3((nb + MW_WPB - 1) / MW_WPB), dim3(64 * MW_WPB),
-                     static_cast<uint32_t>(mixed_wave_lds_bytes(R)), st, a, ma, wva,
+                     static_cast<uint32_t>(mixed_wave_lds_bytes(R)) + mw_pad, st, a, ma, wva,
                      WaveLists{env->wl_list.p, env->wl_len.p, static_cast<uint32_t>(R) * 64u});
       else if (MIXED == 2 && M > 1)
         launch_timed(env, 1, &k_agents_mixed_lanes<R, true>, dim3((nb + 63) / 64), dim3(64), mixed_lanes_lds_bytes(R, true), st, a,
@@ -679,7 +689,7 @@ int launch_split(bk_env* env, const DevArgs& a0, uint64_t first_step, uint32_t n
       else if (MIXED == 1)
         launch_timed(env, 1, &k_agents_mixed<R>, dim3((nb + 3) / 4), dim3(256), 0u, st, a, ma);
       else if (wave)
-        launch_timed(env, 1, &k_agents_wave<R>, dim3((nb + 3) / 4), dim3(256), 0u, st, a, wva);
+        launch_timed(env, 1, &k_agents_wave<R>, dim3((nb + 3) / 4), dim3(256), wave_pad, st, a, wva);
       else
         launch_timed(env, 1, &k_agents_fsm<R>, dim3((nb + 63) / 64), dim3(64), fsm_lds, st, a);
       if (P > 1 && s == 0) HIPCHK(hipEventRecord(env->ev_first[i], st));
