@@ -1661,8 +1661,15 @@ __device__ __forceinline__ int find_free_slot(const Book<R>& B) {
   return -1;
 }
 
+// timing experiments only (scripts/ev_phase_times.sh): -DBOURSE_AMD_EV_SKIP=bits leaves phases of k_step_events out (results
+// are then wrong): 1 the shuffle's swaps, 2 the order-log writes, 4 matching
+#ifndef BOURSE_AMD_EV_SKIP
+#define BOURSE_AMD_EV_SKIP 0
+#endif
 template <int R>
-__global__ __launch_bounds__(64) void k_step_events(DevArgs a, uint64_t step_index) {
+// (eight waves per SIMD for pools of <= 256 slots: 8 192 books - the C4 shard, the ingress rate scripts - are then ONE residency round;
+// at the 69 VGPRs the compiler took for R = 4 a seventh of the waves ran as a second round)
+__global__ __launch_bounds__(64, R <= 4 ? 8 : 4) void k_step_events(DevArgs a, uint64_t step_index) {
   __shared__ uint32_t bins[LDS_DW_PER_WAVE];
   // the shuffle permutation: dynamic LDS sized by the host to this step's longest queue (<= EV_LDS_CAP entries), so
   // that quiet steps do not pay 16 KB of LDS per one-wave workgroup in occupancy
@@ -1681,7 +1688,7 @@ __global__ __launch_bounds__(64) void k_step_events(DevArgs a, uint64_t step_ind
   const uint32_t e0 = a.ev_len ? mkt * a.ev_stride : a.ev_off[mkt];
   const uint32_t n_ev = a.ev_len ? a.ev_len[mkt] : a.ev_off[mkt + 1] - e0;
   uint32_t n_own = 0;
-  LogCtx lg{a.order_log ? a.order_log + (size_t)book * a.log_cap : nullptr, a.log_cap};
+  LogCtx lg{(a.order_log && !(BOURSE_AMD_EV_SKIP & 2)) ? a.order_log + (size_t)book * a.log_cap : nullptr, a.log_cap};
 
   const uint64_t t0 = B.t;
   B.trade_vol = 0;
@@ -1690,7 +1697,7 @@ __global__ __launch_bounds__(64) void k_step_events(DevArgs a, uint64_t step_ind
   for (uint32_t j = lane; j < n_ev; j += 64) perm[j] = (uint16_t)j;
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
-  for (uint32_t i = n_ev; i-- > 1;) {  // shuffle (env.rs:121)
+  for (uint32_t i = (BOURSE_AMD_EV_SKIP & 1) ? 0u : n_ev; i-- > 1;) {  // shuffle (env.rs:121)
     const uint32_t j = rng.below(i + 1);
     const uint32_t pi = rfl(perm[i]), pj = rfl(perm[j]);
     if (lane == 0) {
@@ -1728,7 +1735,7 @@ __global__ __launch_bounds__(64) void k_step_events(DevArgs a, uint64_t step_ind
       bool filled = false;
       uint32_t status = 1;  // Active
       uint64_t end = ~0ull;
-      if (B.trading) {
+      if (B.trading && !(BOURSE_AMD_EV_SKIP & 4)) {
         filled = match<R>(B, a, book, t0, lane, k, is_bid, p, v, id, lg);
         if (filled) {
           status = 2;

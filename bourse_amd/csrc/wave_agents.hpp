@@ -260,6 +260,7 @@ struct WaveDecoder {
   __device__ __forceinline__ uint32_t agents(const DevArgs& a, uint32_t lim, uint32_t livev, uint32_t live_base, uint64_t lv0,
                                              uint64_t lv1) {
     uint32_t n_ev = 0, ag = 0, gbase = 0;
+    uint32_t lblk = 0xFFFFFFFFu, lw = 0;  // (R > 2) the cached live word of the walk and which 32 agents it covers
     for (uint32_t g = 0; g < a.n_groups; ++g) {
       const Group G = a.groups[g];
       const uint32_t gend = gbase + G.n;
@@ -313,96 +314,87 @@ struct WaveDecoder {
         uint32_t agw = 0;
         bool slow = false;
         BK_STAMP(*this, 2, 1, lane);  // the window's masks, searches, placements and continuations
-        if constexpr (R <= 2) {
-          {
-            // to the first hit at or after p (or the end of the window / group)
-            const uint64_t m = H >> p;
-            const uint32_t d = m ? (uint32_t)__builtin_ctzll(m) : 64u - p;
-            if (ag + d >= gend || m == 0) {
-              const uint32_t adv = d < gend - ag ? d : gend - ag;
-              p += adv;
-              ag += adv;
-            } else {
-              p += d;
-              ag += d;
-              // The walk itself, hand-written (this loop is ~half of the kernel's scalar instructions, and under eight
-              // waves' contention for the scalar port every one of them is a link of the wave's chain; the compiled form
-              // spends 24-26 per hit on loop-exit flags and re-materialised booleans, round 2's 19-21, this one 14-17).
-              // The position lives in m0 (lane select of the v_readlane / v_writelane, no copy), the agent index carries the
-              // event word's marker bit (bit 16: no OR per event; `gm` = the group's end with the same bit), the word's
-              // first field is the DISTANCE to the next hit.  One iteration:
-              //   w = pack[p]; live bit of agent ag; cancellation -> event word ag | ACTED into lane p, p += w[6:0];
-              //   placement -> (w[31]: not resolvable -> slow) event word ag | NEW | ACTED, p = w[14:7], agents += w[29:23];
-              //   the group ends before the next hit -> position of agent `gend`'s draw from the run start (p + 1 or f).
-              if constexpr (R <= 2) {
-                // pools of <= 128 slots: the live masks sit in two SGPR pairs.  A walk that stays inside one 64-agent half
-                // (always, with groups of 64) tests ONE mask chosen up front - one scalar instruction per hit; else the
-                // mask is chosen per hit (three)
-                uint32_t st, w, t0, t1, gm;
-                if ((ag >> 6) == ((gend - 1u) >> 6)) {
-                  const uint64_t lm = (ag & 64u) ? lv1 : lv0;
-                  // (the live test IN FRONT of the lane read: a scalar instruction issued right behind a vector write of a
-                  // scalar register waits ~16 clocks for it, whether it reads it or not - the branch and the cancellation's
-                  // v_writelane do not)
-                  asm volatile(WV_WALK_BEGIN
-                               "s_bitcmp1_b64 %[lm], %[ag]\n\t"              /* (the bit index is ag[5:0]) */
-                               "v_readlane_b32 %[w], %[pack], m0\n\t"
-                               WV_WALK_REST
-                               : [st] "=&s"(st), [w] "=&s"(w), [t0] "=&s"(t0), [t1] "=&s"(t1), [gm] "=&s"(gm), [p] "+s"(p),
-                                 [ag] "+s"(ag), [agw] "+v"(agw)
-                               : [pack] "v"(pack), [lm] "s"(lm), [gend] "s"(gend)
-                               : "scc", "m0", "memory");
-                } else {
-                  uint64_t lm;
-                  asm volatile(WV_WALK_BEGIN
-                               "s_bitcmp1_b32 %[ag], 6\n\t"                  /* agent 64..127: the second mask */
-                               "s_cselect_b64 %[lm], %[lv1], %[lv0]\n\t"
-                               "s_bitcmp1_b64 %[lm], %[ag]\n\t"
-                               "v_readlane_b32 %[w], %[pack], m0\n\t"
-                               WV_WALK_REST
-                               : [st] "=&s"(st), [w] "=&s"(w), [t0] "=&s"(t0), [t1] "=&s"(t1), [gm] "=&s"(gm), [p] "+s"(p),
-                                 [ag] "+s"(ag), [agw] "+v"(agw), [lm] "=&s"(lm)
-                               : [pack] "v"(pack), [lv0] "s"(lv0), [lv1] "s"(lv1), [gend] "s"(gend)
-                               : "scc", "m0", "memory");
-                }
-                slow = st == 2u;
+        {
+          // to the first hit at or after p (or the end of the window / group)
+          const uint64_t m = H >> p;
+          const uint32_t d = m ? (uint32_t)__builtin_ctzll(m) : 64u - p;
+          if (ag + d >= gend || m == 0) {
+            const uint32_t adv = d < gend - ag ? d : gend - ag;
+            p += adv;
+            ag += adv;
+          } else {
+            p += d;
+            ag += d;
+            // The walk itself, hand-written (this loop is ~half of the kernel's scalar instructions, and under eight
+            // waves' contention for the scalar port every one of them is a link of the wave's chain; the compiled form
+            // spends 24-26 per hit on loop-exit flags and re-materialised booleans, round 2's 19-21, this one 14-17).
+            // The position lives in m0 (lane select of the v_readlane / v_writelane, no copy), the agent index carries the
+            // event word's marker bit (bit 16: no OR per event; `gm` = the group's end with the same bit), the word's
+            // first field is the DISTANCE to the next hit.  One iteration:
+            //   w = pack[p]; live bit of agent ag; cancellation -> event word ag | ACTED into lane p, p += w[6:0];
+            //   placement -> (w[31]: not resolvable -> slow) event word ag | NEW | ACTED, p = w[14:7], agents += w[29:23];
+            //   the group ends before the next hit -> position of agent `gend`'s draw from the run start (p + 1 or f).
+            if constexpr (R <= 2) {
+              // pools of <= 128 slots: the live masks sit in two SGPR pairs.  A walk that stays inside one 64-agent half
+              // (always, with groups of 64) tests ONE mask chosen up front - one scalar instruction per hit; else the
+              // mask is chosen per hit (three)
+              uint32_t st, w, t0, t1, gm;
+              if ((ag >> 6) == ((gend - 1u) >> 6)) {
+                const uint64_t lm = (ag & 64u) ? lv1 : lv0;
+                // (the live test IN FRONT of the lane read: a scalar instruction issued right behind a vector write of a
+                // scalar register waits ~16 clocks for it, whether it reads it or not - the branch and the cancellation's
+                // v_writelane do not)
+                asm volatile(WV_WALK_BEGIN
+                             "s_bitcmp1_b64 %[lm], %[ag]\n\t"              /* (the bit index is ag[5:0]) */
+                             "v_readlane_b32 %[w], %[pack], m0\n\t"
+                             WV_WALK_REST
+                             : [st] "=&s"(st), [w] "=&s"(w), [t0] "=&s"(t0), [t1] "=&s"(t1), [gm] "=&s"(gm), [p] "+s"(p),
+                               [ag] "+s"(ag), [agw] "+v"(agw)
+                             : [pack] "v"(pack), [lm] "s"(lm), [gend] "s"(gend)
+                             : "scc", "m0", "memory");
+              } else {
+                uint64_t lm;
+                asm volatile(WV_WALK_BEGIN
+                             "s_bitcmp1_b32 %[ag], 6\n\t"                  /* agent 64..127: the second mask */
+                             "s_cselect_b64 %[lm], %[lv1], %[lv0]\n\t"
+                             "s_bitcmp1_b64 %[lm], %[ag]\n\t"
+                             "v_readlane_b32 %[w], %[pack], m0\n\t"
+                             WV_WALK_REST
+                             : [st] "=&s"(st), [w] "=&s"(w), [t0] "=&s"(t0), [t1] "=&s"(t1), [gm] "=&s"(gm), [p] "+s"(p),
+                               [ag] "+s"(ag), [agw] "+v"(agw), [lm] "=&s"(lm)
+                             : [pack] "v"(pack), [lv0] "s"(lv0), [lv1] "s"(lv1), [gend] "s"(gend)
+                             : "scc", "m0", "memory");
               }
-            }
-          }
-        } else {
-          // Larger pools (round 5): the walk runs per 64-AGENT BLOCK on the single-mask form above - the block's live mask in
-          // one scalar pair (two v_readlane per block and window, not a block test per hit: round 4's form spent three scalar
-          // instructions of each hit's 17 on "still the cached 32 agents?"), the block's end playing the group's end: the
-          // walk's exit arithmetic (position of the next agent's activity draw from the run start) is the same for both, and
-          // a window goes on into the next block without being decoded again.
-          for (;;) {
-            const uint64_t m = H >> p;  // (p < 64)
-            const uint32_t d = m ? (uint32_t)__builtin_ctzll(m) : 64u - p;
-            const uint32_t bend = (ag | 63u) + 1u, lend = bend < gend ? bend : gend;
-            if (ag + d >= lend || m == 0) {
-              const uint32_t adv = d < lend - ag ? d : lend - ag;
-              p += adv;
-              ag += adv;
+              slow = st == 2u;
             } else {
-              p += d;
-              ag += d;
-              const uint32_t blk = ag >> 6;
-              const uint64_t lm = mk64(rdl(livev, live_base + 2u * blk), rdl(livev, live_base + 2u * blk + 1u));
+              // larger pools: the live word of the current 32 agents is CACHED in a scalar register across hits, windows
+              // and groups (`lblk` = which; the masks do not change during the decode) and re-read from the vector
+              // register only when the walk enters another block - round 2 read it for every hit: one more v_readlane and
+              // a second vector-to-scalar hand-over on each hit's chain
               uint32_t st, w, t0, t1, gm;
               asm volatile(WV_WALK_BEGIN
-                           "s_bitcmp1_b64 %[lm], %[ag]\n\t"              /* (the bit index is ag[5:0]) */
+                           "s_bfe_u32 %[t0], %[ag], 0xb0005\n\t"          /* agent / 32 (without the marker bit) */
+                           "s_cmp_lg_u32 %[t0], %[lblk]\n\t"
+                           "s_cbranch_scc1 7f\n\t"
+                           "3:\n\t"
+                           "s_bitcmp1_b32 %[lw], %[ag]\n\t"               /* (the bit index is ag[4:0]) */
                            "v_readlane_b32 %[w], %[pack], m0\n\t"
                            WV_WALK_REST
+                           "\n\t"
+                           "s_branch 4f\n\t"
+                           "7:\n\t"
+                           "s_mov_b32 %[lblk], %[t0]\n\t"
+                           "s_add_u32 %[t0], %[t0], %[lb]\n\t"
+                           "v_readlane_b32 %[lw], %[livev], %[t0]\n\t"
+                           "s_branch 3b\n\t"
+                           "4:\n\t"
+                           "s_nop 0"
                            : [st] "=&s"(st), [w] "=&s"(w), [t0] "=&s"(t0), [t1] "=&s"(t1), [gm] "=&s"(gm), [p] "+s"(p),
-                             [ag] "+s"(ag), [agw] "+v"(agw)
-                           : [pack] "v"(pack), [lm] "s"(lm), [gend] "s"(lend)
+                             [ag] "+s"(ag), [agw] "+v"(agw), [lblk] "+s"(lblk), [lw] "+s"(lw)
+                           : [pack] "v"(pack), [livev] "v"(livev), [lb] "s"(live_base), [gend] "s"(gend)
                            : "scc", "m0", "memory");
-              if (st == 2u) {
-                slow = true;
-                break;
-              }
+              slow = st == 2u;
             }
-            if (p >= 64u || ag >= gend) break;
           }
         }
         BK_STAMP(*this, 2, 2, lane);  // the walk

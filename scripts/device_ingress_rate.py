@@ -7,7 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np, torch, bourse_amd as bk
 B, N, T = int(sys.argv[1]) if len(sys.argv) > 1 else 8192, 48, 30  # (as scripts/host_driven_rate.py)
-POOL = 512 if B > 16384 else 256  # round 4's 65 536-book line ran with pool 256 and DROPPED orders (flags [0 1]): VERDICT r4 Weak #7
+POOL = 512 if B > 8192 else 256  # round 4's 65 536-book line ran with pool 256 and DROPPED orders (flags [0 1]): VERDICT r4 Weak #7
 env = bk.ManyBookEnv(B, 1, 0, 1, 100_000, levels=16, max_live_orders=POOL, max_orders=N * (T + 8), trade_capacity=64 * (T + 8), strict=False,
                      history_capacity=0, stream=torch.cuda.current_stream().cuda_stream)
 env.enable_device_ingress(N)

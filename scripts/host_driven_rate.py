@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np, bourse_amd as bk
 B, N, T = int(sys.argv[1]) if len(sys.argv) > 1 else 8192, 48, 30
-POOL = 512 if B > 16384 else 256
+POOL = 512 if B > 8192 else 256
 n = B * N
 off = (np.arange(B + 1, dtype=np.uint64) * N)
 rng = np.random.default_rng(0)
