@@ -609,6 +609,13 @@ int launch_split(bk_env* env, const DevArgs& a0, uint64_t first_step, uint32_t n
     const char* e = std::getenv("BOURSE_AMD_MW_LDS_PAD");
     return e ? static_cast<uint32_t>(std::max(0, std::atoi(e))) & ~3u : 0u;
   }();
+  // (experiment, docs/EXPERIMENTS.md: BOURSE_AMD_STEP_DECODE=1 runs a part's inner steps of the wave_split pipeline as ONE launch
+  // each - k_step_decode = events of step s + decode of step s + 1)
+  static const bool step_decode = [] {
+    const char* e = std::getenv("BOURSE_AMD_STEP_DECODE");
+    return e && std::atoi(e) != 0;
+  }();
+  const bool fuse_sd = step_decode && wave && MIXED == 0 && env->M == 1 && !env->warming;
   static const uint32_t wave_pad = [] {  // (the same probe for k_agents_wave: BOURSE_AMD_WAVE_LDS_PAD)
     const char* e = std::getenv("BOURSE_AMD_WAVE_LDS_PAD");
     return e ? static_cast<uint32_t>(std::max(0, std::atoi(e))) & ~3u : 0u;
@@ -688,6 +695,8 @@ int launch_split(bk_env* env, const DevArgs& a0, uint64_t first_step, uint32_t n
                      a, ma, ml);
       else if (MIXED == 1)
         launch_timed(env, 1, &k_agents_mixed<R>, dim3((nb + 3) / 4), dim3(256), 0u, st, a, ma);
+      else if (wave && fuse_sd && s > 0)
+        ;  // (the previous step's k_step_decode has decoded this step already)
       else if (wave)
         launch_timed(env, 1, &k_agents_wave<R>, dim3((nb + 3) / 4), dim3(256), wave_pad, st, a, wva);
       else
@@ -701,7 +710,10 @@ int launch_split(bk_env* env, const DevArgs& a0, uint64_t first_step, uint32_t n
         launch_timed(env, 2, &k_step_batch<R, false, true>, dim3(nb), dim3(64), 0u, st, a, step_no, write_last);
       else if (M > 1)
         launch_timed(env, 2, &k_step_batch<R, true>, dim3(nb * M), dim3(64), 0u, st, a, step_no, write_last);
-      else
+      else if (fuse_sd && s + 1 < n_steps) {
+        DevArgs an = a;  // (the decode half belongs to the NEXT step; nothing in it reads the history slot)
+        launch_timed(env, 2, &k_step_decode<R>, dim3((nb + 3) / 4), dim3(256), 0u, st, an, wva, step_no, write_last);
+      } else
         launch_timed(env, 2, &k_step_batch<R, false>, dim3(nb), dim3(64), 0u, st, a, step_no, write_last);
     }
   }

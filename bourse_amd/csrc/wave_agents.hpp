@@ -664,9 +664,15 @@ struct WaveLds {
 // One book's RNG-serial half of a step: RandomAgents::update for every group + the shuffle, written as the book's step
 // batch; the body of k_agents_wave.  hdr: lane i holds dword i of the book's header
 // (RNG state, live masks at H_LIVE0 ..).
+// `given` (k_step_decode): the RNG state and live masks handed over in registers by the event half that has just STORED them -
+// the scalar cache would still hold the header as it was at kernel start.
+struct WaveHdrScalars {
+  uint32_t s0l, s0h, s1l, s1h;
+  uint64_t lv0, lv1;
+};
 template <int R>
 __device__ __forceinline__ void agents_wave_book(const DevArgs& a, const WaveArgs& wa, WaveLds<R>& L, int wv, uint32_t book, int lane,
-                                                 uint32_t hdr) {
+                                                 uint32_t hdr, const WaveHdrScalars* given = nullptr) {
   uint32_t* st = a.state + (size_t)book * a.state_stride;
   uint32_t* bt = a.batch + (size_t)book * a.batch_stride;
   uint32_t* wc = wa.wcache + (size_t)book * WC_STRIDE;
@@ -693,7 +699,10 @@ __device__ __forceinline__ void agents_wave_book(const DevArgs& a, const WaveArg
   // state is dwords 2..5, the live masks 32..35 - explicit s_loads, this kernel stores the RNG state at its end)
   bk_u32x8 h0 = {};
   bk_u32x4 hl = {};
-  if constexpr (R <= 2) {
+  if (given) {
+    D.load_cache(wc, given->s0l, given->s0h, given->s1l, given->s1h, wa.jt_lane);
+    hl[0] = (uint32_t)given->lv0, hl[1] = (uint32_t)(given->lv0 >> 32), hl[2] = (uint32_t)given->lv1, hl[3] = (uint32_t)(given->lv1 >> 32);
+  } else if constexpr (R <= 2) {
     h0 = sload_x8(st);
     asm volatile("s_load_dwordx4 %0, %1, 0x80\n\ts_waitcnt lgkmcnt(0)" : "=&s"(hl) : "s"(st) : "memory");
     D.load_cache(wc, h0[H_S0_LO], h0[H_S0_HI], h0[H_S1_LO], h0[H_S1_HI], wa.jt_lane);
@@ -739,10 +748,48 @@ __global__ __launch_bounds__(256, BOURSE_AMD_AW_OCC(R)) void k_agents_wave(DevAr
   agents_wave_book<R>(a, wa, L, wv, book, lane, hdr);
 }
 
-// (Round 4 built and measured two more arrangements of these two halves, both parity-green, neither faster - removed again,
-//  docs/EXPERIMENTS.md "Tried and not shipped": k_step_decode = the events of step s and the decode of step s + 1 of a part in
-//  ONE launch (commit 1526074..03eed16), and k_run_split = the whole launch persistent with the book parked in its state block
-//  between the halves, eight waves per SIMD, every book of a C4 shard resident (commit 0ff3c3c): 112.5 M against 118.0 M.)
+// ==================================================================================
+// k_step_decode (OPT-IN, BOURSE_AMD_STEP_DECODE=1; round 4's experiment re-tried on round 5's kernels as VERDICT r4 item 2 asked):
+// Env::step of step s (the body of k_step_batch) FOLLOWED BY the decode of step s + 1 (the body of k_agents_wave) for the same
+// book in one launch - a part's inner steps are ONE launch instead of two, a wave goes from its events straight into its next
+// decode.  Nothing is carried between the halves but the header words a decode reads (RNG state, live masks), taken from the
+// registers the store has just written.  The level bins of the event half live in the ring's LDS (dead until the decode
+// generates into it).  Measured: docs/EXPERIMENTS.md (round 4: neutral at 8 192 books, slower above; round 5: see there).
+// (Round 4 also built k_run_split = the whole launch persistent with the book parked in its state block between the halves,
+//  eight waves per SIMD, every book of a C4 shard resident (commit 0ff3c3c): 112.5 M against 118.0 M - removed.)
+// ==================================================================================
+#ifndef BOURSE_AMD_SD_OCC
+#define BOURSE_AMD_SD_OCC(R) BOURSE_AMD_AW_OCC(R)
+#endif
+template <int R>
+__global__ __launch_bounds__(256, BOURSE_AMD_SD_OCC(R)) void k_step_decode(DevArgs a, WaveArgs wa, uint64_t step_index, uint32_t write_last) {
+  __shared__ WaveLds<R> L;
+  static_assert(WV_RING >= (uint32_t)LDS_DW_PER_WAVE, "the level bins alias the ring");
+  const int lane = threadIdx.x & 63;
+  const int wv = (int)rfl(threadIdx.x >> 6);
+  for (int i = threadIdx.x; i < 512; i += 256) L.tab[i] = wa.jt_block[i];
+  __syncthreads();
+  const uint32_t book = rfl(a.book_begin + blockIdx.x * 4 + wv);
+  if (book >= a.book_end) return;
+  uint32_t hdr = 0;
+  WaveHdrScalars hs{};
+  {
+    Book<R> B;
+    Rng rng;
+    step_batch_book<R, false, false>(a, book, lane, L.ring[wv], step_index, write_last, B, rng, a.hist_slot0);
+    hs.s0l = rfl((uint32_t)rng.s0), hs.s0h = rfl((uint32_t)(rng.s0 >> 32));
+    hs.s1l = rfl((uint32_t)rng.s1), hs.s1h = rfl((uint32_t)(rng.s1 >> 32));
+    hs.lv0 = B.live[0];
+    hs.lv1 = R >= 2 ? B.live[R >= 2 ? 1 : 0] : 0ull;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {  // (the larger pools' walk reads the live words from lanes H_LIVE0 .. of this register)
+      hdr = wrl((uint32_t)B.live[r], H_LIVE0 + 2 * r, hdr);
+      hdr = wrl((uint32_t)(B.live[r] >> 32), H_LIVE0 + 2 * r + 1, hdr);
+    }
+  }
+  wave_sync();  // the bins' LDS becomes the ring
+  agents_wave_book<R>(a, wa, L, wv, book, lane, hdr, &hs);
+}
 
 // ==================================================================================
 // Fused form: n_steps x { agents.update (wave-parallel decode); Env::step } per book with the book in registers and the

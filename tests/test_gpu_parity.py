@@ -1827,6 +1827,46 @@ def test_strict_env_reports_a_flag_once_and_step_size_only_warns(bk):
         tiny.step()                              # 3 events >= step_size 2: flagged, warned, not raised
     assert tiny.flags()[0] == 4
     assert int(tiny.level2()[0][4]) == 3
+    # a workload that queues >= step_size events EVERY step (which the reference tolerates) is warned about once;
+    # the warning-only bit stays on the device and is no longer polled, clear_flags() re-arms it
+    import warnings
+
+    for i in range(3):
+        tiny.place_order(0, True, 1, 0, 20 + i)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        tiny.step()
+    assert tiny.flags()[0] == 4 and tiny.flags_summary()[0] == 4
+    tiny.clear_flags()
+    for i in range(3):
+        tiny.place_order(0, True, 1, 0, 30 + i)
+    with pytest.warns(RuntimeWarning, match="STEP_SIZE"):
+        tiny.step()
+
+
+def test_reported_flag_bits_travel_with_the_python_checkpoint(bk):
+    """raise_on_flags moves reported ERROR bits off the device into a host-side record; ManyBookEnv.checkpoint()
+    carries that record as a trailer, so flags() reads the same after a restore into a fresh env."""
+    kw = dict(levels=32, max_live_orders=128, trade_capacity=8, history_capacity=4)
+    env = bk.ManyBookEnv(64, 101, 0, 2, 100_000, **kw)
+    env.set_random_agents(C3_GROUPS)
+    with pytest.raises(bk.CapacityError, match="TRADE_OVERFLOW"):
+        env.run(4)  # ~35 trades per book-step against 8 retained records
+    f = env.flags()
+    assert (f & 2).any() and env.flags_summary()[0] == 0  # reported: moved to the host-side record
+    img = env.checkpoint()
+    assert img.nbytes == int(env._L.bk_checkpoint_bytes(env._h)) + 16 + 4 * 64
+    fresh = bk.ManyBookEnv(64, 101, 0, 2, 100_000, **kw)
+    fresh.set_random_agents(C3_GROUPS)
+    fresh.restore(img)
+    assert np.array_equal(fresh.flags(), f)
+    plain = bk.ManyBookEnv(64, 101, 0, 2, 100_000, strict=False, **kw)  # an env that never reported anything: no trailer
+    plain.set_random_agents(C3_GROUPS)
+    plain.run(4)
+    img2 = plain.checkpoint()
+    assert img2.nbytes == int(plain._L.bk_checkpoint_bytes(plain._h))
+    fresh.restore(img2)
+    assert np.array_equal(fresh.flags(), plain.flags()) and (plain.flags() & 2).any()
 
 
 def test_step_env_trades_outlive_the_device_trade_buffer(bk, oracle):
