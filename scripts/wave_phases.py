@@ -11,6 +11,8 @@ WL = sys.argv[3] if len(sys.argv) > 3 else "C3"
 SKEW = "--skew" in sys.argv  # also: one step on its own, every wave's absolute start / end inside its launch
 if WL == "C5":
     G, LV, POOL = [(256, (100, 164), (10, 20), 2, 0.8), (256, (100, 164), (50, 70), 2, 0.2)], 64, 512
+elif WL == "C2":
+    G, LV, POOL = [(32, (40, 56), (10, 20), 2, 0.8), (32, (40, 56), (50, 70), 2, 0.2)], 16, 64
 else:
     G, LV, POOL = [(64, (32, 64), (10, 20), 2, 0.8), (64, (32, 64), (50, 70), 2, 0.2)], 32, 128
 env = bk.ManyBookEnv(B, 101, 0, 2, 100_000, levels=LV, max_live_orders=POOL, trade_capacity=POOL // 2 * 50, history_capacity=50, strict=False)
