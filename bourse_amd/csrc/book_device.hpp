@@ -1661,15 +1661,38 @@ __device__ __forceinline__ int find_free_slot(const Book<R>& B) {
   return -1;
 }
 
+// A new order into pool slot n (k_step_events): all four fields and both masks from ONE per-lane predicate per pool register -
+// a vector compare whose result is the slot's bit (the ballot), four selects, three scalar mask operations.  slot_write /
+// mask_set do the same through a wave-uniform branch per register and field: ~56 scalar-port instructions per order at
+// R = 4 against 12, on the kernel's binding port (round 5, docs/EXPERIMENTS.md).
+template <int R>
+__device__ __forceinline__ void insert_order(Book<R>& B, int lane, uint32_t n, uint32_t price, uint32_t vol, uint32_t id,
+                                             uint32_t seq, bool is_bid) {
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const bool mine = (uint32_t)lane + 64u * (uint32_t)r == n;
+    const uint64_t M = __ballot(mine);
+    B.price[r] = mine ? price : B.price[r];
+    B.vol[r] = mine ? vol : B.vol[r];
+    B.id[r] = mine ? id : B.id[r];
+    B.seq[r] = mine ? seq : B.seq[r];
+    B.live[r] |= M;
+    B.bid[r] = is_bid ? (B.bid[r] | M) : (B.bid[r] & ~M);
+  }
+}
+
 // timing experiments only (scripts/ev_phase_times.sh): -DBOURSE_AMD_EV_SKIP=bits leaves phases of k_step_events out (results
 // are then wrong): 1 the shuffle's swaps, 2 the order-log writes, 4 matching
 #ifndef BOURSE_AMD_EV_SKIP
 #define BOURSE_AMD_EV_SKIP 0
 #endif
+#ifndef BOURSE_AMD_EV_OCC
+#define BOURSE_AMD_EV_OCC(R) ((R) <= 4 ? 8 : 5)
+#endif
 template <int R>
-// (eight waves per SIMD for pools of <= 256 slots: 8 192 books - the C4 shard, the ingress rate scripts - are then ONE residency round;
+// (eight waves per SIMD for pools of <= 256 slots, five for 512: 8 192 books - the C4 shard, the ingress rate scripts - are then ONE residency round;
 // at the 69 VGPRs the compiler took for R = 4 a seventh of the waves ran as a second round)
-__global__ __launch_bounds__(64, R <= 4 ? 8 : 4) void k_step_events(DevArgs a, uint64_t step_index) {
+__global__ __launch_bounds__(64, BOURSE_AMD_EV_OCC(R)) void k_step_events(DevArgs a, uint64_t step_index) {
   __shared__ uint32_t bins[LDS_DW_PER_WAVE];
   // the shuffle permutation: dynamic LDS sized by the host to this step's longest queue (<= EV_LDS_CAP entries), so
   // that quiet steps do not pay 16 KB of LDS per one-wave workgroup in occupancy
@@ -1697,15 +1720,32 @@ __global__ __launch_bounds__(64, R <= 4 ? 8 : 4) void k_step_events(DevArgs a, u
   for (uint32_t j = lane; j < n_ev; j += 64) perm[j] = (uint16_t)j;
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
-  for (uint32_t i = (BOURSE_AMD_EV_SKIP & 1) ? 0u : n_ev; i-- > 1;) {  // shuffle (env.rs:121)
-    const uint32_t j = rng.below(i + 1);
-    const uint32_t pi = rfl(perm[i]), pj = rfl(perm[j]);
-    if (lane == 0) {
+  // shuffle (env.rs:121): for i in (1..n).rev() swap(i, gen_range(0..i + 1)).  Round 5: the kernel is bound by the CU's ONE
+  // scalar port (9.9 k scalar-port instructions per book-step, 43 % of the wave-cycles waiting for issue; docs/EXPERIMENTS.md), and
+  // this loop was a quarter of them - the generator's 64-bit arithmetic (~22 scalar instructions per draw), the rejection
+  // test, the swap's lane-0 masking.  The SAME arithmetic now runs on the vector unit, which has the slots: the state as
+  // four 32-bit halves in vector registers (RngLane - every lane computes the same value), the swap as plain LDS reads and
+  // writes by all lanes (same address, same value), one vector-to-scalar hand-over per draw for the accept test.
+  {
+    RngLane v{(uint32_t)rng.s0, (uint32_t)(rng.s0 >> 32), (uint32_t)rng.s1, (uint32_t)(rng.s1 >> 32)};
+    asm volatile("" : "+v"(v.a0), "+v"(v.a1), "+v"(v.b0), "+v"(v.b1));  // (uniform values: keep the compiler from moving them back to the scalar unit)
+    for (uint32_t i = (BOURSE_AMD_EV_SKIP & 1) ? 0u : n_ev; i-- > 1;) {
+      const uint32_t range = i + 1u, zone = (range << __builtin_clz(range)) - 1u;  // UniformInt<u32>::sample_single (App. B.3)
+      uint32_t j;
+      for (;;) {
+        const uint32_t x = v.next_u32();
+        const uint32_t lo = x * range;
+        j = __umulhi(x, range);
+        if (rfl((uint32_t)(lo <= zone))) break;
+      }
+      const uint32_t pi = perm[i], pj = perm[j];
       perm[i] = (uint16_t)pj;
       perm[j] = (uint16_t)pi;
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
+    rng.s0 = mk64(rfl(v.a0), rfl(v.a1));
+    rng.s1 = mk64(rfl(v.b0), rfl(v.b1));
   }
   uint4 evr = make_uint4(0u, 0u, 0u, 0u);
   for (uint32_t k = 0; k < n_ev; ++k) {
@@ -1753,25 +1793,29 @@ __global__ __launch_bounds__(64, R <= 4 ? 8 : 4) void k_step_events(DevArgs a, u
         if (n < 0) {
           B.flags |= FLAG_POOL_OVERFLOW;
         } else {
-          slot_write<R>(B.price, n, p);
-          slot_write<R>(B.vol, n, v);
-          slot_write<R>(B.id, n, id);
-          slot_write<R>(B.seq, n, B.seq_ctr);
+          insert_order<R>(B, lane, (uint32_t)n, p, v, id, B.seq_ctr, is_bid);
           B.seq_ctr += 1;
-          mask_set<R>(B.bid, n, is_bid);
-          mask_set<R>(B.live, n, true);
         }
       }
       // key: provisional (price, 0) from create_order (orderbook.rs:388-391) unless the order rests (:501-505)
       log_write(lg, B.flags, lane, id, status, v, p, tk, end, true, true, status == 1 ? tk : 0ull);
     } else if (kind == 1) {
       // ---- Cancellation (orderbook.rs:622-644): only an Active order changes
-      const int n = find_live_by_id<R>(B, id);
-      if (n >= 0) {
-        const uint32_t v = slot_read<R>(B.vol, n);
-        const uint32_t p = slot_read<R>(B.price, n);
-        mask_set<R>(B.live, n, false);
-        log_write(lg, B.flags, lane, id, 3, v, p, 0, tk, false);
+      // (one pass over the pool registers: the order's bit, if it is live, from a per-lane compare; its volume and price
+      // picked by that lane - no slot index, no per-register scalar selects; ids are unique, so at most one bit is set)
+      uint64_t any = 0;
+      uint32_t vsel = 0, psel = 0;
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const uint64_t hit = B.live[r] & __ballot(B.id[r] == id);
+        B.live[r] &= ~hit;
+        any |= hit;
+        vsel = lane_bit(hit) ? B.vol[r] : vsel;
+        psel = lane_bit(hit) ? B.price[r] : psel;
+      }
+      if (any) {
+        const uint32_t l = (uint32_t)__builtin_ctzll(any);
+        log_write(lg, B.flags, lane, id, 3, rdl(vsel, l), rdl(psel, l), 0, tk, false);
       }
     } else {
       // ---- Modify (orderbook.rs:743-772, 656-723): only an Active order changes
