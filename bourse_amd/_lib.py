@@ -116,6 +116,7 @@ SIGNATURES = {
     "bk_ingress_staging": (_i32, [_vp, _u64, C.POINTER(IngressArrays)]),
     "bk_submit_instructions_host": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _p64]),
     "bk_submit_result": (_i32, [_vp, _u64, _vp, _vp, _p32]),
+    "bk_submit_result_view": (_i32, [_vp, _u64, C.POINTER(_vp), C.POINTER(_vp), _p32]),
     "bk_order_status": (_i32, [_vp, _u32, _u64, _p8]),
     "bk_order_count": (_i32, [_vp, _u32, _p64]),
     "bk_get_orders": (_i32, [_vp, _u32, _u64, _u64, _vp]),

@@ -1291,32 +1291,44 @@ int hi_ensure(bk_env* env, size_t n_elem) {
   return BK_OK;
 }
 
-// large host copies on the env's host threads (a 10 MB batch is ~1 ms on one thread, more than its upload takes): all
-// arrays of a submit in ONE run of the pool, cut into 256 KB pieces
+// The staging copies: the calling thread alone below 1 MB, else FOUR threads of the env's pool claiming 256 KB pieces one at a
+// time.  Measured on three boxes at 9.8 MB per step (scripts/host_driven_rate.py, `tickets`): one thread 0.30 - 0.40 ms (the copy
+// then bounds the step: 15 M book-steps/s), sixteen threads 0.19 ms on a quiet box (24.6 M) but 0.9 ms on a busy one (a parallel
+// copy is as fast as its slowest worker gets scheduled, and sixteen runnable threads meet the container's CPU quota), four
+// threads with pieces claimed dynamically: see docs/EXPERIMENTS.md.
 struct HiSeg {
   void* dst;
   const void* src;
   size_t bytes;
 };
 void hi_copy(bk_env* env, const HiSeg* segs, int n_segs) {
-  constexpr size_t CHUNK = 256u << 10;
+  constexpr size_t PIECE = 256u << 10, PARALLEL_FROM = 1u << 20;
+  size_t total = 0;
+  for (int i = 0; i < n_segs; ++i)
+    if (segs[i].dst != segs[i].src) total += segs[i].bytes;  // (dst == src: the caller filled the staging array in place)
+  if (total < PARALLEL_FROM) {
+    for (int i = 0; i < n_segs; ++i)
+      if (segs[i].dst != segs[i].src && segs[i].bytes) std::memcpy(segs[i].dst, segs[i].src, segs[i].bytes);
+    return;
+  }
   struct Piece {
     char* d;
     const char* s;
     size_t n;
   };
   std::vector<Piece> pieces;
-  size_t total = 0;
   for (int i = 0; i < n_segs; ++i) {
     const HiSeg& g = segs[i];
-    if (g.dst == g.src || g.bytes == 0) continue;  // the caller filled the staging array in place (bk_ingress_staging)
-    total += g.bytes;
-    for (size_t o = 0; o < g.bytes; o += CHUNK)
-      pieces.push_back({static_cast<char*>(g.dst) + o, static_cast<const char*>(g.src) + o, std::min(CHUNK, g.bytes - o)});
+    if (g.dst == g.src) continue;
+    for (size_t o = 0; o < g.bytes; o += PIECE)
+      pieces.push_back({static_cast<char*>(g.dst) + o, static_cast<const char*>(g.src) + o, std::min(PIECE, g.bytes - o)});
   }
-  auto task = [&](unsigned t) { std::memcpy(pieces[t].d, pieces[t].s, pieces[t].n); };
-  if (total < 4 * CHUNK || pieces.size() > HostPool::MAX_TASKS || !env->host_pool().run(static_cast<unsigned>(pieces.size()), task))
-    for (unsigned t = 0; t < pieces.size(); ++t) task(t);
+  std::atomic<size_t> next{0};
+  auto worker = [&](unsigned) {
+    for (size_t k = next.fetch_add(1); k < pieces.size(); k = next.fetch_add(1)) std::memcpy(pieces[k].d, pieces[k].s, pieces[k].n);
+  };
+  const unsigned nt = std::min<unsigned>(4u, env->host_pool().threads());
+  if (nt <= 1 || !env->host_pool().run(nt, worker)) worker(0);
 }
 }  // namespace
 
@@ -1398,6 +1410,30 @@ int bk_submit_instructions_host(bk_env* env, const uint64_t* book_offsets, const
   h.n_elem[s] = n;
   h.next_ticket = ticket + 1;
   if (out_ticket) *out_ticket = ticket;
+  return BK_OK;
+}
+
+int bk_submit_result_view(bk_env* env, uint64_t ticket, const uint64_t** out_ids, const uint32_t** status,
+                          uint32_t* first_failed_book) {
+  if (!env) return fail(BK_INVALID_ARGUMENT, "null env");
+  bk_env::HostIngress& h = env->hi;
+  const int s = static_cast<int>(ticket % bk_env::HostIngress::SLOTS);
+  if (ticket >= h.next_ticket || h.ticket_of[s] != ticket)
+    return fail(BK_INVALID_ARGUMENT, "unknown or expired ticket (a ticket's results stay readable until two more submits)");
+  if (int rc = use_device(env)) return rc;
+  HIPCHK(hipEventSynchronize(h.e_done[s]));
+  const size_t B = env->cfg.n_books;
+  const uint32_t* st = reinterpret_cast<const uint32_t*>(h.pin[s] + h.o_st);
+  if (out_ids) *out_ids = reinterpret_cast<const uint64_t*>(h.pin[s] + h.o_out);
+  if (status) *status = st;
+  if (first_failed_book) {
+    *first_failed_book = 0xFFFFFFFFu;
+    for (size_t b = 0; b < B; ++b)
+      if (st[2 * b] != BK_OK) {
+        *first_failed_book = static_cast<uint32_t>(b);
+        break;
+      }
+  }
   return BK_OK;
 }
 

@@ -244,13 +244,28 @@ class ManyBookEnv:
         self._ticket_n.pop(int(t.value) - 2, None)
         return int(t.value)
 
-    def submit_result(self, ticket: int, ids: bool = True, out: Optional[np.ndarray] = None, status: Optional[np.ndarray] = None):
+    def submit_result(self, ticket: int, ids: bool = True, out: Optional[np.ndarray] = None, status: Optional[np.ndarray] = None,
+                      view: bool = False):
         """(ids u64[n] or None, status u32[n_books, 2] = {code, elements applied}, lowest failing book or None) of a ticket.
-        ``out`` / ``status``: arrays to fill instead of fresh ones (a loop that fetches every step saves their page faults)."""
+        ``out`` / ``status``: arrays to fill instead of fresh ones (a loop that fetches every step saves their page faults).
+        ``view=True``: no copy at all - read-only numpy views of the library's pinned staging, valid until two more submits."""
         n = getattr(self, "_ticket_n", {}).get(int(ticket))
         if n is None:  # not a ticket of this env, or two submits old: the library says which
             check(self._L.bk_submit_result(self._h, int(ticket), None, None, None))
             raise _lib.BourseError(_lib.BK_INVALID, f"ticket {ticket}: its element count is no longer known")
+        if view:
+            pi, ps, bad = C.c_void_p(0), C.c_void_p(0), C.c_uint32(0)
+            check(self._L.bk_submit_result_view(self._h, int(ticket), C.byref(pi), C.byref(ps), C.byref(bad)))
+
+            def ro(ptr, dtype, count, shape):
+                if count == 0:
+                    return np.zeros(shape, dtype=dtype)
+                a = np.frombuffer((C.c_char * (count * np.dtype(dtype).itemsize)).from_address(ptr), dtype=dtype, count=count).reshape(shape)
+                a.flags.writeable = False
+                return a
+
+            return ((ro(pi.value, np.uint64, n, (n,)) if ids else None), ro(ps.value, np.uint32, 2 * self.n_books, (self.n_books, 2)),
+                    (None if bad.value == 0xFFFFFFFF else int(bad.value)))
         if ids:
             if out is None:
                 out = np.empty(n, dtype=np.uint64)

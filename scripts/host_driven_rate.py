@@ -6,6 +6,7 @@ rust/src/step_sim_numpy.rs:233-275), then the books step.  Four ways through the
              threads), 16 B per event uploaded (rounds 1-4's only way for host arrays)
   sync       bk_submit_instructions_host on a device-ingress env, ids fetched before the step (the reference's call shape)
   tickets    the same with the ids of step s fetched after step s + 1 went out (two submits in flight)
+  views      tickets with the results read in place (read-only views of the pinned staging, no copy out)
   staging    tickets + the arrays written in place into the library's pinned staging (no host copy inside the library)
 
 The instruction arrays are generated ahead of the timed loops: the rates are the library's, not numpy's RNG.
@@ -95,6 +96,23 @@ ids, st, bad = env.submit_result(prev, out=IDS, status=ST)
 env.sync()
 report("tickets", env, time.perf_counter() - t0)
 assert np.array_equal(env.level2(), ref_l2) and np.array_equal(env.trade_counts(), ref_tc), "tickets != host-env"
+env.close()
+
+# ---- tickets, results as views of the pinned staging (no copy out)
+env = env_new(True)
+prev = None
+for s in range(T + 3):
+    if s == 3:
+        env.sync(); t0 = time.perf_counter()
+    t = env.submit_instructions_all_async(off, batches[s])
+    env.step(sync=False)
+    if prev is not None:
+        ids, st, bad = env.submit_result(prev, view=True)
+    prev = t
+ids, st, bad = env.submit_result(prev, view=True)
+env.sync()
+report("views", env, time.perf_counter() - t0)
+assert np.array_equal(env.level2(), ref_l2) and np.array_equal(env.trade_counts(), ref_tc), "views != host-env"
 env.close()
 
 # ---- staging: the agent layer writes into the pinned arrays (here: a copy out of the pre-generated batch = the agent's
