@@ -1274,19 +1274,24 @@ int hi_ensure(bk_env* env, size_t n_elem) {
     }
   }
   if (n_elem <= h.cap && h.pin[0]) return BK_OK;
-  // grow: everything in flight must have landed first (results of earlier tickets are dropped with their slots)
+  // grow: everything in flight must have landed first; the results the slots hold (ids + status of the last two tickets - a
+  // caller that fetches one submit late has not read them yet) move into the new staging
   HIPCHK(hipStreamSynchronize(h.in));
   HIPCHK(hipStreamSynchronize(env->stream));
   HIPCHK(hipStreamSynchronize(h.out));
   const size_t cap = std::max<size_t>((n_elem + n_elem / 4 + 1023) & ~size_t(1023), 1024);
+  const bk_env::HostIngress old = h;
   h.layout(env->cfg.n_books, cap);
   for (int i = 0; i < bk_env::HostIngress::SLOTS; ++i) {
-    if (h.pin[i]) HIPCHK(hipHostFree(h.pin[i]));
-    if (h.dev[i]) HIPCHK(hipFree(h.dev[i]));
     h.pin[i] = h.dev[i] = nullptr;
-    h.ticket_of[i] = ~0ull;
     HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&h.pin[i]), h.bytes, hipHostMallocDefault));
     HIPCHK(hipMalloc(reinterpret_cast<void**>(&h.dev[i]), h.bytes));
+    if (old.pin[i] && old.ticket_of[i] != ~0ull) {
+      std::memcpy(h.pin[i] + h.o_out, old.pin[i] + old.o_out, old.n_elem[i] * 8);
+      std::memcpy(h.pin[i] + h.o_st, old.pin[i] + old.o_st, static_cast<size_t>(env->cfg.n_books) * 8);
+    }
+    if (old.pin[i]) HIPCHK(hipHostFree(old.pin[i]));
+    if (old.dev[i]) HIPCHK(hipFree(old.dev[i]));
   }
   return BK_OK;
 }

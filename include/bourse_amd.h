@@ -214,7 +214,8 @@ int bk_step_async(bk_env* env);
  * stages them in pinned memory (host threads), uploads them on a copy stream of its own, runs the ingest kernel on the
  * env's stream and brings ids and per-book status back on a second copy stream.  Asynchronous: returns a ticket at
  * once; two tickets are in flight at most (the upload of one under the step kernel of the other), and
- * bk_submit_result(ticket) waits for that ticket only.  A ticket's results stay readable until two more submits.
+ * bk_submit_result(ticket) waits for that ticket only.  A ticket's results stay readable until two more submits (also
+ * across a batch that outgrows the staging: the results move with it).
  *   bk_ingress_staging: OPTIONAL zero-copy - pinned arrays (>= min_elements each; book_offsets n_books + 1) that the NEXT
  *     bk_submit_instructions_host call will upload from: fill them in place and pass these very pointers (any array
  *     passed from elsewhere is copied as usual).  Valid until that submit returns.

@@ -260,6 +260,20 @@ def test_host_arrays_through_device_ingress_equal_host_calls_and_oracle_on_8192_
     assert np.array_equal(ids.reshape(B, 40), np.tile(np.arange(1, 41, dtype=np.uint64), (B, 1)))
     dq.step()
     assert (dq.level2()[:, 1] == 80).all() and (dq.level2()[:, 2] == 90).all() and not dq.flags().any()
+    # ... and a ticket whose results have not been fetched yet survives the re-allocation a LATER, larger batch causes
+    # (scripts/fuzz_device_ingress.py seed 3529, round 5: "unknown or expired ticket")
+    dg = bk.ManyBookEnv(B, 1, 0, 1, 100_000, levels=10, max_live_orders=128, max_orders=128, trade_capacity=64)
+    dg.enable_device_ingress(128)
+    one = lambda n, v, dt: np.full(n, v, dtype=dt)  # noqa: E731
+    ta = dg.submit_instructions_all_async(np.arange(B + 1, dtype=np.uint64), (one(B, 1, np.uint32), one(B, 0, np.uint8), one(B, 1, np.uint32),
+                                                                           one(B, 0, np.uint32), one(B, 90, np.uint32), one(B, 0, np.uint64)))
+    tb = dg.submit_instructions_all_async(offb, (one(big, 1, np.uint32), one(big, 1, np.uint8), one(big, 1, np.uint32), one(big, 0, np.uint32),
+                                                 one(big, 80, np.uint32), one(big, 0, np.uint64)))
+    ids_a, st_a, bad_a = dg.submit_result(ta)
+    ids_b, st_b, bad_b = dg.submit_result(tb, view=True)
+    assert (ids_a == 0).all() and bad_a is None and (st_a[:, 1] == 1).all()
+    assert np.array_equal(ids_b.reshape(B, 40), np.tile(np.arange(1, 41, dtype=np.uint64), (B, 1))) and (st_b[:, 1] == 40).all()
+    dg.close()
     dq.close()
     for d in devs.values():
         d.close()
