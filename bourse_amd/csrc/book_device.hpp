@@ -70,7 +70,11 @@ __device__ unsigned int* g_stamp_ptr;
     g_stamp_ptr[(size_t)(obj).stamp_book * BK_STAMP_WORDS + (kernel) * 8 + ((kernel) ? 4 : 6)] = (obj).stamp_t0;            \
     g_stamp_ptr[(size_t)(obj).stamp_book * BK_STAMP_WORDS + (kernel) * 8 + ((kernel) ? 5 : 2)] = (unsigned int)(obj).stamp_t; \
   }
+// (diagnostic tallies in the words a run does not stamp: C5 as written leaves 8..23 - the k_agents_wave rows - free)
+#define BK_STAMP_TALLY(obj, word, lane) \
+  if ((lane) == 0) g_stamp_ptr[(size_t)(obj).stamp_book * BK_STAMP_WORDS + (word)] += 1u
 #else
+#define BK_STAMP_TALLY(obj, word, lane)
 #define BK_STAMP_FIELD
 #define BK_STAMP_START(obj, book)
 #define BK_STAMP(obj, kernel, phase, lane)
@@ -875,6 +879,10 @@ __device__ __forceinline__ void store_book(const Book<R>& B, const Rng& rng, uin
 #ifndef BOURSE_AMD_KEY_SEQ_BITS
 #define BOURSE_AMD_KEY_SEQ_BITS 16
 #endif
+// 0: a step whose prices do not fit the window always runs the two-reduction loop (rounds 2 - 4); 1: keys_begin_wide first
+#ifndef BOURSE_AMD_KEYED_WIDE
+#define BOURSE_AMD_KEYED_WIDE 1
+#endif
 constexpr uint32_t KEY_SB = BOURSE_AMD_KEY_SEQ_BITS;
 constexpr uint32_t KEY_SMASK = (1u << (KEY_SB < 16u ? KEY_SB : 16u)) - 1u;       // arrival window
 constexpr uint32_t KEY_PSPAN = (1u << (31u - (KEY_SB > 16u ? KEY_SB : 16u))) - 6u;  // price window
@@ -925,6 +933,100 @@ __device__ __forceinline__ bool keys_begin(const Book<R>& B, const uint64_t (&ne
     K.key[r] = lane_bit(B.live[r]) ? ((pf << 16) | (bidl ? 0xFFFFu - sf : KEY_ASK | sf)) : 0u;
     // (0 for a lane without a pending order: a members' list, which holds bare slots, is classified by this word alone -
     // New iff it is not 0, a bid iff bit 15 is set)
+    K.pk[r] = lane_bit(lim[r]) ? (bidl ? 0x8000u | pf : pf) : 0u;
+    if (MARKETS) K.pk[r] = lane_bit(newm[r] & ~lim[r]) ? (bidl ? 0xFFFFu : 1u) : K.pk[r];
+  }
+  K.sq = KEY_ASK | (B.seq_ctr - K.sbase);
+  K.alo = (int32_t)0x80000000u;
+  K.bhi = 0x7FFFFFFF;
+  return true;
+}
+// The keyed loop for a step whose prices do NOT fit the window (round 5).  C5 as written: MomentumAgent limit buys sit at
+// mid - exp(N(0, 10^2)), a third of them clamped to price 0 - far below everything that trades - and 12 % of the book-steps
+// failed key_window and ran the two-reduction loop at ~3 x the cost per event; one such book holds its whole launch.
+// Here the window is anchored at the TOP price and the bids below it are SATURATED: price field 1, below every in-window
+// field (>= 2) - so they lose every reduction to any in-window bid, no limit ask of the window crosses them (its compare
+// value has field >= 2), a market ask does (KP_MKT_ASK is field 1, arrival 0) - exactly the reference's semantics as long as
+// no aggressor REACHES one, because among themselves they are ordered by arrival only, not by price.  That is guaranteed up
+// front: the volume that this step's new asks can take - the market asks', and the limit asks' priced at or below the
+// highest bid that rests in this step - must not exceed the volume of the in-window bids that rest now and are not
+// cancelled in this step (new bids only add to it): asks consume the best bids first, and those outlast them.  An ask below the window, a price at u32::MAX, a volume >= 2^22 (the sums stay in 32 bits) or a
+// failed guard: the caller falls back to the two-reduction loop as before.  ev / n_ev: the step's event list (a slot per
+// entry: the cancellations are the listed slots without a pending order); bins: >= 16 words of LDS not in use yet.
+template <int R, bool MARKETS>
+__device__ __forceinline__ bool keys_begin_wide(const Book<R>& B, const uint64_t (&newm)[R], uint32_t n_ev, KeyState<R>& K,
+                                                const uint32_t (&ev)[R], uint32_t* bins, int lane) {
+  uint64_t lim[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+    lim[r] = MARKETS ? newm[r] & ~__ballot(B.price[r] == (lane_bit(B.bid[r]) ? 0xFFFFFFFFu : 0u)) : newm[r];
+  BK_STAMP_TALLY(B, 9, lane);  // (diagnostic build: the narrow window failed)
+  uint32_t pmax = 0, age = 0, vbig = 0;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const bool lv = lane_bit(B.live[r]), in = lv | lane_bit(lim[r]);
+    pmax = max(pmax, in ? B.price[r] : 0u);
+    age = max(age, lv ? B.seq_ctr - B.seq[r] : 0u);
+    vbig = max(vbig, (lv | lane_bit(newm[r])) ? B.vol[r] : 0u);
+  }
+  uint32_t dummy = 0xFFFFFFFFu;
+  wave_reduce3(pmax, dummy, age);
+  vbig = wave_umax(vbig);
+  if (pmax == 0xFFFFFFFFu || pmax < 2u || age + n_ev >= KEY_SMASK - 1u || vbig >= (1u << 22)) {
+    BK_STAMP_TALLY(B, pmax == 0xFFFFFFFFu ? 10 : (age + n_ev >= KEY_SMASK - 1u ? 11 : 12), lane);
+    return false;
+  }
+  const uint32_t pbase = pmax > KEY_PSPAN ? pmax - KEY_PSPAN : 0u, lowp = pbase + 2u;  // in the window: lowp <= price <= pmax
+  // this step's listed slots (one event per slot at most): a 512-bit map in LDS
+  if (lane < 2 * R) bins[lane] = 0u;
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int re = 0; re < R; ++re) {
+    const uint32_t slot = ev[re] & EV_SLOT & (64u * R - 1u);
+    if ((uint32_t)(re * 64 + lane) < n_ev) atomicOr(&bins[slot >> 5], 1u << (slot & 31u));
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  // Which asks can take bid volume at all?  A MARKET ask always; a LIMIT ask only from bids priced at or above it - in-window
+  // bids by construction (its compare value has field >= 2) - and only if some bid that rests in this step is priced that
+  // high: the highest price among the live and the new limit bids bounds it.  (Counting every new ask, the first version of
+  // this guard turned away half of the steps it was built for: most of a NoiseAgent's limit asks sit above the book.)
+  uint32_t pbid = 0;
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+    pbid = max(pbid, ((lane_bit(B.live[r]) | lane_bit(lim[r])) && lane_bit(B.bid[r])) ? B.price[r] : 0u);
+  pbid = wave_umax(pbid);
+  uint32_t w_bid = 0, a_ask = 0;
+  uint64_t bad = 0;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const bool lv = lane_bit(B.live[r]), bidl = lane_bit(B.bid[r]), nw = lane_bit(newm[r]);
+    const bool below = (lv | lane_bit(lim[r])) && B.price[r] < lowp;
+    const bool listed = ((bins[(uint32_t)(r * 64 + lane) >> 5] >> ((uint32_t)lane & 31u)) & 1u) != 0u;
+    bad |= __ballot(below && !bidl);  // an ask below the window: not this path
+    w_bid += (lv && bidl && !below && !listed) ? B.vol[r] : 0u;
+    // (a market ask's price is 0 <= pbid: counted by the same compare)
+    a_ask += (nw && !bidl && B.price[r] <= pbid) ? B.vol[r] : 0u;
+  }
+  if (bad) {
+    BK_STAMP_TALLY(B, 13, lane);
+    return false;
+  }
+  w_bid = wave_add(w_bid);
+  a_ask = wave_add(a_ask);
+  if (a_ask > w_bid) {
+    BK_STAMP_TALLY(B, 14, lane);
+    return false;
+  }
+  BK_STAMP_TALLY(B, 15, lane);
+  K.pbase = pbase;
+  K.sbase = B.seq_ctr - age - 1u;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const bool bidl = lane_bit(B.bid[r]);
+    const uint32_t pf = B.price[r] < lowp ? 1u : B.price[r] - pbase, sf = B.seq[r] - K.sbase;  // (below the window: a bid, saturated)
+    K.key[r] = lane_bit(B.live[r]) ? ((pf << 16) | (bidl ? 0xFFFFu - sf : KEY_ASK | sf)) : 0u;
     K.pk[r] = lane_bit(lim[r]) ? (bidl ? 0x8000u | pf : pf) : 0u;
     if (MARKETS) K.pk[r] = lane_bit(newm[r] & ~lim[r]) ? (bidl ? 0xFFFFu : 1u) : K.pk[r];
   }
@@ -1118,7 +1220,11 @@ __device__ __forceinline__ uint32_t step_from_list(Book<R>& B, const DevArgs& a,
                            B.seq[0], ev[0], B.tr_k, B.tr_price, B.tr_vol, B.tr_act, B.tr_pas))
         flush_trades<R>(B, a, book, t0, lane);
     }
-  } else if (KeyState<R> K; (CLS || PENDKEY) && !MKT && BOURSE_AMD_KEYED_EVENTS && keys_begin<R, !CLS>(B, newm, rfl(n_ev), K)) {
+  } else if (KeyState<R> K; (CLS || PENDKEY) && !MKT && BOURSE_AMD_KEYED_EVENTS &&
+             (keys_begin<R, !CLS>(B, newm, rfl(n_ev), K) ||
+              // (members' lists only: RandomAgents draw their prices from a bounded tick window, and the extra path costs
+              // k_step_batch<8>'s RandomAgents instantiation 32 B of scratch at its 96-register claim)
+              (BOURSE_AMD_KEYED_WIDE && !CLS && keys_begin_wide<R, true>(B, newm, rfl(n_ev), K, ev, bins, lane)))) {
    if constexpr ((R == 4 || R == 8) && BOURSE_AMD_ASM_EVENTS && BOURSE_AMD_ASM_R48) {
     // the generated assembly loop (event_asm_gen.hpp): signed keys, compact trade records.
     // It reads SELF-CLASSIFYING event words (slot | EV_NEW | EV_BID) with the new order's compare value in the upper half.
