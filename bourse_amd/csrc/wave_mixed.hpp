@@ -42,12 +42,21 @@ namespace bkd {
 constexpr uint32_t FLAG_DECODE_LOOKAHEAD = 256u;  // a ziggurat ran past the decode's look-ahead (p < 2^-90): flagged
 constexpr uint32_t MW_RING = 512;                 // generated u64 draws kept in LDS
 constexpr uint32_t MW_LOOK = 192;                 // a window's draws + look-ahead: positions [w0, w0 + MW_LOOK)
-constexpr int MW_WPB = 8;                         // books (waves) per workgroup
+// books (waves) per workgroup: 8 (69.7 KB of LDS per workgroup since round 5's 64-entry price queue, two per CU = four waves
+// per SIMD).  Until the event kernel's launches got 40 % shorter (the top-anchored key window, book_device.hpp
+// keys_begin_wide) this kernel's occupancy did not matter - halving it cost 5 % -; since then the four parts' decode launches
+// queue for LDS and halving it costs 13 %.  NINE waves per workgroup (76.8 KB, 18 waves per CU, 80 VGPRs) was tried: 36.0
+// against 39.8 M - 228 workgroups per 2 048-book launch leave 28 CUs without one (docs/EXPERIMENTS.md).
+#ifndef BOURSE_AMD_MW_WPB
+#define BOURSE_AMD_MW_WPB 8
+#endif
+constexpr int MW_WPB = BOURSE_AMD_MW_WPB;
 
 // per wave: the u64 ring | event list, free-slot table (u16 x 64 R each; the table's memory becomes the shuffle's swap
-// targets) | orbit marks (72) + the pool's live words (16) + pad | deferred-price queue: 128 x f64 argument (its memory
-// becomes the shuffle's buckets) + 128 x u16 {slot, side}
-constexpr uint32_t MW_QCAP = 128;
+// targets) | orbit marks (72) + the pool's live words (16) + pad | deferred-price queue: 64 x f64 argument + 64 x u16
+// {slot, side} - marks + live words + queue are 1 KB together, which becomes the shuffle's buckets
+constexpr uint32_t MW_QCAP = 64;
+static_assert(96 * 4 + MW_QCAP * 8 + MW_QCAP * 2 >= 64 * 8 * 2, "the shuffle's buckets (u16 x 512) alias marks + live words + queue");
 constexpr uint32_t mw_wave_dwords(int R) { return 2 * MW_RING + 2 * 32 * R + 96 + 2 * MW_QCAP + MW_QCAP / 2; }
 constexpr uint32_t MW_SHARED_DW = 2048 + 2 * 514 + 4;  // T^256 table, ziggurat x / f tables (257 doubles each), pad
 constexpr size_t mixed_wave_lds_bytes(int R) { return (size_t)(MW_SHARED_DW + MW_WPB * mw_wave_dwords(R)) * 4; }
@@ -192,7 +201,7 @@ __device__ __forceinline__ double zig_from_stream(const Stream64& S, const doubl
 }
 
 template <int R>
-__global__ __launch_bounds__(512, 4) void k_agents_mixed_wave(DevArgs a, MixedArgs ma, WaveArgs wa, WaveLists wl) {
+__global__ __launch_bounds__(64 * MW_WPB, MW_WPB > 8 ? 5 : 4) void k_agents_mixed_wave(DevArgs a, MixedArgs ma, WaveArgs wa, WaveLists wl) {
   extern __shared__ uint32_t mw_lds[];
   constexpr uint32_t SL = 64u * R;
   uint4* tab = reinterpret_cast<uint4*>(mw_lds);
@@ -200,8 +209,8 @@ __global__ __launch_bounds__(512, 4) void k_agents_mixed_wave(DevArgs a, MixedAr
   double* zf = zx + 257;
   const int lane = threadIdx.x & 63;
   const int wv = (int)rfl(threadIdx.x >> 6);
-  for (int i = threadIdx.x; i < 512; i += 512) tab[i] = wa.jt_block[i];
-  for (int i = threadIdx.x; i < 257; i += 512) {
+  for (int i = threadIdx.x; i < 512; i += 64 * MW_WPB) tab[i] = wa.jt_block[i];
+  for (int i = threadIdx.x; i < 257; i += 64 * MW_WPB) {
     zx[i] = ZIG_NORM_X[i];
     zf[i] = ZIG_NORM_F[i];
   }
@@ -480,13 +489,14 @@ __global__ __launch_bounds__(512, 4) void k_agents_mixed_wave(DevArgs a, MixedAr
       {  // the orders whose price is still to come
         const bool qd = defer_a && n_created + before < n_free;
         const uint64_t qm = __ballot(qd);
+        if (qc + (uint32_t)__builtin_popcountll(qm) > MW_QCAP) drain(1u);  // (no room for this window's: price what waits first)
         if (qd) {
           const uint32_t qi = qc + __builtin_amdgcn_mbcnt_hi((uint32_t)(qm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)qm, 0u));
           q_arg[qi] = arg_a;
           q_info[qi] = (uint16_t)(freelist[n_created + before] | (buy_a ? 0x8000u : 0u));
         }
         qc += (uint32_t)__builtin_popcountll(qm);
-        drain(64u);
+        drain(MW_QCAP);
       }
       if (do_b) emit(n_created + before + ((do_a && ok_a) ? 1u : 0u), buy_b, buy_b ? 0xFFFFFFFFu : 0u, 0u);
       const uint32_t cnt = (uint32_t)__builtin_popcountll(CA) + (uint32_t)__builtin_popcountll(CB);
@@ -538,7 +548,7 @@ __global__ __launch_bounds__(512, 4) void k_agents_mixed_wave(DevArgs a, MixedAr
     Dc.wmask = reinterpret_cast<uint4*>(r32 + MW_RING);  // the upper half of the 64-bit ring's memory (2 KB), R <= 2 only
     if (R > 2) {  // large pools: the bucketed resolution's words there instead, its buckets in the price queue's memory
       Dc.co = r32 + MW_RING;
-      Dc.bucket = reinterpret_cast<uint16_t*>(q_arg);
+      Dc.bucket = reinterpret_cast<uint16_t*>(mark);  // (marks, live words and the price queue are dead here: 1 KB)
     }
     Dc.wcs = S.wcs;
     Dc.lane = lane;
