@@ -148,3 +148,82 @@ def test_the_model_and_the_device_header_agree_on_the_constants():
     for text in (asm, gen):
         assert "0xffff0000" in text and ", 0xffff" in text and "s_xor_b32" in text
     assert '"-1" if agg_bid else "0x10000"' in gen
+
+
+def test_saturated_low_bids_never_change_a_pick_when_the_liquidity_guard_holds():
+    """Round 5 (keys_begin_wide): a window anchored at the top price with the bids below it saturated at price field 1, plus
+    the up-front guard, picks exactly what price-time priority on the TRUE prices picks - over random steps of new limit /
+    market orders and cancellations in shuffled order on books that hold far-low bids (MomentumAgent bids clamped to 0)."""
+    import random
+
+    rng = random.Random(5)
+    exact = refused = 0
+    for trial in range(1500):
+        mid = rng.randrange(40_000, 60_000)
+        seq_ctr, live = 100, {}
+        for s in range(rng.randrange(4, 40)):  # resting book: near orders around the mid, some bids far below
+            is_bid = rng.random() < 0.6
+            far = is_bid and rng.random() < 0.35
+            price = rng.choice([0, 1, 7, mid - 40_000]) if far else (mid - rng.randrange(1, 200) if is_bid else mid + rng.randrange(1, 200))
+            live[s] = [price, rng.randrange(1, 120), is_bid, seq_ctr]
+            seq_ctr += 1
+        new = []
+        for _ in range(rng.randrange(1, 25)):
+            is_bid, market = rng.random() < 0.5, rng.random() < 0.3
+            off = rng.randrange(-60, 200)
+            price = (0xFFFFFFFF if is_bid else 0) if market else (mid - off if is_bid else mid + off)
+            if not market and is_bid and rng.random() < 0.2:
+                price = rng.choice([0, 3, mid - 39_000])
+            new.append((price, rng.randrange(1, 150), is_bid, market))
+        cancelled = set(rng.sample(sorted(live), rng.randrange(0, max(1, len(live) // 3))))
+        prices = [p for p, _, _, _ in live.values()] + [p for p, _, _, m in new if not m]
+        pbase = K.wide_pbase(max(prices))
+        g = K.wide_guard({s: (p, v, b) for s, (p, v, b, _) in live.items()}, new, cancelled, pbase)
+        if g is None or g[0] > g[1]:
+            refused += 1
+            continue
+        exact += 1
+        sbase = min(q for _, _, _, q in live.values()) - 1
+        events = [("new", i) for i in range(len(new))] + [("cancel", s) for s in cancelled]
+        rng.shuffle(events)
+        ref = {s: list(o) for s, o in live.items()}   # the reference: true prices
+        dev = {s: list(o) for s, o in live.items()}   # the keyed loop: keys with saturation
+        nxt, sq = max(live) + 1, seq_ctr
+        for kind, i in events:
+            if kind == "cancel":
+                ref.pop(i, None), dev.pop(i, None)
+                continue
+            price, vol, is_bid, market = new[i]
+            v_ref = v_dev = vol
+            kp = K.wide_prefix(price, is_bid, pbase, market)
+            while v_ref > 0:  # reference pick: best price, then oldest, on the other side
+                cand = [(s, o) for s, o in ref.items() if o[2] != is_bid]
+                if not cand:
+                    break
+                s_ref, o = min(cand, key=lambda so: ((so[1][0] if is_bid else -so[1][0]), so[1][3]))
+                if (price < o[0]) if is_bid else (price > o[0]):
+                    break
+                keys = [K.wide_key(o2[0], o2[3], o2[2], pbase, sbase) for o2 in dev.values()] + [K.DEAD]
+                best = K.best_of(keys, is_bid)
+                assert v_dev > 0 and K.crosses(kp, best, is_bid), (trial, "the keyed loop stops where the reference trades")
+                s_dev = next(s for s, o2 in dev.items() if K.wide_key(o2[0], o2[3], o2[2], pbase, sbase) == best)
+                assert s_dev == s_ref, (trial, "different passive order", s_dev, s_ref)
+                assert o[0] >= pbase + 2 or not o[2], (trial, "an aggressor reached a saturated bid")
+                tv = min(v_ref, o[1])
+                for book, s in ((ref, s_ref), (dev, s_dev)):
+                    book[s][1] -= tv
+                    if book[s][1] == 0:
+                        del book[s]
+                v_ref -= tv
+                v_dev -= tv
+            else:
+                pass
+            if v_dev > 0:  # the keyed loop stops too where the reference stopped
+                keys = [K.wide_key(o2[0], o2[3], o2[2], pbase, sbase) for o2 in dev.values()] + [K.DEAD]
+                assert not K.crosses(kp, K.best_of(keys, is_bid), is_bid) or not any(o2[2] != is_bid for o2 in dev.values()), trial
+            if v_ref > 0 and not market:
+                ref[nxt] = [price, v_ref, is_bid, sq]
+                dev[nxt] = [price, v_dev, is_bid, sq]
+                nxt, sq = nxt + 1, sq + 1
+        assert ref == dev, trial
+    assert exact > 500 and refused > 50, (exact, refused)

@@ -77,3 +77,39 @@ def rest(kp, arrival):
 def seq_of(k, sbase):
     f = k & 0xFFFF
     return sbase + (f if k & ASK else 0xFFFF - f)
+
+
+# ---- round 5: a step whose prices do not fit the window (book_device.hpp keys_begin_wide, members' lists) -----------------
+def wide_pbase(pmax):
+    """Window anchored at the TOP price: in-window prices are pbase + 2 .. pmax, fields 2 .. PSPAN."""
+    return pmax - PSPAN if pmax > PSPAN else 0
+
+
+def wide_field(price, pbase):
+    """Price field with the bids below the window SATURATED at 1 (asks are never below it: the set-up refuses such a step)."""
+    return 1 if price < pbase + 2 else price - pbase
+
+
+def wide_key(price, seq, is_bid, pbase, sbase):
+    s, f = seq - sbase, wide_field(price, pbase)
+    return ((f << 16) | (0xFFFF - s)) if is_bid else (ASK | (f << 16) | s)
+
+
+def wide_prefix(price, is_bid, pbase, market=False):
+    if market:
+        return MARKET_BID if is_bid else MARKET_ASK
+    f = wide_field(price, pbase)
+    return (((0x8000 | f) << 16) | 0xFFFF) if is_bid else (f << 16)
+
+
+def wide_guard(live, new, cancelled, pbase):
+    """live: {slot: (price, vol, is_bid)} resting now; new: [(price, vol, is_bid, market)] of this step; cancelled: slots with a
+    cancellation in this step's list.  None = "not this path" (an ask below the window); else (volume the asks can take,
+    volume of the in-window bids that outlast the step): the keyed loop is exact iff the first does not exceed the second."""
+    lowp = pbase + 2
+    if any(not b and p < lowp for p, _, b in live.values()) or any(not b and not m and p < lowp for p, _, b, m in new):
+        return None
+    pbid = max([p for p, _, b in live.values() if b] + [p for p, _, b, m in new if b and not m], default=0)
+    a_ask = sum(v for p, v, b, m in new if not b and (m or p <= pbid))
+    w_bid = sum(v for s, (p, v, b) in live.items() if b and p >= lowp and s not in cancelled)
+    return a_ask, w_bid
