@@ -191,6 +191,8 @@ struct WaveDecoder {
   uint4* wmask;        // LDS (R <= 2): 128 x 128-bit "steps that target this position" masks of the shuffle resolution
   uint32_t* co = nullptr;      // LDS (R > 2, optional): 64 R words {count << 16 | offset} of the bucketed resolution; without
   uint16_t* bucket = nullptr;  // them (+ 64 R u16) the swaps of a pool of more than 128 slots run one by one
+  uint4* wmask2 = nullptr;     // LDS (R > 2, optional; needs co for the targets): 256 x 128-bit masks = 4 KB - up to 256 events are
+                               // then resolved by the small pools' mask rule in TWO rounds instead of through the buckets
   uint4* wcs;          // global: the 64 lane states of the cache record
   int lane;
   uint4 cs;            // this lane's chunk-start state in the last generated block
@@ -499,6 +501,9 @@ struct WaveDecoder {
       pos = w0 + ((i < 1u && acc) ? (64u - (uint32_t)__builtin_clzll(acc)) : 64u);
     }
     BK_STAMP(*this, 2, 4, lane);  // the shuffle's draws: acceptance fixed point, swap targets
+#ifdef BOURSE_AMD_SKIP_RESOLUTION  // (timing experiment: the draws and their acceptance only - results are then wrong)
+    return;
+#endif
     if constexpr (R <= 2) {
       // All swap targets j_i are known: resolve the whole Fisher-Yates in parallel instead of n dependent LDS round
       // trips.  Steps run i = n-1 .. 1; the value that ends at position x was at position j_x just before step x, and a
@@ -544,6 +549,84 @@ struct WaveDecoder {
         }
         wave_sync();
       }
+    } else if (wmask2 != nullptr && co != nullptr && n_ev >= 2u && n_ev <= 256u) {
+      // Up to 256 events of a larger pool by the mask rule above in TWO rounds (round 5: the bucketed form below - LDS atomics to
+      // count, prefix and fill, a loop over the bucket per hop - was 33 us of C5 as written's 120 us decode launch).  Steps run
+      // i = n-1 .. 1 and a step s < 128 only touches positions <= s, so the shuffle is (steps 127 .. 1) after (steps n-1 .. 128):
+      //   round A: masks of the steps >= 128 per target position (bit s - 128); a position x >= 128 is final after its own step
+      //            - chase from (j_x, x) -, a position x < 128 holds what the most recent of those steps moved there - chase
+      //            from (x, "before step 127") -; the values are written back;
+      //   round B: the small pools' rule on positions 0 .. 127 of that array.
+      // (tools/wave_decode_proto.py two_round_resolution checks the rule against the swaps done in order.)
+      uint4* WM = wmask2;
+      uint32_t* w32 = reinterpret_cast<uint32_t*>(WM);
+      wave_sync();
+#pragma unroll
+      for (int g = 0; g < 4; ++g) WM[lane + 64 * g] = make_uint4(0u, 0u, 0u, 0u);
+      wave_sync();
+      uint32_t jx[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const uint32_t x = (uint32_t)lane + 64u * g;
+        jx[g] = (x >= 1u && x < n_ev) ? jarr[x] : x;
+        if (g >= 2 && jx[g] != x) atomicOr(&w32[jx[g] * 4u + ((x - 128u) >> 5)], 1u << (x & 31u));
+      }
+      wave_sync();
+      uint32_t av[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const uint32_t x = (uint32_t)lane + 64u * g;
+        uint32_t y = g >= 2 ? jx[g] : x, t = g >= 2 ? x - 128u : 0xFFFFFFFFu;  // t: bit index of the step, -1 = before step 127
+        bool go = x < n_ev;
+        while (__ballot(go)) {
+          const uint4 m = WM[y & 255u];
+          const uint32_t sx = first_above(m.x, m.y, m.z, m.w, t);
+          const bool hop = go && sx < 128u;
+          y = hop ? sx + 128u : y;
+          t = hop ? sx : t;
+          go = hop;
+        }
+        av[g] = evl[y & (64u * R - 1u)];
+      }
+      wave_sync();
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const uint32_t x = (uint32_t)lane + 64u * g;
+        if (x < n_ev) evl[x] = (uint16_t)av[g];
+      }
+      WM[lane] = make_uint4(0u, 0u, 0u, 0u);
+      WM[lane + 64] = make_uint4(0u, 0u, 0u, 0u);
+      wave_sync();
+      const uint32_t nb = n_ev < 128u ? n_ev : 128u;
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        const uint32_t x = (uint32_t)lane + 64u * g;
+        if (x < nb && jx[g] != x) atomicOr(&w32[jx[g] * 4u + (x >> 5)], 1u << (x & 31u));
+      }
+      wave_sync();
+      uint32_t bv[2];
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        const uint32_t x = (uint32_t)lane + 64u * g;
+        uint32_t y = jx[g], t = x;
+        bool go = x < nb;
+        while (__ballot(go)) {
+          const uint4 m = WM[y & 127u];
+          const uint32_t sx = first_above(m.x, m.y, m.z, m.w, t);
+          const bool hop = go && sx < 128u;
+          y = hop ? sx : y;
+          t = hop ? sx : t;
+          go = hop;
+        }
+        bv[g] = evl[y & (64u * R - 1u)];
+      }
+      wave_sync();
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        const uint32_t x = (uint32_t)lane + 64u * g;
+        if (x < nb) evl[x] = (uint16_t)bv[g];
+      }
+      wave_sync();
     } else if (co != nullptr && n_ev >= 2u) {
       // The same rule for up to 512 positions, where a mask per position would be 32 KB: the steps are BUCKETED by their
       // target instead (counting sort through LDS atomics: count, exclusive prefix, fill), and "the most recent earlier

@@ -39,6 +39,9 @@ namespace bkd {
 #ifndef BOURSE_AMD_MW_SKIP
 #define BOURSE_AMD_MW_SKIP 0
 #endif
+#ifndef BOURSE_AMD_TWO_ROUND
+#define BOURSE_AMD_TWO_ROUND 1
+#endif
 constexpr uint32_t FLAG_DECODE_LOOKAHEAD = 256u;  // a ziggurat ran past the decode's look-ahead (p < 2^-90): flagged
 constexpr uint32_t MW_RING = 512;                 // generated u64 draws kept in LDS
 constexpr uint32_t MW_LOOK = 192;                 // a window's draws + look-ahead: positions [w0, w0 + MW_LOOK)
@@ -549,6 +552,8 @@ __global__ __launch_bounds__(64 * MW_WPB, MW_WPB > 8 ? 5 : 4) void k_agents_mixe
     if (R > 2) {  // large pools: the bucketed resolution's words there instead, its buckets in the price queue's memory
       Dc.co = r32 + MW_RING;
       Dc.bucket = reinterpret_cast<uint16_t*>(mark);  // (marks, live words and the price queue are dead here: 1 KB)
+      // (the 64-bit ring's 4 KB: the draws are dead once the targets are known; -DBOURSE_AMD_TWO_ROUND=0: the buckets for every size)
+      Dc.wmask2 = BOURSE_AMD_TWO_ROUND ? reinterpret_cast<uint4*>(r32) : nullptr;
     }
     Dc.wcs = S.wcs;
     Dc.lane = lane;

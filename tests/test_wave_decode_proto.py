@@ -49,3 +49,18 @@ def test_parallel_fisher_yates_resolution_equals_sequential_swaps():
     for n in (1, 2, 128):  # all self-swaps / all to position 0
         assert w.fisher_yates_parallel(n, list(range(n))) == list(range(n))
         assert w.fisher_yates_parallel(n, [0] * n) == w.fisher_yates_serial(n, [0] * n)
+
+
+def test_two_round_resolution_of_up_to_256_positions_equals_sequential_swaps():
+    import random
+
+    import wave_decode_proto as w
+
+    rnd = random.Random(6)
+    for _ in range(1500):
+        n = rnd.choice([1, 2, 127, 128, 129, 130, 160, 255, 256, rnd.randrange(1, 257)])
+        j = [0] + [rnd.randrange(0, i + 1) for i in range(1, n)]
+        assert w.two_round_resolution(n, j) == w.fisher_yates_serial(n, j), n
+    for n in (129, 200, 256):
+        assert w.two_round_resolution(n, list(range(n))) == list(range(n))
+        assert w.two_round_resolution(n, [0] * n) == w.fisher_yates_serial(n, [0] * n)

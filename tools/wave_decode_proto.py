@@ -335,6 +335,36 @@ def fisher_yates_parallel(n, j):
     return out
 
 
+def two_round_resolution(n, j):
+    """fisher_yates_parallel for up to 256 positions with 128-bit masks only (round 5: the members' decode of the larger pools).
+    A step s < 128 only touches positions <= s, so the shuffle is (steps 127 .. 1) after (steps n-1 .. 128):
+    round A - masks of the steps >= 128 (bit s - 128) per target position; a position x >= 128 is final after its own step:
+    chase from (j[x], x); a position x < 128 holds what the most recent of those steps moved there: chase from (x, "before
+    step 127"); round B - the rule above on positions 0 .. 127 of round A's array."""
+    assert n <= 256
+
+    def chase(W, y, t, base):
+        while True:
+            m = W[y] >> (t + 1)
+            if m == 0:
+                return y
+            t = t + 1 + ((m & -m).bit_length() - 1)
+            y = t + base
+
+    jx = [j[x] if 1 <= x < n else x for x in range(n)]
+    WA = [0] * n
+    for x in range(128, n):
+        if jx[x] != x:
+            WA[jx[x]] |= 1 << (x - 128)
+    a = [chase(WA, jx[x], x - 128, 128) if x >= 128 else chase(WA, x, -1, 128) for x in range(n)]
+    nb = min(n, 128)
+    WB = [0] * nb
+    for x in range(nb):
+        if jx[x] != x:
+            WB[jx[x]] |= 1 << x
+    return [a[chase(WB, jx[x], x, 0)] if x < nb else a[x] for x in range(n)]
+
+
 def selftest(n_cases=60, seed=1, lookahead=64, verbose=False):
     rnd = random.Random(seed)
     tab_block = build_jump_tables(BLOCK)
