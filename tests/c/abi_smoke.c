@@ -132,6 +132,71 @@ int main(void) {
     bk_env_destroy(env);
   }
   EXPECT(sum[0] == sum[1]);
+
+  /* host arrays through the device ingress (StepEnvNumpy.submit_instructions for many books, rust/src/step_sim_numpy.rs:233-275):
+   * 64 books x 3 instructions, a bad price planted in book 5, a BK_ACTION_MODIFY and an action the reference ignores in book 7;
+   * the second batch is written in place into the library's pinned staging, its results read as views */
+  memset(&cfg, 0, sizeof cfg);
+  cfg.n_books = 64;
+  cfg.levels = 10;
+  cfg.tick_size = 2;
+  cfg.trading = 1;
+  cfg.step_size = 1000;
+  cfg.seed = 7;
+  cfg.max_live_orders = 64;
+  cfg.max_orders = 32;
+  cfg.trade_capacity = 64;
+  cfg.history_capacity = 4;
+  CHECK(bk_env_create(&cfg, &env));
+  EXPECT(bk_submit_instructions_host(env, NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL) == BK_INVALID_ARGUMENT);
+  CHECK(bk_device_ingress_enable(env, 16));
+  {
+    enum { NB = 64, PER = 3, N = NB * PER };
+    uint64_t off[NB + 1], oid[N], ids[N], ticket = 99, t2 = 99;
+    uint32_t act[N], vol[N], trd[N], prc[N], st[2 * NB], bad = 0;
+    uint8_t side[N];
+    for (int b = 0; b <= NB; ++b) off[b] = (uint64_t)b * PER;
+    for (int i = 0; i < N; ++i) {
+      act[i] = 1; side[i] = (uint8_t)(i % PER == 0); vol[i] = 10; trd[i] = (uint32_t)(i % PER); oid[i] = 0;
+      prc[i] = i % PER == 0 ? 100 : 110 + 2 * (uint32_t)(i % PER);   /* bid 100, asks 112 and 114 */
+    }
+    prc[5 * PER + 1] = 113;                /* book 5: its second element is off-tick -> the book stops there, element 0 stays queued */
+    CHECK(bk_submit_instructions_host(env, off, act, side, vol, trd, prc, oid, &ticket));
+    EXPECT(ticket == 0);
+    CHECK(bk_submit_result(env, ticket, ids, st, &bad));
+    EXPECT(bad == 5 && st[2 * 5] == BK_PRICE_NOT_TICK_MULTIPLE && st[2 * 5 + 1] == 1 && st[0] == BK_OK && st[1] == PER);
+    EXPECT(ids[0] == 0 && ids[1] == 1 && ids[2] == 2 && ids[5 * PER] == 0 && ids[5 * PER + 1] == UINT64_MAX && ids[5 * PER + 2] == UINT64_MAX);
+    CHECK(bk_step(env));
+    uint32_t lw = bk_l2_width(env), *rec = (uint32_t*)malloc((size_t)NB * lw * 4);
+    CHECK(bk_level2(env, 0, NB, rec));
+    EXPECT(rec[1] == 100 && rec[2] == 112 && rec[5 * lw + 1] == 100 && rec[5 * lw + 2] == UINT32_MAX);  /* book 5 holds its bid only */
+    bk_ingress_arrays stg;
+    CHECK(bk_ingress_staging(env, N, &stg));
+    EXPECT(stg.capacity >= N);
+    for (int b = 0; b <= NB; ++b) stg.book_offsets[b] = (uint64_t)b * 2;
+    for (int b = 0; b < NB; ++b) {         /* every book: cancel its ask 112 (id 1), lift its bid's volume to 25 (a replace) */
+      stg.action[2 * b] = 2; stg.order_id[2 * b] = 1; stg.side[2 * b] = 0; stg.vol[2 * b] = 0; stg.trader_id[2 * b] = 0; stg.price[2 * b] = 0;
+      stg.action[2 * b + 1] = BK_ACTION_MODIFY; stg.order_id[2 * b + 1] = 0; stg.side[2 * b + 1] = 4; stg.vol[2 * b + 1] = 25;
+      stg.trader_id[2 * b + 1] = 0; stg.price[2 * b + 1] = 0;
+    }
+    stg.action[2 * 7] = 3;                 /* book 7: action 3 is nothing the reference knows: a no-op, its ask 112 stays */
+    CHECK(bk_submit_instructions_host(env, stg.book_offsets, stg.action, stg.side, stg.vol, stg.trader_id, stg.price, stg.order_id, &t2));
+    EXPECT(t2 == 1);
+    CHECK(bk_step_async(env));
+    const uint64_t* vids = NULL;
+    const uint32_t* vst = NULL;
+    CHECK(bk_submit_result_view(env, t2, &vids, &vst, &bad));
+    EXPECT(bad == UINT32_MAX && vids != NULL && vids[0] == UINT64_MAX && vst[1] == 2);
+    EXPECT(bk_submit_result(env, 7, ids, st, &bad) == BK_INVALID_ARGUMENT);   /* not a ticket */
+    CHECK(bk_env_sync(env));
+    CHECK(bk_level2(env, 0, NB, rec));
+    EXPECT(rec[1] == 100 && rec[2] == 114 && rec[4] == 25 && rec[7 * lw + 2] == 112 && rec[5 * lw + 2] == UINT32_MAX);
+    uint32_t fl[NB];
+    CHECK(bk_book_flags(env, fl));
+    EXPECT(fl[0] == 0 && fl[5] == BK_FLAG_UNKNOWN_ORDER);   /* book 5 never created id 1: dropped and flagged, as on the device entry */
+    free(rec);
+  }
+  bk_env_destroy(env);
   printf("abi_smoke: ok (history checksum %u)\n", sum[0]);
   return 0;
 }
