@@ -169,6 +169,7 @@ SIGNATURES = {
     "bk_set_wave_options": (_i32, [_vp, _u32, _i32]),
     "bk_pipeline_fallbacks": (_i32, [_vp, _p64]),
     "bk_order_counts": (_i32, [_vp, _p64]),
+    "bk_event_steps_keyed": (_i32, [_vp, _p64]),
     "bk_checkpoint_bytes": (_u64, [_vp]),
     "bk_checkpoint_save": (_i32, [_vp, _vp, _u64]),
     "bk_checkpoint_load": (_i32, [_vp, _vp, _u64]),

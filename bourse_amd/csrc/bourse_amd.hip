@@ -438,7 +438,8 @@ template <int R>
 int launch_events(bk_env* env, const DevArgs& a, uint64_t step_index, uint32_t max_queue) {
   env->prof_now = env->profile > 0;
   ProfScope ps(env, 3);
-  const uint32_t perm_bytes = ((max_queue + 63u) & ~63u) * 2u + 128u;  // u16 permutation of the longest queue
+  uint32_t perm_bytes = ((max_queue + 63u) & ~63u) * 2u + 128u;  // u16 permutation of the longest queue
+  if (perm_bytes < ev_keyed_lds_bytes(R)) perm_bytes = ev_keyed_lds_bytes(R);  // ... and the keyed form's lists (step_events_keyed)
   hipLaunchKernelGGL(k_step_events<R>, dim3(env->cfg.n_books), dim3(64), perm_bytes, env->stream, a, step_index);
   HIPCHK(hipGetLastError());
   return BK_OK;
@@ -2442,6 +2443,12 @@ int bk_order_counts(bk_env* env, uint64_t* totals) {
   if (!env || !totals) return fail(BK_INVALID_ARGUMENT, "null argument");
   if (int rc = use_device(env)) return rc;
   return gather_header(env, H_NEXT_ID, 1, totals);
+}
+
+int bk_event_steps_keyed(bk_env* env, uint64_t* counts) {
+  if (!env || !counts) return fail(BK_INVALID_ARGUMENT, "null argument");
+  if (int rc = use_device(env)) return rc;
+  return gather_header(env, H_EV_KEYED, 1, counts);
 }
 
 // ---------------------------------------------------------------- checkpoint / resume (on-device order flow)

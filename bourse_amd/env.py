@@ -731,6 +731,12 @@ class ManyBookEnv:
         check(self._L.bk_order_counts(self._h, _lib.p64(out)))
         return out
 
+    def event_steps_keyed(self) -> np.ndarray:
+        """Per book: how many host-driven / ingress steps ran on the keyed event loop (a diagnostic; ``bk_event_steps_keyed``)."""
+        out = np.zeros(self.n_books, dtype=np.uint64)
+        check(self._L.bk_event_steps_keyed(self._h, _lib.p64(out)))
+        return out
+
     def time(self, book: int = 0) -> int:
         out = C.c_uint64(0)
         check(self._L.bk_time(self._h, book, C.byref(out)))

@@ -388,6 +388,11 @@ int bk_get_split_parts(bk_env* env, int* n_parts, uint32_t* min_part); /* the tw
 /* orders created so far in every book by the on-device agents: OrderBook::current_order_id / orders.len()
  * (crates/order_book/src/orderbook.rs:327-329), totals[n_books] */
 int bk_order_counts(bk_env* env, uint64_t* totals /* [n_books] */);
+/* A diagnostic of the host-driven / ingress step (bk_step, bk_step_async: Env::step over submitted instructions,
+ * crates/step_sim/src/env.rs:116-135): how many of each book's steps ran on the keyed event loop - steps without
+ * modifications whose events fit one per pool slot, on a trading book, with prices and arrival stamps inside the key window
+ * (bourse_amd/csrc/book_device.hpp step_events_keyed); the others ran the event-by-event loop.  Results never depend on it. */
+int bk_event_steps_keyed(bk_env* env, uint64_t* counts /* [n_books] */);
 
 /* ------------------------------------------------------ checkpoint / resume */
 /* Dump / restore the complete simulation state of an on-device-order-flow env (pool, clock, counters, per-book

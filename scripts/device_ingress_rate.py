@@ -8,9 +8,14 @@ sys.path.insert(0, ROOT)
 import numpy as np, torch, bourse_amd as bk
 B, N, T = int(sys.argv[1]) if len(sys.argv) > 1 else 8192, 48, 30  # (as scripts/host_driven_rate.py)
 POOL = 512 if B > 8192 else 256  # round 4's 65 536-book line ran with pool 256 and DROPPED orders (flags [0 1]): VERDICT r4 Weak #7
-env = bk.ManyBookEnv(B, 1, 0, 1, 100_000, levels=16, max_live_orders=POOL, max_orders=N * (T + 8), trade_capacity=64 * (T + 8), strict=False,
+def new_env():
+    e = bk.ManyBookEnv(B, 1, 0, 1, 100_000, levels=16, max_live_orders=POOL, max_orders=N * (T + 8), trade_capacity=64 * (T + 8), strict=False,
                      history_capacity=0, stream=torch.cuda.current_stream().cuda_stream)
-env.enable_device_ingress(N)
+    e.enable_device_ingress(N)
+    return e
+
+
+env = new_env()
 g = torch.Generator(device="cuda").manual_seed(0)
 off = (torch.arange(B + 1, dtype=torch.int64, device="cuda") * N)
 n = B * N
@@ -47,17 +52,25 @@ assert int(status[:, 0].max()) == 0, status[:, 0].unique()
 flags = np.unique(env.flags())
 assert not flags.any(), f"capacity flags {flags}: orders were dropped - raise the pool or thin the flow before quoting a rate"
 print(f"device ingress: B={B} x {N} instructions/book/step, {T} steps: {dt / T * 1e3:.3f} ms/step -> {B * T / dt / 1e6:.1f} M book-steps/s "
-      f"({n * T / dt / 1e6:.0f} M instructions/s), flags {np.unique(env.flags())}, trades/book-step {env.trade_counts().sum() / (B * (T + 3)):.1f}")
-# the two kernels of a step, each timed on the env's stream (= torch's current stream here), and their HBM fraction from the
-# algorithmic bytes of DESIGN.md 2's table: k_ingest 27 B per instruction in + 16 B per event + 80 B per new order out;
-# k_step_events 2 S + 2 x (5 + 4 L) x 4 + 20 N_ev + 32 N_tr per book-step
-tc0 = int(env.trade_counts().sum())
+      f"({n * T / dt / 1e6:.0f} M instructions/s), flags {np.unique(env.flags())}, trades/book-step {env.trade_counts().sum() / (B * (T + 3)):.1f}, "
+      f"{env.event_steps_keyed().sum() / (B * (T + 3)) * 100:.1f} % of the book-steps on the keyed loop")
+# the two kernels of a step, each timed on the env's stream (= torch's current stream here) over the LAST K steps of the same
+# stream on a fresh env (the timed loop above runs unprofiled), and their HBM fraction from the algorithmic bytes of DESIGN.md
+# 2's table: k_ingest 27 B per instruction in + 16 B per event + 80 B per new order out; k_step_events 2 S + 2 x (5 + 4 L) x 4 +
+# 20 N_ev + 32 N_tr per book-step
+env.close()
+env, K = new_env(), 6
+for s in range(T + 3 - K):
+    env.submit_instructions_device(off, *batches[s], out_ids=out_ids, status=status)
+    env.step(sync=False)
+torch.cuda.synchronize()
+tc0, keyed0 = int(env.trade_counts().sum()), int(env.event_steps_keyed().sum())
 env.profile(1)
-ing_ms, K = 0.0, 8
-for s in range(K):
+ing_ms = 0.0
+for s in range(T + 3 - K, T + 3):
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
-    env.submit_instructions_device(off, *batches[s % len(batches)], out_ids=out_ids, status=status)
+    env.submit_instructions_device(off, *batches[s], out_ids=out_ids, status=status)
     b.record()
     env.step(sync=False)
     torch.cuda.synchronize()
@@ -65,11 +78,13 @@ for s in range(K):
 ms, nl = env.profile_read_kind(3)
 env.profile_read()
 tr = (int(env.trade_counts().sum()) - tc0) / (B * K)
-new = sum(int((batches[s % len(batches)][0] == 1).sum()) for s in range(K)) / (B * K)
+new = sum(int((batches[s][0] == 1).sum()) for s in range(T + 3 - K, T + 3)) / (B * K)
 S, W4 = env.state_bytes_per_book(), env.width * 4
 ev_bytes = (2 * S + 2 * W4 + 20 * N + 32 * tr) * B
 ing_bytes = (27 * N + 16 * N + 80 * new) * B
 ev_ms, ing = ms / max(nl, 1), ing_ms / K
+assert not np.unique(env.flags()).any()
 print(f"k_step_events: {ev_ms:.3f} ms per launch ({nl} launches), {ev_bytes / 1e6:.1f} MB algorithmic -> {ev_bytes / ev_ms / 1e6:.0f} GB/s = "
       f"{ev_bytes / ev_ms / 1e6 / 8000 * 100:.1f} % of HBM; k_ingest: {ing:.3f} ms per launch, {ing_bytes / 1e6:.1f} MB -> "
-      f"{ing_bytes / ing / 1e6:.0f} GB/s = {ing_bytes / ing / 1e6 / 8000 * 100:.1f} % of HBM; pool {POOL} slots, {tr:.1f} trades and {new:.1f} new orders per book-step")
+      f"{ing_bytes / ing / 1e6:.0f} GB/s = {ing_bytes / ing / 1e6 / 8000 * 100:.1f} % of HBM; pool {POOL} slots, {tr:.1f} trades and {new:.1f} new orders per book-step; "
+      f"{(int(env.event_steps_keyed().sum()) - keyed0) / (B * K) * 100:.1f} % of these book-steps on the keyed loop")

@@ -49,7 +49,7 @@ def env_new(ingress):
 def report(name, env, dt, extra=""):
     f = np.unique(env.flags())
     print(f"{name:9s} B={B} x {N} instructions/book/step: {dt / T * 1e3:.3f} ms/step -> {B * T / dt / 1e6:.2f} M book-steps/s "
-          f"({n * T / dt / 1e6:.0f} M instructions/s), flags {f}, trades/book-step {env.trade_counts().sum() / (B * (T + 3)):.1f}{extra}", flush=True)
+          f"({n * T / dt / 1e6:.0f} M instructions/s), flags {f}, trades/book-step {env.trade_counts().sum() / (B * (T + 3)):.1f}, keyed steps {env.event_steps_keyed().sum() / (B * (T + 3)) * 100:.0f} %{extra}", flush=True)
     assert not f.any(), "a capacity flag is set: the rate above would be of a run that dropped orders"
 
 
