@@ -9,7 +9,7 @@ import subprocess
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libbourse_amd.so")
-SOURCES = ["bourse_amd.hip", "fsm_unit.hip", "book_device.hpp", "event_asm.hpp", "event_asm_gen.hpp", "wave_agents.hpp", "mixed_agents.hpp", "wave_mixed.hpp", "pm_math.hpp",
+SOURCES = ["bourse_amd.hip", "fsm_unit.hip", "book_device.hpp", "event_asm.hpp", "event_asm_gen.hpp", "wave_agents.hpp", "mixed_agents.hpp", "wave_mixed.hpp", "step_events.hpp", "pm_math.hpp",
            "host_pool.hpp", "host_math.hpp",
            os.path.join("..", "..", "include", "bourse_amd.h")]
 

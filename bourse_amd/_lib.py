@@ -182,11 +182,38 @@ def lib_path() -> str:
     return _build.LIB
 
 
+def _share_torch_hip_runtime():
+    """PyTorch's ROCm wheels bundle their own libamdhip64.so.7 - the SONAME of /opt/rocm's, which this library links.  A process
+    gets ONE of the two (the first loaded), and torch does not find the GPU on the system's copy ("No HIP GPUs are available"
+    when `import torch` comes AFTER this library's first use; the other order has always worked, and is what bench.py and the
+    tests do).  So when torch is installed but not imported yet, its copy of the runtime is loaded first - without importing
+    torch.  BOURSE_AMD_OWN_HIP_RUNTIME=1 skips this (a process that never imports torch then runs on /opt/rocm's runtime, as a
+    plain C client of the library does)."""
+    import importlib.util
+    import sys
+
+    if "torch" in sys.modules or os.environ.get("BOURSE_AMD_OWN_HIP_RUNTIME") == "1":
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        return
+    if not spec or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass  # (not loadable here: the library's own dependency resolves as before)
+
+
 def load() -> C.CDLL:
     """Load libbourse_amd.so (building it first if hipcc is here and the sources are newer)."""
     global _lib
     if _lib is not None:
         return _lib
+    _share_torch_hip_runtime()
     path = _build.LIB
     override = os.environ.get("BOURSE_AMD_LIBRARY")  # a variant build (scripts/asm_ab.sh); never rebuilt implicitly
     if override:

@@ -37,6 +37,7 @@ extern template __global__ void k_agents_fsm<8>(DevArgs);
 #include "mixed_agents.hpp"
 #include "wave_agents.hpp"
 #include "wave_mixed.hpp"
+#include "step_events.hpp"
 
 using namespace bkd;
 
@@ -434,13 +435,24 @@ int launch_run(bk_env* env, const DevArgs& a, uint64_t first_step, uint32_t n_st
   HIPCHK(hipGetLastError());
   return BK_OK;
 }
+int wave_args(bk_env* env, WaveArgs* wva);
 template <int R>
 int launch_events(bk_env* env, const DevArgs& a, uint64_t step_index, uint32_t max_queue) {
   env->prof_now = env->profile > 0;
   ProfScope ps(env, 3);
   uint32_t perm_bytes = ((max_queue + 63u) & ~63u) * 2u + 128u;  // u16 permutation of the longest queue
-  if (perm_bytes < ev_keyed_lds_bytes(R)) perm_bytes = ev_keyed_lds_bytes(R);  // ... and the keyed form's lists (step_events_keyed)
-  hipLaunchKernelGGL(k_step_events<R>, dim3(env->cfg.n_books), dim3(64), perm_bytes, env->stream, a, step_index);
+  if (perm_bytes < ev_lds_bytes(R)) perm_bytes = ev_lds_bytes(R);  // ... the wave-parallel shuffle's and the keyed form's lists (step_events.hpp)
+  // the shuffle borrows the decode's jump tables and per-book lane-state cache (BOURSE_AMD_EV_SEQ_SHUFFLE=1: the draw-by-draw
+  // loop, for measurements)
+  static const bool seq_shuffle = [] { const char* e = getenv("BOURSE_AMD_EV_SEQ_SHUFFLE"); return e && *e == '1'; }();
+  WaveArgs wva{};
+  if (!seq_shuffle && env->M == 1)
+    if (int rc = wave_args(env, &wva)) return rc;
+  // (its fixed cost - the cache record, a block of draws, a resolution over all 64 R positions - pays from a queue length that
+  // grows with the pool: docs/EXPERIMENTS.md; BOURSE_AMD_EV_WAVE_SHUFFLE_MIN overrides, for measurements)
+  static const int min_env = [] { const char* e = getenv("BOURSE_AMD_EV_WAVE_SHUFFLE_MIN"); return e ? atoi(e) : -1; }();
+  const uint32_t shuffle_min = min_env >= 0 ? static_cast<uint32_t>(min_env) : (12u * R > 32u ? 12u * R : 32u);  // (measured: 256 slots 24 events -3 %, 48 +5 %; 512 slots 48 -7 %, 96 +3 %)
+  hipLaunchKernelGGL(k_step_events<R>, dim3(env->cfg.n_books), dim3(64), perm_bytes, env->stream, a, wva, step_index, shuffle_min);
   HIPCHK(hipGetLastError());
   return BK_OK;
 }

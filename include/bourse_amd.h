@@ -391,7 +391,7 @@ int bk_order_counts(bk_env* env, uint64_t* totals /* [n_books] */);
 /* A diagnostic of the host-driven / ingress step (bk_step, bk_step_async: Env::step over submitted instructions,
  * crates/step_sim/src/env.rs:116-135): how many of each book's steps ran on the keyed event loop - steps without
  * modifications whose events fit one per pool slot, on a trading book, with prices and arrival stamps inside the key window
- * (bourse_amd/csrc/book_device.hpp step_events_keyed); the others ran the event-by-event loop.  Results never depend on it. */
+ * (bourse_amd/csrc/step_events.hpp step_events_keyed); the others ran the event-by-event loop.  Results never depend on it. */
 int bk_event_steps_keyed(bk_env* env, uint64_t* counts /* [n_books] */);
 
 /* ------------------------------------------------------ checkpoint / resume */

@@ -1,4 +1,4 @@
-"""Fuzz the host-driven step on the keyed loop (book_device.hpp step_events_keyed) over fresh seeds: every book of small
+"""Fuzz the host-driven step on the keyed loop (step_events.hpp step_events_keyed) over fresh seeds: every book of small
 batches against its own oracle env - level 2 of every step, every trade, the whole order log - on random mixes of clean
 steps (new / cancel / market orders: the keyed form) and steps that must fall back (modifications, volume 0, more events
 than pool slots, prices outside the key window, full pools), all four pool sizes, three tick sizes, narrow and wide price

@@ -1,4 +1,4 @@
-"""The host-driven step on the keyed loop (bourse_amd/csrc/book_device.hpp step_events_keyed, round 5).
+"""The host-driven step on the keyed loop (bourse_amd/csrc/step_events.hpp step_events_keyed, round 5).
 
 `Env::step` over submitted instructions (ref crates/step_sim/src/env.rs:116-135; place / cancel / modify:
 crates/order_book/src/orderbook.rs:583-611, 622-644, 743-772) runs on the slot-addressed assembly loops whenever a step has
