@@ -444,13 +444,16 @@ int launch_events(bk_env* env, const DevArgs& a, uint64_t step_index, uint32_t m
   if (perm_bytes < ev_lds_bytes(R)) perm_bytes = ev_lds_bytes(R);  // ... the wave-parallel shuffle's and the keyed form's lists (step_events.hpp)
   // the shuffle borrows the decode's jump tables and per-book lane-state cache (BOURSE_AMD_EV_SEQ_SHUFFLE=1: the draw-by-draw
   // loop, for measurements)
-  static const bool seq_shuffle = [] { const char* e = getenv("BOURSE_AMD_EV_SEQ_SHUFFLE"); return e && *e == '1'; }();
+  // (both knobs are read at every launch - a getenv, ~0.1 us - so that a test can switch them inside one process)
+  const char* seq_env = getenv("BOURSE_AMD_EV_SEQ_SHUFFLE");
+  const bool seq_shuffle = seq_env && *seq_env == '1';
   WaveArgs wva{};
   if (!seq_shuffle && env->M == 1)
     if (int rc = wave_args(env, &wva)) return rc;
   // (its fixed cost - the cache record, a block of draws, a resolution over all 64 R positions - pays from a queue length that
   // grows with the pool: docs/EXPERIMENTS.md; BOURSE_AMD_EV_WAVE_SHUFFLE_MIN overrides, for measurements)
-  static const int min_env = [] { const char* e = getenv("BOURSE_AMD_EV_WAVE_SHUFFLE_MIN"); return e ? atoi(e) : -1; }();
+  const char* min_str = getenv("BOURSE_AMD_EV_WAVE_SHUFFLE_MIN");
+  const int min_env = min_str ? atoi(min_str) : -1;
   const uint32_t shuffle_min = min_env >= 0 ? static_cast<uint32_t>(min_env) : (12u * R > 32u ? 12u * R : 32u);  // (measured: 256 slots 24 events -3 %, 48 +5 %; 512 slots 48 -7 %, 96 +3 %)
   hipLaunchKernelGGL(k_step_events<R>, dim3(env->cfg.n_books), dim3(64), perm_bytes, env->stream, a, wva, step_index, shuffle_min);
   HIPCHK(hipGetLastError());

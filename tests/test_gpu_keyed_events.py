@@ -83,8 +83,18 @@ def _same_as_oracle(env, refs, allow_flags=False):
             assert np.array_equal(got[f], want[f]), ("order", b, f, np.nonzero(got[f] != want[f])[0][:5])
 
 
+# The step's shuffle (env.rs:121) has two forms as well: draw by draw, and - queues of at least max(32, 12 x pool registers)
+# events - the decode's wave-parallel Fisher-Yates (step_events.hpp, wave_agents.hpp WaveDecoder::shuffle).  The library reads
+# its two measurement knobs at every launch, so each stream runs under the shipped rule, with the wave-parallel form from two
+# events on, and draw by draw.
+SHUFFLES = {"shipped rule": {}, "wave-parallel from 2 events": {"BOURSE_AMD_EV_WAVE_SHUFFLE_MIN": "2"}, "draw by draw": {"BOURSE_AMD_EV_SEQ_SHUFFLE": "1"}}
+
+
+@pytest.mark.parametrize("shuffle", list(SHUFFLES))
 @pytest.mark.parametrize("pool,n_max,p_market", [(64, 12, 0.004), (128, 28, 0.004), (256, 44, 0.04), (512, 72, 0.04)])
-def test_mixed_streams_alternate_between_the_keyed_and_the_event_by_event_loop(bk, oracle, pool, n_max, p_market):
+def test_mixed_streams_alternate_between_the_keyed_and_the_event_by_event_loop(bk, oracle, monkeypatch, pool, n_max, p_market, shuffle):
+    for k, v in SHUFFLES[shuffle].items():
+        monkeypatch.setenv(k, v)
     B, T = 192, 12
     env, refs, busy, clean = _drive(bk, oracle, pool, n_max, B, T, 500 + pool, p_market, p_mod=0.004, p_zero=0.002)
     _same_as_oracle(env, refs)
@@ -100,7 +110,8 @@ def test_mixed_streams_alternate_between_the_keyed_and_the_event_by_event_loop(b
 
 def test_clean_streams_run_every_step_keyed(bk, oracle):
     B, T = 256, 10
-    env, refs, busy, clean = _drive(bk, oracle, 256, 40, B, T, 77, p_market=0.03, p_mod=0.0, p_zero=0.0)
+    # (up to 70 events per step on 256 slots: most steps are past the shipped rule's 48 - the wave-parallel shuffle)
+    env, refs, busy, clean = _drive(bk, oracle, 256, 70, B, T, 77, p_market=0.03, p_mod=0.0, p_zero=0.0)
     _same_as_oracle(env, refs)
     assert np.array_equal(busy, clean)
     assert np.array_equal(env.event_steps_keyed(), busy.sum(axis=0))
