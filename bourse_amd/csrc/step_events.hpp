@@ -81,11 +81,6 @@ __device__ __forceinline__ void insert_order(Book<R>& B, int lane, uint32_t n, u
 #define BOURSE_AMD_EV_KEYED 1
 #endif
 constexpr uint32_t ev_keyed_lds_bytes(int R) { return 12u * 64u * (uint32_t)R; }
-#define BK_WAVE_SYNC()                                          \
-  do {                                                          \
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");      \
-    __builtin_amdgcn_wave_barrier();                            \
-  } while (0)
 template <int R>
 __device__ __forceinline__ bool step_events_keyed(Book<R>& B, const DevArgs& a, uint32_t book, uint64_t t0, int lane,
                                                   uint32_t n_ev, uint32_t e0, uint16_t* perm, const LogCtx& lg) {
@@ -125,7 +120,7 @@ __device__ __forceinline__ bool step_events_keyed(Book<R>& B, const DevArgs& a, 
     if (lane_bit(is_new[re])) rank2ev[rank] = (uint16_t)(re * 64 + lane);
     n_new += __builtin_popcountll(is_new[re]);
   }
-  BK_WAVE_SYNC();
+  wave_sync();
   uint64_t newm[R], live0[R], mkt = 0;
   uint32_t s_nop = 0xFFFFFFFFu, nf = 0;
 #pragma unroll
@@ -155,7 +150,7 @@ __device__ __forceinline__ bool step_events_keyed(Book<R>& B, const DevArgs& a, 
   }
   if (s_nop == 0xFFFFFFFFu) return false;  // fewer than n_new + 1 free slots
   if (R <= 2 && mkt) return false;         // (the hand-written loops of the small pools carry no market orders)
-  BK_WAVE_SYNC();
+  wave_sync();
   // ---- the cancellations' slots: one id search each, among the orders live now and this step's new ones
   uint32_t evs[R];
 #pragma unroll
@@ -186,13 +181,13 @@ __device__ __forceinline__ bool step_events_keyed(Book<R>& B, const DevArgs& a, 
   if (!keys_begin<R, true>(B, newm, n_ev, K)) return false;  // (the permutation is still intact for the caller's loop)
   uint32_t evw[R];
   key_event_words<R>(K, evs, n_ev, evw);
-  BK_WAVE_SYNC();
+  wave_sync();
 #pragma unroll
   for (int r = 0; r < R; ++r) {  // (perm, rank2ev, ev2slot are consumed: their bytes now hold W1, W2)
     W1[r * 64 + lane] = 0u;
     W2[r * 64 + lane] = lane_bit(newm[r]) ? B.vol[r] : 0u;
   }
-  BK_WAVE_SYNC();
+  wave_sync();
   uint32_t k = 0;
   const uint32_t nev = rfl(n_ev);
   for (;;) {
@@ -225,7 +220,7 @@ __device__ __forceinline__ bool step_events_keyed(Book<R>& B, const DevArgs& a, 
   for (int r = 0; r < R; ++r) B.pend[r] = 0;
   if (!lg.base) return true;
   // ---- the order log, one pool lane per order touched in this step
-  BK_WAVE_SYNC();
+  wave_sync();
   uint64_t over = 0;
 #pragma unroll
   for (int r = 0; r < R; ++r) {
