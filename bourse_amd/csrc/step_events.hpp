@@ -96,6 +96,14 @@ __device__ __forceinline__ bool step_events_keyed(Book<R>& B, const DevArgs& a, 
   bool bad = false;
 #pragma unroll
   for (int re = 0; re < R; ++re) {
+    // (pools of <= 256 slots: list registers past the queue's end - all but the first at the ingress scripts' 48 events - cost
+    // one uniform branch each; at 512 slots the branches take the kernel from 8 to 60 B of scratch at its 96 registers and
+    // cost 9 %, same box: profiles/r05/device_ingress_rate_guards.txt)
+    if constexpr (R <= 4) {
+      is_new[re] = is_can[re] = 0ull;
+      eww[re] = eid[re] = evq[re] = 0u;
+      if (n_ev <= (uint32_t)re * 64u) continue;
+    }
     const uint32_t pos = (uint32_t)(re * 64 + lane);
     const bool valid = pos < n_ev;
     uint4 rec = make_uint4(0xFFu, 0u, 0u, 0u);
@@ -116,6 +124,7 @@ __device__ __forceinline__ bool step_events_keyed(Book<R>& B, const DevArgs& a, 
   uint32_t n_new = 0;
 #pragma unroll
   for (int re = 0; re < R; ++re) {
+    if (R <= 4 && !is_new[re]) continue;
     const uint32_t rank = n_new + __builtin_amdgcn_mbcnt_hi((uint32_t)(is_new[re] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)is_new[re], 0u));
     if (lane_bit(is_new[re])) rank2ev[rank] = (uint16_t)(re * 64 + lane);
     n_new += __builtin_popcountll(is_new[re]);
@@ -155,6 +164,10 @@ __device__ __forceinline__ bool step_events_keyed(Book<R>& B, const DevArgs& a, 
   uint32_t evs[R];
 #pragma unroll
   for (int re = 0; re < R; ++re) {
+    if constexpr (R <= 4) {
+      evs[re] = s_nop;
+      if (n_ev <= (uint32_t)re * 64u) continue;
+    }
     uint32_t cs = s_nop;
     uint64_t m = is_can[re];
     while (m) {
