@@ -17,7 +17,8 @@ total, 65 536 / N per GPU, seeds by global book index; `--scaling weak` keeps 65
 
 Timing: W warm-up steps, barrier + synchronize, K timed steps, synchronize (each rank's time; the job's = the MAX over
 ranks), barrier.  Right before the warm-up the env's public `bk_warm` entry runs scratch steps in chunks (`--preheat-steps`
-per chunk, grown to >= 10 ms of load; 0 = off) until three consecutive chunk rates agree within 1 % (capped; what ran is
+per chunk, grown to >= 10 ms of load; 0 = off) until three consecutive chunk rates agree within 1 % and at least
+`--preheat-min-ms` (200) have passed (capped; what ran is
 reported as the top-level `preheat_steps` and `config.preheat_chunk_rates`): the GPU's clocks fall within milliseconds
 of idling and need tens of ms of load to come back - how many differs from box to box - which a short timed region (the
 driver's `--steps 20 --warmup 5` = 6 ms) would otherwise measure.  bk_warm steps the env's own books with its own
@@ -225,6 +226,9 @@ def main():
                          "afterwards), so that the timed region starts at steady clocks; chunks repeat until three consecutive "
                          "chunk rates agree within 1 %% (0 = no pre-heat)")
     ap.add_argument("--preheat-max-chunks", type=int, default=40, help="cap of the adaptive pre-heat (1 = one fixed chunk)")
+    ap.add_argument("--preheat-min-ms", type=float, default=200.0,
+                    help="the first pre-heat also lasts at least this long: on some boxes the chunk rates agree within 1 %% "
+                         "after 40 ms while the regions behind still climb 5 %% for another ~60 ms (profiles/r05/bench_ramp_probe.txt)")
     ap.add_argument("--repeats", type=int, default=4, help="extra timed regions of --steps after the reported one (median in `runs`)")
     args = ap.parse_args()
 
@@ -321,13 +325,15 @@ def main():
     # library, include/bourse_amd.h) steps THIS env's books with its own kernels and puts the state back.  How much load
     # the ramp needs differs from box to box (round 4: 100 steps = 22 ms were enough on the builder's boxes, not on the
     # driver's, whose regions climbed 272 -> 294 M), so the pre-heat is ADAPTIVE: chunks of --preheat-steps scratch steps
-    # until the last three chunk rates agree within 1 % (at most --preheat-max-chunks), and the line reports what ran.
+    # until the last three chunk rates agree within 1 % AND --preheat-min-ms have passed (at most --preheat-max-chunks), and the
+    # line reports what ran.
     preheat_chunk, preheat_ran = [max(1, args.preheat_steps)], [0]
 
     def preheat(first):
         if args.preheat_steps <= 0:
             return []
         rates = []
+        began = time.perf_counter()
         while len(rates) < max(1, args.preheat_max_chunks):
             torch.cuda.synchronize()
             t = time.perf_counter()
@@ -339,7 +345,8 @@ def main():
             if d < 8e-3 and args.preheat_max_chunks > 1:  # a chunk is >= ~10 ms of load whatever the batch size
                 preheat_chunk[0] = int(min(4000, max(preheat_chunk[0] + 1, preheat_chunk[0] * 10e-3 / d)))
             # (every rank stops on its own clock: the ranks share nothing, and the barrier in front of t0 lines them up)
-            if len(rates) >= (3 if first else 2) and max(rates[-3:]) / min(rates[-3:]) < 1.01:
+            long_enough = not first or args.preheat_max_chunks <= 1 or (time.perf_counter() - began) * 1e3 >= args.preheat_min_ms
+            if len(rates) >= (3 if first else 2) and max(rates[-3:]) / min(rates[-3:]) < 1.01 and long_enough:
                 break
         return rates
 
