@@ -56,6 +56,141 @@ MOM_P = dict(tick_size=2, p_cancel=0.1, trade_vol=100, decay=1.0, demand=20.0, s
 NOISE_P = dict(tick_size=2, p_limit=0.3, p_market=0.2, p_cancel=0.2, trade_vol=100, price_dist_mu=0.0, price_dist_sigma=1.0)
 WORKLOADS["C5M"] = (8192, 64, [("momentum", 0, 256, MOM_P), ("noise", 256, 256, NOISE_P)])
 TICK, STEP_SIZE, SEED = 2, 100_000, 101
+# External agents: every step an agent layer ON THE GPU hands over 48 instructions per book (70 %
+# new limit orders around 100, 30 % cancellations of earlier ids) as the six SoA arrays of `submit_instructions`
+# (rust/src/step_sim_numpy.rs:233-275), bk_submit_instructions_device queues them, bk_step_async is Env::step.  The flow
+# lets the books fill up, so a run is at most 33 steps (scripts/device_ingress_rate.py is the same stream).
+WORKLOADS["INGRESS"] = (8192, 16, None)
+INGRESS_N, INGRESS_MAX_STEPS = 48, 33
+
+
+def bench_ingress(args, torch):
+    import bourse_amd as bk
+
+    B = args.books or WORKLOADS["INGRESS"][0]
+    N, LV = INGRESS_N, WORKLOADS["INGRESS"][1]
+    W, K = args.warmup, args.steps
+    if W + K > INGRESS_MAX_STEPS:
+        raise SystemExit(f"--workload INGRESS: warm-up + steps <= {INGRESS_MAX_STEPS} (the flow fills the pools; e.g. --steps 24 --warmup 6)")
+    pool = 512 if B > 8192 else 256
+    n = B * N
+    T = W + K
+
+    def new_env():
+        e = bk.ManyBookEnv(B, 1, 0, 1, STEP_SIZE, levels=LV, max_live_orders=pool, max_orders=N * (T + 8), trade_capacity=64 * (T + 8),
+                           strict=False, history_capacity=0, stream=torch.cuda.current_stream().cuda_stream)
+        e.enable_device_ingress(N)
+        return e
+
+    g = torch.Generator(device="cuda").manual_seed(0)
+    off = torch.arange(B + 1, dtype=torch.int64, device="cuda") * N
+
+    def make(s):
+        canc = (torch.rand(n, device="cuda", generator=g) < 0.3) if s else torch.zeros(n, dtype=torch.bool, device="cuda")
+        action = torch.where(canc, 2, 1).to(torch.int32)
+        ids = (torch.rand(n, device="cuda", generator=g) * max(1, int(s * N * 0.6))).to(torch.int64) * canc
+        side = torch.randint(0, 2, (n,), device="cuda", generator=g, dtype=torch.uint8)
+        vol = torch.randint(1, 30, (n,), device="cuda", generator=g, dtype=torch.int32)
+        price = torch.randint(90, 111, (n,), device="cuda", generator=g, dtype=torch.int32)
+        return action, side, vol, torch.zeros(n, dtype=torch.int32, device="cuda"), price, ids
+
+    batches = [make(s) for s in range(T)]  # generated ahead: the rate is the library's, not torch's RNG
+    out_ids = torch.empty(n, dtype=torch.int64, device="cuda")
+    status = torch.empty((B, 2), dtype=torch.int32, device="cuda")
+
+    def run(env, lo, hi):
+        for s in range(lo, hi):
+            env.submit_instructions_device(off, *batches[s], out_ids=out_ids, status=status)
+            env.step(sync=False)
+
+    # clocks: the same scratch-step pre-heat as the agent workloads needs an agent set; here a throw-away env runs the stream
+    t_heat = time.perf_counter()
+    while (time.perf_counter() - t_heat) * 1e3 < args.preheat_min_ms and args.preheat_steps > 0:
+        e = new_env()
+        run(e, 0, T)
+        torch.cuda.synchronize()
+        e.close()
+    env = new_env()
+    run(env, 0, W)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(env, W, T)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if int(status[:, 0].max()) != 0 or env.flags().any():
+        raise SystemExit(f"INGRESS: status / capacity flags set ({np.unique(env.flags())}): the rate would be of a run that dropped orders")
+    keyed = float(env.event_steps_keyed().sum()) / (B * T)
+    tr_total = int(env.trade_counts().sum())
+    env.close()
+    # kernel times: the last steps of the same stream on a fresh env, every launch between two events on the env's stream
+    P = min(6, K)
+    env = new_env()
+    run(env, 0, T - P)
+    torch.cuda.synchronize()
+    tc0 = int(env.trade_counts().sum())
+    env.profile(1)
+    ing_ms = 0.0
+    for s in range(T - P, T):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        env.submit_instructions_device(off, *batches[s], out_ids=out_ids, status=status)
+        b.record()
+        env.step(sync=False)
+        torch.cuda.synchronize()
+        ing_ms += a.elapsed_time(b)
+    ev_ms, nl = env.profile_read_kind(3)
+    env.profile_read()
+    tr = (int(env.trade_counts().sum()) - tc0) / (B * P)
+    new = sum(int((batches[s][0] == 1).sum()) for s in range(T - P, T)) / (B * P)
+    S, W4 = env.state_bytes_per_book(), env.width * 4
+    env.close()
+    ev_bytes = 2.0 * S + 2.0 * W4 + 20.0 * N + 32.0 * tr           # k_step_events, per book-step (DESIGN.md 2's table)
+    ing_bytes = 27.0 * N + 16.0 * N + 80.0 * new                     # k_ingest: arrays in, event records + new orders' records out
+    ev_launch_ms, ing_launch_ms = ev_ms / max(nl, 1), ing_ms / P
+    ach = ev_bytes * B / (ev_launch_ms * 1e-3) / 1e9
+    line = {
+        "metric": "book-steps/sec", "value": B * K / dt, "unit": "book-steps/s", "n_gpus": 1, "steps": K, "warmup": W,
+        "ms_per_step": dt * 1e3 / K, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u32",
+        "data": "synthetic",
+        "config": {"workload": f"INGRESS: {B} books x {N} instructions per book-step (70 % new limit orders at 90..110, 30 % cancellations of "
+                               f"earlier ids) as device arrays through bk_submit_instructions_device + bk_step_async, {pool}-slot pools, "
+                               f"{LV} levels; stream = scripts/device_ingress_rate.py",
+                   "books_total": B, "instructions_per_book_step": N, "instructions_per_s": n * K / dt,
+                   "trades_per_book_step": tr_total / (B * T), "keyed_step_fraction": keyed,
+                   "preheat": f"the whole {T}-step stream on throw-away envs for >= {args.preheat_min_ms:.0f} ms"},
+        "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS, "traffic": None,
+                     "kernel": "k_step_events", "avg_launch_ms": ev_launch_ms, "launches": int(nl), "bytes_per_book_step": ev_bytes,
+                     "book_steps_per_launch": B,
+                     "launches_sampled_in": f"the last {P} steps of the same stream on a fresh env (HIP events around every launch: they "
+                                            f"read ~25 us longer than the launch takes inside the timed loop)",
+                     "kernels": {"k_step_events": {"avg_launch_ms": ev_launch_ms, "bytes_per_book_step": ev_bytes},
+                                 "k_ingest": {"avg_launch_ms": ing_launch_ms, "bytes_per_book_step": ing_bytes,
+                                              "frac": ing_bytes * B / (ing_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS}}},
+    }
+    if not args.no_cpu_baseline:
+        line["cpu_baseline"] = _cpu_baseline_ingress(batches, B, N, T)
+    print(json.dumps(line))
+
+
+def _cpu_baseline_ingress(batches, B, N, T, sample=256):
+    """The same instruction stream through the CPU oracle (one StepEnv per book: place / cancel calls + step) for the first
+    `sample` books, one thread."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pyoracle
+
+    nb = min(sample, B)
+    dts = (np.uint32, np.uint8, np.uint32, np.uint32, np.uint32, np.uint64)
+    host = [[[np.ascontiguousarray(x[b * N:(b + 1) * N].cpu().numpy(), dtype=dt) for x, dt in zip(step, dts)] for b in range(nb)] for step in batches]
+    envs = [pyoracle.StepEnvNumpy(1 + b, 0, 1, STEP_SIZE) for b in range(nb)]
+    t = time.perf_counter()
+    for s in range(T):
+        for b, e in enumerate(envs):
+            e.submit_instructions_native(host[s][b])  # (the loop over the arrays runs in the library, as the reference's in Rust)
+            e.step()
+    d = time.perf_counter() - t
+    return {"value": nb * T / d, "unit": "book-steps/s", "cores": 1, "kind": "port",
+            "sample": f"the first {nb} books x {T} steps of the same instruction stream: one oracle StepEnvNumpy per book, one native "
+                      f"submit_instructions + one step per book-step (oracle/libbourse_oracle.so -O3 through ctypes), one thread"}
 
 
 def effective_cores():
@@ -258,6 +393,10 @@ def main():
             dist.init_process_group(backend="gloo")
         else:
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    if args.workload == "INGRESS":
+        if world > 1:
+            raise SystemExit("--workload INGRESS is a one-GPU line (books shard as for the agent workloads: bourse_amd/parallel.py)")
+        return bench_ingress(args, torch)
     coll_dev = "cpu" if args.dry_ranks else "cuda"  # where the small bookkeeping tensors of the collectives live
 
     def all_ranks(x):

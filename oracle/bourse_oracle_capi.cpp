@@ -370,6 +370,30 @@ void orc_env_cancel_order(void* e, uint64_t id) { static_cast<OrcEnv*>(e)->env.c
 void orc_env_modify_order(void* e, uint64_t id, int has_price, uint32_t price, int has_vol, uint32_t vol) {
   static_cast<OrcEnv*>(e)->env.modify_order(id, opt(has_price, price), opt(has_vol, vol));
 }
+// StepEnvNumpy.submit_instructions as ONE native call (ref rust/src/step_sim_numpy.rs:233-275: the loop over the six arrays runs
+// in Rust there): action 1 = new limit order, 2 = cancellation, anything else nothing (:266); the first price that is not a
+// multiple of the tick size stops the batch - earlier elements stay queued (:255-268).  out_ids[i] = the id element i created,
+// else u64::MAX.  Returns 0, or 1 for that price error with *applied = elements applied before it.
+int orc_env_submit_instructions(void* e, uint64_t n, const uint32_t* action, const uint8_t* side, const uint32_t* vol,
+                                const uint32_t* trader, const uint32_t* price, const uint64_t* order_id, uint64_t* out_ids,
+                                uint64_t* applied) {
+  auto& env = static_cast<OrcEnv*>(e)->env;
+  for (uint64_t i = 0; i < n; ++i) {
+    if (out_ids) out_ids[i] = ~0ull;
+    if (action[i] == 1u) {
+      uint64_t id = 0;
+      if (int rc = env.place_order(side_from_bool((side[i] & 1u) != 0), vol[i], trader[i], opt(1, price[i]), &id)) {
+        if (applied) *applied = i;
+        return rc;
+      }
+      if (out_ids) out_ids[i] = id;
+    } else if (action[i] == 2u) {
+      env.cancel_order(order_id[i]);
+    }
+  }
+  if (applied) *applied = n;
+  return 0;
+}
 uint64_t orc_env_n_transactions(void* e) { return static_cast<OrcEnv*>(e)->env.transactions.size(); }
 // kinds of queued events (0 New, 1 Cancellation, 2 Modify) — for the agent structure tests
 void orc_env_transaction_kinds(void* e, uint8_t* out) {

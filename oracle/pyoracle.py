@@ -678,6 +678,23 @@ class StepEnvNumpy(_EnvBase):
         for i in np.asarray(order_ids):
             lib().orc_env_cancel_order(self._e, int(i))
 
+    def submit_instructions_native(self, instructions):
+        """``submit_instructions`` with the loop over the arrays in the library (as the reference's runs in Rust,
+        rust/src/step_sim_numpy.rs:233-275) - what bench.py's INGRESS CPU baseline times.  Same ids, same stop at a bad price."""
+        action, sides, vols, traders, prices, order_ids = [np.ascontiguousarray(a, dtype=t) for a, t in zip(
+            instructions, (np.uint32, np.uint8, np.uint32, np.uint32, np.uint32, np.uint64))]
+        n = len(action)
+        ids = np.empty(n, dtype=np.uint64)
+        applied = C.c_uint64(0)
+        f = lib().orc_env_submit_instructions
+        f.restype = C.c_int
+        vp = C.c_void_p
+        f.argtypes = [vp, C.c_uint64, vp, vp, vp, vp, vp, vp, vp, C.POINTER(C.c_uint64)]
+        rc = f(self._e, n, *[a.ctypes.data for a in (action, sides, vols, traders, prices, order_ids)], ids.ctypes.data, C.byref(applied))
+        if rc == 1:
+            raise _price_error(int(prices[applied.value]), self._tick)
+        return ids
+
     def submit_instructions(self, instructions):
         action, sides, vols, traders, prices, order_ids = instructions
         ids = []

@@ -61,3 +61,19 @@ def test_bench_default_sampling_and_adaptive_preheat():
     out = _bench("--books", "8192", "--steps", "6", "--warmup", "2", "--repeats", "1", "--no-cpu-baseline")
     assert out["roofline"]["launches_sampled_in"] == "the timed region" and len(out["runs"]["values"]) == 2
     assert out["preheat_steps"] > 0 and out["config"]["preheat"].startswith("bk_warm")
+
+
+@pytest.mark.gpu
+def test_bench_ingress_workload_prints_a_contract_line_with_roofline_and_cpu_baseline():
+    """External agents' instructions through the device-resident ingress (ref rust/src/step_sim_numpy.rs:233-275,
+    crates/step_sim/src/env.rs:116-135) as a bench line of the same shape as the agent workloads'."""
+    out = _bench("--workload", "INGRESS", "--books", "1024", "--steps", "8", "--warmup", "3", "--preheat-min-ms", "20")
+    R, C = out["roofline"], out["cpu_baseline"]
+    assert out["metric"] == "book-steps/sec" and out["value"] > 0 and out["steps"] == 8 and out["dtype"] == "u32"
+    assert R["kernel"] == "k_step_events" and R["bound"] == "hbm" and 0 < R["frac"] < 1 and R["launches"] > 0
+    assert set(R["kernels"]) == {"k_step_events", "k_ingest"}
+    assert C["kind"] == "port" and C["cores"] == 1 and 0 < C["value"] < out["value"]
+    assert out["config"]["keyed_step_fraction"] > 0.9  # (the stream has no modifications: its steps run on the keyed loop)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "INGRESS", "--steps", "40", "--warmup", "5"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "warm-up + steps <=" in (r.stdout + r.stderr)  # the flow fills the pools: refused, not flagged

@@ -453,3 +453,37 @@ def test_rng_pin_file_is_what_the_oracle_produces(oracle):
     # published known answers the file must carry: SplitMix64 seeding of xoroshiro128** (rand_core seed_from_u64)
     assert want[0].startswith("next_u64: ")
     assert len(want) == 12
+
+
+def test_native_submit_instructions_equals_the_python_loop(oracle):
+    """oracle.StepEnvNumpy.submit_instructions_native (the loop over the six arrays inside the library, as the reference's runs in
+    Rust: rust/src/step_sim_numpy.rs:233-275) == submit_instructions (the same loop in Python): ids, the stop at a bad price
+    with the earlier elements queued, every step's level 2, trades and orders.  bench.py's INGRESS CPU baseline times the native one."""
+    import numpy as np
+
+    rng = np.random.default_rng(11)
+    a, b = oracle.StepEnvNumpy(3, 0, 2, 100_000), oracle.StepEnvNumpy(3, 0, 2, 100_000)
+    made = 0
+    for s in range(12):
+        n = int(rng.integers(0, 40))
+        action = rng.choice([0, 1, 2, 3], size=n, p=[0.05, 0.6, 0.3, 0.05]).astype(np.uint32)
+        if made == 0:
+            action[action == 2] = 1
+        ins = (action, rng.integers(0, 2, size=n).astype(np.uint8), rng.integers(1, 30, size=n).astype(np.uint32),
+               rng.integers(0, 9, size=n).astype(np.uint32), (rng.integers(45, 56, size=n) * 2).astype(np.uint32),
+               rng.integers(0, max(1, made), size=n).astype(np.uint64))
+        if s == 5 and (action == 1).sum() > 2:
+            ins[4][np.nonzero(action == 1)[0][2]] += 1  # an odd price at tick size 2: both stop there, the two before it stay queued
+            with pytest.raises(ValueError):
+                a.submit_instructions(ins)
+            with pytest.raises(ValueError):
+                b.submit_instructions_native(ins)
+        else:
+            ia, ib = a.submit_instructions(ins), b.submit_instructions_native(ins)
+            assert np.array_equal(ia, ib)
+        made = a.book.n_orders()
+        assert made == b.book.n_orders() and a.n_transactions() == b.n_transactions()
+        a.step(), b.step()
+        assert np.array_equal(a.level_2_data(), b.level_2_data())
+    assert np.array_equal(a.book.trades_array(), b.book.trades_array()) and np.array_equal(a.book.orders_array(), b.book.orders_array())
+    assert a.book.n_trades() > 20
