@@ -123,21 +123,22 @@ def bench_ingress(args, torch):
     tr_total = int(env.trade_counts().sum())
     env.close()
     # kernel times: the last steps of the same stream on a fresh env, every launch between two events on the env's stream
-    P = min(6, K)
+    P = min(12, K)
     env = new_env()
     run(env, 0, T - P)
     torch.cuda.synchronize()
     tc0 = int(env.trade_counts().sum())
     env.profile(1)
-    ing_ms = 0.0
-    for s in range(T - P, T):
+    evs = []
+    for s in range(T - P, T):  # (no synchronize between the steps: a launch that starts on an idle GPU reads ~10 us long)
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
         env.submit_instructions_device(off, *batches[s], out_ids=out_ids, status=status)
         b.record()
         env.step(sync=False)
-        torch.cuda.synchronize()
-        ing_ms += a.elapsed_time(b)
+        evs.append((a, b))
+    torch.cuda.synchronize()
+    ing_ms = sum(a.elapsed_time(b) for a, b in evs)
     ev_ms, nl = env.profile_read_kind(3)
     env.profile_read()
     tr = (int(env.trade_counts().sum()) - tc0) / (B * P)
@@ -161,8 +162,7 @@ def bench_ingress(args, torch):
         "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS, "traffic": None,
                      "kernel": "k_step_events", "avg_launch_ms": ev_launch_ms, "launches": int(nl), "bytes_per_book_step": ev_bytes,
                      "book_steps_per_launch": B,
-                     "launches_sampled_in": f"the last {P} steps of the same stream on a fresh env (HIP events around every launch: they "
-                                            f"read ~25 us longer than the launch takes inside the timed loop)",
+                     "launches_sampled_in": f"the last {P} steps of the same stream on a fresh env, HIP events around every launch",
                      "kernels": {"k_step_events": {"avg_launch_ms": ev_launch_ms, "bytes_per_book_step": ev_bytes},
                                  "k_ingest": {"avg_launch_ms": ing_launch_ms, "bytes_per_book_step": ing_bytes,
                                               "frac": ing_bytes * B / (ing_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS}}},
