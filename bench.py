@@ -149,6 +149,15 @@ def bench_ingress(args, torch):
     ing_bytes = 27.0 * N + 16.0 * N + 80.0 * new                     # k_ingest: arrays in, event records + new orders' records out
     ev_launch_ms, ing_launch_ms = ev_ms / max(nl, 1), ing_ms / P
     ach = ev_bytes * B / (ev_launch_ms * 1e-3) / 1e9
+    traffic = traffic_src = None  # (PMC passes of this command, committed and replayed: as for the agent workloads)
+    try:
+        allp = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        rec = allp.get(f"INGRESS/{B}", {}).get("k_step_events", {})
+        if "hbm_bytes_per_book_step" in rec:
+            traffic = rec["hbm_bytes_per_book_step"] * B
+            traffic_src = f"profiles/pmc_traffic.json[INGRESS/{B}]: {allp.get('_source', '')}; replayed, not measured in this run"
+    except Exception:  # noqa: BLE001
+        pass
     line = {
         "metric": "book-steps/sec", "value": B * K / dt, "unit": "book-steps/s", "n_gpus": 1, "steps": K, "warmup": W,
         "ms_per_step": dt * 1e3 / K, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u32",
@@ -158,9 +167,10 @@ def bench_ingress(args, torch):
                                f"{LV} levels; stream = scripts/device_ingress_rate.py",
                    "books_total": B, "instructions_per_book_step": N, "instructions_per_s": n * K / dt,
                    "trades_per_book_step": tr_total / (B * T), "keyed_step_fraction": keyed,
+                   "pipeline": "k_ingest + k_step_events per step (host-driven kernels; no agents pipeline)",
                    "preheat": f"the whole {T}-step stream on throw-away envs for >= {args.preheat_min_ms:.0f} ms"},
-        "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS, "traffic": None,
-                     "kernel": "k_step_events", "avg_launch_ms": ev_launch_ms, "launches": int(nl), "bytes_per_book_step": ev_bytes,
+        "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS, "traffic": traffic,
+                     "traffic_source": traffic_src, "kernel": "k_step_events", "avg_launch_ms": ev_launch_ms, "launches": int(nl), "bytes_per_book_step": ev_bytes,
                      "book_steps_per_launch": B,
                      "launches_sampled_in": f"the last {P} steps of the same stream on a fresh env, HIP events around every launch",
                      "kernels": {"k_step_events": {"avg_launch_ms": ev_launch_ms, "bytes_per_book_step": ev_bytes},

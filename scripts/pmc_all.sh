@@ -14,8 +14,11 @@ cd /tmp && export TMPDIR=/tmp
 # the timed region is left alone (--profile-every 0, no repeats, no pre-heat: bk_warm's one 100-step launch would mix a
 # second launch shape into the fused kernels' means); 20 steps per launch so that a fused launch is 20 book-steps per book
 PA="--steps 40 --warmup 20 --steps-per-launch 20 --no-cpu-baseline --profile-every 0 --repeats 0 --preheat-steps 0"
+PA_AGENTS=$PA
 for C in $CONFIGS; do
   W=${C%%:*}; B=${C##*:}
+  # (the external-agents stream fills the pools: at most 33 steps, bench.py bench_ingress)
+  if [ $W = INGRESS ]; then PA="--steps 24 --warmup 6 --no-cpu-baseline --preheat-steps 0"; else PA=$PA_AGENTS; fi
   run() { d=$1; shift; rocprofv3 --pmc "$@" -d $OUT/${W}_${B}_$d -o p -f csv -- python3 $R/bench.py --workload $W --books $B $PA > $OUT/${W}_${B}_$d.json 2> $OUT/${W}_${B}_$d.err
           # a pass whose bench died (round 4: a NameError AFTER the timed region, stdout empty) must not pass silently
           grep -q '^{' $OUT/${W}_${B}_$d.json || { echo "pmc_all: $W:$B pass '$d' printed no bench line" >&2; grep -v "^W2\|rocprofiler" $OUT/${W}_${B}_$d.err | tail -n 8 >&2; FAILED="$FAILED ${W}_${B}_$d"; }; }

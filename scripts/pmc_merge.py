@@ -1,7 +1,8 @@
 """Fold the summary of a scripts/pmc_all.sh run into the committed record:
   gpurun_out/pmc_<tag>/summary.json  ->  profiles/<round>/pmc_summary.json  (as measured, per config and kernel)
                                      ->  profiles/pmc_traffic.json          (what bench.py replays into roofline.traffic / .issue)
-usage: pmc_merge.py <tag> <round>      e.g.  pmc_merge.py r04a r04"""
+usage: pmc_merge.py <tag> <round> [--add]     e.g.  pmc_merge.py r04a r04;  --add: the round's record keeps its other configurations
+(a later pmc_all.sh run of some configurations only)"""
 import json
 import os
 import sys
@@ -10,6 +11,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag, rnd = sys.argv[1], sys.argv[2]
 summ = json.load(open(os.path.join(ROOT, "gpurun_out", "pmc_" + tag, "summary.json")))
 os.makedirs(os.path.join(ROOT, "profiles", rnd), exist_ok=True)
+if "--add" in sys.argv:
+    summ = {**json.load(open(os.path.join(ROOT, "profiles", rnd, "pmc_summary.json"))), **summ}
 json.dump(summ, open(os.path.join(ROOT, "profiles", rnd, "pmc_summary.json"), "w"), indent=1)
 src = (f"profiles/{rnd}/pmc_summary.json (rocprofv3 --pmc passes of `bench.py --workload W --books B`, FETCH_SIZE / WRITE_SIZE / "
        f"SQ_INSTS_* / SQ_WAIT_* in separate passes, every counter divided by the book-steps of its dispatches: "
