@@ -31,13 +31,33 @@ def run(P):
         data.append((off, bs, torch.empty(n, dtype=torch.int64, device="cuda"), torch.empty((B, 2), dtype=torch.int32, device="cuda")))
     torch.cuda.synchronize()
 
+    def join():  # every stream waits for every other's work so far: what parts INSIDE one env would pay after each call
+        evs = []
+        for p in range(P):
+            ev = torch.cuda.Event()
+            ev.record(streams[p])
+            evs.append(ev)
+        for p in range(P):
+            for q in range(P):
+                if q != p:
+                    streams[p].wait_event(evs[q])
+
     def steps(lo, hi):
         for s in range(lo, hi):
             for p in range(P):
                 off, bs, ids, st = data[p]
                 with torch.cuda.stream(streams[p]):
                     envs[p].submit_instructions_device(off, *bs[s], out_ids=ids, status=st)
-                    envs[p].step(sync=False)
+                    if not JOIN:
+                        envs[p].step(sync=False)
+            if JOIN:
+                if P > 1:
+                    join()
+                for p in range(P):
+                    with torch.cuda.stream(streams[p]):
+                        envs[p].step(sync=False)
+                if P > 1:
+                    join()
     steps(0, 3)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -45,10 +65,11 @@ def run(P):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     fl = np.unique(np.concatenate([e.flags() for e in envs]))
-    print(f"{P} env(s) x {B} books on {P} stream(s): {dt / T * 1e3:.3f} ms/step -> {BT * T / dt / 1e6:.1f} M book-steps/s, flags {fl}", flush=True)
+    print(f"{'joined after every call: ' if JOIN else ''}{P} env(s) x {B} books on {P} stream(s): {dt / T * 1e3:.3f} ms/step -> {BT * T / dt / 1e6:.1f} M book-steps/s, flags {fl}", flush=True)
     for e in envs:
         e.close()
 
 
-for P in (1, 2, 4, 1, 2, 4):
-    run(P)
+for JOIN in (False, True):
+    for P in ((1, 2, 4, 1, 2, 4) if not JOIN else (2, 2)):
+        run(P)
