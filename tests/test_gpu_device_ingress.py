@@ -441,3 +441,48 @@ class _BookView:
 
     def modify_order(self, b, i, p, v):
         return self.base.modify_order(self.env, b, i, p, v)
+
+
+def test_two_envs_on_two_streams_equal_one_env(bk):
+    """INTEGRATION.md's two-env form of the ingress: the books of one env as two envs with `book_offset` on two streams (each
+    env's k_ingest under the other's k_step_events) - same seeds per global book (ref crates/step_sim/src/runner.py-style
+    independence: crates/step_sim/src/runner.rs:46-69), same instructions, same results."""
+    import torch
+
+    B, H, N, T = 1024, 512, 24, 6
+    kw = dict(levels=10, max_live_orders=128, max_orders=N * T + 8, trade_capacity=4 * N * T, history_capacity=T, strict=False)
+    one = bk.ManyBookEnv(B, 9, 0, 1, 100_000, stream=torch.cuda.current_stream().cuda_stream, **kw)
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    two = [bk.ManyBookEnv(H, 9, 0, 1, 100_000, book_offset=H * p, stream=streams[p].cuda_stream, **kw) for p in (0, 1)]
+    for e in [one] + two:
+        e.enable_device_ingress(N)
+    rng = np.random.default_rng(3)
+    off_all = _dev(torch, (np.arange(B + 1) * N).astype(np.int64))
+    off_half = _dev(torch, (np.arange(H + 1) * N).astype(np.int64))
+    for s in range(T):
+        n = B * N
+        canc = (rng.random(n) < 0.3) & (s > 0)
+        ins = (np.where(canc, 2, 1).astype(np.uint32), rng.integers(0, 2, size=n).astype(np.uint8), rng.integers(1, 30, size=n).astype(np.uint32),
+               np.zeros(n, dtype=np.uint32), rng.integers(95, 106, size=n).astype(np.uint32),
+               np.where(canc, rng.integers(0, max(1, s * N // 2), size=n), 0).astype(np.uint64))
+        one.submit_instructions_device(off_all, *[_dev(torch, x) for x in ins])
+        one.step(sync=False)
+        torch.cuda.synchronize()  # (the halves' uploads below happen on the current stream)
+        for p in (0, 1):
+            part = [_dev(torch, x[p * H * N:(p + 1) * H * N]) for x in ins]
+            torch.cuda.synchronize()
+            with torch.cuda.stream(streams[p]):
+                two[p].submit_instructions_device(off_half, *part)
+                two[p].step(sync=False)
+    torch.cuda.synchronize()
+    assert not one.flags().any() and not two[0].flags().any() and not two[1].flags().any()
+    h1 = one.history()
+    assert np.array_equal(h1[:, :H], two[0].history()) and np.array_equal(h1[:, H:], two[1].history())
+    tc = one.trade_counts()
+    assert np.array_equal(tc[:H], two[0].trade_counts()) and np.array_equal(tc[H:], two[1].trade_counts()) and int(tc.sum()) > 1000
+    for b in (0, 77, H - 1):
+        for p in (0, 1):
+            a, c = one.trades(p * H + b, first=0), two[p].trades(b, first=0)
+            assert all(np.array_equal(a[f], c[f]) for f in a.dtype.names)
+    for e in [one] + two:
+        e.close()
