@@ -486,3 +486,45 @@ def test_two_envs_on_two_streams_equal_one_env(bk):
             assert all(np.array_equal(a[f], c[f]) for f in a.dtype.names)
     for e in [one] + two:
         e.close()
+
+
+def test_the_rate_scripts_stream_at_full_size_runs_keyed_and_equals_the_oracle(bk, oracle):
+    """The stream of scripts/device_ingress_rate.py / `bench.py --workload INGRESS` at its full size (8 192 books x 48 instructions
+    per book-step, 70 % new limit orders, 30 % cancellations of earlier ids): every book-step on the keyed form of the host-driven
+    step (step_events.hpp), every 64th book against the oracle's StepEnvNumpy fed the same arrays (native submit_instructions,
+    ref rust/src/step_sim_numpy.rs:233-275; Env::step crates/step_sim/src/env.rs:116-135): level 2 of every step, trades, orders."""
+    import torch
+
+    B, N, T = 8192, 48, 10
+    env = bk.ManyBookEnv(B, 1, 0, 1, 100_000, levels=10, max_live_orders=256, max_orders=N * T + 8, trade_capacity=64 * T, history_capacity=T,
+                         strict=False, stream=torch.cuda.current_stream().cuda_stream)
+    env.enable_device_ingress(N)
+    sample = list(range(0, B, 64))
+    refs = {b: oracle.StepEnvNumpy(1 + b, 0, 1, 100_000) for b in sample}
+    rng = np.random.default_rng(0)
+    off = _dev(torch, (np.arange(B + 1) * N).astype(np.int64))
+    n = B * N
+    for s in range(T):
+        canc = (rng.random(n) < 0.3) & (s > 0)
+        ins = (np.where(canc, 2, 1).astype(np.uint32), rng.integers(0, 2, size=n).astype(np.uint8), rng.integers(1, 30, size=n).astype(np.uint32),
+               np.zeros(n, dtype=np.uint32), rng.integers(90, 111, size=n).astype(np.uint32),
+               np.where(canc, (rng.random(n) * max(1, int(s * N * 0.6))).astype(np.uint64), 0).astype(np.uint64))
+        env.submit_instructions_device(off, *[_dev(torch, x) for x in ins])
+        env.step(sync=False)
+        for b in sample:
+            refs[b].submit_instructions_native(tuple(x[b * N:(b + 1) * N] for x in ins))
+            refs[b].step()
+    env.sync()
+    assert not env.flags().any()
+    assert np.array_equal(env.event_steps_keyed(), np.full(B, T, dtype=np.uint64)), "a book-step of this stream left the keyed form"
+    h = env.history()
+    n_tr = 0
+    for b in sample:
+        assert np.array_equal(h[:, b], refs[b].history()), b
+        got, want = env.trades(b, first=0), refs[b].book.trades_array()
+        assert len(got) == len(want) and all(np.array_equal(got[f], want[f]) for f in got.dtype.names), b
+        got, want = env.orders(b), refs[b].book.orders_array()
+        assert len(got) == len(want) and all(np.array_equal(got[f], want[f]) for f in got.dtype.names), b
+        n_tr += len(want)
+    assert n_tr > 100 * len(sample)
+    env.close()
