@@ -455,7 +455,10 @@ int launch_events(bk_env* env, const DevArgs& a, uint64_t step_index, uint32_t m
   const char* min_str = getenv("BOURSE_AMD_EV_WAVE_SHUFFLE_MIN");
   const int min_env = min_str ? atoi(min_str) : -1;
   const uint32_t shuffle_min = min_env >= 0 ? static_cast<uint32_t>(min_env) : (12u * R > 32u ? 12u * R : 32u);  // (measured: 256 slots 24 events -3 %, 48 +5 %; 512 slots 48 -7 %, 96 +3 %)
-  hipLaunchKernelGGL(k_step_events<R>, dim3(env->cfg.n_books), dim3(64), perm_bytes, env->stream, a, wva, step_index, shuffle_min);
+  if (env->M == 1)
+    hipLaunchKernelGGL((k_step_events<R, false>), dim3(env->cfg.n_books), dim3(64), perm_bytes, env->stream, a, wva, step_index, shuffle_min);
+  else
+    hipLaunchKernelGGL((k_step_events<R, true>), dim3(env->cfg.n_books), dim3(64), perm_bytes, env->stream, a, wva, step_index, shuffle_min);
   HIPCHK(hipGetLastError());
   return BK_OK;
 }

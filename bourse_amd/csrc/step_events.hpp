@@ -73,7 +73,7 @@ __device__ __forceinline__ void insert_order(Book<R>& B, int lane, uint32_t n, u
 //     took from it while it rested, and what was left of it on arrival (its volume minus what it took as the aggressor:
 //     the compact trade records are scattered into those words before each flush).
 // Returns false - nothing that matters changed: only fields of FREE pool slots - when the step is not of that form (a
-// modification, another asset's events, an unknown id, a volume of 0 anywhere, fewer free slots than new orders + 1, prices or
+// modification, an unknown id, a volume of 0 anywhere, fewer free slots than new orders + 1, prices or
 // arrival stamps outside the key window, market orders on the pools the hand-written loops serve): the caller runs the
 // event-by-event loop.  LDS (dynamic, `perm`): 12 x 64 R bytes (ev_keyed_lds_bytes).
 // ----------------------------------------------------------------------------------
@@ -81,9 +81,15 @@ __device__ __forceinline__ void insert_order(Book<R>& B, int lane, uint32_t n, u
 #define BOURSE_AMD_EV_KEYED 1
 #endif
 constexpr uint32_t ev_keyed_lds_bytes(int R) { return 12u * 64u * (uint32_t)R; }
-template <int R>
+// MKT (the kernel's): the book belongs to a market of several assets (MarketEnv, market_env.rs:110-121).  The market's queue
+// holds every asset's events at their global positions; the other assets' stay in this book's list as events that do nothing,
+// so that the positions - the time stamps - are the market's; n_own = this book's events.  (A template parameter, and the
+// single-asset text left exactly as it was: the run-time form cost the single-asset kernel 1.5 %, a first templated form that
+// simplified its expressions 4 % - the register allocation of this kernel sits on an edge: profiles/r05/ab_ev_markets*.txt.)
+template <int R, bool MKT>
 __device__ __forceinline__ bool step_events_keyed(Book<R>& B, const DevArgs& a, uint32_t book, uint64_t t0, int lane,
-                                                  uint32_t n_ev, uint32_t e0, uint16_t* perm, const LogCtx& lg) {
+                                                  uint32_t n_ev, uint32_t e0, uint16_t* perm, const LogCtx& lg, uint32_t asset,
+                                                  uint32_t& n_own) {
   constexpr uint32_t S = 64u * R;
   uint16_t* rank2ev = perm + S;       // bytes [2S, 4S): event position of the i-th new order
   uint16_t* ev2slot = perm + 2u * S;  // bytes [4S, 6S): pool slot of the new order at an event position
@@ -109,10 +115,17 @@ __device__ __forceinline__ bool step_events_keyed(Book<R>& B, const DevArgs& a, 
     uint4 rec = make_uint4(0xFFu, 0u, 0u, 0u);
     if (valid) rec = a.ev[e0 + perm[pos]];
     const uint32_t kind = rec.x & 0xFFu;
-    is_new[re] = __ballot(valid && kind == 0u);
-    is_can[re] = __ballot(valid && kind == 1u);
-    bad |= valid && (kind >= 2u || ((rec.x >> 16) & 0xFFu) != 0u || (kind == 0u && rec.w == 0u) ||
-                     (a.ev_len && kind != 0u && rec.y >= B.next_id));
+    if constexpr (MKT) {
+      const bool own = valid && ((rec.x >> 16) & 0xFFu) == asset;
+      is_new[re] = __ballot(own && kind == 0u);
+      is_can[re] = __ballot(own && kind == 1u);
+      bad |= own && (kind >= 2u || (kind == 0u && rec.w == 0u) || (a.ev_len && kind != 0u && rec.y >= B.next_id));
+    } else {
+      is_new[re] = __ballot(valid && kind == 0u);
+      is_can[re] = __ballot(valid && kind == 1u);
+      bad |= valid && (kind >= 2u || ((rec.x >> 16) & 0xFFu) != 0u || (kind == 0u && rec.w == 0u) ||
+                       (a.ev_len && kind != 0u && rec.y >= B.next_id));
+    }
     eww[re] = rec.x;
     eid[re] = rec.y;
     evq[re] = rec.w;
@@ -120,6 +133,11 @@ __device__ __forceinline__ bool step_events_keyed(Book<R>& B, const DevArgs& a, 
 #pragma unroll
   for (int r = 0; r < R; ++r) bad |= lane_bit(B.live[r]) && B.vol[r] == 0u;
   if (__ballot(bad)) return false;
+  if constexpr (MKT) {  // (this book's events: every one of them is a New or a Cancellation here)
+    n_own = 0;
+#pragma unroll
+    for (int re = 0; re < R; ++re) n_own += (uint32_t)__builtin_popcountll(is_new[re] | is_can[re]);
+  }
   // ---- slots for the new orders
   uint32_t n_new = 0;
 #pragma unroll
@@ -298,7 +316,8 @@ constexpr uint32_t ev_lds_bytes(int R) {
   const uint32_t S = 64u * (uint32_t)R, sh = 6u * S + WV_RING * 4u, ky = ev_keyed_lds_bytes(R);
   return sh > ky ? sh : ky;
 }
-template <int R>
+template <int R, bool MKT = false>
+// (MKT: launched for the books of markets with more than one asset, bk_config.assets > 1 - only the keyed form differs)
 // (eight waves per SIMD for pools of <= 256 slots, five for 512: 8 192 books - the C4 shard, the ingress rate scripts - are then ONE residency round;
 // at the 69 VGPRs the compiler took for R = 4 a seventh of the waves ran as a second round)
 __global__ __launch_bounds__(64, BOURSE_AMD_EV_OCC(R)) void k_step_events(DevArgs a, WaveArgs wa, uint64_t step_index, uint32_t wave_shuffle_min) {
@@ -393,9 +412,9 @@ __global__ __launch_bounds__(64, BOURSE_AMD_EV_OCC(R)) void k_step_events(DevArg
   // (the keyed form first: see step_events_keyed; the event-by-event loop below is the general case)
   // (the keyed form runs on the assembly loops only: a -DBOURSE_AMD_ASM_EVENTS=0 / -DBOURSE_AMD_ASM_R48=0 build steps event by event)
   constexpr bool has_asm = BOURSE_AMD_ASM_EVENTS && (R <= 2 || BOURSE_AMD_ASM_R48);
-  const bool keyed = BOURSE_AMD_EV_KEYED && has_asm && !(BOURSE_AMD_EV_SKIP & ~1) && a.assets == 1u && B.trading && n_ev != 0u && n_ev <= 64u * R &&
-                     step_events_keyed<R>(B, a, book, t0, lane, n_ev, e0, perm, lg);
-  if (keyed) n_own = n_ev;
+  const bool keyed = BOURSE_AMD_EV_KEYED && has_asm && !(BOURSE_AMD_EV_SKIP & ~1) && (MKT || a.assets == 1u) && B.trading && n_ev != 0u && n_ev <= 64u * R &&
+                     step_events_keyed<R, MKT>(B, a, book, t0, lane, n_ev, e0, perm, lg, asset, n_own);
+  if (MKT ? !keyed : keyed) n_own = MKT ? 0u : n_ev;  // (MKT: the keyed form counted them, unless it gave up half-way)
   uint4 evr = make_uint4(0u, 0u, 0u, 0u);
   for (uint32_t k = 0; k < (keyed ? 0u : n_ev); ++k) {
     // the 16-byte records of 64 shuffled positions are fetched at once, one per lane (one memory round trip per 64

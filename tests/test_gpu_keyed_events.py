@@ -179,3 +179,52 @@ def test_a_book_with_trading_disabled_steps_event_by_event(bk, oracle):
     assert env.event_steps_keyed().tolist() == [2, 2]
     _same_as_oracle(env, refs)
     env.close()
+
+
+@pytest.mark.parametrize("assets,pool", [(2, 128), (3, 256), (4, 512)])
+def test_markets_books_run_the_keyed_form_on_their_markets_queue(bk, oracle, assets, pool):
+    """MarketEnv (ref crates/step_sim/src/market_env.rs:110-121): ONE shuffled queue per market, every asset's book processes its
+    own events at the market's positions.  In the keyed form the other assets' events stay in a book's list as events that do
+    nothing; a modification for one asset sends only THAT asset's book to the event-by-event loop."""
+    NM, T = 48, 10
+    ticks = [1, 2, 5, 1][:assets]
+    env = bk.ManyMarketEnv(NM, 70, 0, ticks, 100_000, levels=10, max_live_orders=pool, max_orders=2048, trade_capacity=4096, history_capacity=T)
+    ref = oracle.ManyMarkets(NM, 70, 0, ticks, 100_000, True, 10)
+    rng = np.random.default_rng(assets)
+    clean = np.zeros((T, NM, assets), dtype=bool)
+    for s in range(T):
+        for m in range(NM):
+            n = int(rng.integers(1, min(60, pool // 2)))
+            ok = [True] * assets
+            for _ in range(n):
+                a = int(rng.integers(0, assets))
+                made = ref.book(m, a).n_orders()
+                u = rng.random()
+                if u < 0.35 and made:
+                    oid = int(made - 1 - rng.integers(0, min(made, 60)))
+                    env.cancel_order(m, a, oid)
+                    ref.cancel_order(m, a, oid)
+                elif u < 0.36 and made:
+                    oid = int(rng.integers(0, made))
+                    nv = int(rng.integers(1, 30))
+                    env.modify_order(m, a, oid, None, nv)
+                    ref.modify_order(m, a, oid, None, nv)
+                    ok[a] = False
+                else:
+                    bid, vol = bool(rng.integers(0, 2)), int(rng.integers(1, 30))
+                    price = None if (rng.random() < 0.04 and pool > 128) else int(rng.integers(95, 106)) * ticks[a]
+                    assert env.place_order(m, a, bid, vol, 7, price) == ref.place_order(m, a, bid, vol, 7, price)
+            clean[s, m] = ok
+        env.step()
+        ref.step()
+    assert np.array_equal(env.history(), ref.history())
+    for m in range(NM):
+        for a in range(assets):
+            b = env.book(m, a)
+            got, want = env.trades(b, first=0), ref.book(m, a).trades_array()
+            assert len(got) == len(want) and all(np.array_equal(got[f], want[f]) for f in got.dtype.names), (m, a)
+            got, want = env.orders(b), ref.book(m, a).orders_array()
+            assert len(got) == len(want) and all(np.array_equal(got[f], want[f]) for f in got.dtype.names), (m, a)
+    keyed = env.event_steps_keyed().reshape(NM, assets)
+    assert np.all(keyed <= clean.sum(axis=0)) and keyed.sum() >= 0.9 * clean.sum(), (int(keyed.sum()), int(clean.sum()))
+    env.close()
