@@ -448,7 +448,7 @@ int launch_events(bk_env* env, const DevArgs& a, uint64_t step_index, uint32_t m
   const char* seq_env = getenv("BOURSE_AMD_EV_SEQ_SHUFFLE");
   const bool seq_shuffle = seq_env && *seq_env == '1';
   WaveArgs wva{};
-  if (!seq_shuffle && env->M == 1)
+  if (!seq_shuffle)
     if (int rc = wave_args(env, &wva)) return rc;
   // (its fixed cost - the cache record, a block of draws, a resolution over all 64 R positions - pays from a queue length that
   // grows with the pool: docs/EXPERIMENTS.md; BOURSE_AMD_EV_WAVE_SHUFFLE_MIN overrides, for measurements)

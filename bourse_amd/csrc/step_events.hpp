@@ -359,8 +359,9 @@ __global__ __launch_bounds__(64, BOURSE_AMD_EV_OCC(R)) void k_step_events(DevArg
   // per pool slot is therefore shuffled by the decode's wave-parallel Fisher-Yates (wave_agents.hpp WaveDecoder::shuffle: 64
   // draws per window from the book's cached lane states, the acceptance fixed point, all swaps resolved at once); the T^256
   // table is read from global memory (one block change every few steps), the draws, targets and bucket words use the LDS
-  // the keyed form takes over afterwards.  Longer queues and the markets' shared queues keep the loop below.
-  const bool wave_shuffle = BOURSE_AMD_EV_WAVE_SHUFFLE && !BOURSE_AMD_EV_SKIP && wa.wcache != nullptr && a.assets == 1u && n_ev >= 2u &&
+  // the keyed form takes over afterwards (a market's books each shuffle their copy of the market's stream, from their own
+  // cache record).  Longer queues keep the loop below.
+  const bool wave_shuffle = BOURSE_AMD_EV_WAVE_SHUFFLE && !BOURSE_AMD_EV_SKIP && wa.wcache != nullptr && (MKT || a.assets == 1u) && n_ev >= 2u &&
                             n_ev >= wave_shuffle_min && n_ev <= 64u * R;
   if (wave_shuffle) {
     constexpr uint32_t S = 64u * R;
