@@ -1182,7 +1182,26 @@ __device__ __forceinline__ uint32_t step_from_list(Book<R>& B, const DevArgs& a,
     newm[r] = (CLS || PENDKEY) ? B.pend[r] : 0ull;
     if (CLS) B.pend[r] = 0;
   }
-  if constexpr ((R == 2 || R == 1) && !MKT && CLS && BOURSE_AMD_ASM_EVENTS) {
+  // MKTK (round 5): a MARKET's self-classifying list on the keyed / assembly loops too.  The other assets' events become events
+  // that do nothing - a Cancellation of a slot that belongs to another asset's agent, which this book never fills - at their
+  // positions in the market's queue (the time stamps are the market's, market_env.rs:110-121); n_own = this book's events.
+  constexpr bool MKTK = MKT && CLS && !TAGGED;
+  uint32_t evm[R], own_cnt = 0;
+  bool listed = false;
+#pragma unroll
+  for (int re = 0; re < R; ++re) {
+    evm[re] = ev[re];
+    if constexpr (MKTK) {
+      const uint32_t slot = ev[re] & EV_SLOT & (64u * R - 1u);
+      bool own = false;
+#pragma unroll
+      for (int r = 0; r < R; ++r) own = (slot >> 6) == (uint32_t)r ? ((mine[r] >> (slot & 63u)) & 1ull) != 0ull : own;
+      evm[re] = own ? ev[re] : (ev[re] & ~(EV_NEW | EV_BID));
+      own_cnt += (uint32_t)__builtin_popcountll(__ballot(own && (uint32_t)(re * 64 + lane) < n_ev));
+    }
+  }
+  if constexpr ((R == 2 || R == 1) && (!MKT || MKTK) && CLS && BOURSE_AMD_ASM_EVENTS) {
+    listed = true;
     // hand-written event loops (event_asm.hpp); they return whenever the 64-record trade buffer is full
     uint32_t k = 0;
     const uint32_t nev = rfl(n_ev), tmask = B.trading ? 0xFFFFFFFFu : 0u;
@@ -1191,7 +1210,7 @@ __device__ __forceinline__ uint32_t step_from_list(Book<R>& B, const DevArgs& a,
       // keyed loop: one signed sort key per order (side | price field | arrival field), rebuilt from {price, seq} every
       // step; the event words get their new orders' compare values here
       uint32_t evw[R];
-      key_event_words<R>(K, ev, nev, evw);
+      key_event_words<R>(K, evm, nev, evw);
       // the loop tests "no volume or trading disabled" on every new order (two scalar instructions) unless this step is
       // known not to need it: trading enabled and no new order with volume 0 (one ballot per pool register here)
       uint64_t zero_vol = 0;
@@ -1215,15 +1234,15 @@ __device__ __forceinline__ uint32_t step_from_list(Book<R>& B, const DevArgs& a,
       keys_end<R>(B, K);
     } else if constexpr (R == 2) {
       while (events_asm_r2(k, nev, tmask, B.tr_n, B.seq_ctr, B.trade_vol, B.live[0], B.live[1], B.bid[0], B.bid[1],
-                           B.price[0], B.price[1], B.vol[0], B.vol[1], B.id[0], B.id[1], B.seq[0], B.seq[1], ev[0], ev[1],
+                           B.price[0], B.price[1], B.vol[0], B.vol[1], B.id[0], B.id[1], B.seq[0], B.seq[1], evm[0], evm[1],
                            B.tr_k, B.tr_price, B.tr_vol, B.tr_act, B.tr_pas))
         flush_trades<R>(B, a, book, t0, lane);
     } else {
       while (events_asm_r1(k, nev, tmask, B.tr_n, B.seq_ctr, B.trade_vol, B.live[0], B.bid[0], B.price[0], B.vol[0], B.id[0],
-                           B.seq[0], ev[0], B.tr_k, B.tr_price, B.tr_vol, B.tr_act, B.tr_pas))
+                           B.seq[0], evm[0], B.tr_k, B.tr_price, B.tr_vol, B.tr_act, B.tr_pas))
         flush_trades<R>(B, a, book, t0, lane);
     }
-  } else if (KeyState<R> K; (CLS || PENDKEY) && !MKT && BOURSE_AMD_KEYED_EVENTS &&
+  } else if (KeyState<R> K; (CLS || PENDKEY) && (!MKT || MKTK) && BOURSE_AMD_KEYED_EVENTS &&
              (keys_begin<R, !CLS>(B, newm, rfl(n_ev), K) ||
               // (members' lists only: RandomAgents draw their prices from a bounded tick window, and the extra path costs
               // k_step_batch<8>'s RandomAgents instantiation 32 B of scratch at its 96-register claim)
@@ -1236,8 +1255,9 @@ __device__ __forceinline__ uint32_t step_from_list(Book<R>& B, const DevArgs& a,
     // classified by it (round 4's first version selected the slot's mask words from 4 R scalar pairs per list register:
     // ~100 vector instructions each).  A slot holds at most one event per step (a pending order sits in a slot that was
     // free when the step began), so classifying up front is the same as classifying at the event.
+    listed = true;
     uint32_t evw[R];
-    key_event_words<R>(K, ev, rfl(n_ev), evw);
+    key_event_words<R>(K, evm, rfl(n_ev), evw);
     if (!CLS) {
 #pragma unroll
       for (int re = 0; re < R; ++re) {
@@ -1281,12 +1301,13 @@ __device__ __forceinline__ uint32_t step_from_list(Book<R>& B, const DevArgs& a,
       if (n_ev > kb) {
         const uint32_t cnt = rfl((n_ev - kb) < 64u ? (n_ev - kb) : 64u);
         for (uint32_t l = 0; l < cnt; ++l) {
-          const uint32_t ew = rdl(ev[re], l);
-          slot_event_keyed<R, 0, CLS>(B, K, a, book, t0, lane, kb + l, CLS ? (ew & EV_SLOT) : ew, ew, ev);
+          const uint32_t ew = rdl(evm[re], l);
+          slot_event_keyed<R, 0, CLS>(B, K, a, book, t0, lane, kb + l, CLS ? (ew & EV_SLOT) : ew, ew, evm);
         }
       }
     }
-    flush_trades_compact<R>(B, a, book, t0, lane, ev);  // (the loop's records are compact: filled in before the snapshot)
+    listed = true;
+    flush_trades_compact<R>(B, a, book, t0, lane, evm);  // (the loop's records are compact: filled in before the snapshot)
    }
     keys_end<R>(B, K);
   } else
@@ -1312,6 +1333,7 @@ __device__ __forceinline__ uint32_t step_from_list(Book<R>& B, const DevArgs& a,
     }
   }
   if (!MKT) n_own = n_ev;
+  if (MKTK && listed) n_own = own_cnt;
   BK_STAMP(B, 0, 3, lane);  // key set-up + event loop
   B.n_events += n_own;
   B.t = t0 + step_size;  // env.rs:129
