@@ -13,3 +13,6 @@ tail -n 3 $O/*.txt
 FUZZ_LO=${LO_PARTS:-900000} FUZZ_HI=${N_PARTS:-900400} timeout 1500 python3 scripts/fuzz_parts.py > $O/fuzz_parts.txt 2>&1
 timeout 900 python3 scripts/soak_agents.py > $O/soak_agents.txt 2>&1
 tail -n 2 $O/fuzz_parts.txt $O/soak_agents.txt
+# (late round 5) the host-driven step's keyed form, every book against its oracle env; RandomMarketAgents shapes against ManyMarkets
+FUZZ_LO=${LO_KEYED:-0} FUZZ_HI=${N_KEYED:-1500} timeout 900 python3 scripts/fuzz_keyed_events.py 2>&1 | grep -v amdgpu.ids | tail -n 3 | tee $O/fuzz_keyed_events.txt
+FUZZ_LO=${LO_MARKETS:-0} FUZZ_HI=${N_MARKETS:-1000} timeout 900 python3 scripts/fuzz_markets.py 2>&1 | grep -v amdgpu.ids | tail -n 3 | tee $O/fuzz_markets.txt
