@@ -64,6 +64,42 @@ WORKLOADS["INGRESS"] = (8192, 16, None)
 INGRESS_N, INGRESS_MAX_STEPS = 48, 33
 
 
+def algorithmic_bytes(kind, S, W4, ev, tr, new, spl=1, pipe="split", n_ins=0.0):
+    """COMPULSORY HBM bytes per book-step of one step kernel -> (hbm_bytes, l2_bytes).
+
+    hbm_bytes is what `roofline.achieved` is computed from: only what a launch MUST read from and write to HBM in the layout
+    shipped (S = the per-book state block, W4 = the level-2 record, 32 B per trade record, 2 B per event word, 8 B per new
+    order of a step batch).  l2_bytes are the working bytes a kernel round-trips through global memory but that stay
+    cache-resident at the sizes they occur (the wave-parallel decode's 1.3 KB lane-state record and its ~1 KB block-start
+    spills): rounds 2 - 5 charged them as HBM bytes, and PMC showed two kernels "moving" more algorithmic bytes than the
+    counters saw (C2 k_run_wave 3.5 KB claimed vs 1.0 KB measured).  tests/test_roofline_accounting.py
+    asserts hbm_bytes <= 1.05 x the FETCH_SIZE / WRITE_SIZE traffic of every kernel in profiles/pmc_traffic.json.
+    ev / tr / new: events, trades and new orders per book-step (measured by the run); spl: steps per launch of a fused kernel;
+    n_ins: instructions per book-step (k_ingest)."""
+    rec = 2.0 * 1280.0  # lane-state record of the wave-parallel decode, in and out
+    if kind in ("k_run_random", "k_run_mixed", "k_run_wave"):
+        # fused: the book block in and out once per launch, the L2 record and the trade records every step
+        hbm = 2.0 * S / spl + W4 + 32.0 * tr
+        return hbm, ((rec / spl + 2.5 * 1024.0) if (kind == "k_run_wave" or pipe == "wave") else 0.0)
+    if kind == "k_agents_fsm":  # 32 B in (RNG + live masks); RNG + N_ev + the shuffled list + the new orders out
+        return 32.0 + 20.0 + 2.0 * ev + 8.0 * new, 0.0
+    if kind == "k_agents_wave":  # header line in; RNG state + step batch (256 B header + list + new orders) out
+        return 256.0 + 16.0 + 256.0 + 2.0 * ev + 8.0 * new, rec + 2.5 * 1024.0
+    if kind == "k_agents_mixed_lanes":
+        # RNG + live-mask line + touches in; the members' lists in and out (2-byte slots, about one entry per resting order),
+        # 16 B per new order into the pool, the shuffled event list out
+        return 192.0 + 4.0 * ev + 16.0 * new + 2.0 * ev, 0.0
+    if kind == "k_agents_mixed_wave":  # header line in; the members' lists in and out, new orders into the pool, the batch out
+        return 256.0 + 256.0 + 4.0 * ev + 16.0 * new + 256.0 + 2.0 * ev, rec + 6.0 * 1024.0
+    if kind == "k_step_batch":  # the state block in and out, the batch in, the L2 record and the trade records out
+        return 2.0 * S + 64.0 + 2.0 * ev + 8.0 * new + W4 + 32.0 * tr, 0.0
+    if kind == "k_step_events":  # state in and out, the last and the new L2 record, 20 B per queued event, trade records
+        return 2.0 * S + 2.0 * W4 + 20.0 * ev + 32.0 * tr, 0.0
+    if kind == "k_ingest":  # the six arrays in, event records + the new orders' immutable halves and log entries out
+        return 27.0 * n_ins + 16.0 * ev + 80.0 * new, 0.0
+    raise KeyError(kind)
+
+
 def bench_ingress(args, torch):
     import bourse_amd as bk
 
@@ -145,8 +181,9 @@ def bench_ingress(args, torch):
     new = sum(int((batches[s][0] == 1).sum()) for s in range(T - P, T)) / (B * P)
     S, W4 = env.state_bytes_per_book(), env.width * 4
     env.close()
-    ev_bytes = 2.0 * S + 2.0 * W4 + 20.0 * N + 32.0 * tr           # k_step_events, per book-step (DESIGN.md 2's table)
-    ing_bytes = 27.0 * N + 16.0 * N + 80.0 * new                     # k_ingest: arrays in, event records + new orders' records out
+    acct = {"S": S, "W4": W4, "ev": float(N), "tr": tr, "new": new, "spl": 1, "pipe": "ingress", "n_ins": float(N)}
+    ev_bytes, _ = algorithmic_bytes("k_step_events", **acct)         # per book-step (DESIGN.md 2's table)
+    ing_bytes, _ = algorithmic_bytes("k_ingest", **acct)             # arrays in, event records + new orders' records out
     ev_launch_ms, ing_launch_ms = ev_ms / max(nl, 1), ing_ms / P
     ach = ev_bytes * B / (ev_launch_ms * 1e-3) / 1e9
     traffic = traffic_src = None  # (PMC passes of this command, committed and replayed: as for the agent workloads)
@@ -171,7 +208,7 @@ def bench_ingress(args, torch):
                    "preheat": f"the whole {T}-step stream on throw-away envs for >= {args.preheat_min_ms:.0f} ms"},
         "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS, "traffic": traffic,
                      "traffic_source": traffic_src, "kernel": "k_step_events", "avg_launch_ms": ev_launch_ms, "launches": int(nl), "bytes_per_book_step": ev_bytes,
-                     "book_steps_per_launch": B,
+                     "book_steps_per_launch": B, "accounting": acct,
                      "launches_sampled_in": f"the last {P} steps of the same stream on a fresh env, HIP events around every launch",
                      "kernels": {"k_step_events": {"avg_launch_ms": ev_launch_ms, "bytes_per_book_step": ev_bytes},
                                  "k_ingest": {"avg_launch_ms": ing_launch_ms, "bytes_per_book_step": ing_bytes,
@@ -568,24 +605,10 @@ def main():
     tr_per_bs = n_trades / (B * (args.steps + args.warmup))
     ev_per_bs = st["sum_events"] / (B * (args.steps + args.warmup))
     new_per_bs = n_new / (B * (args.steps + args.warmup))
-    per_bs = {
-        # fused kernels: the book block in and out once per launch, the L2 record and the trade records every step;
-        # k_run_wave adds its lane-state record (1.3 KB in / out per launch, ~2.5 KB of block-start spills per step)
-        kind0: 2.0 * S / spl + W4 + 32.0 * tr_per_bs + ((2.0 * 1280.0 / spl + 2.5 * 1024.0) if pipe == "wave" else 0.0),
-        "k_agents_fsm": 32.0 + 20.0 + 2.0 * ev_per_bs + 8.0 * new_per_bs,
-        # wave-per-book decode: header line + lane-state record (64 x 16 B + 256 B) in; record out, ~2.5 block-start
-        # spills of 1 KB (one per 256-draw block crossed), RNG state, step batch (256 B header + list + new orders) out
-        "k_agents_wave": 256.0 + 1280.0 + 1280.0 + 2.5 * 1024.0 + 16.0 + 256.0 + 2.0 * ev_per_bs + 8.0 * new_per_bs,
-        # lane-per-book members' update: RNG + live-mask line + touches in; the members' lists in and out (2-byte slots,
-        # about one entry per resting order ~ events), 16 B per new order into the pool, the shuffled event list out
-        "k_agents_mixed_lanes": 192.0 + 4.0 * ev_per_bs + 16.0 * new_per_bs + 2.0 * ev_per_bs,
-        # wave-per-book members' update: header line + lane-state record in and out (as k_agents_wave, ~6 block-start spills
-        # for ~1 500 draws), the members' lists in and out (2-byte slots, about one entry per resting order), 16 B per new
-        # order into the pool, the step batch out
-        "k_agents_mixed_wave": 256.0 + 1280.0 + 1280.0 + 6.0 * 1024.0 + 256.0 + 4.0 * ev_per_bs + 16.0 * new_per_bs + 256.0 + 2.0 * ev_per_bs,
-        "k_step_batch": 2.0 * S + 64.0 + 2.0 * ev_per_bs + 8.0 * new_per_bs + W4 + 32.0 * tr_per_bs,
-        "k_step_events": 2.0 * S + 2.0 * W4 + 20.0 * ev_per_bs + 32.0 * tr_per_bs,
-    }
+    acct = {"S": S, "W4": W4, "ev": ev_per_bs, "tr": tr_per_bs, "new": new_per_bs, "spl": spl, "pipe": pipe}
+    per_bs, l2_bs = {}, {}
+    for k in (kind0, "k_agents_fsm", "k_agents_wave", "k_agents_mixed_lanes", "k_agents_mixed_wave", "k_step_batch", "k_step_events"):
+        per_bs[k], l2_bs[k] = algorithmic_bytes(k, **acct)
     bs_per_launch = {kind0: B * spl, "k_agents_fsm": B / parts, "k_agents_wave": B / parts, "k_agents_mixed_lanes": B / parts,
                      "k_agents_mixed_wave": B / parts,
                      "k_step_batch": B / parts,
@@ -610,6 +633,7 @@ def main():
         ach = per_bs[k] * bs_per_launch[k] / (avg * 1e-3) / 1e9
         tb = pmc.get(k if k != "k_run_mixed" else "k_run_random", {}).get("hbm_bytes_per_book_step")
         kernels[k] = {"avg_launch_ms": avg, "launches": nl, "bytes_per_book_step": per_bs[k],
+                      "l2_bytes_per_book_step": l2_bs[k],
                       "book_steps_per_launch": bs_per_launch[k], "achieved": ach, "frac": ach / HBM_PEAK_GBPS,
                       "traffic": tb * bs_per_launch[k] if tb is not None else None}
     # the roofline kernel is the one that moves the bytes (the HBM roofline is about bytes); in the split pipeline the
@@ -674,6 +698,7 @@ def main():
             "avg_launch_ms": avg_ms, "launches": n_launch, "bytes_per_book_step": bytes_per_bookstep,
             "book_steps_per_launch": book_steps_per_launch,
             "kernels": kernels,
+            "accounting": acct,
             "issue": issue,
             "launches_sampled_in": sampled_in,
         },

@@ -45,12 +45,16 @@ for key, cfg in summ.items():
             wc["note"] = "the profiler serialises dispatches: each kernel ran ALONE on one part of the batch (no overlap with the other parts' kernels)"
             rec["occupancy"] = wc
         e[k] = rec
+    if cfg.get("_bench", {}).get("accounting"):
+        e["_accounting"] = cfg["_bench"]["accounting"]
     out[key] = e
 json.dump(out, open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w"), indent=1)
 for key, e in out.items():
     if key.startswith("_"):
         continue
     for k, rec in e.items():
+        if k.startswith("_"):
+            continue
         i = rec.get("insts_per_book_step", {})
         print("%-10s %-22s hbm %7.0f B/book-step  scalar+branch %6.0f  vector %6.0f" % (
             key, k, rec.get("hbm_bytes_per_book_step", float("nan")), i.get("salu", 0) + i.get("branch", 0), i.get("valu", 0)))

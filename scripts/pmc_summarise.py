@@ -60,6 +60,9 @@ for d in sorted(glob.glob(os.path.join(out_dir, "*_*_sq"))):
         line = [l for l in open(os.path.join(out_dir, f"{wl}_{books}_sq.json")) if l.startswith("{")][-1]
         b = json.loads(line)
         cfg["_bench"] = {"value": b["value"], "pipeline": b["config"]["pipeline"], "ms_per_step": b["ms_per_step"],
+                         # the run's own event / trade / order rates and shape: what bench.algorithmic_bytes() is evaluated on
+                         # (tests/test_roofline_accounting.py: algorithmic <= 1.05 x these passes' measured traffic)
+                         "accounting": b["roofline"].get("accounting"),
                          "note": "the bench line of the SQ_INSTS pass (under the profiler: slower than an unprofiled run)"}
     except Exception as ex:  # noqa: BLE001
         cfg["_bench"] = {"error": str(ex)}
