@@ -121,13 +121,32 @@ def bench_ingress(args, torch):
     g = torch.Generator(device="cuda").manual_seed(0)
     off = torch.arange(B + 1, dtype=torch.int64, device="cuda") * N
 
+    f_mod, f_mkt = float(args.modify_frac), float(args.market_frac)
+    ACT_MODIFY = 0x80000003 - (1 << 32)  # BK_ACTION_MODIFY as the int32 the 4-byte array holds
+
     def make(s):
-        canc = (torch.rand(n, device="cuda", generator=g) < 0.3) if s else torch.zeros(n, dtype=torch.bool, device="cuda")
-        action = torch.where(canc, 2, 1).to(torch.int32)
-        ids = (torch.rand(n, device="cuda", generator=g) * max(1, int(s * N * 0.6))).to(torch.int64) * canc
+        # per element: 30 % cancellations of earlier ids (from the second step on), then --modify-frac modifications of earlier
+        # ids (Env::modify_order, orderbook.rs:743-772: a third price only, a third volume only, a third both - side bit 1 = has
+        # price, bit 2 = has volume), --market-frac market orders (price u32::MAX for a bid / 0 for an ask, orderbook.rs:594-606),
+        # the rest new limit orders at 90..110.  With both fractions 0 the draws are round 5's stream exactly.
+        u = torch.rand(n, device="cuda", generator=g) if (s or f_mod > 0.0 or f_mkt > 0.0) else torch.ones(n, device="cuda")
+        canc = (u < 0.3) if s else torch.zeros(n, dtype=torch.bool, device="cuda")
+        ids = (torch.rand(n, device="cuda", generator=g) * max(1, int(s * N * 0.6))).to(torch.int64)
         side = torch.randint(0, 2, (n,), device="cuda", generator=g, dtype=torch.uint8)
         vol = torch.randint(1, 30, (n,), device="cuda", generator=g, dtype=torch.int32)
         price = torch.randint(90, 111, (n,), device="cuda", generator=g, dtype=torch.int32)
+        action = torch.where(canc, 2, 1).to(torch.int32)
+        if f_mod > 0.0 or f_mkt > 0.0:
+            mod = (u >= 0.3) & (u < 0.3 + f_mod) if s else torch.zeros(n, dtype=torch.bool, device="cuda")
+            mkt = (u >= 0.3 + f_mod) & (u < 0.3 + f_mod + f_mkt)
+            which = torch.randint(0, 3, (n,), device="cuda", generator=g, dtype=torch.uint8)
+            mside = torch.where(which == 0, 2, torch.where(which == 1, 4, 6)).to(torch.uint8)
+            action = torch.where(mod, ACT_MODIFY, action).to(torch.int32)
+            side = torch.where(mod, mside, side)
+            price = torch.where(mkt, torch.where(side == 1, -1, 0).to(torch.int32), price)
+            ids = ids * (canc | mod)
+        else:
+            ids = ids * canc
         return action, side, vol, torch.zeros(n, dtype=torch.int32, device="cuda"), price, ids
 
     batches = [make(s) for s in range(T)]  # generated ahead: the rate is the library's, not torch's RNG
@@ -198,10 +217,12 @@ def bench_ingress(args, torch):
     line = {
         "metric": "book-steps/sec", "value": B * K / dt, "unit": "book-steps/s", "n_gpus": 1, "steps": K, "warmup": W,
         "ms_per_step": dt * 1e3 / K, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u32",
-        "data": "synthetic",
-        "config": {"workload": f"INGRESS: {B} books x {N} instructions per book-step (70 % new limit orders at 90..110, 30 % cancellations of "
-                               f"earlier ids) as device arrays through bk_submit_instructions_device + bk_step_async, {pool}-slot pools, "
-                               f"{LV} levels; stream = scripts/device_ingress_rate.py",
+        "data": "synthetic", "keyed_frac": keyed,
+        "config": {"workload": f"INGRESS: {B} books x {N} instructions per book-step (30 % cancellations of earlier ids, "
+                               f"{100 * f_mod:g} % modifications of earlier ids, {100 * f_mkt:g} % market orders, the rest new limit orders at "
+                               f"90..110) as device arrays through bk_submit_instructions_device + bk_step_async, {pool}-slot pools, "
+                               f"{LV} levels" + ("; stream = scripts/device_ingress_rate.py" if f_mod == f_mkt == 0.0 else ""),
+                   "modify_frac": f_mod, "market_frac": f_mkt,
                    "books_total": B, "instructions_per_book_step": N, "instructions_per_s": n * K / dt,
                    "trades_per_book_step": tr_total / (B * T), "keyed_step_fraction": keyed,
                    "pipeline": "k_ingest + k_step_events per step (host-driven kernels; no agents pipeline)",
@@ -398,6 +419,9 @@ def main():
                          "N processes sharing one GPU, NOT a measurement of N GPUs (the line says `dry_ranks: true`)")
     ap.add_argument("--steps-per-launch", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--modify-frac", type=float, default=0.0,
+                    help="--workload INGRESS: fraction of the instructions that are modifications of earlier ids (Env::modify_order)")
+    ap.add_argument("--market-frac", type=float, default=0.0, help="--workload INGRESS: fraction that are market orders")
     ap.add_argument("--l1-gather", action="store_true", help="also all-gather every book's L1 record per launch (SURVEY 8e ii)")
     ap.add_argument("--no-history", action="store_true", help="keep only the latest L2 record (diagnostic)")
     ap.add_argument("--pipeline", default="auto", choices=["auto", "fused", "split", "wave_split", "wave"])

@@ -98,6 +98,7 @@ _u64, _u32, _i32, _vp, _sz = C.c_uint64, C.c_uint32, C.c_int, C.c_void_p, C.c_si
 _p64, _p32, _p8 = C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(C.c_uint8)
 SIGNATURES = {
     "bk_last_error": (C.c_char_p, []),
+    "bk_hip_versions": (_i32, [C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "bk_device_count": (_i32, [C.POINTER(C.c_int)]),
     "bk_env_create": (_i32, [C.POINTER(Config), C.POINTER(_vp)]),
     "bk_env_destroy": (None, [_vp]),
@@ -204,8 +205,43 @@ def _share_torch_hip_runtime():
     if os.path.exists(cand):
         try:
             C.CDLL(cand, mode=C.RTLD_GLOBAL)
+            _note(f"HIP runtime: torch's bundled copy pre-loaded ({cand}); BOURSE_AMD_OWN_HIP_RUNTIME=1 keeps /opt/rocm's")
+        except OSError as e:
+            # (not loadable here: the library's own dependency resolves as before)
+            _note(f"HIP runtime: torch's bundled copy could not be loaded ({e}); the library binds to its own dependency")
+
+
+def _note(msg: str):
+    if os.environ.get("BOURSE_AMD_VERBOSE"):
+        import sys
+
+        print("[bourse_amd] " + msg, file=sys.stderr)
+
+
+def _check_runtime_version(L):
+    """Which HIP runtime did the library bind to, and is it the major version it was built against?  (the
+    pre-load above silently changes the runtime of every process that has torch installed.)  A mismatch of the major
+    version warns; BOURSE_AMD_VERBOSE=1 prints both versions and the runtime's path."""
+    try:
+        built, run = C.c_int(0), C.c_int(0)
+        if L.bk_hip_versions(C.byref(built), C.byref(run)) != 0:
+            return
+        path = "?"
+        try:
+            for line in open("/proc/self/maps"):
+                if "libamdhip64" in line:
+                    path = line.split()[-1]
+                    break
         except OSError:
-            pass  # (not loadable here: the library's own dependency resolves as before)
+            pass
+        _note(f"HIP runtime bound: version {run.value} at {path}; library built against {built.value}")
+        if built.value // 10_000_000 != run.value // 10_000_000:
+            import warnings
+
+            warnings.warn(f"bourse_amd: built against HIP {built.value} but running on HIP runtime {run.value} ({path}); set "
+                          f"BOURSE_AMD_OWN_HIP_RUNTIME=1 to keep the system runtime", RuntimeWarning)
+    except Exception:  # noqa: BLE001  (diagnostics must never stop a load)
+        pass
 
 
 def load() -> C.CDLL:
@@ -239,6 +275,7 @@ def load() -> C.CDLL:
     L.bk_selftest_math.restype = _i32
     L.bk_selftest_math.argtypes = [_i32, C.POINTER(C.c_double), _u64, C.POINTER(C.c_double)]
     _lib = L
+    _check_runtime_version(L)
     return L
 
 

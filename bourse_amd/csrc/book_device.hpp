@@ -168,6 +168,9 @@ struct DevArgs {
 constexpr int BT_NEV = 0, BT_EV = 64;
 // event words of k_agents_fsm: slot in bits 0..8, EV_BID / EV_NEW classify the event
 constexpr uint32_t EV_NEW = 0x8000u, EV_BID = 0x4000u, EV_SLOT = 0x1FFu;
+// k_step_events only (step_events.hpp): a MODIFICATION's word - never handed to the loops as an event: the list is cut there -
+// carries its flags where the event record has them (has price 1 << 9, has volume 1 << 10) and its new price's field above
+constexpr uint32_t EV_MOD = 0x800u, EV_MOD_P = 0x200u, EV_MOD_V = 0x400u;
 
 // ----------------------------------------------------------------------------------
 // wave primitives
@@ -893,8 +896,9 @@ constexpr uint32_t KEY_ASK = 0x80000000u;
 constexpr uint32_t KP_MKT_BID = 0xFFFFFFFFu, KP_MKT_ASK = 0x10000u;
 template <int R>
 __device__ __forceinline__ bool key_window(const Book<R>& B, const uint64_t (&newm)[R], uint32_t n_ev, uint32_t& pbase,
-                                           uint32_t& sbase) {
-  uint32_t pmax = 0, pmin = 0xFFFFFFFFu, age = 0;  // age = seq_ctr - seq of the oldest live order (wrapping)
+                                           uint32_t& sbase, uint32_t xmin = 0xFFFFFFFFu, uint32_t xmax = 0u) {
+  // (xmin / xmax: per-lane extra prices that must fit the window too - the new prices of a host-driven step's modifications)
+  uint32_t pmax = xmax, pmin = xmin, age = 0;  // age = seq_ctr - seq of the oldest live order (wrapping)
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     const bool lv = lane_bit(B.live[r]), in = lv | lane_bit(newm[r]);
@@ -921,13 +925,14 @@ struct KeyState {
 };
 // MARKETS: the new orders may include market orders; they stay out of the window test
 template <int R, bool MARKETS = false>
-__device__ __forceinline__ bool keys_begin(const Book<R>& B, const uint64_t (&newm)[R], uint32_t n_ev, KeyState<R>& K) {
+__device__ __forceinline__ bool keys_begin(const Book<R>& B, const uint64_t (&newm)[R], uint32_t n_ev, KeyState<R>& K,
+                                           uint32_t xmin = 0xFFFFFFFFu, uint32_t xmax = 0u) {
   uint32_t pbase;
   uint64_t lim[R];  // the new LIMIT orders
 #pragma unroll
   for (int r = 0; r < R; ++r)
     lim[r] = MARKETS ? newm[r] & ~__ballot(B.price[r] == (lane_bit(B.bid[r]) ? 0xFFFFFFFFu : 0u)) : newm[r];
-  if (!key_window<R>(B, lim, n_ev, pbase, K.sbase)) return false;
+  if (!key_window<R>(B, lim, n_ev, pbase, K.sbase, xmin, xmax)) return false;
   K.pbase = pbase;
 #pragma unroll
   for (int r = 0; r < R; ++r) {

@@ -291,6 +291,13 @@ struct bk_env {
     uint64_t ticket_of[SLOTS] = {~0ull, ~0ull};  // the ticket whose arrays / results a slot holds
     uint64_t n_elem[SLOTS] = {0, 0};
     uint64_t next_ticket = 0;
+    // pinned blocks a growth replaced: a view of their tickets' results (bk_submit_result_view) stays valid until two more
+    // submits, so they are freed only then (they were freed at once and the views dangled)
+    struct Retired {
+      char* pin;
+      uint64_t free_from_ticket;  // freed by the submit that takes this ticket (or by bk_env_destroy)
+    };
+    std::vector<Retired> retired;
     // one slot = [offsets (B + 1) u64 | order_id cap u64 | out_ids cap u64 | status 2 B u32 | action | vol | trader | price
     // cap u32 each | side cap u8], the same layout in pinned and in device memory
     size_t o_off = 0, o_oid = 0, o_out = 0, o_st = 0, o_act = 0, o_vol = 0, o_trd = 0, o_prc = 0, o_side = 0, bytes = 0;
@@ -447,14 +454,17 @@ int launch_events(bk_env* env, const DevArgs& a, uint64_t step_index, uint32_t m
   // (both knobs are read at every launch - a getenv, ~0.1 us - so that a test can switch them inside one process)
   const char* seq_env = getenv("BOURSE_AMD_EV_SEQ_SHUFFLE");
   const bool seq_shuffle = seq_env && *seq_env == '1';
-  WaveArgs wva{};
-  if (!seq_shuffle)
-    if (int rc = wave_args(env, &wva)) return rc;
   // (its fixed cost - the cache record, a block of draws, a resolution over all 64 R positions - pays from a queue length that
   // grows with the pool: docs/EXPERIMENTS.md; BOURSE_AMD_EV_WAVE_SHUFFLE_MIN overrides, for measurements)
   const char* min_str = getenv("BOURSE_AMD_EV_WAVE_SHUFFLE_MIN");
   const int min_env = min_str ? atoi(min_str) : -1;
   const uint32_t shuffle_min = min_env >= 0 ? static_cast<uint32_t>(min_env) : (12u * R > 32u ? 12u * R : 32u);  // (measured: 256 slots 24 events -3 %, 48 +5 %; 512 slots 48 -7 %, 96 +3 %)
+  // the lane-state cache (1 280 B per book) and the jump tables exist only once a step CAN take the wave-parallel shuffle: no
+  // queue of this launch reaches its threshold -> wcache stays null and the kernel draws one by one (every env's
+  // first bk_step allocated 84 MB at 65 536 books whether or not it ever shuffled that way)
+  WaveArgs wva{};
+  if (!seq_shuffle && max_queue >= shuffle_min && max_queue >= 2u)
+    if (int rc = wave_args(env, &wva)) return rc;
   if (env->M == 1)
     hipLaunchKernelGGL((k_step_events<R, false>), dim3(env->cfg.n_books), dim3(64), perm_bytes, env->stream, a, wva, step_index, shuffle_min);
   else
@@ -484,9 +494,11 @@ int wave_args(bk_env* env, WaveArgs* wva) {
       all.insert(all.end(), tab.begin(), tab.end());
     }
     HIPCHK(env->jump_tabs.alloc(all.size() / 4));
-    HIPCHK(hipMemcpy(env->jump_tabs.p, all.data(), all.size() * 4, hipMemcpyHostToDevice));
     HIPCHK(env->wcache.alloc(static_cast<size_t>(env->cfg.n_books) * WC_STRIDE));
-    HIPCHK(hipMemset(env->wcache.p, 0, static_cast<size_t>(env->cfg.n_books) * WC_STRIDE * 4));
+    // on the ENV's stream (a hipStreamNonBlocking stream is not ordered behind the null stream), and waited for: `all` is a local
+    HIPCHK(hipMemcpyAsync(env->jump_tabs.p, all.data(), all.size() * 4, hipMemcpyHostToDevice, env->stream));
+    HIPCHK(hipMemsetAsync(env->wcache.p, 0, static_cast<size_t>(env->cfg.n_books) * WC_STRIDE * 4, env->stream));
+    HIPCHK(hipStreamSynchronize(env->stream));
   }
   wva->jt_block = env->jump_tabs.p;
   wva->jt_lane = env->jump_tabs.p + 512;
@@ -860,6 +872,14 @@ extern "C" {
 
 const char* bk_last_error(void) { return g_err.c_str(); }
 
+int bk_hip_versions(int* built, int* runtime) {
+  int v = 0;
+  if (hipRuntimeGetVersion(&v) != hipSuccess) v = 0;
+  if (built) *built = HIP_VERSION;
+  if (runtime) *runtime = v;
+  return BK_OK;
+}
+
 int bk_device_count(int* out) {
   int n = 0;
   hipError_t e = hipGetDeviceCount(&n);
@@ -969,6 +989,8 @@ void bk_env_destroy(bk_env* env) {
   if (env->off_stage) (void)hipHostFree(env->off_stage);
   if (env->hi.in) (void)hipStreamSynchronize(env->hi.in);
   if (env->hi.out) (void)hipStreamSynchronize(env->hi.out);
+  for (auto& r : env->hi.retired) (void)hipHostFree(r.pin);
+  env->hi.retired.clear();
   for (int i = 0; i < bk_env::HostIngress::SLOTS; ++i) {
     if (env->hi.pin[i]) (void)hipHostFree(env->hi.pin[i]);
     if (env->hi.dev[i]) (void)hipFree(env->hi.dev[i]);
@@ -1051,7 +1073,8 @@ int bk_submit_instructions(bk_env* env, uint32_t book, size_t n, const uint32_t*
   for (size_t i = 0; i < n; ++i) {
     uint64_t id = ~0ull;  // usize::MAX for non-new instructions (step_sim_numpy.rs:255-268)
     if (action[i] == 1) {
-      int rc = bk_place_order(env, book, side[i] != 0, vol[i], trader_id[i], 1, price[i], &id);
+      // (bit 0 is the side on EVERY entry - k_ingest reads `side & 1`; bits 1 / 2 belong to BK_ACTION_MODIFY: ADVICE r5)
+      int rc = bk_place_order(env, book, (side[i] & 1) != 0, vol[i], trader_id[i], 1, price[i], &id);
       if (rc != BK_OK) return rc;  // earlier elements stay created and queued (:167-177)
     } else if (action[i] == 2) {
       int rc = bk_cancel_order(env, book, order_id[i]);
@@ -1292,27 +1315,56 @@ int hi_ensure(bk_env* env, size_t n_elem) {
       HIPCHK(hipEventCreateWithFlags(&h.e_done[i], hipEventDisableTiming));
     }
   }
-  if (n_elem <= h.cap && h.pin[0]) return BK_OK;
+  if (n_elem <= h.cap && h.pin[0] && h.pin[1]) return BK_OK;
   // grow: everything in flight must have landed first; the results the slots hold (ids + status of the last two tickets - a
   // caller that fetches one submit late has not read them yet) move into the new staging
   HIPCHK(hipStreamSynchronize(h.in));
   HIPCHK(hipStreamSynchronize(env->stream));
   HIPCHK(hipStreamSynchronize(h.out));
   const size_t cap = std::max<size_t>((n_elem + n_elem / 4 + 1023) & ~size_t(1023), 1024);
+  // BOTH new slots are allocated before anything of the old staging is given up: a failed allocation leaves the env as it was
+  bk_env::HostIngress lay = h;
+  lay.layout(env->cfg.n_books, cap);
+  char *npin[bk_env::HostIngress::SLOTS] = {}, *ndev[bk_env::HostIngress::SLOTS] = {};
+  for (int i = 0; i < bk_env::HostIngress::SLOTS; ++i) {
+    if (hipHostMalloc(reinterpret_cast<void**>(&npin[i]), lay.bytes, hipHostMallocDefault) != hipSuccess) npin[i] = nullptr;
+    if (npin[i] && hipMalloc(reinterpret_cast<void**>(&ndev[i]), lay.bytes) != hipSuccess) ndev[i] = nullptr;
+    if (!npin[i] || !ndev[i]) {
+      (void)hipGetLastError();
+      for (int j = 0; j <= i; ++j) {
+        if (npin[j]) (void)hipHostFree(npin[j]);
+        if (ndev[j]) (void)hipFree(ndev[j]);
+      }
+      return fail(BK_CAPACITY, "bk_submit_instructions_host: out of pinned / device memory for the staging");
+    }
+  }
   const bk_env::HostIngress old = h;
   h.layout(env->cfg.n_books, cap);
   for (int i = 0; i < bk_env::HostIngress::SLOTS; ++i) {
-    h.pin[i] = h.dev[i] = nullptr;
-    HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&h.pin[i]), h.bytes, hipHostMallocDefault));
-    HIPCHK(hipMalloc(reinterpret_cast<void**>(&h.dev[i]), h.bytes));
+    h.pin[i] = npin[i];
+    h.dev[i] = ndev[i];
     if (old.pin[i] && old.ticket_of[i] != ~0ull) {
       std::memcpy(h.pin[i] + h.o_out, old.pin[i] + old.o_out, old.n_elem[i] * 8);
       std::memcpy(h.pin[i] + h.o_st, old.pin[i] + old.o_st, static_cast<size_t>(env->cfg.n_books) * 8);
     }
-    if (old.pin[i]) HIPCHK(hipHostFree(old.pin[i]));
+    // a view into the old pinned block (of a ticket < next_ticket) is valid until two more submits: the block goes when the
+    // submit of ticket next_ticket + 1 starts.  The device block has no outside references (every stream was drained above).
+    if (old.pin[i]) h.retired.push_back({old.pin[i], h.next_ticket + 1});
     if (old.dev[i]) HIPCHK(hipFree(old.dev[i]));
   }
   return BK_OK;
+}
+void hi_release_retired(bk_env* env, bool all) {
+  auto& r = env->hi.retired;
+  for (size_t i = 0; i < r.size();) {
+    if (all || env->hi.next_ticket >= r[i].free_from_ticket) {
+      (void)hipHostFree(r[i].pin);
+      r[i] = r.back();
+      r.pop_back();
+    } else {
+      ++i;
+    }
+  }
 }
 
 // The staging copies: the calling thread alone below 1 MB, else FOUR threads of the env's pool claiming 256 KB pieces one at a
@@ -1391,6 +1443,7 @@ int bk_submit_instructions_host(bk_env* env, const uint64_t* book_offsets, const
     return fail(BK_INVALID_ARGUMENT, "null instruction array");
   if (int rc = use_device(env)) return rc;
   if (int rc = hi_ensure(env, n)) return rc;
+  hi_release_retired(env, false);  // (pinned blocks replaced by a growth two submits ago: their tickets' views have expired)
   bk_env::HostIngress& h = env->hi;
   const uint64_t ticket = h.next_ticket;
   const int s = static_cast<int>(ticket % bk_env::HostIngress::SLOTS);

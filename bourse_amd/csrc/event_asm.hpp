@@ -397,7 +397,14 @@ __device__ __forceinline__ uint32_t events_asm_r1(uint32_t& k, uint32_t n_ev, ui
 //   VLATE the order's volume, read only once it is known to reach the reduction (the copies without VCHK: an order beyond
 //   the bound rests with the volume its slot already holds - one lane read and one hand-over wait less)
 #define EK_VRD(RG) "v_readlane_b32 " EA_V ", %[vol" RG "], " EA_EW "\n\t"
-#define EK_SIDE(L, PH, KEND, RG, NR, KPI, VOP, DOP, NOX, KKI, OPPB, SKIP, OWNB, PULL, VCHK, VLATE)     \
+//   MK    "" or EK_MKT(value): a MARKET order's compare value never rests (orderbook.rs:521-524, :564-567) - the lists of the
+//   host-driven step (step_events.hpp) can carry them; two scalar instructions per order that would rest
+#define EK_MKT(PH, KEND, L, MKTV)                                                                     \
+  "s_cmp_eq_u32 " EK_KP ", " MKTV "\n\t"                                                              \
+  "s_cbranch_scc0 L_dorest_" L "\n\t"                                                                \
+  EA_LOOP(PH, KEND)                                                                                   \
+  "L_dorest_" L ":\n\t"
+#define EK_SIDE(L, PH, KEND, RG, NR, KPI, VOP, DOP, NOX, KKI, OPPB, SKIP, OWNB, PULL, VCHK, VLATE, MK) \
   KPI "\n\t"                                                                                          \
   VCHK                                                                                                \
   SKIP " " EK_KP ", " OPPB "\n\t"                      /* beyond the bound: cannot cross */           \
@@ -429,6 +436,7 @@ __device__ __forceinline__ uint32_t events_asm_r1(uint32_t& k, uint32_t n_ev, ui
   "s_mov_b32 m0, " EA_EW "\n\t"                                                                       \
   "v_writelane_b32 %[vol" RG "], " EA_V ", m0\n\t"                                                    \
   "L_restq_" L ":\n\t"                                 /* ... or untouched */                         \
+  MK                                                                                                  \
   "s_mov_b32 m0, " EA_EW "\n\t"                                                                       \
   "s_xor_b32 " EA_X ", " EK_KP ", %[sq]\n\t"                                                          \
   PULL " " OWNB ", " OWNB ", " EA_X "\n\t"             /* this side's bound covers the new order */  \
@@ -436,23 +444,25 @@ __device__ __forceinline__ uint32_t events_asm_r1(uint32_t& k, uint32_t n_ev, ui
   "s_add_u32 %[sq], %[sq], 1\n\t"                                                                     \
   EA_LOOP(PH, KEND)
 
-#define EK_NEW(PH, KEND, RG, NR, CHK, VE, VL)                                                         \
+#define EK_NOMK(PH, KEND, L, MKTV) ""
+#define EK_NEW(PH, KEND, RG, NR, CHK, VE, VL, MKM)                                                    \
   VE(EK_VRD(RG))                                                                                      \
   "s_bitcmp1_b32 " EA_EW ", 14\n\t"                                                                   \
   "s_cbranch_scc1 L_bid_" PH RG "_%=\n\t"                                                             \
   /* an ask: searches the bids (cannot cross if kp > bid bound), rests among the asks (ask bound = min) */ \
   EK_SIDE("a" PH RG "_%=", PH, KEND, RG, NR, "s_and_b32 " EK_KP ", " EA_EW ", 0xffff0000", "v_max_i32", "v_max_i32_dpp", \
           "s_cmp_lt_i32", "s_or_b32 " EA_KK ", %[k], 0x80000000", EK_BHI, "s_cmp_gt_i32", EK_ALO, "s_min_i32", \
-          CHK("a" PH RG "_%="), VL(EK_VRD(RG)))                                                        \
+          CHK("a" PH RG "_%="), VL(EK_VRD(RG)), MKM(PH, KEND, "a" PH RG "_%=", "0x10000"))             \
   "L_bid_" PH RG "_%=:\n\t"                                                                           \
   EK_SIDE("b" PH RG "_%=", PH, KEND, RG, NR, "s_or_b32 " EK_KP ", " EA_EW ", 0xffff", "v_min_i32", "v_min_i32_dpp", \
           "s_cmp_gt_i32", "s_mov_b32 " EA_KK ", %[k]", EK_ALO, "s_cmp_lt_i32", EK_BHI, "s_max_i32", CHK("b" PH RG "_%="), \
-          VL(EK_VRD(RG)))
+          VL(EK_VRD(RG)), MKM(PH, KEND, "b" PH RG "_%=", "-1"))
 
 #define EK_NOCHK(L) ""
 #define EK_ID(x) x
 #define EK_NONE(x) ""
-#define EK_PHASE(PH, EVN, KEND, NR, CHK, VE, VL)                                                              \
+#define EK_PHASE(PH, EVN, KEND, NR, CHK, VE, VL) EK_PHASE_M(PH, EVN, KEND, NR, CHK, VE, VL, EK_NOMK)
+#define EK_PHASE_M(PH, EVN, KEND, NR, CHK, VE, VL, MKM)                                               \
   "L_top_" PH "_%=:\n\t"                                                                              \
   "v_readlane_b32 " EA_EW ", %[ev" EVN "], %[k]\n\t"                                                  \
   "s_bitcmp1_b32 " EA_EW ", 15\n\t"                                                                   \
@@ -471,9 +481,9 @@ __device__ __forceinline__ uint32_t events_asm_r1(uint32_t& k, uint32_t n_ev, ui
   EA_IF2_##NR("s_bitcmp1_b32 " EA_EW ", 6\n\t"                                                        \
               "s_cbranch_scc1 L_new1_" PH "_%=\n\t")                                                  \
   EA_IF1_##NR("s_nop 1\n\t")                            /* ew as a lane select: 4 wait states */      \
-  EK_NEW(PH, KEND, "0", NR, CHK, VE, VL)                                                              \
+  EK_NEW(PH, KEND, "0", NR, CHK, VE, VL, MKM)                                                         \
   EA_IF2_##NR("L_new1_" PH "_%=:\n\t"                                                                 \
-              EK_NEW(PH, KEND, "1", NR, CHK, VE, VL))
+              EK_NEW(PH, KEND, "1", NR, CHK, VE, VL, MKM))
 
 #define EK_TAIL                     \
   "L_done_%=:\n\t"                  \
@@ -494,7 +504,7 @@ __device__ __forceinline__ uint32_t events_asm_r1(uint32_t& k, uint32_t n_ev, ui
 // without it (phases 2 / 3; %[chk] = 0: the caller has established that trading is on and no new order of the step has
 // volume 0).  Two statements - one per variant - cost the kernel 10 VGPRs (46 instead of 36), and with them two of the
 // seven event waves that fit beside a k_agents_fsm wave on a SIMD: C3 277 -> 210 M.
-#define EK_R2_STMT \
+#define EK_R2_STMT_X(MKM) \
   asm volatile( \
       "s_mov_b32 " EK_ALO ", 0x80000000\n\t" \
       "s_mov_b32 " EK_BHI ", 0x7fffffff\n\t" \
@@ -503,22 +513,22 @@ __device__ __forceinline__ uint32_t events_asm_r1(uint32_t& k, uint32_t n_ev, ui
       "s_cmp_lt_u32 %[k], %[kend0]\n\t" \
       "s_cbranch_scc1 L_top_0_%=\n\t" \
       "s_branch L_end_0_%=\n\t" \
-      EK_PHASE("0", "0", "%[kend0]", 2, EK_VCHK, EK_ID, EK_NONE) \
+      EK_PHASE_M("0", "0", "%[kend0]", 2, EK_VCHK, EK_ID, EK_NONE, MKM) \
       "L_end_0_%=:\n\t" \
       "s_cmp_lt_u32 %[k], %[nev]\n\t" \
       "s_cbranch_scc0 L_done_%=\n\t" \
-      EK_PHASE("1", "1", "%[nev]", 2, EK_VCHK, EK_ID, EK_NONE) \
+      EK_PHASE_M("1", "1", "%[nev]", 2, EK_VCHK, EK_ID, EK_NONE, MKM) \
       "L_end_1_%=:\n\t" \
       "s_branch L_done_%=\n\t" \
       "L_fast_%=:\n\t" \
       "s_cmp_lt_u32 %[k], %[kend0]\n\t" \
       "s_cbranch_scc1 L_top_2_%=\n\t" \
       "s_branch L_end_2_%=\n\t" \
-      EK_PHASE("2", "0", "%[kend0]", 2, EK_NOCHK, EK_NONE, EK_ID) \
+      EK_PHASE_M("2", "0", "%[kend0]", 2, EK_NOCHK, EK_NONE, EK_ID, MKM) \
       "L_end_2_%=:\n\t" \
       "s_cmp_lt_u32 %[k], %[nev]\n\t" \
       "s_cbranch_scc0 L_done_%=\n\t" \
-      EK_PHASE("3", "1", "%[nev]", 2, EK_NOCHK, EK_NONE, EK_ID) \
+      EK_PHASE_M("3", "1", "%[nev]", 2, EK_NOCHK, EK_NONE, EK_ID, MKM) \
       "L_end_3_%=:\n\t" \
       EK_TAIL \
       : [st] "=&s"(st), [vm] "=&v"(vm), [k] "+s"(k), [trn] "+s"(trn), [sq] "+s"(sq), \
@@ -528,7 +538,7 @@ __device__ __forceinline__ uint32_t events_asm_r1(uint32_t& k, uint32_t n_ev, ui
         [nev] "s"(n_ev), [kend0] "s"(kend0), [tmask] "s"(tmask), [chk] "s"(checked) \
       : EK_CLOBBERS);
 
-#define EK_R1_STMT \
+#define EK_R1_STMT_X(MKM) \
   asm volatile( \
       "s_mov_b32 " EK_ALO ", 0x80000000\n\t" \
       "s_mov_b32 " EK_BHI ", 0x7fffffff\n\t" \
@@ -536,16 +546,22 @@ __device__ __forceinline__ uint32_t events_asm_r1(uint32_t& k, uint32_t n_ev, ui
       "s_cbranch_scc0 L_done_%=\n\t" \
       "s_cmp_eq_u32 %[chk], 0\n\t" \
       "s_cbranch_scc1 L_top_2_%=\n\t" \
-      EK_PHASE("0", "0", "%[nev]", 1, EK_VCHK, EK_ID, EK_NONE) \
+      EK_PHASE_M("0", "0", "%[nev]", 1, EK_VCHK, EK_ID, EK_NONE, MKM) \
       "L_end_0_%=:\n\t" \
       "s_branch L_done_%=\n\t" \
-      EK_PHASE("2", "0", "%[nev]", 1, EK_NOCHK, EK_NONE, EK_ID) \
+      EK_PHASE_M("2", "0", "%[nev]", 1, EK_NOCHK, EK_NONE, EK_ID, MKM) \
       "L_end_2_%=:\n\t" \
       EK_TAIL \
       : [st] "=&s"(st), [vm] "=&v"(vm), [k] "+s"(k), [trn] "+s"(trn), [sq] "+s"(sq), \
         [vol0] "+v"(vol0), [key0] "+v"(key0), [trk] "+v"(trk), [trv] "+v"(trv), [trs] "+v"(trs) \
       : [ev0] "v"(ev0), [nev] "s"(n_ev), [tmask] "s"(tmask), [chk] "s"(checked) \
       : EK_CLOBBERS);
+
+#define EK_R2_STMT EK_R2_STMT_X(EK_NOMK)
+#define EK_R1_STMT EK_R1_STMT_X(EK_NOMK)
+// ... and for lists that may carry MARKET orders (the host-driven step, step_events.hpp)
+#define EK_R2M_STMT EK_R2_STMT_X(EK_MKT)
+#define EK_R1M_STMT EK_R1_STMT_X(EK_MKT)
 
 // Keyed form of events_asm_r2: `sq` = 0x80000000 | (seq_ctr - sbase) (the caller converts back), key0 / key1 and the event
 // words (compare value in the upper half) as described above.
@@ -580,6 +596,42 @@ __device__ __forceinline__ uint32_t events_key_r1(uint32_t checked, uint32_t& k,
   uint32_t trn = u32(tr_n) - 64u;
   sq = u32(sq);
   EK_R1_STMT
+  tr_n = trn + 64u;
+  return st;
+}
+
+// The same two loops for lists that may carry MARKET orders (compare value -1 for a market bid, 0x10000 for a market ask:
+// book_device.hpp keys_begin<R, MARKETS>): they match like any order and never rest.  k_step_events only - the agent
+// pipelines' lists of these pool sizes (RandomAgents) carry none and keep the loops above.
+__device__ __forceinline__ uint32_t events_key_r2m(uint32_t checked, uint32_t& k, uint32_t n_ev, uint32_t tmask, uint32_t& tr_n, uint32_t& sq,
+                                                   uint32_t& vol0, uint32_t& vol1, uint32_t& key0, uint32_t& key1, uint32_t ev0,
+                                                   uint32_t ev1, uint32_t& trk, uint32_t& trv, uint32_t& trs) {
+  uint32_t st, vm;
+  auto u32 = [](uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane(x); };
+  checked = u32(checked);
+  k = u32(k);
+  n_ev = u32(n_ev);
+  tmask = u32(tmask);
+  uint32_t trn = u32(tr_n) - 64u;
+  sq = u32(sq);
+  const uint32_t kend0 = n_ev < 64u ? n_ev : 64u;
+  EK_R2M_STMT
+  tr_n = trn + 64u;
+  return st;
+}
+
+__device__ __forceinline__ uint32_t events_key_r1m(uint32_t checked, uint32_t& k, uint32_t n_ev, uint32_t tmask, uint32_t& tr_n, uint32_t& sq,
+                                                   uint32_t& vol0, uint32_t& key0, uint32_t ev0, uint32_t& trk, uint32_t& trv,
+                                                   uint32_t& trs) {
+  uint32_t st, vm;
+  auto u32 = [](uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane(x); };
+  checked = u32(checked);
+  k = u32(k);
+  n_ev = u32(n_ev);
+  tmask = u32(tmask);
+  uint32_t trn = u32(tr_n) - 64u;
+  sq = u32(sq);
+  EK_R1M_STMT
   tr_n = trn + 64u;
   return st;
 }

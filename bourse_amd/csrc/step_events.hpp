@@ -72,10 +72,23 @@ __device__ __forceinline__ void insert_order(Book<R>& B, int lane, uint32_t n, u
 //     per-slot facts collected in LDS: the order's arrival position, the first cancellation after it, the last trade that
 //     took from it while it rested, and what was left of it on arrival (its volume minus what it took as the aggressor:
 //     the compact trade records are scattered into those words before each flush).
-// Returns false - nothing that matters changed: only fields of FREE pool slots - when the step is not of that form (a
-// modification, an unknown id, a volume of 0 anywhere, fewer free slots than new orders + 1, prices or
-// arrival stamps outside the key window, market orders on the pools the hand-written loops serve): the caller runs the
-// event-by-event loop.  LDS (dynamic, `perm`): 12 x 64 R bytes (ev_keyed_lds_bytes).
+// MODIFICATIONS (round 6; orderbook.rs:743-772, 656-723).  What a modification does depends on the state of
+// its order WHEN ITS EVENT IS PROCESSED (Active?  is the new volume below what is left of it?), so it cannot be turned into
+// list entries up front.  The assembly loops take a range of positions [k, n): the list is cut at every modification, the
+// loop runs up to it, and the modification itself is a few lines of C++ between two statements, on the real state:
+//   * order not Active (its key lane is 0: filled, cancelled, not yet placed, or no such order) or neither field given: nothing;
+//   * volume only and below the order's: the volume in its pool lane, priority kept (reduce_order_vol);
+//   * otherwise replace_order: the trade buffer is flushed (its records' prices are read from the pool at the flush), the
+//     order leaves the book (key := 0), its slot takes the new price / volume, and the event word AT THAT POSITION becomes a
+//     New of that slot with the new price's compare value - the loop then matches it and rests the remainder with a fresh
+//     arrival stamp, exactly replace_order's re-match and re-insert with key time = now (:699-721).  The order keeps its slot
+//     and id, so later cancellations / modifications of the same step find it where the set-up looked it up.
+//   The order log: the rebuild below also visits the slots a modification touched; price and priority key of a replaced order
+//   are written at the modification (the rebuild leaves those fields of such a slot alone).
+// Returns false - nothing that matters changed: only fields of FREE pool slots - when the step is not of that form (an unknown
+// id, a volume of 0 anywhere, fewer free slots than new orders + 1, prices - a modification's new one included - or arrival
+// stamps outside the key window): the caller runs the event-by-event loop.  Market orders run on the `m` forms of the loops
+// (round 6: also on the hand-written ones of the small pools).  LDS (dynamic, `perm`): 12 x 64 R bytes (ev_keyed_lds_bytes).
 // ----------------------------------------------------------------------------------
 #ifndef BOURSE_AMD_EV_KEYED
 #define BOURSE_AMD_EV_KEYED 1
@@ -98,15 +111,16 @@ __device__ __forceinline__ bool step_events_keyed(Book<R>& B, const DevArgs& a, 
   uint32_t* W2 = reinterpret_cast<uint32_t*>(perm + 2u * S);  // bytes [4S, 8S): a new order's volume minus what it took as the aggressor
   // ---- the events in shuffled order, one per lane
   uint32_t eww[R], eid[R], evq[R];
-  uint64_t is_new[R], is_can[R];
+  uint64_t is_new[R], is_can[R], is_mod[R];
   bool bad = false;
+  uint32_t xmin = 0xFFFFFFFFu, xmax = 0u;  // the modifications' new prices: part of the key window
 #pragma unroll
   for (int re = 0; re < R; ++re) {
     // (pools of <= 256 slots: list registers past the queue's end - all but the first at the ingress scripts' 48 events - cost
     // one uniform branch each; at 512 slots the branches take the kernel from 8 to 60 B of scratch at its 96 registers and
     // cost 9 %, same box: profiles/r05/device_ingress_rate_guards.txt)
     if constexpr (R <= 4) {
-      is_new[re] = is_can[re] = 0ull;
+      is_new[re] = is_can[re] = is_mod[re] = 0ull;
       eww[re] = eid[re] = evq[re] = 0u;
       if (n_ev <= (uint32_t)re * 64u) continue;
     }
@@ -119,12 +133,19 @@ __device__ __forceinline__ bool step_events_keyed(Book<R>& B, const DevArgs& a, 
       const bool own = valid && ((rec.x >> 16) & 0xFFu) == asset;
       is_new[re] = __ballot(own && kind == 0u);
       is_can[re] = __ballot(own && kind == 1u);
-      bad |= own && (kind >= 2u || (kind == 0u && rec.w == 0u) || (a.ev_len && kind != 0u && rec.y >= B.next_id));
+      is_mod[re] = __ballot(own && kind == 2u);
+      bad |= own && (kind > 2u || (kind == 0u && rec.w == 0u) || (kind == 2u && (rec.x & 0x400u) && rec.w == 0u) ||
+                     (a.ev_len && kind != 0u && rec.y >= B.next_id));
     } else {
       is_new[re] = __ballot(valid && kind == 0u);
       is_can[re] = __ballot(valid && kind == 1u);
-      bad |= valid && (kind >= 2u || ((rec.x >> 16) & 0xFFu) != 0u || (kind == 0u && rec.w == 0u) ||
-                       (a.ev_len && kind != 0u && rec.y >= B.next_id));
+      is_mod[re] = __ballot(valid && kind == 2u);
+      bad |= valid && (kind > 2u || ((rec.x >> 16) & 0xFFu) != 0u || (kind == 0u && rec.w == 0u) ||
+                       (kind == 2u && (rec.x & 0x400u) && rec.w == 0u) || (a.ev_len && kind != 0u && rec.y >= B.next_id));
+    }
+    if (lane_bit(is_mod[re]) && (rec.x & 0x200u)) {  // (a modification to volume 0 leaves an Active order of volume 0: not this path)
+      xmin = min(xmin, rec.z);
+      xmax = max(xmax, rec.z);
     }
     eww[re] = rec.x;
     eid[re] = rec.y;
@@ -136,7 +157,7 @@ __device__ __forceinline__ bool step_events_keyed(Book<R>& B, const DevArgs& a, 
   if constexpr (MKT) {  // (this book's events: every one of them is a New or a Cancellation here)
     n_own = 0;
 #pragma unroll
-    for (int re = 0; re < R; ++re) n_own += (uint32_t)__builtin_popcountll(is_new[re] | is_can[re]);
+    for (int re = 0; re < R; ++re) n_own += (uint32_t)__builtin_popcountll(is_new[re] | is_can[re] | is_mod[re]);
   }
   // ---- slots for the new orders
   uint32_t n_new = 0;
@@ -176,10 +197,13 @@ __device__ __forceinline__ bool step_events_keyed(Book<R>& B, const DevArgs& a, 
     nf += __builtin_popcountll(freem);
   }
   if (s_nop == 0xFFFFFFFFu) return false;  // fewer than n_new + 1 free slots
-  if (R <= 2 && mkt) return false;         // (the hand-written loops of the small pools carry no market orders)
+  (void)mkt;  // (round 6: the small pools' hand-written loops have their `m` forms too - event_asm.hpp events_key_r1m / _r2m)
   wave_sync();
-  // ---- the cancellations' slots: one id search each, among the orders live now and this step's new ones
+  // ---- the cancellations' and the modifications' slots: one id search each, among the orders live now and this step's new ones
   uint32_t evs[R];
+  uint64_t any_mod = 0;
+#pragma unroll
+  for (int re = 0; re < R; ++re) any_mod |= is_mod[re];
 #pragma unroll
   for (int re = 0; re < R; ++re) {
     if constexpr (R <= 4) {
@@ -187,7 +211,7 @@ __device__ __forceinline__ bool step_events_keyed(Book<R>& B, const DevArgs& a, 
       if (n_ev <= (uint32_t)re * 64u) continue;
     }
     uint32_t cs = s_nop;
-    uint64_t m = is_can[re];
+    uint64_t m = is_can[re] | is_mod[re];
     while (m) {
       const uint32_t l = (uint32_t)__builtin_ctzll(m);
       m &= m - 1ull;
@@ -206,12 +230,26 @@ __device__ __forceinline__ bool step_events_keyed(Book<R>& B, const DevArgs& a, 
       if (pos + 1u > arr) atomicMin(&W0[cs], (pos << 16) | arr);
     }
     evs[re] = lane_bit(is_new[re]) ? ((uint32_t)ev2slot[pos & (S - 1u)] | EV_NEW | (((eww[re] >> 8) & 1u) ? EV_BID : 0u)) : cs;
+    // a modification keeps {slot, EV_MOD, has-price, has-volume} in its event word, its new volume in evq, and - once the key
+    // window is known, below - its new price's FIELD in the word's upper half; the price itself is read again from the
+    // record here (the permutation is still intact; the id in eid is not needed any more)
+    if (is_mod[re]) {
+      if (lane_bit(is_mod[re])) {
+        eid[re] = a.ev[e0 + perm[pos]].z;
+        evs[re] = cs | EV_MOD | (eww[re] & (EV_MOD_P | EV_MOD_V));
+      }
+    }
   }
   // ---- keys, event words, the loop
   KeyState<R> K;
-  if (!keys_begin<R, true>(B, newm, n_ev, K)) return false;  // (the permutation is still intact for the caller's loop)
+  if (!keys_begin<R, true>(B, newm, n_ev, K, xmin, xmax)) return false;  // (the permutation is still intact for the caller's loop)
   uint32_t evw[R];
   key_event_words<R>(K, evs, n_ev, evw);
+  if (any_mod) {
+#pragma unroll
+    for (int re = 0; re < R; ++re)
+      if (lane_bit(is_mod[re])) evw[re] = (evw[re] & 0xFFFFu) | ((eid[re] - K.pbase) << 16);
+  }
   wave_sync();
 #pragma unroll
   for (int r = 0; r < R; ++r) {  // (perm, rank2ev, ev2slot are consumed: their bytes now hold W1, W2)
@@ -219,19 +257,14 @@ __device__ __forceinline__ bool step_events_keyed(Book<R>& B, const DevArgs& a, 
     W2[r * 64 + lane] = lane_bit(newm[r]) ? B.vol[r] : 0u;
   }
   wave_sync();
-  uint32_t k = 0;
   const uint32_t nev = rfl(n_ev);
-  for (;;) {
-    uint32_t full;
-    if constexpr (R == 1)
-      full = events_key_r1(0u, k, nev, 0xFFFFFFFFu, B.tr_n, K.sq, B.vol[0], K.key[0], evw[0], B.tr_k, B.tr_vol, B.tr_pas);
-    else if constexpr (R == 2)
-      full = events_key_r2(0u, k, nev, 0xFFFFFFFFu, B.tr_n, K.sq, B.vol[0], B.vol[1], K.key[0], K.key[1], evw[0], evw[1], B.tr_k,
-                           B.tr_vol, B.tr_pas);
-    else if constexpr (R == 4)
-      full = events_key_r4m(0u, k, nev, 0xFFFFFFFFu, B.tr_n, K.sq, B.vol, K.key, evw, evq, B.tr_k, B.tr_vol, B.tr_pas);
-    else
-      full = events_key_r8m(0u, k, nev, 0xFFFFFFFFu, B.tr_n, K.sq, B.vol, K.key, evw, evq, B.tr_k, B.tr_vol, B.tr_pas);
+  // the list is cut at the modifications: [k, kend) runs on the assembly loop, a modification is handled between two statements
+  uint32_t k = 0, kend = any_mod ? 0u : nev;
+  uint32_t post = 0xFFFFFFFFu, post_p = 0;  // the slot (and its old price) of the replacement whose New event the last range was
+  uint64_t modm[R], repl[R];                // pool slots a modification changed / replaced in this step
+#pragma unroll
+  for (int r = 0; r < R; ++r) modm[r] = repl[r] = 0ull;
+  auto scatter_and_flush = [&]() {
     if (B.tr_n) {
       B.trade_vol += wave_add((uint32_t)lane < B.tr_n ? B.tr_vol : 0u);
       if (lg.base && (uint32_t)lane < B.tr_n) {  // the log's facts of these trades
@@ -244,7 +277,96 @@ __device__ __forceinline__ bool step_events_keyed(Book<R>& B, const DevArgs& a, 
       }
     }
     flush_trades_compact<R>(B, a, book, t0, lane, evw);
-    if (!full) break;
+  };
+  for (;;) {
+    if (any_mod && k == kend) {
+      if (post != 0xFFFFFFFFu) {
+        // ---- the replaced order's New event has run: did it come to rest? (replace_order's tail, orderbook.rs:699-721)
+        const bool rested = slot_read<R>(K.key, post) != 0u;
+        if (!rested) {  // Filled in the re-match: for the rebuild, a dead order of volume 0 whose last trade was this event
+          slot_write<R>(B.vol, post, 0u);
+          if (lane == 0) W1[post] = k;  // (position + 1 of the event just processed; no earlier record is pending: flushed before it)
+        }
+        if (lg.base) {
+          const uint32_t id = slot_read<R>(B.id, post);
+          if (id >= lg.cap) {
+            B.flags |= FLAG_ORDER_LOG_FULL;
+          } else if (lane == 0) {
+            DevOrderLog* e = lg.base + id;
+            const uint64_t tk = t0 + (k - 1u);
+            e->price = slot_read<R>(B.price, post);
+            const uint32_t arr = W0[post] & 0xFFFFu;
+            if (rested) {  // re-keyed: (new price, now)
+              e->key_price = e->price;
+              e->key_lo = (uint32_t)tk;
+              e->key_hi = (uint32_t)(tk >> 32);
+            } else if (arr != 0u && !mask_test<R>(repl, post)) {
+              // an order of THIS step keeps the key it rested with on arrival (the rebuild leaves a replaced slot's key alone)
+              const uint64_t ta = t0 + (arr - 1u);
+              e->key_price = post_p;
+              e->key_lo = (uint32_t)ta;
+              e->key_hi = (uint32_t)(ta >> 32);
+            }
+          }
+        }
+        mask_set<R>(repl, post, true);
+        wave_sync();
+        post = 0xFFFFFFFFu;
+      }
+      if (k >= nev) break;
+      // the next modification at or behind k
+      uint32_t km = nev;
+#pragma unroll
+      for (int re = R - 1; re >= 0; --re) {
+        uint64_t m = __ballot((evw[re] & (EV_NEW | EV_MOD)) == EV_MOD && (uint32_t)(re * 64 + lane) < nev);
+        const uint32_t base = 64u * (uint32_t)re;
+        if (k > base) m = (k - base >= 64u) ? 0ull : (m & (~0ull << (k - base)));
+        if (m) km = base + (uint32_t)__builtin_ctzll(m);
+      }
+      kend = km;
+      if (km == k) {
+        // ---- the modification at position k (orderbook.rs:743-772)
+        const uint32_t w = slot_read<R>(evw, k), sl = w & EV_SLOT & (S - 1u);
+        const bool has_p = (w & EV_MOD_P) != 0u, has_v = (w & EV_MOD_V) != 0u;
+        const uint32_t keyv = slot_read<R>(K.key, sl);
+        k += 1;
+        kend = k;  // (nothing to run: the boundary code above looks for the next modification)
+        if (keyv == 0u || !(has_p || has_v)) continue;  // not Active (or no such order: the spare slot's key is 0) / (None, None)
+        const uint32_t cur_v = slot_read<R>(B.vol, sl), cur_p = slot_read<R>(B.price, sl), nv_in = slot_read<R>(evq, k - 1u);
+        mask_set<R>(modm, sl, true);
+        if (!has_p && nv_in < cur_v) {  // reduce_order_vol: in place, priority kept
+          slot_write<R>(B.vol, sl, nv_in);
+          continue;
+        }
+        // replace_order (:679-723): out of the book, new price / volume, then the same slot's New event at this position
+        scatter_and_flush();  // (the buffered records' prices are read from the pool: before this slot's changes)
+        const bool is_bid = (int32_t)keyv > 0;
+        const uint32_t np = has_p ? K.pbase + (w >> 16) : cur_p, nv = has_v ? nv_in : cur_v;
+        slot_write<R>(K.key, sl, 0u);
+        slot_write<R>(B.price, sl, np);
+        slot_write<R>(B.vol, sl, nv);
+        slot_write<R>(evq, k - 1u, nv);
+        const uint32_t pf = np - K.pbase;
+        slot_write<R>(evw, k - 1u, sl | EV_NEW | (is_bid ? EV_BID : 0u) | ((is_bid ? 0x8000u | pf : pf) << 16));
+        post = sl;
+        post_p = cur_p;
+        k -= 1;  // run [k, k + 1)
+        kend = k + 1u;
+      }
+      if (k == kend) continue;
+    }
+    uint32_t full;
+    if constexpr (R == 1)
+      full = events_key_r1m(0u, k, kend, 0xFFFFFFFFu, B.tr_n, K.sq, B.vol[0], K.key[0], evw[0], B.tr_k, B.tr_vol, B.tr_pas);
+    else if constexpr (R == 2)
+      full = events_key_r2m(0u, k, kend, 0xFFFFFFFFu, B.tr_n, K.sq, B.vol[0], B.vol[1], K.key[0], K.key[1], evw[0], evw[1], B.tr_k,
+                            B.tr_vol, B.tr_pas);
+    else if constexpr (R == 4)
+      full = events_key_r4m(0u, k, kend, 0xFFFFFFFFu, B.tr_n, K.sq, B.vol, K.key, evw, evq, B.tr_k, B.tr_vol, B.tr_pas);
+    else
+      full = events_key_r8m(0u, k, kend, 0xFFFFFFFFu, B.tr_n, K.sq, B.vol, K.key, evw, evq, B.tr_k, B.tr_vol, B.tr_pas);
+    scatter_and_flush();
+    if (!any_mod && !full) break;
   }
   keys_end<R>(B, K);
 #pragma unroll
@@ -257,11 +379,12 @@ __device__ __forceinline__ bool step_events_keyed(Book<R>& B, const DevArgs& a, 
   for (int r = 0; r < R; ++r) {
     const uint32_t w0 = W0[r * 64 + lane], arr = w0 & 0xFFFFu, c = w0 >> 16, f = W1[r * 64 + lane], rem = W2[r * 64 + lane];
     const bool alive = lane_bit(B.live[r]), was = lane_bit(live0[r]), isnew = arr != 0u, bidl = lane_bit(B.bid[r]);
-    const bool touched = isnew || (was && (f != 0u || !alive));
+    const bool rp = lane_bit(repl[r]);  // replaced in this step: price and key were written at the modification
+    const bool touched = isnew || (was && (f != 0u || !alive)) || lane_bit(modm[r]);
     const uint32_t id = B.id[r], price = B.price[r];
     const bool market = price == (bidl ? 0xFFFFFFFFu : 0u);
     // a new order that did not come to rest: a market order, or filled on arrival
-    const bool norest = isnew && (market || rem == 0u);
+    const bool norest = isnew && !rp && (market || rem == 0u);
     uint32_t status, vol;
     uint64_t end = ~0ull, key_t = 0ull;
     const uint64_t t_arr = t0 + (arr - 1u);
@@ -286,10 +409,12 @@ __device__ __forceinline__ bool step_events_keyed(Book<R>& B, const DevArgs& a, 
         e[7] = (uint32_t)(end >> 32);
       }
       if (isnew) {
-        e[2] = price;
-        e[3] = price;
         e[4] = (uint32_t)t_arr;
         e[5] = (uint32_t)(t_arr >> 32);
+      }
+      if (isnew && !rp) {
+        e[2] = price;
+        e[3] = price;
         e[8] = (uint32_t)key_t;
         e[9] = (uint32_t)(key_t >> 32);
       }

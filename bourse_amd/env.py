@@ -866,9 +866,19 @@ class ManyBookEnv:
         """Load a checkpoint taken from an env of the same shape; the run continues bit-identically."""
         buf = np.ascontiguousarray(buf, dtype=np.uint8)
         n = int(self._L.bk_checkpoint_bytes(self._h))
-        check(self._L.bk_checkpoint_load(self._h, buf.ctypes.data_as(C.c_void_p), min(n, buf.nbytes)))
+        # exactly the library's image, or the image + the sticky-flags trailer of checkpoint() with its magic and this env's
+        # book count; anything else - a checkpoint of another shape, a truncated or padded file - is refused, not loaded in part
+        tail = 16 + 4 * self.n_books
+        has_tail = buf.nbytes == n + tail
+        if has_tail and not (buf[n:n + 8].tobytes() == _STICKY_MAGIC and
+                             int(np.frombuffer(buf[n + 8:n + 16].tobytes(), dtype=np.uint64)[0]) == self.n_books):
+            raise ValueError("restore: the checkpoint's trailer is not this env's (magic / book count)")
+        if not has_tail and buf.nbytes != n:
+            raise ValueError(f"restore: {buf.nbytes} bytes is not a checkpoint of this env's shape ({n} bytes, or {n + tail} with "
+                             f"the reported-flags trailer)")
+        check(self._L.bk_checkpoint_load(self._h, buf.ctypes.data_as(C.c_void_p), n))
         self._flags_sticky, self._warned_bits = None, 0
-        if buf.nbytes == n + 16 + 4 * self.n_books and buf[n:n + 8].tobytes() == _STICKY_MAGIC:
+        if has_tail:
             self._flags_sticky = buf[n + 16:].view(np.uint32).copy()
 
     def state_bytes_per_book(self) -> int:

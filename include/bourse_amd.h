@@ -142,6 +142,9 @@ typedef struct bk_stats {
 
 const char* bk_last_error(void);
 int bk_device_count(int* out);
+/* HIP_VERSION the library was compiled against / hipRuntimeGetVersion() of the runtime this process bound it to (no
+ * reference counterpart: diagnostics - a Python process may run the library on PyTorch's bundled runtime, bourse_amd/_lib.py) */
+int bk_hip_versions(int* built, int* runtime);
 
 /* ------------------------------------------------------------------ lifetime */
 int bk_env_create(const bk_config* cfg, bk_env** out);   /* Env::new, env.rs:84-95 (x B) */

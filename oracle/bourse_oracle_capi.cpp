@@ -389,6 +389,10 @@ int orc_env_submit_instructions(void* e, uint64_t n, const uint32_t* action, con
       if (out_ids) out_ids[i] = id;
     } else if (action[i] == 2u) {
       env.cancel_order(order_id[i]);
+    } else if (action[i] == 0x80000003u) {
+      // BK_ACTION_MODIFY (include/bourse_amd.h): the library's one extension of the action codes - Env::modify_order
+      // (env.rs:208-219), side bit 1 = has price, bit 2 = has volume; the reference's own submit_instructions ignores it (:266)
+      env.modify_order(order_id[i], opt((side[i] & 2u) != 0, price[i]), opt((side[i] & 4u) != 0, vol[i]));
     }
   }
   if (applied) *applied = n;

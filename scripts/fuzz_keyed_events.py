@@ -1,6 +1,6 @@
 """Fuzz the host-driven step on the keyed loop (step_events.hpp step_events_keyed) over fresh seeds: every book of small
 batches against its own oracle env - level 2 of every step, every trade, the whole order log - on random mixes of clean
-steps (new / cancel / market orders: the keyed form) and steps that must fall back (modifications, volume 0, more events
+steps (new / cancel / modify / market orders: the keyed form) and steps that must fall back (volume 0, more events
 than pool slots, prices outside the key window, full pools), all four pool sizes, three tick sizes, narrow and wide price
 ranges, ordinary and extreme volumes.  Prints how many book-steps ran keyed.  GPU box.  FUZZ_LO / FUZZ_HI."""
 import os, sys
@@ -23,7 +23,7 @@ for seed in range(lo, hi):
     centre = int(rng.choice([100, 100, 20_000, 3_000_000, (2**32 - 1) // tick - 40]))
     width = int(rng.choice([3, 8, 8, 30, 40_000]))  # 40 000 ticks: wider than the key window
     lo_p, hi_p = max(1, centre - width), min((2**32 - 1) // tick, centre + width + 1)
-    kw = dict(p_market=float(rng.choice([0.0, 0.01, 0.05])), p_mod=float(rng.choice([0.0, 0.0, 0.003, 0.03])),
+    kw = dict(p_market=float(rng.choice([0.0, 0.01, 0.05])), p_mod=float(rng.choice([0.0, 0.003, 0.03, 0.1, 0.25])),
               p_zero=float(rng.choice([0.0, 0.0, 0.002, 0.02])), tick=tick, lo=lo_p, hi=hi_p,
               vols=[1, 2, 7, 2**31, 2**32 - 1, 2**32 - 2, 123456789] if rng.random() < 0.15 else None)
     try:

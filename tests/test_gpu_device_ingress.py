@@ -273,6 +273,22 @@ def test_host_arrays_through_device_ingress_equal_host_calls_and_oracle_on_8192_
     ids_b, st_b, bad_b = dg.submit_result(tb, view=True)
     assert (ids_a == 0).all() and bad_a is None and (st_a[:, 1] == 1).all()
     assert np.array_equal(ids_b.reshape(B, 40), np.tile(np.arange(1, 41, dtype=np.uint64), (B, 1))) and (st_b[:, 1] == 40).all()
+    # ... and a VIEW taken before a growth stays readable until two more submits (the growth freed the pinned block
+    # under it): view of ticket tc, then a batch that outgrows the staging, then read the view
+    dg.step()
+    tc = dg.submit_instructions_all_async(np.arange(B + 1, dtype=np.uint64), (one(B, 1, np.uint32), one(B, 0, np.uint8), one(B, 2, np.uint32),
+                                                                           one(B, 0, np.uint32), one(B, 95, np.uint32), one(B, 0, np.uint64)))
+    ids_c, st_c, bad_c = dg.submit_result(tc, view=True)
+    want_c = ids_c.copy()
+    assert (want_c == 41).all() and bad_c is None
+    huge = 120 * B  # 3 x the staging's capacity: re-allocated
+    offh = np.arange(B + 1, dtype=np.uint64) * 120
+    td = dg.submit_instructions_all_async(offh, (one(huge, 0, np.uint32), one(huge, 1, np.uint8), one(huge, 1, np.uint32), one(huge, 0, np.uint32),
+                                                 one(huge, 80, np.uint32), one(huge, 0, np.uint64)))  # (null instructions: nothing queued)
+    assert np.array_equal(ids_c, want_c) and (st_c[:, 1] == 1).all(), "a view of ticket t must survive the growth caused by ticket t + 1"
+    ids_d, st_d, bad_d = dg.submit_result(td)
+    assert (ids_d == 2**64 - 1).all() and bad_d is None
+    assert np.array_equal(ids_c, want_c)
     dg.close()
     dq.close()
     for d in devs.values():

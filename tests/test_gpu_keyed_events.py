@@ -1,9 +1,11 @@
-"""The host-driven step on the keyed loop (bourse_amd/csrc/step_events.hpp step_events_keyed, round 5).
+"""The host-driven step on the keyed loop (bourse_amd/csrc/step_events.hpp step_events_keyed, round 5; modifications and the
+small pools' market orders since round 6).
 
 `Env::step` over submitted instructions (ref crates/step_sim/src/env.rs:116-135; place / cancel / modify:
-crates/order_book/src/orderbook.rs:583-611, 622-644, 743-772) runs on the slot-addressed assembly loops whenever a step has
-no modification, fits one event per pool slot, and its prices fit the key window; everything else runs the event-by-event
-loop.  Both must be the reference's step, and a book must be able to alternate between them: EVERY book of a batch is compared
+crates/order_book/src/orderbook.rs:583-611, 622-644, 743-772) runs on the slot-addressed assembly loops whenever a step
+fits one event per pool slot, has no volume of 0 and its prices fit the key window - modifications included: the list is cut at
+each of them and the modification (reduce in place / replace = out, re-match, rest with a fresh stamp: :656-723) happens
+between two statements; everything else runs the event-by-event loop.  Both must be the reference's step, and a book must be able to alternate between them: EVERY book of a batch is compared
 with its own oracle env - every step's level-2 record, every trade, the whole order log and the priority keys - on streams
 that mix the two kinds of step and lean on what the keyed form re-derives instead of observing: cancellations of orders
 placed in the same step (before and after their placement in the shuffled order), repeated cancellations, cancellations of
@@ -46,17 +48,19 @@ def _drive(bk, oracle, pool, n_max, B, T, seed, p_market, p_mod, p_zero, tick=1,
                 elif u < 0.36 + p_mod and made[b] > 0:
                     oid = int(made[b] - 1 - rng.integers(0, min(made[b], 2 * n_max)))
                     new_p = int(rng.integers(lo, hi)) * tick if rng.random() < 0.6 else None
-                    new_v = int(rng.integers(1, 40)) if rng.random() < 0.6 else None
-                    env.modify_order(b, oid, new_p, new_v)
-                    refs[b].modify_order(oid, new_p, new_v)
-                    ok, n_ev = False, n_ev + 1
+                    new_v = (0 if rng.random() < p_zero else int(rng.integers(1, 40))) if rng.random() < 0.6 else None
+                    for _ in range(2 if rng.random() < 0.1 else 1):  # ... sometimes the same order twice in a step
+                        env.modify_order(b, oid, new_p, new_v)
+                        refs[b].modify_order(oid, new_p, new_v)
+                        n_ev += 1
+                    ok = ok and new_v != 0  # (a modification to volume 0 leaves an Active order of volume 0: event by event)
                 else:
                     bid, trader = bool(rng.integers(0, 2)), int(rng.integers(0, 50))
                     vol = 0 if rng.random() < p_zero else (int(rng.integers(1, 40)) if vols is None else int(rng.choice(vols)))
                     price = None if rng.random() < p_market else int(rng.integers(lo, hi)) * tick
                     assert env.place_order(b, bid, vol, trader, price) == made[b] == refs[b].place_order(bid, vol, trader, price)
                     made[b] += 1
-                    ok, n_ev = ok and vol != 0 and (price is not None or pool > 128), n_ev + 1
+                    ok, n_ev = ok and vol != 0, n_ev + 1
             busy[s, b], clean[s, b] = n_ev > 0, ok and 0 < n_ev <= pool
         env.step()
         for r in refs:
@@ -96,13 +100,13 @@ def test_mixed_streams_alternate_between_the_keyed_and_the_event_by_event_loop(b
     for k, v in SHUFFLES[shuffle].items():
         monkeypatch.setenv(k, v)
     B, T = 192, 12
-    env, refs, busy, clean = _drive(bk, oracle, pool, n_max, B, T, 500 + pool, p_market, p_mod=0.004, p_zero=0.002)
+    env, refs, busy, clean = _drive(bk, oracle, pool, n_max, B, T, 500 + pool, p_market, p_mod=0.05, p_zero=0.004)
     _same_as_oracle(env, refs)
     keyed = env.event_steps_keyed()
     # every keyed step was a step the keyed form may take; and it took (nearly) all of those - what the calls cannot tell is
     # a pool without a spare slot, a resting order of volume 0 and the key window
-    assert np.all(keyed <= clean.sum(axis=0)), "a step with a modification / volume 0 / too many events ran keyed"
-    assert keyed.sum() >= 0.9 * clean.sum(), (int(keyed.sum()), int(clean.sum()))
+    assert np.all(keyed <= clean.sum(axis=0)), "a step with a volume of 0 / too many events ran keyed"
+    assert keyed.sum() >= 0.85 * clean.sum(), (int(keyed.sum()), int(clean.sum()))
     assert 0.25 * busy.sum() < clean.sum() < busy.sum(), "the stream should mix both kinds of step"
     assert sum(len(r.book.trades_array()) for r in refs) > 20 * B
     env.close()
@@ -128,7 +132,8 @@ def test_steps_outside_the_keyed_form_fall_back_and_the_books_go_on(bk, oracle):
     apart = [("place_order", i % 2 == 0, 5, i, (90 - i) if i % 2 == 0 else (110 + i)) for i in range(62)]  # nothing trades: 62 rest
     cases = {
         "clean": ([_std(), _std(1), _std(2)], {3}),
-        "modify": ([_std(), _std(1) + [("modify_order", 1, 101, None)], _std(2)], {2}),
+        "modify": ([_std(), _std(1) + [("modify_order", 1, 101, None)], _std(2)], {3}),  # (round 6: keyed)
+        "modify to volume 0": ([_std(), _std(1) + [("modify_order", 1, None, 0)], _std(2)], {1, 2}),
         # (the order of volume 0 rests - orderbook.rs:430 never enters the match loop with it - and while it does, steps stay
         # on the event-by-event loop; whether step 2 finds it still there depends on the shuffle)
         "zero volume": ([_std(), _std(1) + [("place_order", True, 0, 3, 100)], _std(2)], {1, 2}),
@@ -185,7 +190,7 @@ def test_a_book_with_trading_disabled_steps_event_by_event(bk, oracle):
 def test_markets_books_run_the_keyed_form_on_their_markets_queue(bk, oracle, assets, pool):
     """MarketEnv (ref crates/step_sim/src/market_env.rs:110-121): ONE shuffled queue per market, every asset's book processes its
     own events at the market's positions.  In the keyed form the other assets' events stay in a book's list as events that do
-    nothing; a modification for one asset sends only THAT asset's book to the event-by-event loop."""
+    nothing; an asset's modifications cut only THAT asset's book's list (round 6)."""
     NM, T = 48, 10
     ticks = [1, 2, 5, 1][:assets]
     env = bk.ManyMarketEnv(NM, 70, 0, ticks, 100_000, levels=10, max_live_orders=pool, max_orders=2048, trade_capacity=4096, history_capacity=T)
@@ -204,15 +209,15 @@ def test_markets_books_run_the_keyed_form_on_their_markets_queue(bk, oracle, ass
                     oid = int(made - 1 - rng.integers(0, min(made, 60)))
                     env.cancel_order(m, a, oid)
                     ref.cancel_order(m, a, oid)
-                elif u < 0.36 and made:
-                    oid = int(rng.integers(0, made))
+                elif u < 0.40 and made:
+                    oid = int(made - 1 - rng.integers(0, min(made, 60)))
                     nv = int(rng.integers(1, 30))
-                    env.modify_order(m, a, oid, None, nv)
-                    ref.modify_order(m, a, oid, None, nv)
-                    ok[a] = False
+                    np_ = int(rng.integers(95, 106)) * ticks[a] if rng.random() < 0.5 else None
+                    env.modify_order(m, a, oid, np_, nv)
+                    ref.modify_order(m, a, oid, np_, nv)
                 else:
                     bid, vol = bool(rng.integers(0, 2)), int(rng.integers(1, 30))
-                    price = None if (rng.random() < 0.04 and pool > 128) else int(rng.integers(95, 106)) * ticks[a]
+                    price = None if rng.random() < 0.04 else int(rng.integers(95, 106)) * ticks[a]
                     assert env.place_order(m, a, bid, vol, 7, price) == ref.place_order(m, a, bid, vol, 7, price)
             clean[s, m] = ok
         env.step()
@@ -227,4 +232,64 @@ def test_markets_books_run_the_keyed_form_on_their_markets_queue(bk, oracle, ass
             assert len(got) == len(want) and all(np.array_equal(got[f], want[f]) for f in got.dtype.names), (m, a)
     keyed = env.event_steps_keyed().reshape(NM, assets)
     assert np.all(keyed <= clean.sum(axis=0)) and keyed.sum() >= 0.9 * clean.sum(), (int(keyed.sum()), int(clean.sum()))
+    env.close()
+
+
+@pytest.mark.parametrize("pool", [64, 128, 256, 512])
+def test_modifications_on_the_keyed_loop_case_by_case(bk, oracle, pool):
+    """orderbook.rs:743-772 through the cut list: every branch of modify_order, on orders resting from an earlier step and on
+    orders of the same step (the shuffle decides which side of its placement a modification lands on - several seeds of the
+    same calls), each book against its oracle env: level 2, every trade, the whole order log with the priority keys."""
+    rest = [("place_order", True, 10, 1, 95), ("place_order", True, 7, 2, 96), ("place_order", False, 9, 3, 104), ("place_order", False, 6, 4, 105),
+            ("place_order", True, 5, 5, 96), ("place_order", False, 4, 6, 104)]  # ids 0..5, nothing crosses; 96 and 104 hold two orders each
+    cases = {
+        "reduce in place keeps priority": [rest, [("modify_order", 1, None, 3), ("place_order", False, 8, 9, 96)]],
+        "same volume is a replace: priority lost": [rest, [("modify_order", 1, None, 7), ("place_order", False, 8, 9, 96)]],
+        "larger volume: replace": [rest, [("modify_order", 1, None, 20), ("place_order", False, 30, 9, 96)]],
+        "price only, still resting": [rest, [("modify_order", 0, 97, None), ("place_order", False, 8, 9, 96)]],
+        "price that crosses: re-match, remainder rests": [rest, [("modify_order", 0, 104, None)]],
+        "price that crosses and fills": [rest, [("modify_order", 4, 105, 3)]],
+        "ask down through the bids": [rest, [("modify_order", 3, 95, 30)]],
+        "price and volume": [rest, [("modify_order", 2, 103, 2), ("modify_order", 5, 103, 2), ("place_order", True, 3, 9, 103)]],
+        "neither field": [rest, [("modify_order", 2, None, None)] + _std(1, 4)],
+        "twice in one step": [rest, [("modify_order", 1, 97, None), ("modify_order", 1, None, 2), ("place_order", False, 8, 9, 96)]],
+        "modify then cancel then modify": [rest, [("modify_order", 1, 97, 9), ("cancel_order", 1), ("modify_order", 1, 98, 9), ("place_order", False, 8, 9, 95)]],
+        "of an order of the same step": [rest, [("place_order", True, 6, 7, 97), ("modify_order", 6, 98, None), ("modify_order", 6, None, 2), ("place_order", False, 9, 8, 97)]],
+        "same step, crossing after the change": [rest, [("place_order", True, 6, 7, 97), ("modify_order", 6, 104, 12), ("cancel_order", 6)]],
+        "of a filled and of a cancelled order": [rest + [("place_order", False, 10, 8, 95)], [("cancel_order", 1), ("modify_order", 0, 99, 5), ("modify_order", 1, 99, 5)] + _std(1, 4)],
+        "of a market order's id": [rest, [("place_order", True, 3, 7, None), ("modify_order", 6, 99, 4)] + _std(1, 4)],
+        "three steps of them": [rest, [("modify_order", i, 96 + i, 5 + i) for i in range(6)], [("modify_order", i, None, 2) for i in range(6)] + _std(2, 6)],
+    }
+    for seed_shift in range(3):  # (the same calls under three shuffles)
+        shifted = {f"{k} #{seed_shift}": [[("place_order", True, 1, 0, 50)] * 0 + step for step in v] for k, v in cases.items()}
+        names = list(shifted)
+        B, T = len(names), 3
+        env = bk.ManyBookEnv(B, 31 + 1000 * seed_shift, 0, 1, 100_000, levels=10, max_live_orders=pool, max_orders=600, trade_capacity=800, history_capacity=T)
+        refs = [oracle.StepEnv(31 + 1000 * seed_shift + b, 0, 1, 100_000) for b in range(B)]
+        for s in range(T):
+            for b, name in enumerate(names):
+                for f, *args in (shifted[name][s] if s < len(shifted[name]) else []):
+                    getattr(env, f)(b, *args)
+                    getattr(refs[b], f)(*args)
+            env.step()
+            for r in refs:
+                r.step()
+        assert not env.flags().any()
+        _same_as_oracle(env, refs)
+        keyed = dict(zip(names, env.event_steps_keyed().tolist()))
+        assert all(v == sum(1 for st in shifted[k] if st) for k, v in keyed.items()), keyed  # every step with events ran keyed
+        env.close()
+
+
+@pytest.mark.parametrize("pool,n_max", [(64, 14), (128, 30), (256, 48), (512, 90)])
+def test_streams_with_many_modifications_and_market_orders_run_keyed(bk, oracle, pool, n_max):
+    """The stream shape VERDICT r5 asked a rate for: 5 - 10 % modifications, 2 - 4 % market orders, no volume of 0 - every step with
+    events must run on the keyed loop (minus the few whose pool has no spare slot) and equal the oracle."""
+    B, T = 160, 12
+    env, refs, busy, clean = _drive(bk, oracle, pool, n_max, B, T, 900 + pool, p_market=0.03, p_mod=0.08, p_zero=0.0)
+    _same_as_oracle(env, refs)
+    assert np.array_equal(busy, clean)
+    keyed = env.event_steps_keyed()
+    assert np.all(keyed <= busy.sum(axis=0)) and keyed.sum() >= 0.97 * busy.sum(), (int(keyed.sum()), int(busy.sum()))
+    assert sum(len(r.book.trades_array()) for r in refs) > 10 * B
     env.close()
