@@ -93,8 +93,14 @@ def algorithmic_bytes(kind, S, W4, ev, tr, new, spl=1, pipe="split", n_ins=0.0):
         return 256.0 + 256.0 + 4.0 * ev + 16.0 * new + 256.0 + 2.0 * ev, rec + 6.0 * 1024.0
     if kind == "k_step_batch":  # the state block in and out, the batch in, the L2 record and the trade records out
         return 2.0 * S + 64.0 + 2.0 * ev + 8.0 * new + W4 + 32.0 * tr, 0.0
-    if kind == "k_step_events":  # state in and out, the last and the new L2 record, 20 B per queued event, trade records
-        return 2.0 * S + 2.0 * W4 + 20.0 * ev + 32.0 * tr, 0.0
+    if kind == "k_step_events":
+        # state in and out, the last and the new L2 record, 20 B per queued event, trade records, and the ORDER LOG the path
+        # keeps (orderbook.rs:113-115: every order's status / volume / times / key): the ten words of a new order's entry, two
+        # words (volume + status or end time) per cancellation and per fill of a resting order.  Round 6's toggled PMC passes
+        # (profiles/r06/pmc_step_events.txt): without the log the kernel moves 0.99 x the rest of this sum, the log adds 2.1 KB
+        # of writes at 48 events per book-step - rounds 4 - 5 left it out of the sum and read it as 1.36 x "wasted" traffic.
+        # l2: the wave-parallel shuffle's lane-state record (1.0 KB read per step, written back when the block changed)
+        return 2.0 * S + 2.0 * W4 + 20.0 * ev + 32.0 * tr + 40.0 * new + 8.0 * max(ev - new, 0.0) + 8.0 * tr, 1280.0 + 320.0
     if kind == "k_ingest":  # the six arrays in, event records + the new orders' immutable halves and log entries out
         return 27.0 * n_ins + 16.0 * ev + 80.0 * new, 0.0
     raise KeyError(kind)

@@ -196,6 +196,7 @@ struct WaveDecoder {
   uint4* wcs;          // global: the 64 lane states of the cache record
   int lane;
   uint4 cs;            // this lane's chunk-start state in the last generated block
+  bool was_cached;     // load_cache found the record valid: finish() then stores the lane states only if the block changed
   uint32_t gen_end;    // draws generated so far (stream origin = start of the cached block)
   uint32_t pos;        // stream position: draws consumed so far
   BK_STAMP_FIELD
@@ -215,7 +216,7 @@ struct WaveDecoder {
       cached = cwc[WC_TAG] == WC_MAGIC && cwc[WC_S0_LO] == s0l && cwc[WC_S0_HI] == s0h && cwc[WC_S1_LO] == s1l &&
                cwc[WC_S1_HI] == s1h && pos < WV_BLOCK;
     } else {
-      const uint32_t wch = wc[lane];
+      const uint32_t wch = lane < 8 ? wc[lane] : 0u;  // (six words of the 256-byte header are in use: one 32-byte sector)
       pos = rdl(wch, WC_OFF);
       cached = rdl(wch, WC_TAG) == WC_MAGIC && rdl(wch, WC_S0_LO) == s0l && rdl(wch, WC_S0_HI) == s0h &&
                rdl(wch, WC_S1_LO) == s1l && rdl(wch, WC_S1_HI) == s1h && pos < WV_BLOCK;
@@ -232,6 +233,7 @@ struct WaveDecoder {
       }
       pos = 0;
     }
+    was_cached = cached;
     gen_end = 0;
   }
 
@@ -702,9 +704,11 @@ struct WaveDecoder {
     if (!in_last) bs = wcs[lane];  // the block before the last generated one: stored when it was left (same lane)
     uint32_t c2 = pos - (in_last ? gen_end - WV_BLOCK : gen_end - 2u * WV_BLOCK);
     if (gen_end == 0) c2 = pos;  // nothing generated (no agents, no events): the cached block start is still `cs`
+    bool end_jump = false;
     if (c2 == WV_BLOCK) {        // exactly at the block end: the cache describes the next block
       bs = wv_jump(tab, bs);
       c2 = 0;
+      end_jump = true;
     }
     RngLane t{bs.x, bs.y, bs.z, bs.w};
     const uint32_t nst = c2 & (WV_K - 1u);
@@ -718,8 +722,12 @@ struct WaveDecoder {
     cw = lane == WC_S1_HI ? n3 : cw;
     cw = lane == WC_OFF ? c2 : cw;
     cw = lane == WC_TAG ? WC_MAGIC : cw;
-    wc[lane] = cw;
-    wcs[lane] = bs;
+    if (lane < 8) wc[lane] = cw;
+    // The 1 KB of lane states goes out only when the record in memory is not already this block's: the block the position
+    // lies in is the one load_cache found (nothing written), or a block that was stored when generation left it (gen_block).
+    // A host-driven step's shuffle (~60 draws of a 256-draw block, step_events.hpp) re-used its block three steps in four and
+    // wrote the same kilobyte back every time (round 6: 1.36 x of k_step_events' algorithmic bytes at 8 192 books).
+    if (!was_cached || end_jump || (in_last && gen_end > WV_BLOCK)) wcs[lane] = bs;
   }
 };
 

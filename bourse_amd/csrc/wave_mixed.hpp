@@ -560,6 +560,7 @@ __global__ __launch_bounds__(64 * MW_WPB, MW_WPB > 8 ? 5 : 4) void k_agents_mixe
     Dc.cs = S.cs;
     Dc.gen_end = S.gen_end;
     Dc.pos = S.pos;
+    Dc.was_cached = false;  // (finish() always stores the lane states: ~1 500 draws per step cross several blocks)
   }
   if (!(BOURSE_AMD_MW_SKIP & 1)) Dc.shuffle(n_ev);
 
