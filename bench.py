@@ -383,6 +383,44 @@ def spawn_ranks(n_gpus: int, argv) -> int:
     return subprocess.call(cmd, env=env)
 
 
+def rank_watchdog(seconds: float):
+    """A rank that hangs - RCCL's rendezvous or communicator init, a collective a peer never joins, a stream probe - must END,
+    non-zero, so that torch.distributed.run tears the job down and the parent propagates the failure (the
+    first real multi-GPU run is also the first test of all of these).  faulthandler's timer thread prints every thread's stack
+    and calls _exit(1) when `seconds` pass; `rank_watchdog(0)` disarms it."""
+    import faulthandler
+
+    if seconds > 0:
+        faulthandler.dump_traceback_later(seconds, exit=True)
+    else:
+        faulthandler.cancel_dump_traceback_later()
+
+
+def init_ranks(dist, torch, backend, local_rank, timeout_s):
+    """init_process_group with a bounded timeout.  RCCL: first with `device_id` (the communicator is created HERE, so a rank
+    whose device or xGMI link is unusable fails at a named place instead of in the first collective); if that raises, once
+    more without it (lazy communicator on the current device) before giving up."""
+    import datetime
+
+    to = datetime.timedelta(seconds=timeout_s)
+    if backend != "nccl":
+        dist.init_process_group(backend=backend, timeout=to)
+        return "gloo"
+    try:
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank), timeout=to)
+        return "nccl (communicator created at init on cuda:%d)" % local_rank
+    except Exception as e:  # noqa: BLE001
+        print(f"[bench rank {os.environ.get('RANK')}] init_process_group(nccl, device_id=cuda:{local_rank}) failed: {e!r}; "
+              f"retrying without device_id", file=sys.stderr, flush=True)
+        try:
+            if dist.is_initialized():
+                dist.destroy_process_group()
+        except Exception:  # noqa: BLE001
+            pass
+        dist.init_process_group(backend="nccl", timeout=to)
+        return "nccl (lazy communicator)"
+
+
 def selftest_gloo(args, books_total_default):
     """CPU-only check of the multi-rank plumbing (tests/test_bench_spawn.py): rendezvous, shard arithmetic and the
     64-byte stats all-gather over gloo, with NO stepping (there is no CPU execution path to step with)."""
@@ -393,7 +431,14 @@ def selftest_gloo(args, books_total_default):
 
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    dist.init_process_group(backend="gloo")
+    rank_watchdog(args.rank_timeout)
+    # (tests/test_bench_spawn.py: one rank fails before / hangs inside the rendezvous - the job must end non-zero, soon)
+    fault = os.environ.get("BOURSE_AMD_BENCH_TEST_FAULT", "")
+    if fault == f"exit:{rank}":
+        raise SystemExit(f"rank {rank}: injected failure before init_process_group")
+    if fault == f"hang:{rank}":
+        time.sleep(10_000)
+    init_ranks(dist, torch, "gloo", 0, args.dist_timeout)
     total = args.books or books_total_default
     first, B = parallel.shard_books(total, rank, world) if args.scaling == "strong" else (rank * total, total)
     rec = parallel.pack_stats({"n_books": B, "sum_trade_vol": 0, "sum_trades": first, "sum_events": 0, "sum_bid_vol": 0,
@@ -442,6 +487,9 @@ def main():
                     help="the first pre-heat also lasts at least this long: on some boxes the chunk rates agree within 1 %% "
                          "after 40 ms while the regions behind still climb 5 %% for another ~60 ms (profiles/r05/bench_ramp_probe.txt)")
     ap.add_argument("--repeats", type=int, default=4, help="extra timed regions of --steps after the reported one (median in `runs`)")
+    ap.add_argument("--dist-timeout", type=float, default=180.0, help="N > 1: seconds a rendezvous / collective may take before it raises")
+    ap.add_argument("--rank-timeout", type=float, default=900.0,
+                    help="N > 1: seconds after which a rank that has not finished dumps its stacks and exits non-zero (0 = never)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
@@ -466,10 +514,9 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.dry_ranks:  # RCCL refuses two ranks on one device: the 64-byte records travel over gloo instead
-            dist.init_process_group(backend="gloo")
-        else:
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        rank_watchdog(args.rank_timeout)
+        # (RCCL refuses two ranks on one device: in a dry run the 64-byte records travel over gloo instead)
+        dist_backend = init_ranks(dist, torch, "gloo" if args.dry_ranks else "nccl", local_rank, args.dist_timeout)
     if args.workload == "INGRESS":
         if world > 1:
             raise SystemExit("--workload INGRESS is a one-GPU line (books shard as for the agent workloads: bourse_amd/parallel.py)")
@@ -783,6 +830,14 @@ def main():
     flags = env.flags()
     if flags.any():
         raise SystemExit(f"device flags set during the repeated regions: {np.unique(flags)}")
+    if dist is not None:
+        # every rank's shard, pipeline and part count (strong scaling cuts the workload into shards that may take different
+        # pipelines than the one-GPU run: 8 192 books run wave_split where 65 536 run split)
+        pipes = ("fused", "split", "wave_split", "wave")
+        rp, rn, rb, rf = (all_ranks(float(pipes.index(pipe))), all_ranks(float(parts)), all_ranks(float(B)), all_ranks(float(first_book)))
+        out["config"]["ranks_detail"] = [{"rank": r, "first_book": int(rf[r]), "books": int(rb[r]), "pipeline": pipes[int(rp[r])],
+                                          "parts": int(rn[r])} for r in range(world)]
+        out["config"]["dist_backend"] = dist_backend
     if gather is not None:
         g = gather.result()
         out["config"]["stats_allgather"] = {"zero_copy": gather.zero_copy, "ranks_seen": int(gather.out.shape[0]),
@@ -801,6 +856,7 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+        rank_watchdog(0)
     if args.dry_ranks:
         out["dry_ranks"] = True
         out["config"]["parallelism"] += " - DRY RUN: all ranks on ONE GPU, collectives over gloo; the rate is not an N-GPU measurement"

@@ -16,8 +16,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BENCH = os.path.join(ROOT, "bench.py")
 
 
-def _run(*argv, timeout=240):
+def _run(*argv, timeout=240, extra_env=None):
     env = dict(os.environ)
+    env.update(extra_env or {})
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     return subprocess.run([sys.executable, BENCH, *argv], capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
@@ -68,3 +69,27 @@ def test_single_rank_does_not_spawn():
     res = _run("--gpus", "1", "--steps", "1", "--warmup", "0")
     assert res.returncode != 0 and "no GPU visible" in res.stdout + res.stderr
     assert "torch.distributed.run" not in res.stderr
+
+
+def test_a_rank_that_fails_before_the_rendezvous_ends_the_job_non_zero():
+    """a rank whose initialisation fails (RCCL's on the real node; injected here) must not leave its peers
+    waiting in init_process_group for ever: torch.distributed.run tears the job down, the parent returns its code."""
+    import time
+
+    t = time.time()
+    res = _run("--gpus", "2", "--selftest-gloo", "--dist-timeout", "20", extra_env={"BOURSE_AMD_BENCH_TEST_FAULT": "exit:1"}, timeout=180)
+    assert res.returncode != 0, res.stdout[-500:]
+    assert "injected failure" in res.stdout + res.stderr
+    assert time.time() - t < 150
+
+
+def test_a_rank_that_hangs_is_ended_by_its_watchdog():
+    """... and a rank that HANGS (a collective a peer never joins, a stream probe that never returns) dumps its stacks and exits
+    non-zero after --rank-timeout; its peer's rendezvous times out after --dist-timeout.  Either ends the job."""
+    import time
+
+    t = time.time()
+    res = _run("--gpus", "2", "--selftest-gloo", "--dist-timeout", "15", "--rank-timeout", "25",
+               extra_env={"BOURSE_AMD_BENCH_TEST_FAULT": "hang:0"}, timeout=240)
+    assert res.returncode != 0, res.stdout[-500:]
+    assert time.time() - t < 200
