@@ -449,6 +449,8 @@ int launch_events(bk_env* env, const DevArgs& a, uint64_t step_index, uint32_t m
   ProfScope ps(env, 3);
   uint32_t perm_bytes = ((max_queue + 63u) & ~63u) * 2u + 128u;  // u16 permutation of the longest queue
   if (perm_bytes < ev_lds_bytes(R)) perm_bytes = ev_lds_bytes(R);  // ... the wave-parallel shuffle's and the keyed form's lists (step_events.hpp)
+  // a queue longer than the pool runs the keyed form chunk by chunk (round 6): its work area sits BEHIND the permutation
+  if (max_queue > 64u * R) perm_bytes = std::max(perm_bytes, ((max_queue + 63u) & ~63u) * 2u + ev_keyed_lds_bytes(R));
   // the shuffle borrows the decode's jump tables and per-book lane-state cache (BOURSE_AMD_EV_SEQ_SHUFFLE=1: the draw-by-draw
   // loop, for measurements)
   // (both knobs are read at every launch - a getenv, ~0.1 us - so that a test can switch them inside one process)
@@ -465,10 +467,16 @@ int launch_events(bk_env* env, const DevArgs& a, uint64_t step_index, uint32_t m
   WaveArgs wva{};
   if (!seq_shuffle && max_queue >= shuffle_min && max_queue >= 2u)
     if (int rc = wave_args(env, &wva)) return rc;
-  if (env->M == 1)
-    hipLaunchKernelGGL((k_step_events<R, false>), dim3(env->cfg.n_books), dim3(64), perm_bytes, env->stream, a, wva, step_index, shuffle_min);
+  const bool chunks = max_queue > 64u * R;  // a queue longer than the pool: the instantiation whose keyed form runs chunk by chunk
+  const dim3 grid(env->cfg.n_books), block(64);
+  if (env->M == 1 && !chunks)
+    hipLaunchKernelGGL((k_step_events<R, false, false>), grid, block, perm_bytes, env->stream, a, wva, step_index, shuffle_min, perm_bytes);
+  else if (env->M == 1)
+    hipLaunchKernelGGL((k_step_events<R, false, true>), grid, block, perm_bytes, env->stream, a, wva, step_index, shuffle_min, perm_bytes);
+  else if (!chunks)
+    hipLaunchKernelGGL((k_step_events<R, true, false>), grid, block, perm_bytes, env->stream, a, wva, step_index, shuffle_min, perm_bytes);
   else
-    hipLaunchKernelGGL((k_step_events<R, true>), dim3(env->cfg.n_books), dim3(64), perm_bytes, env->stream, a, wva, step_index, shuffle_min);
+    hipLaunchKernelGGL((k_step_events<R, true, true>), grid, block, perm_bytes, env->stream, a, wva, step_index, shuffle_min, perm_bytes);
   HIPCHK(hipGetLastError());
   return BK_OK;
 }

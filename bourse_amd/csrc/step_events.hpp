@@ -100,15 +100,18 @@ constexpr uint32_t ev_keyed_lds_bytes(int R) { return 12u * 64u * (uint32_t)R; }
 // single-asset text left exactly as it was: the run-time form cost the single-asset kernel 1.5 %, a first templated form that
 // simplified its expressions 4 % - the register allocation of this kernel sits on an edge: profiles/r05/ab_ev_markets*.txt.)
 template <int R, bool MKT>
+// perm: the shuffled positions of THESE n_ev events (a whole step's, or one chunk of a longer queue's: then t0 is the chunk's
+// first time stamp); wk: 12 x 64 R bytes of work area - the same bytes as perm for a whole step (the permutation is consumed
+// on the way), behind the permutation for a chunked one (the later chunks still need theirs).  n_own is ADDED to.
 __device__ __forceinline__ bool step_events_keyed(Book<R>& B, const DevArgs& a, uint32_t book, uint64_t t0, int lane,
-                                                  uint32_t n_ev, uint32_t e0, uint16_t* perm, const LogCtx& lg, uint32_t asset,
-                                                  uint32_t& n_own) {
+                                                  uint32_t n_ev, uint32_t e0, const uint16_t* perm, uint16_t* wk, const LogCtx& lg,
+                                                  uint32_t asset, uint32_t& n_own) {
   constexpr uint32_t S = 64u * R;
-  uint16_t* rank2ev = perm + S;       // bytes [2S, 4S): event position of the i-th new order
-  uint16_t* ev2slot = perm + 2u * S;  // bytes [4S, 6S): pool slot of the new order at an event position
-  uint32_t* W0 = reinterpret_cast<uint32_t*>(perm + 4u * S);  // bytes [8S, 12S): first cancellation after arrival << 16 | arrival position + 1
-  uint32_t* W1 = reinterpret_cast<uint32_t*>(perm);           // bytes [0, 4S), once the lists above are consumed: last passive trade's position + 1
-  uint32_t* W2 = reinterpret_cast<uint32_t*>(perm + 2u * S);  // bytes [4S, 8S): a new order's volume minus what it took as the aggressor
+  uint16_t* rank2ev = wk + S;       // bytes [2S, 4S): event position of the i-th new order
+  uint16_t* ev2slot = wk + 2u * S;  // bytes [4S, 6S): pool slot of the new order at an event position
+  uint32_t* W0 = reinterpret_cast<uint32_t*>(wk + 4u * S);  // bytes [8S, 12S): first cancellation after arrival << 16 | arrival position + 1
+  uint32_t* W1 = reinterpret_cast<uint32_t*>(wk);           // bytes [0, 4S), once the lists above are consumed: last passive trade's position + 1
+  uint32_t* W2 = reinterpret_cast<uint32_t*>(wk + 2u * S);  // bytes [4S, 8S): a new order's volume minus what it took as the aggressor
   // ---- the events in shuffled order, one per lane
   uint32_t eww[R], eid[R], evq[R];
   uint64_t is_new[R], is_can[R], is_mod[R];
@@ -154,10 +157,11 @@ __device__ __forceinline__ bool step_events_keyed(Book<R>& B, const DevArgs& a, 
 #pragma unroll
   for (int r = 0; r < R; ++r) bad |= lane_bit(B.live[r]) && B.vol[r] == 0u;
   if (__ballot(bad)) return false;
-  if constexpr (MKT) {  // (this book's events: every one of them is a New or a Cancellation here)
-    n_own = 0;
+  uint32_t own_cnt = n_ev;
+  if constexpr (MKT) {  // (this book's events: News, Cancellations and Modifications of its asset)
+    own_cnt = 0;
 #pragma unroll
-    for (int re = 0; re < R; ++re) n_own += (uint32_t)__builtin_popcountll(is_new[re] | is_can[re] | is_mod[re]);
+    for (int re = 0; re < R; ++re) own_cnt += (uint32_t)__builtin_popcountll(is_new[re] | is_can[re] | is_mod[re]);
   }
   // ---- slots for the new orders
   uint32_t n_new = 0;
@@ -371,6 +375,7 @@ __device__ __forceinline__ bool step_events_keyed(Book<R>& B, const DevArgs& a, 
   keys_end<R>(B, K);
 #pragma unroll
   for (int r = 0; r < R; ++r) B.pend[r] = 0;
+  n_own += own_cnt;
   if (!lg.base) return true;
   // ---- the order log, one pool lane per order touched in this step
   wave_sync();
@@ -441,11 +446,14 @@ constexpr uint32_t ev_lds_bytes(int R) {
   const uint32_t S = 64u * (uint32_t)R, sh = 6u * S + WV_RING * 4u, ky = ev_keyed_lds_bytes(R);
   return sh > ky ? sh : ky;
 }
-template <int R, bool MKT = false>
+template <int R, bool MKT = false, bool CHUNKS = false>
 // (MKT: launched for the books of markets with more than one asset, bk_config.assets > 1 - only the keyed form differs)
+// (CHUNKS: launched when a queue of this step is longer than the pool - the keyed form then runs chunk by chunk, in a loop
+// around its one call site; as a run-time loop in the ONE kernel it cost the ordinary launch 2 %: 32 B more scratch at R = 4)
 // (eight waves per SIMD for pools of <= 256 slots, five for 512: 8 192 books - the C4 shard, the ingress rate scripts - are then ONE residency round;
 // at the 69 VGPRs the compiler took for R = 4 a seventh of the waves ran as a second round)
-__global__ __launch_bounds__(64, BOURSE_AMD_EV_OCC(R)) void k_step_events(DevArgs a, WaveArgs wa, uint64_t step_index, uint32_t wave_shuffle_min) {
+__global__ __launch_bounds__(64, BOURSE_AMD_EV_OCC(R)) void k_step_events(DevArgs a, WaveArgs wa, uint64_t step_index, uint32_t wave_shuffle_min,
+                                                                          uint32_t lds_bytes /* the launch's dynamic LDS */) {
   __shared__ uint32_t bins[LDS_DW_PER_WAVE];
   // the shuffle permutation: dynamic LDS sized by the host to this step's longest queue (<= EV_LDS_CAP entries), so
   // that quiet steps do not pay 16 KB of LDS per one-wave workgroup in occupancy
@@ -538,11 +546,34 @@ __global__ __launch_bounds__(64, BOURSE_AMD_EV_OCC(R)) void k_step_events(DevArg
   // (the keyed form first: see step_events_keyed; the event-by-event loop below is the general case)
   // (the keyed form runs on the assembly loops only: a -DBOURSE_AMD_ASM_EVENTS=0 / -DBOURSE_AMD_ASM_R48=0 build steps event by event)
   constexpr bool has_asm = BOURSE_AMD_ASM_EVENTS && (R <= 2 || BOURSE_AMD_ASM_R48);
-  const bool keyed = BOURSE_AMD_EV_KEYED && has_asm && !(BOURSE_AMD_EV_SKIP & ~1) && (MKT || a.assets == 1u) && B.trading && n_ev != 0u && n_ev <= 64u * R &&
-                     step_events_keyed<R, MKT>(B, a, book, t0, lane, n_ev, e0, perm, lg, asset, n_own);
-  if (MKT ? !keyed : keyed) n_own = MKT ? 0u : n_ev;  // (MKT: the keyed form counted them, unless it gave up half-way)
+  // A queue of more than one event per pool slot (round 6) runs the keyed form CHUNK by chunk: 64 R events at a time, each
+  // chunk with its own slot assignment and key window - an order placed by one chunk rests (or is gone) for the next, the time
+  // stamps carry the chunk's first position - when the launch's LDS holds the work area behind the permutation (`lds_bytes`,
+  // sized by the host to the longest queue).  A chunk that is not of the keyed form hands the REST of the step to the loop below.
+  constexpr uint32_t S_ = 64u * R;
+  bool keyed = false;
+  uint32_t done = 0;  // events already processed (whole chunks)
+  const bool one_chunk = n_ev <= S_;
+  if (BOURSE_AMD_EV_KEYED && has_asm && !(BOURSE_AMD_EV_SKIP & ~1) && (MKT || a.assets == 1u) && B.trading && n_ev != 0u &&
+      (one_chunk || (CHUNKS && 2u * ((n_ev + 63u) & ~63u) + ev_keyed_lds_bytes(R) <= lds_bytes))) {
+    if constexpr (!CHUNKS) {
+      keyed = step_events_keyed<R, MKT>(B, a, book, t0, lane, n_ev, e0, perm, perm, lg, asset, n_own);
+      done = keyed ? n_ev : 0u;
+    } else {
+      uint16_t* wk = one_chunk ? perm : perm + ((n_ev + 63u) & ~63u);  // (one chunk: the work area takes the permutation's bytes over)
+      keyed = true;
+      while (done < n_ev) {
+        const uint32_t len = n_ev - done < S_ ? n_ev - done : S_;
+        if (!step_events_keyed<R, MKT>(B, a, book, t0 + done, lane, len, e0, perm + done, wk, lg, asset, n_own)) {
+          keyed = false;
+          break;
+        }
+        done += len;
+      }
+    }
+  }
   uint4 evr = make_uint4(0u, 0u, 0u, 0u);
-  for (uint32_t k = 0; k < (keyed ? 0u : n_ev); ++k) {
+  for (uint32_t k = done; k < n_ev; ++k) {
     // the 16-byte records of 64 shuffled positions are fetched at once, one per lane (one memory round trip per 64
     // events instead of one per event), then broadcast one by one
     if ((k & 63u) == 0u && k + lane < n_ev) evr = a.ev[e0 + perm[k + lane]];

@@ -61,7 +61,7 @@ def _drive(bk, oracle, pool, n_max, B, T, seed, p_market, p_mod, p_zero, tick=1,
                     assert env.place_order(b, bid, vol, trader, price) == made[b] == refs[b].place_order(bid, vol, trader, price)
                     made[b] += 1
                     ok, n_ev = ok and vol != 0, n_ev + 1
-            busy[s, b], clean[s, b] = n_ev > 0, ok and 0 < n_ev <= pool
+            busy[s, b], clean[s, b] = n_ev > 0, ok and 0 < n_ev  # (round 6: a queue longer than the pool runs keyed chunk by chunk)
         env.step()
         for r in refs:
             r.step()
@@ -105,7 +105,7 @@ def test_mixed_streams_alternate_between_the_keyed_and_the_event_by_event_loop(b
     keyed = env.event_steps_keyed()
     # every keyed step was a step the keyed form may take; and it took (nearly) all of those - what the calls cannot tell is
     # a pool without a spare slot, a resting order of volume 0 and the key window
-    assert np.all(keyed <= clean.sum(axis=0)), "a step with a volume of 0 / too many events ran keyed"
+    assert np.all(keyed <= clean.sum(axis=0)), "a step with a volume of 0 ran keyed"
     assert keyed.sum() >= 0.85 * clean.sum(), (int(keyed.sum()), int(clean.sum()))
     assert 0.25 * busy.sum() < clean.sum() < busy.sum(), "the stream should mix both kinds of step"
     assert sum(len(r.book.trades_array()) for r in refs) > 20 * B
@@ -137,7 +137,7 @@ def test_steps_outside_the_keyed_form_fall_back_and_the_books_go_on(bk, oracle):
         # (the order of volume 0 rests - orderbook.rs:430 never enters the match loop with it - and while it does, steps stay
         # on the event-by-event loop; whether step 2 finds it still there depends on the shuffle)
         "zero volume": ([_std(), _std(1) + [("place_order", True, 0, 3, 100)], _std(2)], {1, 2}),
-        "more events than slots": ([_std(), [("cancel_order", 0)] * 70 + _std(1, 2), _std(2)], {2}),
+        "more events than slots": ([_std(), [("cancel_order", 0)] * 70 + _std(1, 2), _std(2)], {3}),  # (round 6: two chunks)
         "no spare slot": ([apart, [("place_order", True, 5, 1, 20), ("place_order", False, 5, 1, 200)], [("cancel_order", 5), ("cancel_order", 63)]], {1}),  # (step 2 too: 64 live orders leave no spare slot)
         # a bid 39 900 ticks above the asks (the window spans 32 762) and an ask far below the bids: both fill on arrival
         "price window": ([_std(), _std(1) + [("place_order", True, 1, 3, 40_000), ("place_order", False, 1, 3, 1)], _std(2)], {1, 2}),
@@ -292,4 +292,50 @@ def test_streams_with_many_modifications_and_market_orders_run_keyed(bk, oracle,
     keyed = env.event_steps_keyed()
     assert np.all(keyed <= busy.sum(axis=0)) and keyed.sum() >= 0.97 * busy.sum(), (int(keyed.sum()), int(busy.sum()))
     assert sum(len(r.book.trades_array()) for r in refs) > 10 * B
+    env.close()
+
+
+@pytest.mark.parametrize("pool,n_lo,n_hi", [(64, 70, 200), (128, 130, 420), (256, 300, 700)])
+def test_queues_longer_than_the_pool_run_keyed_chunk_by_chunk(bk, oracle, pool, n_lo, n_hi):
+    """More events in a step than the pool has slots (round 6): 64 R events at a time on the keyed loop, an order placed by one
+    chunk resting (or gone) for the next, trade and log time stamps continuing across the chunks - against the oracle, with
+    cancellations and modifications of ids of the same step (after the shuffle: in an earlier, the same or a later chunk)."""
+    B, T = 96, 4
+    env = bk.ManyBookEnv(B, 4242, 0, 1, 100_000, levels=10, max_live_orders=pool, max_orders=T * n_hi + 8, trade_capacity=4 * T * n_hi,
+                         history_capacity=T, strict=False)
+    refs = [oracle.StepEnv(4242 + b, 0, 1, 100_000) for b in range(B)]
+    rng = np.random.default_rng(pool)
+    made = np.zeros(B, dtype=np.int64)
+    n_events = np.zeros((T, B), dtype=np.int64)
+    for s in range(T):
+        for b in range(B):
+            n = int(rng.integers(n_lo, n_hi))
+            for u in rng.random(n):
+                if u < 0.40 and made[b] > 0:
+                    oid = int(made[b] - 1 - rng.integers(0, min(made[b], 60)))  # mostly ids placed earlier in THIS step's calls
+                    if u < 0.32:
+                        env.cancel_order(b, oid)
+                        refs[b].cancel_order(oid)
+                    else:
+                        new_p = int(rng.integers(96, 105)) if rng.random() < 0.5 else None
+                        new_v = int(rng.integers(1, 9)) if (new_p is None or rng.random() < 0.5) else None
+                        env.modify_order(b, oid, new_p, new_v)
+                        refs[b].modify_order(oid, new_p, new_v)
+                else:
+                    # (tight around 100 so that most orders trade away or get cancelled: the pool must not fill up)
+                    bid, vol = bool(rng.integers(0, 2)), int(rng.integers(1, 9))
+                    price = None if rng.random() < 0.02 else int(rng.integers(98, 103))
+                    assert env.place_order(b, bid, vol, 3, price) == made[b] == refs[b].place_order(bid, vol, 3, price)
+                    made[b] += 1
+                n_events[s, b] += 1
+        env.step()
+        for r in refs:
+            r.step()
+    _same_as_oracle(env, refs, allow_flags=True)
+    flags = env.flags()
+    assert (flags == 0).sum() >= 0.7 * B, "most books should get through without a pool overflow"
+    keyed = env.event_steps_keyed()
+    assert n_events.min() > pool
+    # a chunk without a spare pool slot (or outside the key window) hands the rest of its step to the event-by-event loop
+    assert keyed[flags == 0].sum() >= 0.6 * T * int((flags == 0).sum()), (int(keyed.sum()), T * B)
     env.close()
