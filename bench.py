@@ -214,10 +214,11 @@ def bench_ingress(args, torch):
     traffic = traffic_src = None  # (PMC passes of this command, committed and replayed: as for the agent workloads)
     try:
         allp = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-        rec = allp.get(f"INGRESS/{B}", {}).get("k_step_events", {})
+        pkey = f"INGRESS{'MIX' if (f_mod, f_mkt) == (0.05, 0.02) else ''}/{B}"  # (the mixed stream's record is of THESE fractions)
+        rec = allp.get(pkey, {}).get("k_step_events", {}) if (f_mod, f_mkt) in ((0.0, 0.0), (0.05, 0.02)) else {}
         if "hbm_bytes_per_book_step" in rec:
             traffic = rec["hbm_bytes_per_book_step"] * B
-            traffic_src = f"profiles/pmc_traffic.json[INGRESS/{B}]: {allp.get('_source', '')}; replayed, not measured in this run"
+            traffic_src = f"profiles/pmc_traffic.json[{pkey}]: {allp.get('_source', '')}; replayed, not measured in this run"
     except Exception:  # noqa: BLE001
         pass
     line = {

@@ -1443,6 +1443,9 @@ __global__ __launch_bounds__(256) void k_run_random(DevArgs a, uint64_t first_st
 // ==================================================================================
 enum Phase : uint32_t { PH_ACT = 0, PH_SIDE = 1, PH_TICK = 2, PH_VOL = 3, PH_SHUF = 4, PH_DONE = 5 };
 
+#ifndef BOURSE_AMD_FSM_FREERUN
+#define BOURSE_AMD_FSM_FREERUN 0
+#endif
 #ifndef BOURSE_AMD_FSM_TOP_VGPR
 #define BOURSE_AMD_FSM_TOP_VGPR 231  // highest VGPR k_agents_fsm claims (0 = only what it uses); see the kernel's prologue
 #endif
@@ -1534,7 +1537,13 @@ __global__ __launch_bounds__(64) void k_agents_fsm(DevArgs a) {
     // at hand is one register pair per segment, not a per-draw select over the pool's registers (lanes re-converge at
     // a segment's end as they do at a group's; the benchmark groups are 64-aligned: no extra boundary there).
     for (uint32_t sbeg = gend - G.n; sbeg < gend;) {
+#if BOURSE_AMD_FSM_FREERUN
+      // MEASUREMENT BUILD (docs/EXPERIMENTS.md): no re-convergence at the 64-slot segment boundary inside a
+      // group - the live word is selected per lane from the lane's own agent index (2 (R - 1) more vector instructions per draw)
+      const uint32_t send = gend;
+#else
       const uint32_t send = gend < (sbeg | 63u) + 1u ? gend : (sbeg | 63u) + 1u;
+#endif
       uint64_t w = live[0];
 #pragma unroll
       for (int r = 1; r < R; ++r) w = ((sbeg >> 6) == (uint32_t)r) ? live[r] : w;
@@ -1554,7 +1563,14 @@ __global__ __launch_bounds__(64) void k_agents_fsm(DevArgs a) {
         // gen::<f32>() < activity_rate (:91-93): (x >> 8) < thr as ONE 64-bit compare x < thr << 8 (thr <= 2^24)
         uint64_t C_HIT = __builtin_amdgcn_ballot_w64((uint64_t)x < thr8);
         uint64_t C_ACC = __builtin_amdgcn_ballot_w64((uint32_t)m <= zone);
+#if BOURSE_AMD_FSM_FREERUN
+        uint64_t wl = live[0];
+#pragma unroll
+        for (int r = 1; r < R; ++r) wl = ((n >> 6) == (uint32_t)r) ? live[r] : wl;
+        uint64_t C_LIVE = __builtin_amdgcn_ballot_w64(((wl >> (n & 63)) & 1ull) != 0);
+#else
         uint64_t C_LIVE = __builtin_amdgcn_ballot_w64(((w >> (n & 63)) & 1ull) != 0);  // Active order held (:95-97)
+#endif
         asm volatile("" : "+v"(rng.a0), "+v"(rng.a1), "+v"(rng.b0), "+v"(rng.b1)
                      : "s"(P_ACT), "s"(P_SIDE), "s"(P_TICK), "s"(P_VOL), "s"(C_HIT), "s"(C_ACC), "s"(C_LIVE));
         rng.advance();

@@ -18,8 +18,11 @@ PA_AGENTS=$PA
 for C in $CONFIGS; do
   W=${C%%:*}; B=${C##*:}
   # (the external-agents stream fills the pools: at most 33 steps, bench.py bench_ingress)
+  WL=$W
   if [ $W = INGRESS ]; then PA="--steps 24 --warmup 6 --no-cpu-baseline --preheat-steps 0"; else PA=$PA_AGENTS; fi
-  run() { d=$1; shift; rocprofv3 --pmc "$@" -d $OUT/${W}_${B}_$d -o p -f csv -- python3 $R/bench.py --workload $W --books $B $PA > $OUT/${W}_${B}_$d.json 2> $OUT/${W}_${B}_$d.err
+  # INGRESSMIX: the external-agents stream with modifications and market orders (round 6; bench.py keys its PMC record the same way)
+  if [ $W = INGRESSMIX ]; then WL=INGRESS; PA="--steps 24 --warmup 6 --no-cpu-baseline --preheat-steps 0 --modify-frac 0.05 --market-frac 0.02"; fi
+  run() { d=$1; shift; rocprofv3 --pmc "$@" -d $OUT/${W}_${B}_$d -o p -f csv -- python3 $R/bench.py --workload $WL --books $B $PA > $OUT/${W}_${B}_$d.json 2> $OUT/${W}_${B}_$d.err
           # a pass whose bench died (round 4: a NameError AFTER the timed region, stdout empty) must not pass silently
           grep -q '^{' $OUT/${W}_${B}_$d.json || { echo "pmc_all: $W:$B pass '$d' printed no bench line" >&2; grep -v "^W2\|rocprofiler" $OUT/${W}_${B}_$d.err | tail -n 8 >&2; FAILED="$FAILED ${W}_${B}_$d"; }; }
   run fetch FETCH_SIZE
