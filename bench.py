@@ -174,13 +174,15 @@ def bench_ingress(args, torch):
     env = new_env()
     run(env, 0, W)
     torch.cuda.synchronize()
+    keyed0 = float(env.event_steps_keyed().sum())  # (the keyed fraction is the TIMED region's: on 512-slot pools the library switches
+    torch.cuda.synchronize()                       # to the kernel with the keyed modifications a step or more after the first one)
     t0 = time.perf_counter()
     run(env, W, T)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if int(status[:, 0].max()) != 0 or env.flags().any():
         raise SystemExit(f"INGRESS: status / capacity flags set ({np.unique(env.flags())}): the rate would be of a run that dropped orders")
-    keyed = float(env.event_steps_keyed().sum()) / (B * T)
+    keyed = (float(env.event_steps_keyed().sum()) - keyed0) / (B * K)
     tr_total = int(env.trade_counts().sum())
     env.close()
     # kernel times: the last steps of the same stream on a fresh env, every launch between two events on the env's stream

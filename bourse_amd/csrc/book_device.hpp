@@ -1840,6 +1840,8 @@ struct IngestArgs {
   uint32_t* qlen;                 // [n_markets]
   uint32_t qcap;
   uint4* dorders;                 // [n_books][log_cap][2]: {start_vol, trader, price, bid} {create_lo, create_hi, 0, 0}
+  uint32_t* mods_flag;            // nullable: a word in mapped HOST memory, set to 1 when a BK_ACTION_MODIFY element is seen (a hint
+                                  // for the host's choice of k_step_events instantiation: sticky, may lag by a step)
 };
 constexpr uint32_t ING_ACTION_MODIFY = 0x80000003u;  // == BK_ACTION_MODIFY (include/bourse_amd.h)
 constexpr uint32_t ING_OK = 0u, ING_PRICE = 1u, ING_CAPACITY = 3u;  // == BK_OK / BK_PRICE_NOT_TICK_MULTIPLE / BK_CAPACITY
@@ -1865,6 +1867,7 @@ __global__ __launch_bounds__(64) void k_ingest(DevArgs a, IngestArgs g) {
       const uint32_t price = in ? g.price[i] : 0u, trader = in ? g.trader[i] : 0u;
       const unsigned long long oid = in ? g.order_id[i] : 0ull;
       const bool is_new = act == 1u, is_ev = act == 1u || act == 2u || act == ING_ACTION_MODIFY;
+      if (g.mods_flag && __ballot(in && act == ING_ACTION_MODIFY) && lane == 0) *g.mods_flag = 1u;
       // the first bad price of the chunk stops the book's batch (earlier elements are applied)
       const uint64_t badm = __ballot(is_new && price % tick != 0u);
       uint32_t cut = badm ? (uint32_t)__builtin_ctzll(badm) : 64u;

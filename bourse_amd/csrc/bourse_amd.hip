@@ -315,6 +315,9 @@ struct bk_env {
       bytes = (o_side + c + 63) & ~size_t(63);
     }
   } hi;
+  std::atomic<bool> ev_mods_seen{false};  // a modification was submitted to this env (sticky): k_step_events<.., MODS = true> from then on
+  uint32_t* mods_flag_host = nullptr;     // device ingress: k_ingest's hint word in mapped host memory, and its device address
+  uint32_t* mods_flag_dev = nullptr;
   bool device_flow = false;   // bk_run has stepped this env with on-device agents: host-driven orders are refused
   uint64_t steps_done = 0, hist_base = 0;
   uint32_t trading = 1;
@@ -469,6 +472,20 @@ int launch_events(bk_env* env, const DevArgs& a, uint64_t step_index, uint32_t m
     if (int rc = wave_args(env, &wva)) return rc;
   const bool chunks = max_queue > 64u * R;  // a queue longer than the pool: the instantiation whose keyed form runs chunk by chunk
   const dim3 grid(env->cfg.n_books), block(64);
+  // 512-slot pools: the kernel WITH the keyed modifications only once this env has seen one (step_events.hpp k_step_events: the
+  // clean launch is 13 % faster without that code).  Sticky; k_ingest's hint may lag by a step - that step's modifications then
+  // run event by event, with the same results.
+  if (env->mods_flag_host && *static_cast<volatile uint32_t*>(env->mods_flag_host)) env->ev_mods_seen.store(true, std::memory_order_relaxed);
+  if constexpr (R == 8) {
+    if (!chunks && !env->ev_mods_seen.load(std::memory_order_relaxed)) {
+      if (env->M == 1)
+        hipLaunchKernelGGL((k_step_events<R, false, false, false>), grid, block, perm_bytes, env->stream, a, wva, step_index, shuffle_min, perm_bytes);
+      else
+        hipLaunchKernelGGL((k_step_events<R, true, false, false>), grid, block, perm_bytes, env->stream, a, wva, step_index, shuffle_min, perm_bytes);
+      HIPCHK(hipGetLastError());
+      return BK_OK;
+    }
+  }
   if (env->M == 1 && !chunks)
     hipLaunchKernelGGL((k_step_events<R, false, false>), grid, block, perm_bytes, env->stream, a, wva, step_index, shuffle_min, perm_bytes);
   else if (env->M == 1)
@@ -997,6 +1014,7 @@ void bk_env_destroy(bk_env* env) {
   if (env->off_stage) (void)hipHostFree(env->off_stage);
   if (env->hi.in) (void)hipStreamSynchronize(env->hi.in);
   if (env->hi.out) (void)hipStreamSynchronize(env->hi.out);
+  if (env->mods_flag_host) (void)hipHostFree(env->mods_flag_host);
   for (auto& r : env->hi.retired) (void)hipHostFree(r.pin);
   env->hi.retired.clear();
   for (int i = 0; i < bk_env::HostIngress::SLOTS; ++i) {
@@ -1066,6 +1084,7 @@ int bk_modify_order(bk_env* env, uint32_t book, uint64_t order_id, int has_price
   if (int rc = host_flow_ok(env)) return rc;
   const uint32_t asset = book % env->M;
   const uint32_t w = 2u | (has_price ? 1u << 9 : 0u) | (has_vol ? 1u << 10 : 0u) | (asset << 16);
+  env->ev_mods_seen.store(true, std::memory_order_relaxed);  // (launch_events: the k_step_events form with the keyed modifications)
   env->books[book - asset].queue.push_back(
       HostEvent{w, static_cast<uint32_t>(std::min<uint64_t>(order_id, 0xFFFFFFFFull)), new_price, new_vol});
   return BK_OK;
@@ -1267,6 +1286,22 @@ int bk_device_ingress_enable(bk_env* env, uint32_t queue_capacity) {
   HIPCHK(env->dqlen.alloc(NM));
   HIPCHK(hipMemsetAsync(env->dqlen.p, 0, NM * 4, env->stream));
   HIPCHK(env->dorders.alloc(static_cast<size_t>(env->cfg.n_books) * env->cfg.max_orders * 2));
+  // k_ingest's "a modification was submitted" hint: one word of mapped host memory (launch_events reads it without a copy)
+  if (!env->mods_flag_host) {
+    void* hp = nullptr;
+    if (hipHostMalloc(&hp, 64, hipHostMallocMapped) == hipSuccess) {
+      *static_cast<uint32_t*>(hp) = 0u;
+      void* dp = nullptr;
+      if (hipHostGetDevicePointer(&dp, hp, 0) == hipSuccess) {
+        env->mods_flag_host = static_cast<uint32_t*>(hp);
+        env->mods_flag_dev = static_cast<uint32_t*>(dp);
+      } else {
+        (void)hipHostFree(hp);
+      }
+    }
+    (void)hipGetLastError();
+    if (!env->mods_flag_host) env->ev_mods_seen.store(true);  // (no hint available: always the full kernel)
+  }
   env->qcap = queue_capacity;
   env->device_ingress = true;
   return BK_OK;
@@ -1294,6 +1329,7 @@ int bk_submit_instructions_device(bk_env* env, const uint64_t* book_offsets_dev,
   g.qlen = env->dqlen.p;
   g.qcap = env->qcap;
   g.dorders = env->dorders.p;
+  g.mods_flag = env->mods_flag_dev;
   const DevArgs a = env->args();
   hipLaunchKernelGGL(k_ingest, dim3(env->cfg.n_books / env->M), dim3(64), 0, env->stream, a, g);
   HIPCHK(hipGetLastError());

@@ -93,13 +93,18 @@ __device__ __forceinline__ void insert_order(Book<R>& B, int lane, uint32_t n, u
 #ifndef BOURSE_AMD_EV_KEYED
 #define BOURSE_AMD_EV_KEYED 1
 #endif
+// measurement build (profiles/r06/ab_ev_mods.txt): 0 = round 5's rule - a step with a modification, or with a market order on a
+// pool of <= 128 slots, is not of the keyed form
+#ifndef BOURSE_AMD_EV_KEYED_MODS
+#define BOURSE_AMD_EV_KEYED_MODS 1
+#endif
 constexpr uint32_t ev_keyed_lds_bytes(int R) { return 12u * 64u * (uint32_t)R; }
 // MKT (the kernel's): the book belongs to a market of several assets (MarketEnv, market_env.rs:110-121).  The market's queue
 // holds every asset's events at their global positions; the other assets' stay in this book's list as events that do nothing,
 // so that the positions - the time stamps - are the market's; n_own = this book's events.  (A template parameter, and the
 // single-asset text left exactly as it was: the run-time form cost the single-asset kernel 1.5 %, a first templated form that
 // simplified its expressions 4 % - the register allocation of this kernel sits on an edge: profiles/r05/ab_ev_markets*.txt.)
-template <int R, bool MKT>
+template <int R, bool MKT, bool MODS = true>
 // perm: the shuffled positions of THESE n_ev events (a whole step's, or one chunk of a longer queue's: then t0 is the chunk's
 // first time stamp); wk: 12 x 64 R bytes of work area - the same bytes as perm for a whole step (the permutation is consumed
 // on the way), behind the permutation for a chunked one (the later chunks still need theirs).  n_own is ADDED to.
@@ -114,7 +119,11 @@ __device__ __forceinline__ bool step_events_keyed(Book<R>& B, const DevArgs& a, 
   uint32_t* W2 = reinterpret_cast<uint32_t*>(wk + 2u * S);  // bytes [4S, 8S): a new order's volume minus what it took as the aggressor
   // ---- the events in shuffled order, one per lane
   uint32_t eww[R], eid[R], evq[R];
-  uint64_t is_new[R], is_can[R], is_mod[R];
+  // (a modification is known by its KIND in its lane of eww - 0xFF in lanes past the queue's end and in other assets' lanes -
+  // not by a third set of wave masks: at 512 slots the kernel is over its scalar registers as it is, and the spilled masks of a
+  // first version took 65 536 books x 48 clean instructions from 0.52 to 0.60 ms per launch)
+  uint64_t is_new[R], is_can[R];
+  uint64_t any_mod = 0;
   bool bad = false;
   uint32_t xmin = 0xFFFFFFFFu, xmax = 0u;  // the modifications' new prices: part of the key window
 #pragma unroll
@@ -123,8 +132,9 @@ __device__ __forceinline__ bool step_events_keyed(Book<R>& B, const DevArgs& a, 
     // one uniform branch each; at 512 slots the branches take the kernel from 8 to 60 B of scratch at its 96 registers and
     // cost 9 %, same box: profiles/r05/device_ingress_rate_guards.txt)
     if constexpr (R <= 4) {
-      is_new[re] = is_can[re] = is_mod[re] = 0ull;
-      eww[re] = eid[re] = evq[re] = 0u;
+      is_new[re] = is_can[re] = 0ull;
+      eww[re] = 0xFFu;
+      eid[re] = evq[re] = 0u;
       if (n_ev <= (uint32_t)re * 64u) continue;
     }
     const uint32_t pos = (uint32_t)(re * 64 + lane);
@@ -136,17 +146,18 @@ __device__ __forceinline__ bool step_events_keyed(Book<R>& B, const DevArgs& a, 
       const bool own = valid && ((rec.x >> 16) & 0xFFu) == asset;
       is_new[re] = __ballot(own && kind == 0u);
       is_can[re] = __ballot(own && kind == 1u);
-      is_mod[re] = __ballot(own && kind == 2u);
+      any_mod |= __ballot(own && kind == 2u);
+      rec.x = own ? rec.x : 0xFFu;
       bad |= own && (kind > 2u || (kind == 0u && rec.w == 0u) || (kind == 2u && (rec.x & 0x400u) && rec.w == 0u) ||
                      (a.ev_len && kind != 0u && rec.y >= B.next_id));
     } else {
       is_new[re] = __ballot(valid && kind == 0u);
       is_can[re] = __ballot(valid && kind == 1u);
-      is_mod[re] = __ballot(valid && kind == 2u);
+      any_mod |= __ballot(valid && kind == 2u);
       bad |= valid && (kind > 2u || ((rec.x >> 16) & 0xFFu) != 0u || (kind == 0u && rec.w == 0u) ||
                        (kind == 2u && (rec.x & 0x400u) && rec.w == 0u) || (a.ev_len && kind != 0u && rec.y >= B.next_id));
     }
-    if (lane_bit(is_mod[re]) && (rec.x & 0x200u)) {  // (a modification to volume 0 leaves an Active order of volume 0: not this path)
+    if ((rec.x & 0x2FFu) == 0x202u) {  // a modification that carries a price (kind 2, has-price bit)
       xmin = min(xmin, rec.z);
       xmax = max(xmax, rec.z);
     }
@@ -157,11 +168,17 @@ __device__ __forceinline__ bool step_events_keyed(Book<R>& B, const DevArgs& a, 
 #pragma unroll
   for (int r = 0; r < R; ++r) bad |= lane_bit(B.live[r]) && B.vol[r] == 0u;
   if (__ballot(bad)) return false;
+  if constexpr (!MODS) {  // (this instantiation leaves modifications to the event-by-event loop: see k_step_events)
+    if (any_mod) return false;
+    any_mod = 0;
+    xmin = 0xFFFFFFFFu;
+    xmax = 0u;
+  }
   uint32_t own_cnt = n_ev;
   if constexpr (MKT) {  // (this book's events: News, Cancellations and Modifications of its asset)
     own_cnt = 0;
 #pragma unroll
-    for (int re = 0; re < R; ++re) own_cnt += (uint32_t)__builtin_popcountll(is_new[re] | is_can[re] | is_mod[re]);
+    for (int re = 0; re < R; ++re) own_cnt += (uint32_t)__builtin_popcountll(__ballot((eww[re] & 0xFFu) <= 2u));
   }
   // ---- slots for the new orders
   uint32_t n_new = 0;
@@ -201,13 +218,12 @@ __device__ __forceinline__ bool step_events_keyed(Book<R>& B, const DevArgs& a, 
     nf += __builtin_popcountll(freem);
   }
   if (s_nop == 0xFFFFFFFFu) return false;  // fewer than n_new + 1 free slots
-  (void)mkt;  // (round 6: the small pools' hand-written loops have their `m` forms too - event_asm.hpp events_key_r1m / _r2m)
+  // (round 6: the small pools' hand-written loops have their `m` forms too - event_asm.hpp events_key_r1m / _r2m)
+  if (!BOURSE_AMD_EV_KEYED_MODS && R <= 2 && mkt) return false;
   wave_sync();
   // ---- the cancellations' and the modifications' slots: one id search each, among the orders live now and this step's new ones
   uint32_t evs[R];
-  uint64_t any_mod = 0;
-#pragma unroll
-  for (int re = 0; re < R; ++re) any_mod |= is_mod[re];
+  if (!BOURSE_AMD_EV_KEYED_MODS && any_mod) return false;
 #pragma unroll
   for (int re = 0; re < R; ++re) {
     if constexpr (R <= 4) {
@@ -215,7 +231,8 @@ __device__ __forceinline__ bool step_events_keyed(Book<R>& B, const DevArgs& a, 
       if (n_ev <= (uint32_t)re * 64u) continue;
     }
     uint32_t cs = s_nop;
-    uint64_t m = is_can[re] | is_mod[re];
+    const bool ismod = (eww[re] & 0xFFu) == 2u;
+    uint64_t m = is_can[re] | (any_mod ? __ballot(ismod) : 0ull);
     while (m) {
       const uint32_t l = (uint32_t)__builtin_ctzll(m);
       m &= m - 1ull;
@@ -237,8 +254,8 @@ __device__ __forceinline__ bool step_events_keyed(Book<R>& B, const DevArgs& a, 
     // a modification keeps {slot, EV_MOD, has-price, has-volume} in its event word, its new volume in evq, and - once the key
     // window is known, below - its new price's FIELD in the word's upper half; the price itself is read again from the
     // record here (the permutation is still intact; the id in eid is not needed any more)
-    if (is_mod[re]) {
-      if (lane_bit(is_mod[re])) {
+    if (any_mod) {
+      if (ismod) {
         eid[re] = a.ev[e0 + perm[pos]].z;
         evs[re] = cs | EV_MOD | (eww[re] & (EV_MOD_P | EV_MOD_V));
       }
@@ -252,7 +269,7 @@ __device__ __forceinline__ bool step_events_keyed(Book<R>& B, const DevArgs& a, 
   if (any_mod) {
 #pragma unroll
     for (int re = 0; re < R; ++re)
-      if (lane_bit(is_mod[re])) evw[re] = (evw[re] & 0xFFFFu) | ((eid[re] - K.pbase) << 16);
+      if (evw[re] & EV_MOD) evw[re] = (evw[re] & 0xFFFFu) | ((eid[re] - K.pbase) << 16);
   }
   wave_sync();
 #pragma unroll
@@ -265,9 +282,12 @@ __device__ __forceinline__ bool step_events_keyed(Book<R>& B, const DevArgs& a, 
   // the list is cut at the modifications: [k, kend) runs on the assembly loop, a modification is handled between two statements
   uint32_t k = 0, kend = any_mod ? 0u : nev;
   uint32_t post = 0xFFFFFFFFu, post_p = 0;  // the slot (and its old price) of the replacement whose New event the last range was
-  uint64_t modm[R], repl[R];                // pool slots a modification changed / replaced in this step
-#pragma unroll
-  for (int r = 0; r < R; ++r) modm[r] = repl[r] = 0ull;
+  // pool slots a modification changed / replaced in this step: ONE vector register - bit r of a lane's word = slot (r, lane)
+  // changed, bit 8 + r = replaced (not 2 R wave masks: scalar registers are what this kernel is short of)
+  uint32_t mflags = 0;
+  auto mflag_set = [&](uint32_t sl, uint32_t base) {
+    mflags = (uint32_t)lane == (sl & 63u) ? (mflags | (1u << (base + (sl >> 6)))) : mflags;
+  };
   auto scatter_and_flush = [&]() {
     if (B.tr_n) {
       B.trade_vol += wave_add((uint32_t)lane < B.tr_n ? B.tr_vol : 0u);
@@ -282,6 +302,34 @@ __device__ __forceinline__ bool step_events_keyed(Book<R>& B, const DevArgs& a, 
     }
     flush_trades_compact<R>(B, a, book, t0, lane, evw);
   };
+  if constexpr (!MODS) {  // no modification reaches this instantiation: round 5's plain loop (statement, flush, again)
+    for (;;) {
+      uint32_t full;
+      if constexpr (R == 1)
+        full = events_key_r1m(0u, k, nev, 0xFFFFFFFFu, B.tr_n, K.sq, B.vol[0], K.key[0], evw[0], B.tr_k, B.tr_vol, B.tr_pas);
+      else if constexpr (R == 2)
+        full = events_key_r2m(0u, k, nev, 0xFFFFFFFFu, B.tr_n, K.sq, B.vol[0], B.vol[1], K.key[0], K.key[1], evw[0], evw[1], B.tr_k,
+                              B.tr_vol, B.tr_pas);
+      else if constexpr (R == 4)
+        full = events_key_r4m(0u, k, nev, 0xFFFFFFFFu, B.tr_n, K.sq, B.vol, K.key, evw, evq, B.tr_k, B.tr_vol, B.tr_pas);
+      else
+        full = events_key_r8m(0u, k, nev, 0xFFFFFFFFu, B.tr_n, K.sq, B.vol, K.key, evw, evq, B.tr_k, B.tr_vol, B.tr_pas);
+      // (scatter_and_flush()'s text, in line: through the lambda this instantiation takes 32 B of scratch at 512 slots instead of 8)
+      if (B.tr_n) {
+        B.trade_vol += wave_add((uint32_t)lane < B.tr_n ? B.tr_vol : 0u);
+        if (lg.base && (uint32_t)lane < B.tr_n) {
+          const uint32_t kk = B.tr_k & 0x7FFFFFFFu;
+          atomicMax(&W1[B.tr_pas & (S - 1u)], kk + 1u);
+        }
+        if (lg.base) {
+          const uint32_t as = pool_gather<R>(evw, (B.tr_k & 0x7FFFFFFFu) < S ? (B.tr_k & 0x7FFFFFFFu) : 0u) & EV_SLOT & (S - 1u);
+          if ((uint32_t)lane < B.tr_n) atomicSub(&W2[as], B.tr_vol);
+        }
+      }
+      flush_trades_compact<R>(B, a, book, t0, lane, evw);
+      if (!full) break;
+    }
+  } else {
   for (;;) {
     if (any_mod && k == kend) {
       if (post != 0xFFFFFFFFu) {
@@ -304,7 +352,7 @@ __device__ __forceinline__ bool step_events_keyed(Book<R>& B, const DevArgs& a, 
               e->key_price = e->price;
               e->key_lo = (uint32_t)tk;
               e->key_hi = (uint32_t)(tk >> 32);
-            } else if (arr != 0u && !mask_test<R>(repl, post)) {
+            } else if (arr != 0u && !((rdl(mflags, post & 63u) >> (8u + (post >> 6))) & 1u)) {
               // an order of THIS step keeps the key it rested with on arrival (the rebuild leaves a replaced slot's key alone)
               const uint64_t ta = t0 + (arr - 1u);
               e->key_price = post_p;
@@ -313,7 +361,7 @@ __device__ __forceinline__ bool step_events_keyed(Book<R>& B, const DevArgs& a, 
             }
           }
         }
-        mask_set<R>(repl, post, true);
+        mflag_set(post, 8u);
         wave_sync();
         post = 0xFFFFFFFFu;
       }
@@ -337,7 +385,7 @@ __device__ __forceinline__ bool step_events_keyed(Book<R>& B, const DevArgs& a, 
         kend = k;  // (nothing to run: the boundary code above looks for the next modification)
         if (keyv == 0u || !(has_p || has_v)) continue;  // not Active (or no such order: the spare slot's key is 0) / (None, None)
         const uint32_t cur_v = slot_read<R>(B.vol, sl), cur_p = slot_read<R>(B.price, sl), nv_in = slot_read<R>(evq, k - 1u);
-        mask_set<R>(modm, sl, true);
+        mflag_set(sl, 0u);
         if (!has_p && nv_in < cur_v) {  // reduce_order_vol: in place, priority kept
           slot_write<R>(B.vol, sl, nv_in);
           continue;
@@ -372,6 +420,7 @@ __device__ __forceinline__ bool step_events_keyed(Book<R>& B, const DevArgs& a, 
     scatter_and_flush();
     if (!any_mod && !full) break;
   }
+  }
   keys_end<R>(B, K);
 #pragma unroll
   for (int r = 0; r < R; ++r) B.pend[r] = 0;
@@ -384,8 +433,8 @@ __device__ __forceinline__ bool step_events_keyed(Book<R>& B, const DevArgs& a, 
   for (int r = 0; r < R; ++r) {
     const uint32_t w0 = W0[r * 64 + lane], arr = w0 & 0xFFFFu, c = w0 >> 16, f = W1[r * 64 + lane], rem = W2[r * 64 + lane];
     const bool alive = lane_bit(B.live[r]), was = lane_bit(live0[r]), isnew = arr != 0u, bidl = lane_bit(B.bid[r]);
-    const bool rp = lane_bit(repl[r]);  // replaced in this step: price and key were written at the modification
-    const bool touched = isnew || (was && (f != 0u || !alive)) || lane_bit(modm[r]);
+    const bool rp = (mflags >> (8 + r)) & 1u;  // replaced in this step: price and key were written at the modification
+    const bool touched = isnew || (was && (f != 0u || !alive)) || ((mflags >> r) & 1u);
     const uint32_t id = B.id[r], price = B.price[r];
     const bool market = price == (bidl ? 0xFFFFFFFFu : 0u);
     // a new order that did not come to rest: a market order, or filled on arrival
@@ -446,8 +495,12 @@ constexpr uint32_t ev_lds_bytes(int R) {
   const uint32_t S = 64u * (uint32_t)R, sh = 6u * S + WV_RING * 4u, ky = ev_keyed_lds_bytes(R);
   return sh > ky ? sh : ky;
 }
-template <int R, bool MKT = false, bool CHUNKS = false>
+template <int R, bool MKT = false, bool CHUNKS = false, bool MODS = true>
 // (MKT: launched for the books of markets with more than one asset, bk_config.assets > 1 - only the keyed form differs)
+// (MODS = false: modifications stay on the event-by-event loop - the 512-slot kernel is on the edge of its registers (8 B of
+// scratch per lane without the modification code, ~100 B with either half of it, and 65 536 books x 48 clean instructions went from
+// 0.52 to 0.60 ms per launch), so the host launches the form with it only once the env has SEEN a modification: bk_modify_order, or
+// k_ingest's flag word in mapped host memory - bourse_amd.hip launch_events; smaller pools always run MODS = true)
 // (CHUNKS: launched when a queue of this step is longer than the pool - the keyed form then runs chunk by chunk, in a loop
 // around its one call site; as a run-time loop in the ONE kernel it cost the ordinary launch 2 %: 32 B more scratch at R = 4)
 // (eight waves per SIMD for pools of <= 256 slots, five for 512: 8 192 books - the C4 shard, the ingress rate scripts - are then ONE residency round;
@@ -553,23 +606,21 @@ __global__ __launch_bounds__(64, BOURSE_AMD_EV_OCC(R)) void k_step_events(DevArg
   constexpr uint32_t S_ = 64u * R;
   bool keyed = false;
   uint32_t done = 0;  // events already processed (whole chunks)
-  const bool one_chunk = n_ev <= S_;
-  if (BOURSE_AMD_EV_KEYED && has_asm && !(BOURSE_AMD_EV_SKIP & ~1) && (MKT || a.assets == 1u) && B.trading && n_ev != 0u &&
-      (one_chunk || (CHUNKS && 2u * ((n_ev + 63u) & ~63u) + ev_keyed_lds_bytes(R) <= lds_bytes))) {
-    if constexpr (!CHUNKS) {
-      keyed = step_events_keyed<R, MKT>(B, a, book, t0, lane, n_ev, e0, perm, perm, lg, asset, n_own);
-      done = keyed ? n_ev : 0u;
-    } else {
-      uint16_t* wk = one_chunk ? perm : perm + ((n_ev + 63u) & ~63u);  // (one chunk: the work area takes the permutation's bytes over)
-      keyed = true;
-      while (done < n_ev) {
-        const uint32_t len = n_ev - done < S_ ? n_ev - done : S_;
-        if (!step_events_keyed<R, MKT>(B, a, book, t0 + done, lane, len, e0, perm + done, wk, lg, asset, n_own)) {
-          keyed = false;
-          break;
-        }
-        done += len;
+  if constexpr (!CHUNKS) {
+    keyed = BOURSE_AMD_EV_KEYED && has_asm && !(BOURSE_AMD_EV_SKIP & ~1) && (MKT || a.assets == 1u) && B.trading && n_ev != 0u && n_ev <= S_ &&
+            step_events_keyed<R, MKT, MODS>(B, a, book, t0, lane, n_ev, e0, perm, perm, lg, asset, n_own);
+    done = keyed ? n_ev : 0u;
+  } else if (BOURSE_AMD_EV_KEYED && has_asm && !(BOURSE_AMD_EV_SKIP & ~1) && (MKT || a.assets == 1u) && B.trading && n_ev != 0u &&
+             (n_ev <= S_ || 2u * ((n_ev + 63u) & ~63u) + ev_keyed_lds_bytes(R) <= lds_bytes)) {
+    uint16_t* wk = n_ev <= S_ ? perm : perm + ((n_ev + 63u) & ~63u);  // (one chunk: the work area takes the permutation's bytes over)
+    keyed = true;
+    while (done < n_ev) {
+      const uint32_t len = n_ev - done < S_ ? n_ev - done : S_;
+      if (!step_events_keyed<R, MKT, MODS>(B, a, book, t0 + done, lane, len, e0, perm + done, wk, lg, asset, n_own)) {
+        keyed = false;
+        break;
       }
+      done += len;
     }
   }
   uint4 evr = make_uint4(0u, 0u, 0u, 0u);
