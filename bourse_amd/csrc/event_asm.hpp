@@ -504,10 +504,11 @@ __device__ __forceinline__ uint32_t events_asm_r1(uint32_t& k, uint32_t n_ev, ui
 // without it (phases 2 / 3; %[chk] = 0: the caller has established that trading is on and no new order of the step has
 // volume 0).  Two statements - one per variant - cost the kernel 10 VGPRs (46 instead of 36), and with them two of the
 // seven event waves that fit beside a k_agents_fsm wave on a SIMD: C3 277 -> 210 M.
-#define EK_R2_STMT_X(MKM) \
+#define EK_BINIT "s_mov_b32 " EK_ALO ", 0x80000000\n\t" "s_mov_b32 " EK_BHI ", 0x7fffffff\n\t"
+#define EK_NOBOPS
+#define EK_R2_STMT_X(MKM, BINIT, BOPS) \
   asm volatile( \
-      "s_mov_b32 " EK_ALO ", 0x80000000\n\t" \
-      "s_mov_b32 " EK_BHI ", 0x7fffffff\n\t" \
+      BINIT \
       "s_cmp_eq_u32 %[chk], 0\n\t" \
       "s_cbranch_scc1 L_fast_%=\n\t" \
       "s_cmp_lt_u32 %[k], %[kend0]\n\t" \
@@ -533,15 +534,14 @@ __device__ __forceinline__ uint32_t events_asm_r1(uint32_t& k, uint32_t n_ev, ui
       EK_TAIL \
       : [st] "=&s"(st), [vm] "=&v"(vm), [k] "+s"(k), [trn] "+s"(trn), [sq] "+s"(sq), \
         [vol0] "+v"(vol0), [vol1] "+v"(vol1), [key0] "+v"(key0), \
-        [key1] "+v"(key1), [trk] "+v"(trk), [trv] "+v"(trv), [trs] "+v"(trs) \
+        [key1] "+v"(key1), [trk] "+v"(trk), [trv] "+v"(trv), [trs] "+v"(trs) BOPS \
       : [ev0] "v"(ev0), [ev1] "v"(ev1), \
         [nev] "s"(n_ev), [kend0] "s"(kend0), [tmask] "s"(tmask), [chk] "s"(checked) \
       : EK_CLOBBERS);
 
-#define EK_R1_STMT_X(MKM) \
+#define EK_R1_STMT_X(MKM, BINIT, BOPS) \
   asm volatile( \
-      "s_mov_b32 " EK_ALO ", 0x80000000\n\t" \
-      "s_mov_b32 " EK_BHI ", 0x7fffffff\n\t" \
+      BINIT \
       "s_cmp_lt_u32 %[k], %[nev]\n\t" \
       "s_cbranch_scc0 L_done_%=\n\t" \
       "s_cmp_eq_u32 %[chk], 0\n\t" \
@@ -553,15 +553,19 @@ __device__ __forceinline__ uint32_t events_asm_r1(uint32_t& k, uint32_t n_ev, ui
       "L_end_2_%=:\n\t" \
       EK_TAIL \
       : [st] "=&s"(st), [vm] "=&v"(vm), [k] "+s"(k), [trn] "+s"(trn), [sq] "+s"(sq), \
-        [vol0] "+v"(vol0), [key0] "+v"(key0), [trk] "+v"(trk), [trv] "+v"(trv), [trs] "+v"(trs) \
+        [vol0] "+v"(vol0), [key0] "+v"(key0), [trk] "+v"(trk), [trv] "+v"(trv), [trs] "+v"(trs) BOPS \
       : [ev0] "v"(ev0), [nev] "s"(n_ev), [tmask] "s"(tmask), [chk] "s"(checked) \
       : EK_CLOBBERS);
 
-#define EK_R2_STMT EK_R2_STMT_X(EK_NOMK)
-#define EK_R1_STMT EK_R1_STMT_X(EK_NOMK)
-// ... and for lists that may carry MARKET orders (the host-driven step, step_events.hpp)
-#define EK_R2M_STMT EK_R2_STMT_X(EK_MKT)
-#define EK_R1M_STMT EK_R1_STMT_X(EK_MKT)
+#define EK_R2_STMT EK_R2_STMT_X(EK_NOMK, EK_BINIT, EK_NOBOPS)
+#define EK_R1_STMT EK_R1_STMT_X(EK_NOMK, EK_BINIT, EK_NOBOPS)
+// ... and for lists that may carry MARKET orders (the host-driven step, step_events.hpp).  Their bounds are the CALLER's
+// (operands [alo] / [bhi], the loosest values before a step's first statement): that step cuts its list at every modification,
+// and a statement that started from the loosest bounds again made the next new bid and the next new ask pay a reduction each.
+// The bounds stay valid across the cuts: between two statements an order only LEAVES the book (a replacement's key := 0).
+#define EK_BOPS , [alo] "+s"(alo), [bhi] "+s"(bhi)
+#define EK_R2M_STMT EK_R2_STMT_X(EK_MKT, "", EK_BOPS)
+#define EK_R1M_STMT EK_R1_STMT_X(EK_MKT, "", EK_BOPS)
 
 // Keyed form of events_asm_r2: `sq` = 0x80000000 | (seq_ctr - sbase) (the caller converts back), key0 / key1 and the event
 // words (compare value in the upper half) as described above.
@@ -603,10 +607,17 @@ __device__ __forceinline__ uint32_t events_key_r1(uint32_t checked, uint32_t& k,
 // The same two loops for lists that may carry MARKET orders (compare value -1 for a market bid, 0x10000 for a market ask:
 // book_device.hpp keys_begin<R, MARKETS>): they match like any order and never rest.  k_step_events only - the agent
 // pipelines' lists of these pool sizes (RandomAgents) carry none and keep the loops above.
+#undef EK_ALO
+#undef EK_BHI
+#define EK_ALO "%[alo]"
+#define EK_BHI "%[bhi]"
 __device__ __forceinline__ uint32_t events_key_r2m(uint32_t checked, uint32_t& k, uint32_t n_ev, uint32_t tmask, uint32_t& tr_n, uint32_t& sq,
                                                    uint32_t& vol0, uint32_t& vol1, uint32_t& key0, uint32_t& key1, uint32_t ev0,
-                                                   uint32_t ev1, uint32_t& trk, uint32_t& trv, uint32_t& trs) {
+                                                   uint32_t ev1, uint32_t& trk, uint32_t& trv, uint32_t& trs, uint32_t& alo,
+                                                   uint32_t& bhi) {
   uint32_t st, vm;
+  alo = (uint32_t)__builtin_amdgcn_readfirstlane(alo);
+  bhi = (uint32_t)__builtin_amdgcn_readfirstlane(bhi);
   auto u32 = [](uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane(x); };
   checked = u32(checked);
   k = u32(k);
@@ -622,8 +633,10 @@ __device__ __forceinline__ uint32_t events_key_r2m(uint32_t checked, uint32_t& k
 
 __device__ __forceinline__ uint32_t events_key_r1m(uint32_t checked, uint32_t& k, uint32_t n_ev, uint32_t tmask, uint32_t& tr_n, uint32_t& sq,
                                                    uint32_t& vol0, uint32_t& key0, uint32_t ev0, uint32_t& trk, uint32_t& trv,
-                                                   uint32_t& trs) {
+                                                   uint32_t& trs, uint32_t& alo, uint32_t& bhi) {
   uint32_t st, vm;
+  alo = (uint32_t)__builtin_amdgcn_readfirstlane(alo);
+  bhi = (uint32_t)__builtin_amdgcn_readfirstlane(bhi);
   auto u32 = [](uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane(x); };
   checked = u32(checked);
   k = u32(k);

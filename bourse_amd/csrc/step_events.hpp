@@ -280,6 +280,8 @@ __device__ __forceinline__ bool step_events_keyed(Book<R>& B, const DevArgs& a, 
   wave_sync();
   const uint32_t nev = rfl(n_ev);
   // the list is cut at the modifications: [k, kend) runs on the assembly loop, a modification is handled between two statements
+  // alo <= best ask key, bhi >= best bid key: kept across this step's statements (event_asm.hpp EK_R2M_STMT)
+  uint32_t alo = 0x80000000u, bhi = 0x7FFFFFFFu;
   uint32_t k = 0, kend = any_mod ? 0u : nev;
   uint32_t post = 0xFFFFFFFFu, post_p = 0;  // the slot (and its old price) of the replacement whose New event the last range was
   // pool slots a modification changed / replaced in this step: ONE vector register - bit r of a lane's word = slot (r, lane)
@@ -306,14 +308,14 @@ __device__ __forceinline__ bool step_events_keyed(Book<R>& B, const DevArgs& a, 
     for (;;) {
       uint32_t full;
       if constexpr (R == 1)
-        full = events_key_r1m(0u, k, nev, 0xFFFFFFFFu, B.tr_n, K.sq, B.vol[0], K.key[0], evw[0], B.tr_k, B.tr_vol, B.tr_pas);
+        full = events_key_r1m(0u, k, nev, 0xFFFFFFFFu, B.tr_n, K.sq, B.vol[0], K.key[0], evw[0], B.tr_k, B.tr_vol, B.tr_pas, alo, bhi);
       else if constexpr (R == 2)
         full = events_key_r2m(0u, k, nev, 0xFFFFFFFFu, B.tr_n, K.sq, B.vol[0], B.vol[1], K.key[0], K.key[1], evw[0], evw[1], B.tr_k,
-                              B.tr_vol, B.tr_pas);
+                              B.tr_vol, B.tr_pas, alo, bhi);
       else if constexpr (R == 4)
-        full = events_key_r4m(0u, k, nev, 0xFFFFFFFFu, B.tr_n, K.sq, B.vol, K.key, evw, evq, B.tr_k, B.tr_vol, B.tr_pas);
+        full = events_key_r4x(0u, k, nev, 0xFFFFFFFFu, B.tr_n, K.sq, B.vol, K.key, evw, evq, B.tr_k, B.tr_vol, B.tr_pas, alo, bhi);
       else
-        full = events_key_r8m(0u, k, nev, 0xFFFFFFFFu, B.tr_n, K.sq, B.vol, K.key, evw, evq, B.tr_k, B.tr_vol, B.tr_pas);
+        full = events_key_r8x(0u, k, nev, 0xFFFFFFFFu, B.tr_n, K.sq, B.vol, K.key, evw, evq, B.tr_k, B.tr_vol, B.tr_pas, alo, bhi);
       // (scatter_and_flush()'s text, in line: through the lambda this instantiation takes 32 B of scratch at 512 slots instead of 8)
       if (B.tr_n) {
         B.trade_vol += wave_add((uint32_t)lane < B.tr_n ? B.tr_vol : 0u);
@@ -391,9 +393,9 @@ __device__ __forceinline__ bool step_events_keyed(Book<R>& B, const DevArgs& a, 
           continue;
         }
         // replace_order (:679-723): out of the book, new price / volume, then the same slot's New event at this position
-        scatter_and_flush();  // (the buffered records' prices are read from the pool: before this slot's changes)
         const bool is_bid = (int32_t)keyv > 0;
         const uint32_t np = has_p ? K.pbase + (w >> 16) : cur_p, nv = has_v ? nv_in : cur_v;
+        if (np != cur_p) scatter_and_flush();  // (the buffered records' prices are read from the pool: before this slot's changes)
         slot_write<R>(K.key, sl, 0u);
         slot_write<R>(B.price, sl, np);
         slot_write<R>(B.vol, sl, nv);
@@ -409,14 +411,14 @@ __device__ __forceinline__ bool step_events_keyed(Book<R>& B, const DevArgs& a, 
     }
     uint32_t full;
     if constexpr (R == 1)
-      full = events_key_r1m(0u, k, kend, 0xFFFFFFFFu, B.tr_n, K.sq, B.vol[0], K.key[0], evw[0], B.tr_k, B.tr_vol, B.tr_pas);
+      full = events_key_r1m(0u, k, kend, 0xFFFFFFFFu, B.tr_n, K.sq, B.vol[0], K.key[0], evw[0], B.tr_k, B.tr_vol, B.tr_pas, alo, bhi);
     else if constexpr (R == 2)
       full = events_key_r2m(0u, k, kend, 0xFFFFFFFFu, B.tr_n, K.sq, B.vol[0], B.vol[1], K.key[0], K.key[1], evw[0], evw[1], B.tr_k,
-                            B.tr_vol, B.tr_pas);
+                            B.tr_vol, B.tr_pas, alo, bhi);
     else if constexpr (R == 4)
-      full = events_key_r4m(0u, k, kend, 0xFFFFFFFFu, B.tr_n, K.sq, B.vol, K.key, evw, evq, B.tr_k, B.tr_vol, B.tr_pas);
+      full = events_key_r4x(0u, k, kend, 0xFFFFFFFFu, B.tr_n, K.sq, B.vol, K.key, evw, evq, B.tr_k, B.tr_vol, B.tr_pas, alo, bhi);
     else
-      full = events_key_r8m(0u, k, kend, 0xFFFFFFFFu, B.tr_n, K.sq, B.vol, K.key, evw, evq, B.tr_k, B.tr_vol, B.tr_pas);
+      full = events_key_r8x(0u, k, kend, 0xFFFFFFFFu, B.tr_n, K.sq, B.vol, K.key, evw, evq, B.tr_k, B.tr_vol, B.tr_pas, alo, bhi);
     scatter_and_flush();
     if (!any_mod && !full) break;
   }

@@ -872,10 +872,10 @@ class ManyBookEnv:
         has_tail = buf.nbytes == n + tail
         if has_tail and not (buf[n:n + 8].tobytes() == _STICKY_MAGIC and
                              int(np.frombuffer(buf[n + 8:n + 16].tobytes(), dtype=np.uint64)[0]) == self.n_books):
-            raise ValueError("restore: the checkpoint's trailer is not this env's (magic / book count)")
+            raise _lib.BourseError(_lib.BK_INVALID, "restore: the checkpoint's trailer is not this env's (magic / book count)")
         if not has_tail and buf.nbytes != n:
-            raise ValueError(f"restore: {buf.nbytes} bytes is not a checkpoint of this env's shape ({n} bytes, or {n + tail} with "
-                             f"the reported-flags trailer)")
+            raise _lib.BourseError(_lib.BK_INVALID, f"restore: {buf.nbytes} bytes is not a checkpoint of this env's shape ({n} bytes, "
+                                                   f"or {n + tail} with the reported-flags trailer)")
         check(self._L.bk_checkpoint_load(self._h, buf.ctypes.data_as(C.c_void_p), n))
         self._flags_sticky, self._warned_bits = None, 0
         if has_tail:

@@ -339,3 +339,55 @@ def test_queues_longer_than_the_pool_run_keyed_chunk_by_chunk(bk, oracle, pool, 
     # a chunk without a spare pool slot (or outside the key window) hands the rest of its step to the event-by-event loop
     assert keyed[flags == 0].sum() >= 0.6 * T * int((flags == 0).sum()), (int(keyed.sum()), T * B)
     env.close()
+
+
+def test_512_slot_pools_switch_to_the_kernel_with_modifications_once_one_was_seen(bk, oracle):
+    """k_step_events<8, .., MODS>: the 512-slot kernel runs WITHOUT the modification code (round 5's register budget) until its env has
+    seen a modification - k_ingest's hint word for the device ingress - and with it from then on.  The hint may lag a step: that
+    step's modifications run event by event.  Results equal the oracle's throughout; the keyed counter shows the switch."""
+    B, N = 64, 40
+    env = bk.ManyBookEnv(B, 7, 0, 1, 100_000, levels=10, max_live_orders=512, max_orders=N * 8, trade_capacity=N * 16, history_capacity=8)
+    env.enable_device_ingress(N)
+    refs = [oracle.StepEnvNumpy(7 + b, 0, 1, 100_000) for b in range(B)]
+    rng = np.random.default_rng(5)
+    off = np.arange(B + 1, dtype=np.uint64) * N
+    MOD = 0x80000003
+    keyed_after = []
+    for s in range(6):
+        n = B * N
+        action = np.ones(n, np.uint32)
+        side = rng.integers(0, 2, n).astype(np.uint8)
+        vol = rng.integers(1, 20, n).astype(np.uint32)
+        price = rng.integers(95, 106, n).astype(np.uint32)
+        oid = np.zeros(n, np.uint64)
+        if s >= 1:
+            canc = rng.random(n) < 0.3
+            action[canc] = 2
+            oid[canc] = rng.integers(0, s * N // 2, int(canc.sum()))
+        if s >= 3:  # from the fourth step on: modifications of earlier ids (a third price only, a third volume only, a third both)
+            mod = (rng.random(n) < 0.1) & (action == 1)
+            action[mod] = MOD
+            side[mod] = rng.choice([2, 4, 6], int(mod.sum())).astype(np.uint8)
+            oid[mod] = rng.integers(0, s * N // 2, int(mod.sum()))
+        ins = (action, side, vol, np.zeros(n, np.uint32), price, oid)
+        ids = env.submit_instructions_all(off, ins)
+        for b, r in enumerate(refs):
+            want = r.submit_instructions_native(tuple(a[b * N:(b + 1) * N] for a in ins))
+            assert np.array_equal(ids[b * N:(b + 1) * N], want), (s, b)
+        env.step()
+        for r in refs:
+            r.step()
+        keyed_after.append(int(env.event_steps_keyed().sum()))
+    assert not env.flags().any()
+    h = env.history()
+    for b, r in enumerate(refs):
+        assert np.array_equal(h[:, b], r.history()), b
+        got, want = env.trades(b, first=0), r.book.trades_array()
+        assert len(got) == len(want) and all(np.array_equal(got[f], want[f]) for f in got.dtype.names), b
+        got, want = env.orders(b), r.book.orders_array()
+        assert len(got) == len(want) and all(np.array_equal(got[f], want[f]) for f in got.dtype.names), b
+    per_step = np.diff([0] + keyed_after)
+    assert list(per_step[:3]) == [B, B, B], per_step          # clean steps: keyed on the kernel without the modification code
+    assert per_step[3] in (0, B) or per_step[3] < B, per_step   # the first step with modifications may still run on it: event by event
+    assert list(per_step[4:]) == [B, B], per_step              # ... the hint has arrived (env.step() waits): keyed, modifications included
+    env.close()

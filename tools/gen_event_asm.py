@@ -28,13 +28,15 @@ OUT = os.path.join(ROOT, "bourse_amd", "csrc", "event_asm_gen.hpp")
 VOL_LIST = True  # the new orders' volumes travel in a second list (by event position) instead of being read from the slot
 
 
-def gen(N, markets):
+def gen(N, markets, ext_bounds=False):
     KB, VB, EB = 40, 40 + N, 40 + 2 * N                     # VGPR rows: key, vol, event list
     QB = 40 + 3 * N                                           # ... and the new orders' volumes by event position
     EQB = 36                                                  # SGPR: row-compare results, scratch
     SC = EQB + 2 * N
     names = ["EW", "KP", "V", "KK", "BEST", "PV", "LS", "X", "SLOT", "ALO", "BHI", "RG", "KEND"]
     S = {n: f"s{SC + i}" for i, n in enumerate(names)}
+    if ext_bounds:  # the bounds are the caller's (operands): k_step_events cuts its list at the modifications and keeps them across the cuts
+        S["ALO"], S["BHI"] = "%[alo]", "%[bhi]"
     last_s = SC + len(names) - 1
     bits = {4: 2, 8: 3}[N]
 
@@ -58,8 +60,9 @@ def gen(N, markets):
         e("s_mov_b64 exec, -1")
 
     # ---------------------------------------------------------------- entry
-    e(f"s_mov_b32 {S['ALO']}, 0x80000000")
-    e(f"s_mov_b32 {S['BHI']}, 0x7fffffff")
+    if not ext_bounds:
+        e(f"s_mov_b32 {S['ALO']}, 0x80000000")
+        e(f"s_mov_b32 {S['BHI']}, 0x7fffffff")
     e("s_cmp_lt_u32 %[k], %[nev]")
     e("s_cbranch_scc0 L_done_%=")
     e("s_cmp_eq_u32 %[chk], 0")
@@ -235,12 +238,13 @@ def gen(N, markets):
     clob = ", ".join(f'"s{i}"' for i in range(EQB, last_s + 1))
     vt = {4: "u32x4", 8: "u32x8"}[N]
     return f'''
-// ---- R = {N}{', lists that may carry market orders' if markets else ''}: {len(L)} instructions; rows key v[{KB}:{KB + N - 1}], vol v[{VB}:{VB + N - 1}], lists v[{EB}:{EB + N - 1}] (event words), v[{QB}:{QB + N - 1}] (volumes);
+// ---- R = {N}{', lists that may carry market orders' if markets else ''}{', bounds kept by the caller across statements (k_step_events)' if ext_bounds else ''}: {len(L)} instructions; rows key v[{KB}:{KB + N - 1}], vol v[{VB}:{VB + N - 1}], lists v[{EB}:{EB + N - 1}] (event words), v[{QB}:{QB + N - 1}] (volumes);
 // row-compare results s[{EQB}:{EQB + 2 * N - 1}]; scratch s{SC}..s{last_s}.  EXEC must be all ones on entry (it is restored to that).
-__device__ __forceinline__ uint32_t events_key_r{N}{'m' if markets else ''}(uint32_t checked, uint32_t& k, uint32_t n_ev, uint32_t tmask, uint32_t& tr_n, uint32_t& sq,
+__device__ __forceinline__ uint32_t events_key_r{N}{('x' if ext_bounds else 'm') if markets else ''}(uint32_t checked, uint32_t& k, uint32_t n_ev, uint32_t tmask, uint32_t& tr_n, uint32_t& sq,
                                                   uint32_t (&vol)[{N}], uint32_t (&key)[{N}], const uint32_t (&ev)[{N}], uint32_t (&evq)[{N}],
-                                                  uint32_t& trk, uint32_t& trv, uint32_t& trs) {{
+                                                  uint32_t& trk, uint32_t& trv, uint32_t& trs{', uint32_t& alo, uint32_t& bhi' if ext_bounds else ''}) {{
   uint32_t st, vm, vt, evc, evqc;
+{'  alo = (uint32_t)__builtin_amdgcn_readfirstlane(alo);' + chr(10) + '  bhi = (uint32_t)__builtin_amdgcn_readfirstlane(bhi);' + chr(10) if ext_bounds else ''}
   auto u32 = [](uint32_t x) {{ return (uint32_t)__builtin_amdgcn_readfirstlane(x); }};
   checked = u32(checked);
   k = u32(k);
@@ -258,7 +262,7 @@ __device__ __forceinline__ uint32_t events_key_r{N}{'m' if markets else ''}(uint
   }}
   asm volatile(
 {text}      : [st] "=&s"(st), [vm] "=&v"(vm), [vt] "=&v"(vt), [evc] "=&v"(evc), [evq] "=&v"(evqc), [k] "+s"(k), [trn] "+s"(trn), [sq] "+s"(sq),
-        [key] "+{{v[{KB}:{KB + N - 1}]}}"(kv), [vol] "+{{v[{VB}:{VB + N - 1}]}}"(vv), [evqr] "+{{v[{QB}:{QB + N - 1}]}}"(evqv), [trk] "+v"(trk), [trv] "+v"(trv), [trs] "+v"(trs)
+        [key] "+{{v[{KB}:{KB + N - 1}]}}"(kv), [vol] "+{{v[{VB}:{VB + N - 1}]}}"(vv), [evqr] "+{{v[{QB}:{QB + N - 1}]}}"(evqv), [trk] "+v"(trk), [trv] "+v"(trv), [trs] "+v"(trs){', [alo] "+s"(alo), [bhi] "+s"(bhi)' if ext_bounds else ''}
       : [ev] "{{v[{EB}:{EB + N - 1}]}}"(evv), [nev] "s"(n_ev), [tmask] "s"(tmask), [chk] "s"(checked)
       : {clob}, "m0", "vcc", "scc", "memory");
 #pragma unroll
@@ -287,7 +291,8 @@ typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
 '''
 
 if __name__ == "__main__":
-    src = HEADER + gen(4, False) + gen(4, True) + gen(8, False) + gen(8, True) + "\n}  // namespace bkd\n"
+    src = (HEADER + gen(4, False) + gen(4, True) + gen(8, False) + gen(8, True) + gen(4, True, True) + gen(8, True, True) +
+           "\n}  // namespace bkd\n")
     if "--check" in sys.argv:
         sys.exit(0 if os.path.exists(OUT) and open(OUT).read() == src else 1)
     open(OUT, "w").write(src)
