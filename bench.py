@@ -106,6 +106,35 @@ def algorithmic_bytes(kind, S, W4, ev, tr, new, spl=1, pipe="split", n_ins=0.0):
     raise KeyError(kind)
 
 
+def ingress_batch(torch, g, n, N, s, f_mod=0.0, f_mkt=0.0):
+    """Step s of the external-agents stream (--workload INGRESS): n elements = N per book, as the six SoA arrays of
+    `submit_instructions` (rust/src/step_sim_numpy.rs:233-275) on the device.  Per element: 30 % cancellations of earlier ids (from
+    the second step on), then f_mod modifications of earlier ids (Env::modify_order, orderbook.rs:743-772: a third price only, a
+    third volume only, a third both - side bit 1 = has price, bit 2 = has volume), f_mkt market orders (price u32::MAX for a bid / 0
+    for an ask, orderbook.rs:594-606), the rest new limit orders at 90..110.  With both fractions 0 the draws are round 5's stream
+    exactly.  (tests/test_gpu_device_ingress.py steps this very stream against one oracle env per book.)"""
+    ACT_MODIFY = 0x80000003 - (1 << 32)  # BK_ACTION_MODIFY as the int32 the 4-byte array holds
+    u = torch.rand(n, device="cuda", generator=g) if (s or f_mod > 0.0 or f_mkt > 0.0) else torch.ones(n, device="cuda")
+    canc = (u < 0.3) if s else torch.zeros(n, dtype=torch.bool, device="cuda")
+    ids = (torch.rand(n, device="cuda", generator=g) * max(1, int(s * N * 0.6))).to(torch.int64)
+    side = torch.randint(0, 2, (n,), device="cuda", generator=g, dtype=torch.uint8)
+    vol = torch.randint(1, 30, (n,), device="cuda", generator=g, dtype=torch.int32)
+    price = torch.randint(90, 111, (n,), device="cuda", generator=g, dtype=torch.int32)
+    action = torch.where(canc, 2, 1).to(torch.int32)
+    if f_mod > 0.0 or f_mkt > 0.0:
+        mod = (u >= 0.3) & (u < 0.3 + f_mod) if s else torch.zeros(n, dtype=torch.bool, device="cuda")
+        mkt = (u >= 0.3 + f_mod) & (u < 0.3 + f_mod + f_mkt)
+        which = torch.randint(0, 3, (n,), device="cuda", generator=g, dtype=torch.uint8)
+        mside = torch.where(which == 0, 2, torch.where(which == 1, 4, 6)).to(torch.uint8)
+        action = torch.where(mod, ACT_MODIFY, action).to(torch.int32)
+        side = torch.where(mod, mside, side)
+        price = torch.where(mkt, torch.where(side == 1, -1, 0).to(torch.int32), price)
+        ids = ids * (canc | mod)
+    else:
+        ids = ids * canc
+    return action, side, vol, torch.zeros(n, dtype=torch.int32, device="cuda"), price, ids
+
+
 def bench_ingress(args, torch):
     import bourse_amd as bk
 
@@ -128,32 +157,9 @@ def bench_ingress(args, torch):
     off = torch.arange(B + 1, dtype=torch.int64, device="cuda") * N
 
     f_mod, f_mkt = float(args.modify_frac), float(args.market_frac)
-    ACT_MODIFY = 0x80000003 - (1 << 32)  # BK_ACTION_MODIFY as the int32 the 4-byte array holds
 
     def make(s):
-        # per element: 30 % cancellations of earlier ids (from the second step on), then --modify-frac modifications of earlier
-        # ids (Env::modify_order, orderbook.rs:743-772: a third price only, a third volume only, a third both - side bit 1 = has
-        # price, bit 2 = has volume), --market-frac market orders (price u32::MAX for a bid / 0 for an ask, orderbook.rs:594-606),
-        # the rest new limit orders at 90..110.  With both fractions 0 the draws are round 5's stream exactly.
-        u = torch.rand(n, device="cuda", generator=g) if (s or f_mod > 0.0 or f_mkt > 0.0) else torch.ones(n, device="cuda")
-        canc = (u < 0.3) if s else torch.zeros(n, dtype=torch.bool, device="cuda")
-        ids = (torch.rand(n, device="cuda", generator=g) * max(1, int(s * N * 0.6))).to(torch.int64)
-        side = torch.randint(0, 2, (n,), device="cuda", generator=g, dtype=torch.uint8)
-        vol = torch.randint(1, 30, (n,), device="cuda", generator=g, dtype=torch.int32)
-        price = torch.randint(90, 111, (n,), device="cuda", generator=g, dtype=torch.int32)
-        action = torch.where(canc, 2, 1).to(torch.int32)
-        if f_mod > 0.0 or f_mkt > 0.0:
-            mod = (u >= 0.3) & (u < 0.3 + f_mod) if s else torch.zeros(n, dtype=torch.bool, device="cuda")
-            mkt = (u >= 0.3 + f_mod) & (u < 0.3 + f_mod + f_mkt)
-            which = torch.randint(0, 3, (n,), device="cuda", generator=g, dtype=torch.uint8)
-            mside = torch.where(which == 0, 2, torch.where(which == 1, 4, 6)).to(torch.uint8)
-            action = torch.where(mod, ACT_MODIFY, action).to(torch.int32)
-            side = torch.where(mod, mside, side)
-            price = torch.where(mkt, torch.where(side == 1, -1, 0).to(torch.int32), price)
-            ids = ids * (canc | mod)
-        else:
-            ids = ids * canc
-        return action, side, vol, torch.zeros(n, dtype=torch.int32, device="cuda"), price, ids
+        return ingress_batch(torch, g, n, N, s, f_mod, f_mkt)
 
     batches = [make(s) for s in range(T)]  # generated ahead: the rate is the library's, not torch's RNG
     out_ids = torch.empty(n, dtype=torch.int64, device="cuda")

@@ -544,3 +544,62 @@ def test_the_rate_scripts_stream_at_full_size_runs_keyed_and_equals_the_oracle(b
         n_tr += len(want)
     assert n_tr > 100 * len(sample)
     env.close()
+
+
+@pytest.mark.parametrize("pool,fracs", [(256, (0.05, 0.02)), (128, (0.05, 0.02)), (512, (0.10, 0.04)), (256, (0.0, 0.0))])
+def test_the_benchs_external_agents_stream_equals_one_oracle_env_per_book(bk, oracle, pool, fracs):
+    """`bench.py --workload INGRESS [--modify-frac --market-frac]` measures bench.ingress_batch's stream; this steps THAT stream -
+    new limit orders, cancellations, modifications (price / volume / both), market orders - through bk_submit_instructions_device +
+    bk_step_async and through one oracle StepEnvNumpy per book: ids, level 2 of every step, every trade, the whole order log.  On the
+    pools of <= 256 slots every book-step must run on the keyed loop."""
+    import os
+    import sys
+
+    import torch
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+
+    B, N, T = 160, 48, 7
+    n = B * N
+    # (levels = 10: the oracle's StepEnvNumpy has the Python surface's fixed ladder depth; the bench's 16 only widens the record)
+    env = bk.ManyBookEnv(B, 1, 0, 1, 100_000, levels=10, max_live_orders=pool, max_orders=N * (T + 2), trade_capacity=64 * (T + 2),
+                         strict=False, history_capacity=T, stream=torch.cuda.current_stream().cuda_stream)
+    env.enable_device_ingress(N)
+    refs = [oracle.StepEnvNumpy(1 + b, 0, 1, 100_000) for b in range(B)]
+    g = torch.Generator(device="cuda").manual_seed(3)
+    off = torch.arange(B + 1, dtype=torch.int64, device="cuda") * N
+    out_ids = torch.empty(n, dtype=torch.int64, device="cuda")
+    status = torch.empty((B, 2), dtype=torch.int32, device="cuda")
+    dts = (np.uint32, np.uint8, np.uint32, np.uint32, np.uint32, np.uint64)
+    n_mod = n_mkt = 0
+    for s in range(T):
+        batch = bench.ingress_batch(torch, g, n, N, s, *fracs)
+        env.submit_instructions_device(off, *batch, out_ids=out_ids, status=status)
+        env.step(sync=False)
+        host = [np.ascontiguousarray(x.cpu().numpy()).view(dt) if x.cpu().numpy().dtype.itemsize == np.dtype(dt).itemsize
+                else x.cpu().numpy().astype(dt) for x, dt in zip(batch, dts)]
+        n_mod += int((host[0] == 0x80000003).sum())
+        n_mkt += int(((host[0] == 1) & ((host[4] == 0) | (host[4] == 0xFFFFFFFF))).sum())
+        got = out_ids.cpu().numpy().view(np.uint64)
+        for b, r in enumerate(refs):
+            want = r.submit_instructions_native(tuple(a[b * N:(b + 1) * N] for a in host))
+            assert np.array_equal(got[b * N:(b + 1) * N], want), (s, b)
+            r.step()
+    env.sync()
+    assert not int(status[:, 0].max()) and not env.flags().any()
+    if fracs[0]:
+        assert n_mod > 0.5 * fracs[0] * n * (T - 1) and n_mkt > 0.5 * fracs[1] * n * T
+    h = env.history()
+    for b, r in enumerate(refs):
+        assert np.array_equal(h[:, b], r.history()), b
+        for got, want in ((env.trades(b, first=0), r.book.trades_array()), (env.orders(b), r.book.orders_array())):
+            assert len(got) == len(want), b
+            for f in got.dtype.names:
+                assert np.array_equal(got[f], want[f]), (b, f)
+    keyed = env.event_steps_keyed()
+    if pool <= 256:
+        assert (keyed == T).all(), keyed[:16]
+    else:  # (512 slots: the kernel with the modification code takes over a step or more after the first modification - same results)
+        assert keyed.sum() >= 0.3 * B * T
+    env.close()
