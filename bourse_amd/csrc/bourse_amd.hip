@@ -315,6 +315,8 @@ struct bk_env {
       bytes = (o_side + c + 63) & ~size_t(63);
     }
   } hi;
+  bool ev_seq_shuffle = false;  // measurement knobs of k_step_events' shuffle, from the environment at bk_env_create:
+  int ev_shuffle_min = -1;      // draw by draw always / the queue length the wave-parallel form starts at (-1: the rule)
   std::atomic<bool> ev_mods_seen{false};  // a modification was submitted to this env (sticky): k_step_events<.., MODS = true> from then on
   uint32_t* mods_flag_host = nullptr;     // device ingress: k_ingest's hint word in mapped host memory, and its device address
   uint32_t* mods_flag_dev = nullptr;
@@ -456,13 +458,12 @@ int launch_events(bk_env* env, const DevArgs& a, uint64_t step_index, uint32_t m
   if (max_queue > 64u * R) perm_bytes = std::max(perm_bytes, ((max_queue + 63u) & ~63u) * 2u + ev_keyed_lds_bytes(R));
   // the shuffle borrows the decode's jump tables and per-book lane-state cache (BOURSE_AMD_EV_SEQ_SHUFFLE=1: the draw-by-draw
   // loop, for measurements)
-  // (both knobs are read at every launch - a getenv, ~0.1 us - so that a test can switch them inside one process)
-  const char* seq_env = getenv("BOURSE_AMD_EV_SEQ_SHUFFLE");
-  const bool seq_shuffle = seq_env && *seq_env == '1';
+  // (both knobs are read ONCE, when the env is created - bk_env_create -: a getenv per launch raced with another thread's
+  // setenv; a test sets them before it creates its env)
+  const bool seq_shuffle = env->ev_seq_shuffle;
   // (its fixed cost - the cache record, a block of draws, a resolution over all 64 R positions - pays from a queue length that
   // grows with the pool: docs/EXPERIMENTS.md; BOURSE_AMD_EV_WAVE_SHUFFLE_MIN overrides, for measurements)
-  const char* min_str = getenv("BOURSE_AMD_EV_WAVE_SHUFFLE_MIN");
-  const int min_env = min_str ? atoi(min_str) : -1;
+  const int min_env = env->ev_shuffle_min;
   const uint32_t shuffle_min = min_env >= 0 ? static_cast<uint32_t>(min_env) : (12u * R > 32u ? 12u * R : 32u);  // (measured: 256 slots 24 events -3 %, 48 +5 %; 512 slots 48 -7 %, 96 +3 %)
   // the lane-state cache (1 280 B per book) and the jump tables exist only once a step CAN take the wave-parallel shuffle: no
   // queue of this launch reaches its threshold -> wcache stays null and the kernel draws one by one (every env's
@@ -969,6 +970,8 @@ int bk_env_create(const bk_config* cfg, bk_env** out) {
     const int v = std::atoi(np);
     if (v >= 1 && v <= bk_env::MAX_PARTS) env->n_parts = v;
   }
+  if (const char* sq = std::getenv("BOURSE_AMD_EV_SEQ_SHUFFLE")) env->ev_seq_shuffle = *sq == '1';
+  if (const char* sm = std::getenv("BOURSE_AMD_EV_WAVE_SHUFFLE_MIN")) env->ev_shuffle_min = std::atoi(sm);
   if (const char* su = std::getenv("BOURSE_AMD_STAGGER_US")) env->stagger_us = static_cast<uint32_t>(std::max(0, std::atoi(su)));
   if (const char* mp = std::getenv("BOURSE_AMD_MIN_PART")) {
     const int v = std::atoi(mp);
