@@ -488,6 +488,11 @@ __device__ __forceinline__ bool step_events_keyed(Book<R>& B, const DevArgs& a, 
 #ifndef BOURSE_AMD_EV_OCC
 #define BOURSE_AMD_EV_OCC(R) ((R) <= 4 ? 8 : 5)
 #endif
+// (the 512-slot form WITH the keyed modifications: four waves per SIMD - 128 VGPRs, no scratch - instead of five with 116 B of
+// scratch per lane; profiles/r06/ab_ev_mods.txt)
+#ifndef BOURSE_AMD_EV_OCC_M
+#define BOURSE_AMD_EV_OCC_M(R, MODS) (((R) == 8 && (MODS)) ? 4 : BOURSE_AMD_EV_OCC(R))
+#endif
 #ifndef BOURSE_AMD_EV_WAVE_SHUFFLE
 #define BOURSE_AMD_EV_WAVE_SHUFFLE 1
 #endif
@@ -507,7 +512,7 @@ template <int R, bool MKT = false, bool CHUNKS = false, bool MODS = true>
 // around its one call site; as a run-time loop in the ONE kernel it cost the ordinary launch 2 %: 32 B more scratch at R = 4)
 // (eight waves per SIMD for pools of <= 256 slots, five for 512: 8 192 books - the C4 shard, the ingress rate scripts - are then ONE residency round;
 // at the 69 VGPRs the compiler took for R = 4 a seventh of the waves ran as a second round)
-__global__ __launch_bounds__(64, BOURSE_AMD_EV_OCC(R)) void k_step_events(DevArgs a, WaveArgs wa, uint64_t step_index, uint32_t wave_shuffle_min,
+__global__ __launch_bounds__(64, BOURSE_AMD_EV_OCC_M(R, MODS)) void k_step_events(DevArgs a, WaveArgs wa, uint64_t step_index, uint32_t wave_shuffle_min,
                                                                           uint32_t lds_bytes /* the launch's dynamic LDS */) {
   __shared__ uint32_t bins[LDS_DW_PER_WAVE];
   // the shuffle permutation: dynamic LDS sized by the host to this step's longest queue (<= EV_LDS_CAP entries), so
