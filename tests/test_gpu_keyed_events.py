@@ -391,3 +391,52 @@ def test_512_slot_pools_switch_to_the_kernel_with_modifications_once_one_was_see
     assert per_step[3] in (0, B) or per_step[3] < B, per_step   # the first step with modifications may still run on it: event by event
     assert list(per_step[4:]) == [B, B], per_step              # ... the hint has arrived (env.step() waits): keyed, modifications included
     env.close()
+
+
+@pytest.mark.parametrize("assets,pool", [(2, 64), (3, 128)])
+def test_markets_with_queues_longer_than_the_pool_and_modifications(bk, oracle, assets, pool):
+    """The last combination of k_step_events' forms: a MARKET's joint queue (market_env.rs:110-121) longer than a book's pool -
+    chunked - with cancellations and modifications across its assets: every book against the oracle's MarketEnv."""
+    NM, T = 40, 5
+    ticks = [1, 2, 5][:assets]
+    env = bk.ManyMarketEnv(NM, 91, 0, ticks, 100_000, levels=10, max_live_orders=pool, max_orders=4096, trade_capacity=8192, history_capacity=T,
+                           strict=False)
+    ref = oracle.ManyMarkets(NM, 91, 0, ticks, 100_000, True, 10)
+    rng = np.random.default_rng(assets * 7)
+    for s in range(T):
+        for m in range(NM):
+            for _ in range(int(rng.integers(pool + 10, 2 * pool + 30))):
+                a = int(rng.integers(0, assets))
+                made = ref.book(m, a).n_orders()
+                u = rng.random()
+                if u < 0.38 and made:
+                    oid = int(made - 1 - rng.integers(0, min(made, 50)))
+                    env.cancel_order(m, a, oid)
+                    ref.cancel_order(m, a, oid)
+                elif u < 0.46 and made:
+                    oid = int(made - 1 - rng.integers(0, min(made, 50)))
+                    np_ = int(rng.integers(97, 104)) * ticks[a] if rng.random() < 0.5 else None
+                    nv = int(rng.integers(1, 9)) if (np_ is None or rng.random() < 0.5) else None
+                    env.modify_order(m, a, oid, np_, nv)
+                    ref.modify_order(m, a, oid, np_, nv)
+                else:
+                    bid, vol = bool(rng.integers(0, 2)), int(rng.integers(1, 9))
+                    price = None if rng.random() < 0.03 else int(rng.integers(98, 103)) * ticks[a]
+                    assert env.place_order(m, a, bid, vol, 7, price) == ref.place_order(m, a, bid, vol, 7, price)
+        env.step()
+        ref.step()
+    flags = env.flags().reshape(NM, assets)
+    ok_m = ~flags.any(axis=1)  # (a market with a book whose pool overflowed dropped an order: not compared)
+    assert ok_m.sum() >= 0.6 * NM, int(ok_m.sum())
+    h, hr = env.history(), ref.history()
+    for m in np.nonzero(ok_m)[0]:
+        for a in range(assets):
+            b = env.book(int(m), a)
+            assert np.array_equal(h[:, b], hr[:, b]), (m, a)
+            got, want = env.trades(b, first=0), ref.book(int(m), a).trades_array()
+            assert len(got) == len(want) and all(np.array_equal(got[f], want[f]) for f in got.dtype.names), (m, a)
+            got, want = env.orders(b), ref.book(int(m), a).orders_array()
+            assert len(got) == len(want) and all(np.array_equal(got[f], want[f]) for f in got.dtype.names), (m, a)
+    keyed = env.event_steps_keyed().reshape(NM, assets)
+    assert keyed[ok_m].sum() >= 0.5 * T * assets * int(ok_m.sum()), (int(keyed[ok_m].sum()), T * assets * int(ok_m.sum()))
+    env.close()
