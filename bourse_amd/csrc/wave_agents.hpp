@@ -179,6 +179,9 @@ __device__ __forceinline__ uint32_t first_above_near(uint64_t lo, uint64_t hi, u
 // slot) is global memory for the split pipeline (the step batch) and LDS for the fused kernel.
 // MASKS: also keep the placing / side masks of the step's new orders (the fused kernel reads them; the split form's
 // k_step_batch rebuilds them from the event words, so its decode does not pay two LDS atomics per placement for them).
+#ifndef BOURSE_AMD_GEN_FAKE
+#define BOURSE_AMD_GEN_FAKE 0
+#endif
 template <int R, bool MASKS = true>
 struct WaveDecoder {
   const uint4* tab;    // LDS: T^256 table
@@ -242,14 +245,23 @@ struct WaveDecoder {
       // the stream position may still lie in the block being left when the launch ends (look-ahead): its chunk-start
       // states go to the cache record now (a fire-and-forget 1 KB store instead of four live registers)
       wcs[lane] = cs;
+#if BOURSE_AMD_GEN_FAKE  // TIMING EXPERIMENT (results are wrong): what would the decode cost if generation were free?
+      cs.x = cs.x * 0x9E3779B1u + 0x7F4A7C15u; cs.y ^= cs.x >> 7; cs.z += cs.y; cs.w ^= cs.z << 3;
+#else
       cs = wv_jump(tab, cs);
+#endif
     }
     RngLane t{cs.x, cs.y, cs.z, cs.w};
     uint4 x;
+#if BOURSE_AMD_GEN_FAKE >= 2
+    x.x = cs.x * 0x85EBCA6Bu; x.y = (cs.y ^ cs.x) * 0xC2B2AE35u; x.z = (cs.z + cs.x) * 0x27D4EB2Fu; x.w = (cs.w ^ cs.y) * 0x165667B1u;
+    x.x ^= x.x >> 15; x.y ^= x.y >> 13; x.z ^= x.z >> 16; x.w ^= x.w >> 14;
+#else
     x.x = t.next_u32();
     x.y = t.next_u32();
     x.z = t.next_u32();
     x.w = t.next_u32();
+#endif
     reinterpret_cast<uint4*>(ring)[((gen_end >> 2) + lane) & (WV_RING / 4 - 1)] = x;
     gen_end += WV_BLOCK;
     wave_sync();
