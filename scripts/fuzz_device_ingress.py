@@ -21,7 +21,8 @@ for seed in range(lo, hi):
     lcm = int(np.lcm.reduce(ticks))
     T, nmax, subs = int(rng.integers(1, 7)), int(rng.integers(1, 20)), int(rng.integers(1, 3))
     qcap = nmax * subs * M + int(rng.integers(0, 5))  # never full here (the capacity path: tests/test_gpu_device_ingress.py)
-    kw = dict(levels=int(rng.integers(1, 20)), max_live_orders=256, max_orders=nmax * subs * T * M + 8, trade_capacity=nmax * subs * T * 2 + 8,
+    # (512 slots: k_step_events<8> switches to its form with the keyed modifications when k_ingest's hint arrives - round 6)
+    kw = dict(levels=int(rng.integers(1, 20)), max_live_orders=int(rng.choice([256, 512])), max_orders=nmax * subs * T * M + 8, trade_capacity=nmax * subs * T * 2 + 8,
               history_capacity=T)
     try:
         if M == 1:
