@@ -110,7 +110,7 @@ template <int R, bool MKT, bool MODS = true>
 // on the way), behind the permutation for a chunked one (the later chunks still need theirs).  n_own is ADDED to.
 __device__ __forceinline__ bool step_events_keyed(Book<R>& B, const DevArgs& a, uint32_t book, uint64_t t0, int lane,
                                                   uint32_t n_ev, uint32_t e0, const uint16_t* perm, uint16_t* wk, const LogCtx& lg,
-                                                  uint32_t asset, uint32_t& n_own) {
+                                                  uint32_t asset, uint32_t& n_own, uint32_t* bins) {
   constexpr uint32_t S = 64u * R;
   uint16_t* rank2ev = wk + S;       // bytes [2S, 4S): event position of the i-th new order
   uint16_t* ev2slot = wk + 2u * S;  // bytes [4S, 6S): pool slot of the new order at an event position
@@ -263,7 +263,17 @@ __device__ __forceinline__ bool step_events_keyed(Book<R>& B, const DevArgs& a, 
   }
   // ---- keys, event words, the loop
   KeyState<R> K;
-  if (!keys_begin<R, true>(B, newm, n_ev, K, xmin, xmax)) return false;  // (the permutation is still intact for the caller's loop)
+  if (!keys_begin<R, true>(B, newm, n_ev, K, xmin, xmax)) {  // (the permutation is still intact for the caller's loop)
+    // prices that span more than the key window: the top-anchored window with the far-low bids saturated (book_device.hpp
+    // keys_begin_wide, built for MomentumAgent's bids at price 0) - an external agent's far-away bids, round 6.  Not with
+    // modifications (a replacement could move a bid across the window's edge after the guard was evaluated), and not in the 512-slot
+    // kernel (its register budget: see k_step_events).  bins: the snapshot's level bins, not in use yet.
+    if constexpr (BOURSE_AMD_KEYED_WIDE && R <= 4) {
+      if (any_mod || !keys_begin_wide<R, true>(B, newm, n_ev, K, evs, bins, lane)) return false;
+    } else {
+      return false;
+    }
+  }
   uint32_t evw[R];
   key_event_words<R>(K, evs, n_ev, evw);
   if (any_mod) {
@@ -615,7 +625,7 @@ __global__ __launch_bounds__(64, BOURSE_AMD_EV_OCC_M(R, MODS)) void k_step_event
   uint32_t done = 0;  // events already processed (whole chunks)
   if constexpr (!CHUNKS) {
     keyed = BOURSE_AMD_EV_KEYED && has_asm && !(BOURSE_AMD_EV_SKIP & ~1) && (MKT || a.assets == 1u) && B.trading && n_ev != 0u && n_ev <= S_ &&
-            step_events_keyed<R, MKT, MODS>(B, a, book, t0, lane, n_ev, e0, perm, perm, lg, asset, n_own);
+            step_events_keyed<R, MKT, MODS>(B, a, book, t0, lane, n_ev, e0, perm, perm, lg, asset, n_own, bins);
     done = keyed ? n_ev : 0u;
   } else if (BOURSE_AMD_EV_KEYED && has_asm && !(BOURSE_AMD_EV_SKIP & ~1) && (MKT || a.assets == 1u) && B.trading && n_ev != 0u &&
              (n_ev <= S_ || 2u * ((n_ev + 63u) & ~63u) + ev_keyed_lds_bytes(R) <= lds_bytes)) {
@@ -623,7 +633,7 @@ __global__ __launch_bounds__(64, BOURSE_AMD_EV_OCC_M(R, MODS)) void k_step_event
     keyed = true;
     while (done < n_ev) {
       const uint32_t len = n_ev - done < S_ ? n_ev - done : S_;
-      if (!step_events_keyed<R, MKT, MODS>(B, a, book, t0 + done, lane, len, e0, perm + done, wk, lg, asset, n_own)) {
+      if (!step_events_keyed<R, MKT, MODS>(B, a, book, t0 + done, lane, len, e0, perm + done, wk, lg, asset, n_own, bins)) {
         keyed = false;
         break;
       }

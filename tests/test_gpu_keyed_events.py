@@ -440,3 +440,42 @@ def test_markets_with_queues_longer_than_the_pool_and_modifications(bk, oracle, 
     keyed = env.event_steps_keyed().reshape(NM, assets)
     assert keyed[ok_m].sum() >= 0.5 * T * assets * int(ok_m.sum()), (int(keyed[ok_m].sum()), T * assets * int(ok_m.sum()))
     env.close()
+
+
+@pytest.mark.parametrize("pool", [64, 128, 256])
+def test_far_low_bids_keep_the_host_driven_step_on_the_keyed_loop(bk, oracle, pool):
+    """Prices that span more than the key window (32 762 ticks): an external agent's stink bids far below the book.  The host-driven
+    step takes the top-anchored window with those bids saturated (book_device.hpp keys_begin_wide: exact as long as no aggressor
+    can reach them - a guard on the step's ask volume) instead of the event-by-event loop; a step whose asks COULD reach them, an ask
+    below the window, or a modification in such a step falls back.  Every book against its oracle env."""
+    far = [("place_order", True, 3 + i, 9, 1 + i) for i in range(5)]                      # bids at 1..5
+    near = [("place_order", i % 2 == 0, 2 + i % 5, i, 50_000 + (i % 6) - (3 if i % 2 == 0 else 0)) for i in range(14)]
+    busy = lambda s: [("place_order", (i + s) % 2 == 0, 1 + (i + s) % 4, i, 50_000 + ((i + s) % 5) - (2 if (i + s) % 2 == 0 else 0)) for i in range(10)] + [("cancel_order", 6 + s)]  # noqa: E731
+    cases = {
+        # (the first step of every book falls back: the guard counts the bid volume that RESTS when the step begins - none yet -
+        # against the asks of the step that could take bids)
+        "stink bids, ordinary flow": ([far + near, busy(1), busy(2) + [("place_order", False, 2, 3, None)], busy(3)], 3),
+        "a market ask larger than the in-window bids reaches them": ([far + near, busy(1), [("place_order", False, 500, 3, None)], busy(3)], 2),
+        "an ask below the window": ([far + near, busy(1) + [("place_order", False, 1, 3, 10_000)], busy(2)], 1),
+        "a modification in such a step": ([far + near, busy(1) + [("modify_order", 7, None, 1)], busy(2)], 1),
+        "cancelling the stink bids brings the narrow window back": ([far + near, [("cancel_order", i) for i in range(5)] + busy(1), busy(2)], 2),
+    }
+    names = list(cases)
+    B, T = len(names), 4
+    env = bk.ManyBookEnv(B, 77, 0, 1, 100_000, levels=10, max_live_orders=pool, max_orders=400, trade_capacity=800, history_capacity=T)
+    refs = [oracle.StepEnv(77 + b, 0, 1, 100_000) for b in range(B)]
+    for s in range(T):
+        for b, name in enumerate(names):
+            steps = cases[name][0]
+            for f, *args in (steps[s] if s < len(steps) else []):
+                getattr(env, f)(b, *args)
+                getattr(refs[b], f)(*args)
+        env.step()
+        for r in refs:
+            r.step()
+    assert not env.flags().any(), dict(zip(names, env.flags().tolist()))
+    _same_as_oracle(env, refs)
+    keyed = dict(zip(names, env.event_steps_keyed().tolist()))
+    for name in names:
+        assert keyed[name] == cases[name][1], keyed
+    env.close()
