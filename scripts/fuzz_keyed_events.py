@@ -25,7 +25,10 @@ for seed in range(lo, hi):
     lo_p, hi_p = max(1, centre - width), min((2**32 - 1) // tick, centre + width + 1)
     kw = dict(p_market=float(rng.choice([0.0, 0.01, 0.05])), p_mod=float(rng.choice([0.0, 0.003, 0.03, 0.1, 0.25])),
               p_zero=float(rng.choice([0.0, 0.0, 0.002, 0.02])), tick=tick, lo=lo_p, hi=hi_p,
-              vols=[1, 2, 7, 2**31, 2**32 - 1, 2**32 - 2, 123456789] if rng.random() < 0.15 else None)
+              vols=[1, 2, 7, 2**31, 2**32 - 1, 2**32 - 2, 123456789] if rng.random() < 0.15 else None,
+              # a fifth of the narrow-range configurations well above price 40 000 also get stink bids far below the book: the
+              # top-anchored key window with saturated bids (round 6)
+              far=(0.06, 1, 60) if (rng.random() < 0.2 and width <= 30 and centre >= 3_000_000) else None)
     try:
         env, refs, busy, clean = K._drive(bk, oracle, pool, n_max, B, T, 1000 + seed, **kw)
         try:

@@ -23,7 +23,7 @@ def bk():
     return bourse_amd
 
 
-def _drive(bk, oracle, pool, n_max, B, T, seed, p_market, p_mod, p_zero, tick=1, lo=94, hi=107, vols=None):
+def _drive(bk, oracle, pool, n_max, B, T, seed, p_market, p_mod, p_zero, tick=1, lo=94, hi=107, vols=None, far=None):
     """B books x T steps of random host calls, the same calls into one oracle env per book.  Returns the env, the oracle
     envs, and per (step, book): had events / had only what the keyed form takes (as far as the calls alone can tell)."""
     env = bk.ManyBookEnv(B, seed, 0, tick, 100_000, levels=10, max_live_orders=pool, max_orders=2 * n_max * T + 8,
@@ -58,6 +58,8 @@ def _drive(bk, oracle, pool, n_max, B, T, seed, p_market, p_mod, p_zero, tick=1,
                     bid, trader = bool(rng.integers(0, 2)), int(rng.integers(0, 50))
                     vol = 0 if rng.random() < p_zero else (int(rng.integers(1, 40)) if vols is None else int(rng.choice(vols)))
                     price = None if rng.random() < p_market else int(rng.integers(lo, hi)) * tick
+                    if far is not None and bid and price is not None and rng.random() < far[0]:
+                        price = int(rng.integers(far[1], far[2])) * tick  # a stink bid far below the book (the wide key window)
                     assert env.place_order(b, bid, vol, trader, price) == made[b] == refs[b].place_order(bid, vol, trader, price)
                     made[b] += 1
                     ok, n_ev = ok and vol != 0, n_ev + 1
