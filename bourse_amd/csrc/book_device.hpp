@@ -1043,6 +1043,78 @@ __device__ __forceinline__ bool keys_begin_wide(const Book<R>& B, const uint64_t
   K.bhi = 0x7FFFFFFF;
   return true;
 }
+// The MIRROR case (round 6, the host-driven step only - step_events.hpp): asks far ABOVE the book.  The window is anchored at the
+// BOTTOM price and the asks above it are saturated at price field 0x7FFF - above every in-window field (<= KEY_PSPAN + 2), so they
+// lose every reduction to an in-window ask, no in-window limit bid crosses them (its compare value has a smaller field), a market
+// bid does (-1 is at or above every ask key) - exact as long as no aggressor reaches one: the volume of this step's new bids that
+// can take ask volume at all (market bids; limit bids priced at or above the lowest ask that rests in this step) must not exceed
+// the volume of the in-window asks that rest now and have no cancellation in this step's list.  A bid above the window, a price
+// below 2, a volume >= 2^22 or a failed guard: false.
+template <int R, bool MARKETS>
+__device__ __forceinline__ bool keys_begin_wide_high(const Book<R>& B, const uint64_t (&newm)[R], uint32_t n_ev, KeyState<R>& K,
+                                                     const uint32_t (&ev)[R], uint32_t* bins, int lane) {
+  uint64_t lim[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+    lim[r] = MARKETS ? newm[r] & ~__ballot(B.price[r] == (lane_bit(B.bid[r]) ? 0xFFFFFFFFu : 0u)) : newm[r];
+  uint32_t pmin = 0xFFFFFFFFu, age = 0, vbig = 0, pdummy = 0;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const bool lv = lane_bit(B.live[r]), in = lv | lane_bit(lim[r]);
+    pmin = min(pmin, in ? B.price[r] : 0xFFFFFFFFu);
+    age = max(age, lv ? B.seq_ctr - B.seq[r] : 0u);
+    vbig = max(vbig, (lv | lane_bit(newm[r])) ? B.vol[r] : 0u);
+  }
+  wave_reduce3(pdummy, pmin, age);
+  vbig = wave_umax(vbig);
+  if (pmin < 2u || pmin > 0xFFFFFFFFu - KEY_PSPAN - 4u || age + n_ev >= KEY_SMASK - 1u || vbig >= (1u << 22)) return false;
+  const uint32_t pbase = pmin - 2u, highp = pmin + KEY_PSPAN;  // in the window: pmin <= price <= highp
+  if (lane < 2 * R) bins[lane] = 0u;
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int re = 0; re < R; ++re) {
+    const uint32_t slot = ev[re] & EV_SLOT & (64u * R - 1u);
+    if ((uint32_t)(re * 64 + lane) < n_ev) atomicOr(&bins[slot >> 5], 1u << (slot & 31u));
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  uint32_t pask = 0xFFFFFFFFu;  // the lowest price among the asks that rest in this step
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+    pask = min(pask, ((lane_bit(B.live[r]) | lane_bit(lim[r])) && !lane_bit(B.bid[r])) ? B.price[r] : 0xFFFFFFFFu);
+  pask = wave_umin(pask);
+  uint32_t w_ask = 0, b_bid = 0;
+  uint64_t bad = 0;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const bool lv = lane_bit(B.live[r]), bidl = lane_bit(B.bid[r]), nw = lane_bit(newm[r]);
+    const bool above = (lv | lane_bit(lim[r])) && B.price[r] > highp;
+    const bool listed = ((bins[(uint32_t)(r * 64 + lane) >> 5] >> ((uint32_t)lane & 31u)) & 1u) != 0u;
+    bad |= __ballot(above && bidl);  // a bid above the window: not this path
+    w_ask += (lv && !bidl && !above && !listed) ? B.vol[r] : 0u;
+    // (a market bid's price is u32::MAX >= pask: counted by the same compare)
+    b_bid += (nw && bidl && B.price[r] >= pask) ? B.vol[r] : 0u;
+  }
+  if (bad) return false;
+  w_ask = wave_add(w_ask);
+  b_bid = wave_add(b_bid);
+  if (b_bid > w_ask) return false;
+  K.pbase = pbase;
+  K.sbase = B.seq_ctr - age - 1u;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const bool bidl = lane_bit(B.bid[r]);
+    const uint32_t pf = B.price[r] > highp ? 0x7FFFu : B.price[r] - pbase, sf = B.seq[r] - K.sbase;  // (above the window: an ask, saturated)
+    K.key[r] = lane_bit(B.live[r]) ? ((pf << 16) | (bidl ? 0xFFFFu - sf : KEY_ASK | sf)) : 0u;
+    K.pk[r] = lane_bit(lim[r]) ? (bidl ? 0x8000u | pf : pf) : 0u;
+    if (MARKETS) K.pk[r] = lane_bit(newm[r] & ~lim[r]) ? (bidl ? 0xFFFFu : 1u) : K.pk[r];
+  }
+  K.sq = KEY_ASK | (B.seq_ctr - K.sbase);
+  K.alo = (int32_t)0x80000000u;
+  K.bhi = 0x7FFFFFFF;
+  return true;
+}
 // after the loop: the live masks and the arrival stamps of the orders resting now (the others' are never read again)
 template <int R>
 __device__ __forceinline__ void keys_end(Book<R>& B, const KeyState<R>& K) {

@@ -269,7 +269,9 @@ __device__ __forceinline__ bool step_events_keyed(Book<R>& B, const DevArgs& a, 
     // modifications (a replacement could move a bid across the window's edge after the guard was evaluated), and not in the 512-slot
     // kernel (its register budget: see k_step_events).  bins: the snapshot's level bins, not in use yet.
     if constexpr (BOURSE_AMD_KEYED_WIDE && R <= 4) {
-      if (any_mod || !keys_begin_wide<R, true>(B, newm, n_ev, K, evs, bins, lane)) return false;
+      if (any_mod || !(keys_begin_wide<R, true>(B, newm, n_ev, K, evs, bins, lane) ||
+                       keys_begin_wide_high<R, true>(B, newm, n_ev, K, evs, bins, lane)))  // (asks far ABOVE the book: the mirror window)
+        return false;
     } else {
       return false;
     }

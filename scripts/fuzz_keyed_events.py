@@ -28,7 +28,8 @@ for seed in range(lo, hi):
               vols=[1, 2, 7, 2**31, 2**32 - 1, 2**32 - 2, 123456789] if rng.random() < 0.15 else None,
               # a fifth of the narrow-range configurations well above price 40 000 also get stink bids far below the book: the
               # top-anchored key window with saturated bids (round 6)
-              far=(0.06, 1, 60) if (rng.random() < 0.2 and width <= 30 and centre >= 3_000_000) else None)
+              far=((0.06, 1, 60) if rng.random() < 0.5 else (0.06, 20 * centre // 19, 20 * centre // 19 + 60))
+              if (rng.random() < 0.25 and width <= 30 and centre == 3_000_000) else None)
     try:
         env, refs, busy, clean = K._drive(bk, oracle, pool, n_max, B, T, 1000 + seed, **kw)
         try:

@@ -58,8 +58,9 @@ def _drive(bk, oracle, pool, n_max, B, T, seed, p_market, p_mod, p_zero, tick=1,
                     bid, trader = bool(rng.integers(0, 2)), int(rng.integers(0, 50))
                     vol = 0 if rng.random() < p_zero else (int(rng.integers(1, 40)) if vols is None else int(rng.choice(vols)))
                     price = None if rng.random() < p_market else int(rng.integers(lo, hi)) * tick
-                    if far is not None and bid and price is not None and rng.random() < far[0]:
-                        price = int(rng.integers(far[1], far[2])) * tick  # a stink bid far below the book (the wide key window)
+                    if far is not None and bid == (far[1] < lo) and price is not None and rng.random() < far[0]:
+                        # a stink bid far below the book / (far range above it) a stink ask far above: the wide key windows
+                        price = int(rng.integers(far[1], far[2])) * tick
                     assert env.place_order(b, bid, vol, trader, price) == made[b] == refs[b].place_order(bid, vol, trader, price)
                     made[b] += 1
                     ok, n_ev = ok and vol != 0, n_ev + 1
@@ -466,6 +467,44 @@ def test_far_low_bids_keep_the_host_driven_step_on_the_keyed_loop(bk, oracle, po
     B, T = len(names), 4
     env = bk.ManyBookEnv(B, 77, 0, 1, 100_000, levels=10, max_live_orders=pool, max_orders=400, trade_capacity=800, history_capacity=T)
     refs = [oracle.StepEnv(77 + b, 0, 1, 100_000) for b in range(B)]
+    for s in range(T):
+        for b, name in enumerate(names):
+            steps = cases[name][0]
+            for f, *args in (steps[s] if s < len(steps) else []):
+                getattr(env, f)(b, *args)
+                getattr(refs[b], f)(*args)
+        env.step()
+        for r in refs:
+            r.step()
+    assert not env.flags().any(), dict(zip(names, env.flags().tolist()))
+    _same_as_oracle(env, refs)
+    keyed = dict(zip(names, env.event_steps_keyed().tolist()))
+    for name in names:
+        assert keyed[name] == cases[name][1], keyed
+    env.close()
+
+
+@pytest.mark.parametrize("pool", [64, 128, 256])
+def test_far_high_asks_keep_the_host_driven_step_on_the_keyed_loop(bk, oracle, pool):
+    """The mirror window (book_device.hpp keys_begin_wide_high): asks far ABOVE the book are saturated at the top price field; exact as
+    long as no bid can reach them (a guard on the step's bid volume).  A market bid larger than the in-window asks, a bid above the
+    window, a modification, or far orders on BOTH sides fall back.  Every book against its oracle env."""
+    far = [("place_order", False, 3 + i, 9, 3_000_000 + 7 * i) for i in range(5)]        # asks ~60x above the book
+    near = [("place_order", i % 2 == 0, 2 + i % 5, i, 50_000 + (i % 6) - (3 if i % 2 == 0 else 0)) for i in range(14)]
+    busy = lambda s: [("place_order", (i + s) % 2 == 0, 1 + (i + s) % 4, i, 50_000 + ((i + s) % 5) - (2 if (i + s) % 2 == 0 else 0)) for i in range(10)] + [("cancel_order", 6 + s)]  # noqa: E731
+    cases = {
+        # (the first step of every book falls back: no ask volume rests yet when its guard is evaluated)
+        "far asks, ordinary flow": ([far + near, busy(1), busy(2) + [("place_order", True, 2, 3, None)], busy(3)], 3),
+        "a market bid larger than the in-window asks reaches them": ([far + near, busy(1), [("place_order", True, 500, 3, None)], busy(3)], 2),
+        "a bid above the window": ([far + near, busy(1) + [("place_order", True, 1, 3, 2_000_000)], busy(2)], 1),
+        "a modification in such a step": ([far + near, busy(1) + [("modify_order", 8, None, 1)], busy(2)], 1),
+        "far orders on both sides": ([far + near + [("place_order", True, 4, 9, 5)], busy(1), busy(2)], 0),
+        "cancelling the far asks brings the narrow window back": ([far + near, [("cancel_order", i) for i in range(5)] + busy(1), busy(2)], 2),
+    }
+    names = list(cases)
+    B, T = len(names), 4
+    env = bk.ManyBookEnv(B, 78, 0, 1, 100_000, levels=10, max_live_orders=pool, max_orders=400, trade_capacity=800, history_capacity=T)
+    refs = [oracle.StepEnv(78 + b, 0, 1, 100_000) for b in range(B)]
     for s in range(T):
         for b, name in enumerate(names):
             steps = cases[name][0]
