@@ -246,7 +246,11 @@ def bench_ingress(args, torch):
                      "traffic_source": traffic_src, "kernel": "k_step_events", "avg_launch_ms": ev_launch_ms, "launches": int(nl), "bytes_per_book_step": ev_bytes,
                      "book_steps_per_launch": B, "accounting": acct,
                      "launches_sampled_in": f"the last {P} steps of the same stream on a fresh env, HIP events around every launch",
-                     "kernels": {"k_step_events": {"avg_launch_ms": ev_launch_ms, "bytes_per_book_step": ev_bytes},
+                     # aggregate: both kernels' compulsory bytes of a step / the step's wall time in the timed region
+                     "achieved_node": (ev_bytes + ing_bytes) * B / (dt / K) / 1e9, "peak_node": HBM_PEAK_GBPS,
+                     "frac_node": (ev_bytes + ing_bytes) * B / (dt / K) / 1e9 / HBM_PEAK_GBPS,
+                     "kernels": {"k_step_events": {"avg_launch_ms": ev_launch_ms, "bytes_per_book_step": ev_bytes,
+                                                   "frac": ach / HBM_PEAK_GBPS},
                                  "k_ingest": {"avg_launch_ms": ing_launch_ms, "bytes_per_book_step": ing_bytes,
                                               "frac": ing_bytes * B / (ing_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS}}},
     }
